@@ -1,0 +1,224 @@
+"""bench.py -- train images/sec of the DDPM (palette_model) step on N MI355X GPUs of one node.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it as
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU,
+RCCL).  W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize; the MAX
+over ranks is reported; rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1]): palette_model DDPM, efficient UNet (ngf 64, mults 1-2-4-8,
+2 res-blocks/level, mid-block attention 16 heads x 32), 256x256, batch 32 PER GPU (weak scaling),
+inpainting task with synthetic rectangle masks, AdamW + EMA (the example JSON's train section),
+iter_size 1.  = examples/example_ddpm_noglasses2glasses.json + the overrides of SURVEY.md
+Appendix C (data_crop_size 256, train_batch_size 32, train_iter_size 1,
+G_unet_mha_vit_efficient true).  A step = set_input(device-resident batch) + optimize_parameters()
+(forward, backward, gradient all-reduce, fused AdamW + EMA, refresh of the bf16 weights).
+
+Extra objects on the JSON line:
+  roofline     -- dominant kernel = conv_nt_kernel (implicit-GEMM conv forward + input-gradient):
+                  achieved = algorithmic FLOPs per launch (2*M*N*K) / average launch duration, both
+                  from HIP events recorded around EVERY launch on the launch stream during a
+                  separate instrumented pass of 2 steps (the timed region carries no events);
+                  peak = 2500 TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md).
+  cpu_baseline -- the CPU oracle (oracle/jg_oracle.py, a torch-CPU-fp32 port of the reference
+                  step) timed on this box's host cores on a bounded sample (rank 0, N == 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0
+# DDPM UNet, in-ch 6, forward GFLOP per image (conv/linear/attention matmuls x2)
+FWD_GFLOP_PER_IMG = {(256, True): 369.78, (256, False): 413.27, (128, True): 92.04, (128, False): 102.91,
+                     (512, True): 1504.88, (512, False): 1678.83}
+
+
+def synth_batch(B, S, seed, device):
+    """A,B ~ U(-1,1); one rectangle per image covering 10-40 % of the area;
+    A = B (1-m) + N(0,1) m  (mirrors fill_mask_with_random)."""
+    g = torch.Generator().manual_seed(seed)
+    Bimg = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    m = torch.zeros(B, 1, S, S, dtype=torch.int64)
+    for i in range(B):
+        frac = float(torch.rand(1, generator=g)) * 0.3 + 0.1
+        ar = float(torch.rand(1, generator=g)) * 1.0 + 0.5
+        hh = max(1, min(S, int(round((frac * S * S * ar) ** 0.5))))
+        ww = max(1, min(S, int(round(frac * S * S / hh))))
+        h0 = int(torch.randint(0, S - hh + 1, (1,), generator=g))
+        w0 = int(torch.randint(0, S - ww + 1, (1,), generator=g))
+        m[i, :, h0:h0 + hh, w0:w0 + ww] = 1
+    A = Bimg * (1 - m) + torch.randn(B, 3, S, S, generator=g) * m
+    return {"A": A.to(device), "B": Bimg.to(device), "B_label_mask": m.to(device), "A_img_paths": ["synthetic"] * B}
+
+
+def build_model(args, rank, local_rank, world):
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    ov = dict(model_type="palette", G_netG="unet_mha", G_ngf=64, G_unet_mha_channel_mults=[1, 2, 4, 8],
+              G_unet_mha_res_blocks=[2, 2, 2, 2], G_unet_mha_attn_res=[16], G_unet_mha_num_head_channels=32,
+              G_unet_mha_vit_efficient=bool(args.efficient), data_crop_size=args.size, data_load_size=args.size,
+              train_batch_size=args.batch, train_iter_size=1, train_optim="adamw", train_G_ema=True,
+              train_G_ema_beta=0.999, train_G_lr=2e-4, alg_diffusion_task="inpainting", alg_palette_loss="MSE",
+              gpu_ids=",".join(str(i) for i in range(world)), jg_act_dtype=args.dtype, name="bench",
+              checkpoints_dir="/tmp/jg_bench_ckpt/")
+    opt = opt_from_json({}, ov)
+    torch.manual_seed(0)  # reference-style default init (+ zero_module); identical on every rank
+    model = create_model(opt, local_rank if world > 1 else 0)
+    model.setup(opt)
+    if world > 1:
+        model.parallelize(local_rank)
+    else:
+        model.single_gpu()
+    return model, opt
+
+
+def cpu_baseline(args):
+    """The oracle's full step (forward, backward, AdamW, EMA) on the host cores, bounded sample."""
+    import jg_oracle as O
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    S, Bc = args.size, 1
+    opt = opt_from_json({}, dict(G_unet_mha_vit_efficient=bool(args.efficient), data_crop_size=S))
+    torch.manual_seed(0)
+    sd = {k: v.detach().float() for k, v in define_G(**vars(opt)).state_dict().items()}
+    cfg = O.UNetCfg(efficient=bool(args.efficient))
+    tr = O.OraclePaletteTrainer(sd, cfg)
+    batch = synth_batch(Bc, S, 99, "cpu")
+    gen = torch.Generator().manual_seed(3)
+    times = []
+    for it in range(3):  # first call is the warm-up
+        t, u, noise = O.draw_step_randomness(gen, batch["B"], 2000)
+        t0 = time.perf_counter()
+        tr.optimize_parameters(batch["B"], batch["A"], batch["B_label_mask"], noise, t, u)
+        times.append(time.perf_counter() - t0)
+    per_step = sum(times[1:]) / len(times[1:])
+    return {"value": round(Bc / per_step, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"oracle/jg_oracle.py OraclePaletteTrainer, {len(times) - 1} timed full steps (fwd+bwd+AdamW+EMA) "
+                      f"of batch {Bc} at {S}x{S} fp32 after 1 warm-up, {cores} torch threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--efficient", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    model, opt = build_model(args, rank, local_rank, world)
+    batch = synth_batch(args.batch, args.size, 1234 + rank, device)
+
+    def step():
+        model.set_input(batch)
+        model.optimize_parameters()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    loss = float(model.get_current_losses()["G_tot"])
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    ms_per_step = dt / args.steps * 1e3
+    value = args.batch * world * args.steps / dt
+
+    # ---- dominant-kernel roofline: instrumented pass, HIP events around every conv launch ----
+    roofline = None
+    if not args.no_kernel_timing:
+        from joligen_amd import ops
+
+        ops.KERNEL_TIMING = []
+        step()
+        step()
+        torch.cuda.synchronize()
+        recs = ops.KERNEL_TIMING
+        ops.KERNEL_TIMING = None
+        per = {}
+        for name, e0, e1, fl in recs:
+            d = per.setdefault(name, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1) * 1e-3
+            d[2] += fl
+        n, tsum, fsum = per["conv_nt"]
+        achieved = fsum / tsum / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_nt_kernel", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n // 2, "avg_launch_us": round(tsum / n * 1e6, 2),
+                    "avg_flops_per_launch": round(fsum / n, 1), "time_per_step_ms": round(tsum / 2 * 1e3, 3)}
+        if "wgrad_tn" in per:
+            n2, t2, f2 = per["wgrad_tn"]
+            roofline["wgrad_tn_kernel"] = {"achieved": round(f2 / t2 / 1e12, 2), "frac": round(f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                           "launches_per_step": n2 // 2, "avg_launch_us": round(t2 / n2 * 1e6, 2),
+                                           "time_per_step_ms": round(t2 / 2 * 1e3, 3)}
+        gf = FWD_GFLOP_PER_IMG.get((args.size, bool(args.efficient)))
+        if gf:
+            step_tflop = 3 * gf * args.batch / 1e3
+            roofline["step_algorithmic_tflop"] = round(step_tflop, 3)
+            roofline["step_frac_of_mfma_peak"] = round(step_tflop / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        line = {
+            "metric": "train images/sec at 256x256 (DDPM UNet step)" if args.size == 256 else f"train images/sec at {args.size}x{args.size} (DDPM UNet step)",
+            "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"palette_model DDPM, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
+                                   f"res_blocks[2,2,2,2] mid-attn 16x32, {args.size}x{args.size}, batch {args.batch}/GPU, "
+                                   "inpainting synthetic masks, AdamW+EMA, iter_size 1 "
+                                   "(example_ddpm_noglasses2glasses.json + SURVEY Appendix C overrides)",
+                       "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image_size": args.size,
+                       "efficient": bool(args.efficient), "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

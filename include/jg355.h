@@ -1,0 +1,172 @@
+/* jg355.h -- C ABI of libjg355.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * joliGEN training-step hot path.
+ *
+ * Boundary rules (the reference's own precedent for a native op is
+ * models/modules/op/upfirdn2d.cpp:8-30 + upfirdn2d.py:19-167):
+ *   - plain pointers and sizes only, no torch types;
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch caching allocator);
+ *   - the caller passes the HIP stream; no internal synchronisation, no hidden allocation;
+ *   - return 0 on success, a negative JG_ERR_* code otherwise; never throws;
+ *   - thread-safe with respect to distinct streams.
+ * Activations are 16-bit (JG_F16 / JG_BF16) NHWC with C % 8 == 0; statistics, biases,
+ * norm affine parameters, master weights, gradients of parameters are fp32.
+ *
+ * Each entry point names the reference call it replaces (paths relative to /root/reference).
+ */
+#ifndef JG355_H
+#define JG355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* jg_stream_t; /* hipStream_t */
+
+enum { JG_F16 = 0, JG_BF16 = 1 };
+enum { JG_OK = 0, JG_ERR_BAD_ARG = -1, JG_ERR_UNSUPPORTED = -2, JG_ERR_LAUNCH = -3 };
+enum { JG_ACT_NONE = 0, JG_ACT_SILU = 1 };
+enum { JG_OUT_ATOMIC_F32 = 0, JG_OUT_STORE_F32 = 1, JG_OUT_STORE_T = 2 };
+
+int jg_version(void);
+const char* jg_strerror(int code);
+
+/* Implicit-GEMM convolution / batched GEMM "NT" on MFMA (v_mfma_f32_16x16x32_{f16,bf16}).
+ *   y[z][m][n] = alpha * sum_k A[z][m][k] * w[z][n][k] + bias[n] + res_scale * res[z][m][n]
+ * with A the implicit im2col of x[z] = [B,H,W,Cin] (pixel stride ldx), m = (b,oh,ow),
+ * k = (r,s,ci), zero padding `pad`, stride `stride`.  R=S=1,pad=0 gives a plain GEMM.
+ * z = zb*nh + zh with element strides (s*b, s*h) per operand.  out_f32: y is fp32 else T.
+ * Replaces nn.Conv2d / nn.Conv1d(k=1) forward and -- with the flipped/transposed weight
+ * copy of jg_refresh_weights -- its input-gradient
+ * (models/modules/unet_generator_attn/unet_generator_attn.py:186-220,297,305,482,635-642),
+ * and the two einsum matmuls of QKVAttentionLegacy.forward (same file :342-346). */
+typedef struct {
+  const void* x; const void* w; void* y; const float* bias; const void* res;
+  int32_t B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo;
+  int64_t ldx, ldw, ldy, ldres;
+  int32_t nbatch, nh;
+  int64_t sxb, sxh, swb, swh, syb, syh, srb, srh;
+  float alpha, res_scale;
+  int32_t out_f32;
+} jg_conv_args;
+int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
+
+/* Weight gradient / batched GEMM "TN" on MFMA:
+ *   dw[z][co][(r,s,ci)] (+)= alpha * sum_p dy[z][p][co] * xcol[z][p][(r,s,ci)]
+ * p = (b,oh,ow).  Output fp32 KRSC with row stride lddw and inner channel count Cin_out
+ * (<= Cin; lets a channel-padded activation feed an unpadded master gradient), rows
+ * co < Cout_out.  out_mode JG_OUT_ATOMIC_F32 accumulates (split-K + gradient accumulation),
+ * STORE modes need splitk == 1.  dbias (optional, atomic): dbias[co] += sum_p dy[p][co].
+ * Replaces the weight/bias gradient of nn.Conv2d/Conv1d (autograd of the layers above) and
+ * the transposed matmuls of the attention backward. */
+typedef struct {
+  const void* dy; const void* x; void* dw; float* dbias;
+  int32_t B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo;
+  int32_t Cin_out, Cout_out;
+  int64_t lddy, ldx, lddw;
+  int32_t nbatch, nh, splitk;
+  int64_t sdyb, sdyh, sxb, sxh, sdwb, sdwh;
+  float alpha;
+  int32_t out_mode;
+} jg_wgrad_args;
+int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream);
+
+/* GroupNorm (+FiLM scale-shift) (+SiLU), NHWC, statistics in fp32.
+ * Replaces GroupNorm.forward (unet_attn_utils.py:42-48), `h*(1+scale)+shift`
+ * (unet_generator_attn.py:254-258), torch.nn.SiLU, and nn.InstanceNorm1d (groups == C,
+ * gamma = beta = NULL; unet_attn_utils.py:60-66). x: [B, HW, C] T.
+ *   stats : sums[B][C][2] = (sum x, sum x^2)                 (zeroed inside)
+ *   coef  : ab[B][C][2]: y = act(a*x + b); mr[B][G][2] = (mean, rstd)
+ *           film = emb_out[B][2C] (scale | shift) with row stride ldfilm, or NULL
+ *   apply : y = act(a*x+b) */
+int jg_gn_stats(int dtype, const void* x, float* sums, int B, int HW, int C, jg_stream_t s);
+int jg_gn_coef(const float* sums, const float* gamma, const float* beta, const float* film, int64_t ldfilm,
+               float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s);
+int jg_gn_apply(int dtype, const void* x, const float* ab, void* y, int B, int HW, int C, int act, jg_stream_t s);
+/* backward: red[B][C][2] = (sum du, sum du*x), du = dy * act'(a*x+b)      (zeroed inside)
+ *   bwd_coef: pqr[B][C][3] so that dx = du*P + x*Q + R;  dgamma/dbeta += (atomic, may be NULL);
+ *             dfilm[B][2C] (row stride lddfilm) = (d scale | d shift) written (not accumulated)
+ *   bwd_apply: dx */
+int jg_gn_bwd_reduce(int dtype, const void* x, const void* dy, const float* ab, float* red,
+                     int B, int HW, int C, int act, jg_stream_t s);
+int jg_gn_bwd_coef(const float* red, const float* gamma, const float* beta, const float* film, int64_t ldfilm,
+                   const float* mr, float* pqr, float* dgamma, float* dbeta, float* dfilm, int64_t lddfilm,
+                   int B, int HW, int C, int G, jg_stream_t s);
+int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, const float* pqr, void* dx,
+                    int B, int HW, int C, int act, jg_stream_t s);
+
+/* 2x2 sum-pool * scale and nearest x2 upsample * scale, NHWC.  Forward/backward of
+ * nn.AvgPool2d(2,2) (pool scale .25 / upsample scale .25) and of
+ * F.interpolate(scale_factor=2, mode="nearest") (upsample scale 1 / pool scale 1)
+ * (unet_generator_attn.py:81-96,121-140). */
+int jg_pool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s);
+int jg_upsample2x(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s);
+/* dst[p][doff:doff+n] = src[p][soff:soff+n] for p < P (channel-block copy; torch.cat(dim=1) and its
+ * backward split in NHWC; unet_generator_attn.py:687). */
+int jg_copy_channels(int dtype, const void* src, int64_t ldsrc, int64_t soff, void* dst, int64_t lddst, int64_t doff,
+                     int64_t P, int n, jg_stream_t s);
+/* y = alpha * (*alpha_dev) * a + beta * b over n elements (b and alpha_dev may be NULL): gradient
+ * accumulation at a fork, the 1/sqrt(2) skip scale of the "efficient" ResBlock
+ * (unet_generator_attn.py:263-266) and the chain-rule scale of the loss gradient by a device scalar. */
+int jg_axpby(int dtype, const void* a, float alpha, const float* alpha_dev, const void* b, float beta, void* y,
+             int64_t n, jg_stream_t s);
+
+/* Attention helpers (QKVAttentionLegacy.forward, unet_generator_attn.py:331-347).
+ *   transpose_heads: dst[(b*nh+h)][c][t] = src[b][t][coff + h*hstride + c], c < ch
+ *   softmax_fwd: P[row][:] = softmax(S[row][:]) (S fp32 -> P T), rows x T
+ *   softmax_bwd: dS = alpha * P * (dP - sum_j dP_j P_j)  (dP fp32 -> dS T) */
+int jg_transpose_heads(int dtype, const void* src, int64_t ldsrc, int64_t coff, int64_t hstride, void* dst,
+                       int B, int T, int nh, int ch, jg_stream_t s);
+int jg_softmax_fwd(int dtype, const float* S, void* P, int64_t rows, int T, jg_stream_t s);
+int jg_softmax_bwd(int dtype, const void* P, const float* dP, void* dS, int64_t rows, int T, float alpha, jg_stream_t s);
+
+/* Small fp32 linear layers on the embedding path (nn.Linear in ResBlock.emb_layers and
+ * DiffusionGenerator.cond_embed; unet_generator_attn.py:201-207, diffusion_generator.py:74-78).
+ *   fwd: y[b][n] = sum_k act(x[b][k]) W[n][k] + bias[n]
+ *   bwd: dx[b][k] = act'(x[b][k]) sum_n dy[b][n] W[n][k] (dx may be NULL);
+ *        dW[n][k] += sum_b dy[b][n] act(x[b][k]); dbias[n] += sum_b dy[b][n]  (may be NULL) */
+int jg_linear_fwd(const float* x, const float* W, const float* bias, float* y, int Bn, int K, int N, int act, jg_stream_t s);
+int jg_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* dbias,
+                  int Bn, int K, int N, int act, jg_stream_t s);
+/* gamma_embedding (models/modules/diffusion_utils.py:8-42): emb[b] = cat(cos(g f), sin(g f)). */
+int jg_gamma_embedding(const float* gammas, float* emb, int Bn, int dim, float max_period, jg_stream_t s);
+
+/* DDPM glue (DiffusionGenerator.forward, models/modules/diffusion_generator.py:467-491):
+ * y_noisy = sqrt(g) y0 + sqrt(1-g) noise; blended with clamp(mask,0,1); concatenated after
+ * y_cond and written NHWC with Cpad (=8) channels, zero padded.  y0/y_cond/noise: NCHW fp32
+ * [B,3,H,W]; mask int64 [B,1,H,W] or NULL; gammas [B]. */
+int jg_ddpm_prepare(int dtype, const float* y0, const float* ycond, const float* noise, const int64_t* mask,
+                    const float* gammas, void* xin, int B, int C, int H, int W, int Cpad, jg_stream_t s);
+/* Masked / min-SNR-weighted MSE of PaletteModel.compute_palette_loss (models/palette_model.py:597-620):
+ * loss += lambda * mean((w m noise - w m noise_hat)^2) (atomic into *loss, caller zeroes);
+ * dnh (NHWC Cpad, T) = grad_scale * d loss / d noise_hat.  w [B] or NULL. */
+int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
+                     float* loss, void* dnh, int B, int C, int H, int W, int Cpad, float lambda, float grad_scale,
+                     jg_stream_t s);
+/* NHWC(T, Cpad) <-> NCHW(fp32, C) layout converters at the module boundary. */
+int jg_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);
+int jg_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);
+
+/* Fused multi-tensor optimizer over a flat fp32 arena (train.py:51-62 torch.optim.AdamW/Adam;
+ * BaseModel.compute_step + ema_step, models/base_model.py:1250-1297):
+ *   g' = g * grad_scale (+ wd * p when !decoupled); p *= (1 - lr wd) when decoupled;
+ *   m = b1 m + (1-b1) g'; v = b2 v + (1-b2) g'^2; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps);
+ *   ema = p + ema_beta (ema - p)   (ema may be NULL);  g = 0 when zero_grad. */
+int jg_adamw_ema(float* p, float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float wd, int decoupled, int step, float grad_scale, float ema_beta, int zero_grad,
+                 jg_stream_t s);
+/* Stand-alone EMA update ema = p + beta (ema - p) (BaseModel.ema_step, models/base_model.py:1284-1297) for the
+ * micro-iterations of a gradient-accumulation cycle in which the optimizer does not step. */
+int jg_ema_update(float* ema, const float* p, int64_t n, float beta, jg_stream_t s);
+/* 16-bit working copies of the conv weights after an optimizer step.  One descriptor per layer
+ * (device array of int64[8]): {src_off, dst_off, dstT_off, Cout, RS, Cin, CoutPad, CinPad}.
+ *   w16 [CoutPad][R][S][CinPad]  = cast(p[Cout][R][S][Cin]) zero padded
+ *   w16T[CinPad][R][S][CoutPad]  = w16[co][R-1-r][S-1-s][ci]   (input-gradient weights; dstT_off < 0 skips)
+ * R, S taken from desc RS = R*65536 + S. */
+int jg_refresh_weights(int dtype, const float* p, void* w16, void* w16T, const int64_t* desc, int nlayers, jg_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JG355_H */

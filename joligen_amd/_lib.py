@@ -1,0 +1,123 @@
+"""ctypes binding of libjg355.so (the C ABI declared in include/jg355.h).
+
+The library is built in-tree with hipcc for gfx950 (`build()`), loaded once, and every entry
+point gets its argtypes from the table below.  There is NO fallback: if the shared object is
+missing or a symbol is absent, importing the ops fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libjg355.so")
+SOURCES = ["gemm_nt.hip", "gemm_tn.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+
+JG_F16, JG_BF16 = 0, 1
+JG_ACT_NONE, JG_ACT_SILU = 0, 1
+JG_OUT_ATOMIC_F32, JG_OUT_STORE_F32, JG_OUT_STORE_T = 0, 1, 2
+
+c_i32, c_i64, c_f32, c_p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvArgs(C.Structure):
+    _fields_ = (
+        [(n, c_p) for n in ("x", "w", "y", "bias", "res")]
+        + [(n, c_i32) for n in ("B", "H", "W", "Cin", "Cout", "R", "S", "pad", "stride", "Ho", "Wo")]
+        + [(n, c_i64) for n in ("ldx", "ldw", "ldy", "ldres")]
+        + [(n, c_i32) for n in ("nbatch", "nh")]
+        + [(n, c_i64) for n in ("sxb", "sxh", "swb", "swh", "syb", "syh", "srb", "srh")]
+        + [("alpha", c_f32), ("res_scale", c_f32), ("out_f32", c_i32)]
+    )
+
+
+class WgradArgs(C.Structure):
+    _fields_ = (
+        [(n, c_p) for n in ("dy", "x", "dw", "dbias")]
+        + [(n, c_i32) for n in ("B", "H", "W", "Cin", "Cout", "R", "S", "pad", "stride", "Ho", "Wo")]
+        + [(n, c_i32) for n in ("Cin_out", "Cout_out")]
+        + [(n, c_i64) for n in ("lddy", "ldx", "lddw")]
+        + [(n, c_i32) for n in ("nbatch", "nh", "splitk")]
+        + [(n, c_i64) for n in ("sdyb", "sdyh", "sxb", "sxh", "sdwb", "sdwh")]
+        + [("alpha", c_f32), ("out_mode", c_i32)]
+    )
+
+
+# name -> argtypes (restype is int except where noted); mirrors include/jg355.h one to one
+SIGNATURES = {
+    "jg_version": [],
+    "jg_strerror": [c_i32],
+    "jg_conv2d_nt": [c_i32, C.POINTER(ConvArgs), c_p],
+    "jg_conv2d_wgrad_tn": [c_i32, C.POINTER(WgradArgs), c_p],
+    "jg_gn_stats": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_coef": [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
+    "jg_gn_apply": [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_bwd_reduce": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_bwd_coef": [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_bwd_apply": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_pool2x2": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
+    "jg_upsample2x": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
+    "jg_copy_channels": [c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_i32, c_p],
+    "jg_axpby": [c_i32, c_p, c_f32, c_p, c_p, c_f32, c_p, c_i64, c_p],
+    "jg_transpose_heads": [c_i32, c_p, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_softmax_fwd": [c_i32, c_p, c_p, c_i64, c_i32, c_p],
+    "jg_softmax_bwd": [c_i32, c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
+    "jg_linear_fwd": [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_linear_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gamma_embedding": [c_p, c_p, c_i32, c_i32, c_f32, c_p],
+    "jg_ddpm_prepare": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_ddpm_mse_loss": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_p],
+    "jg_nhwc_to_nchw_f32": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_nchw_f32_to_nhwc": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_adamw_ema": [c_p, c_p, c_p, c_p, c_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p],
+    "jg_ema_update": [c_p, c_p, c_i64, c_f32, c_p],
+    "jg_refresh_weights": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_p],
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source into csrc/libjg355.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(_HERE), "include", "jg355.h")]
+    if not force and os.path.exists(LIB_PATH):
+        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library with typed entry points.  Raises if it is missing -- no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  joligen_amd has no CPU / eager fallback."
+        )
+    L = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is absent
+        fn.argtypes = argtypes
+        fn.restype = C.c_char_p if name == "jg_strerror" else c_i32
+    _lib = L
+    return L
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib().jg_strerror(code).decode()
+        raise RuntimeError(f"libjg355 {what} failed: {msg} ({code})")

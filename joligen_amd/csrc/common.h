@@ -1,0 +1,113 @@
+// Shared device helpers for the gfx950 kernels of libjg355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/jg355.h"
+
+typedef _Float16 f16_t;
+typedef __bf16 bf16_t;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define JG_WAVE 64
+
+#define JG_CHECK_LAUNCH()                          \
+  do {                                             \
+    if (hipGetLastError() != hipSuccess) return JG_ERR_LAUNCH; \
+  } while (0)
+
+// ---- 16-bit <-> fp32 ----------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+template <typename T> __device__ __forceinline__ T bits_to(uint16_t b) { return __builtin_bit_cast(T, b); }
+template <typename T> __device__ __forceinline__ uint16_t to_bits(T v) { return __builtin_bit_cast(uint16_t, v); }
+
+// unpack a 16-byte chunk (8 x T) into floats and back
+template <typename T> __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = to_f32(bits_to<T>((uint16_t)(w[i] & 0xffffu)));
+    f[2 * i + 1] = to_f32(bits_to<T>((uint16_t)(w[i] >> 16)));
+  }
+}
+template <typename T> __device__ __forceinline__ uint4 pack8(const float* f) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    w[i] = (uint32_t)to_bits<T>(from_f32<T>(f[2 * i])) | ((uint32_t)to_bits<T>(from_f32<T>(f[2 * i + 1])) << 16);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+template <typename T> __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = (uint32_t)to_bits<T>(from_f32<T>(a)) | ((uint32_t)to_bits<T>(from_f32<T>(b)) << 16);
+  r.y = (uint32_t)to_bits<T>(from_f32<T>(c)) | ((uint32_t)to_bits<T>(from_f32<T>(d)) << 16);
+  return r;
+}
+template <typename T> __device__ __forceinline__ void unpack4(const uint2& v, float* f) {
+  f[0] = to_f32(bits_to<T>((uint16_t)(v.x & 0xffffu)));
+  f[1] = to_f32(bits_to<T>((uint16_t)(v.x >> 16)));
+  f[2] = to_f32(bits_to<T>((uint16_t)(v.y & 0xffffu)));
+  f[3] = to_f32(bits_to<T>((uint16_t)(v.y >> 16)));
+}
+
+// ---- MFMA 16x16x32 (gfx950): D[row][col] += sum_k A[row][k] B[k][col] -----------------
+// operand fragments: lane l holds row/col (l & 15) and the 8 k-values of k-group (l >> 4);
+// D: col = l & 15, row = (l >> 4) * 4 + reg.
+template <typename T> struct Mfma;
+template <> struct Mfma<f16_t> {
+  static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<bf16_t> {
+  static __device__ __forceinline__ f32x4 run(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+
+// Predicated 16-byte global load: the address is always a valid one (callers pass the tensor
+// base when !ok) so the load is unconditional and the zero fill is four v_cndmask; a ternary on
+// the dereference makes hipcc select between the real pointer and a zeroed scratch slot.
+template <typename T> __device__ __forceinline__ uint4 ldg16(const T* ptr, bool ok) {
+  uint4 v = *reinterpret_cast<const uint4*>(ptr);
+  v.x = ok ? v.x : 0u;
+  v.y = ok ? v.y : 0u;
+  v.z = ok ? v.z : 0u;
+  v.w = ok ? v.w : 0u;
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+__device__ __forceinline__ float silu_grad_f(float u) {
+  const float s = 1.0f / (1.0f + __expf(-u));
+  return s * (1.0f + u * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+#define JG_DISPATCH_DTYPE(dtype, ...)                 \
+  do {                                                \
+    if ((dtype) == JG_F16) {                          \
+      typedef f16_t T;                                \
+      __VA_ARGS__                                     \
+    } else if ((dtype) == JG_BF16) {                  \
+      typedef bf16_t T;                               \
+      __VA_ARGS__                                     \
+    } else {                                          \
+      return JG_ERR_BAD_ARG;                          \
+    }                                                 \
+  } while (0)

@@ -1,0 +1,441 @@
+// Bandwidth-bound helper kernels of the DDPM step: resampling, channel concat/split, attention
+// softmax and head transposes, the small fp32 embedding linears, the DDPM q_sample / loss glue
+// and the NCHW<->NHWC converters at the module boundary.  16-byte vector access everywhere the
+// layout allows it.
+#include "common.h"
+
+namespace {
+
+// ---- 2x2 sum pool / nearest upsample --------------------------------------------------------
+template <typename T>
+__global__ void pool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, float scale) {
+  const int Ho = H / 2, Wo = W / 2, noct = C / 8;
+  const long total = (long)B * Ho * Wo * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    long t = i / noct;
+    const int ow = t % Wo; t /= Wo;
+    const int oh = t % Ho;
+    const int b = t / Ho;
+    const T* p00 = x + (((long)b * H + oh * 2) * W + ow * 2) * C + co * 8;
+    float f[8], a[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(p00), a);
+    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + C), f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += f[q];
+    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + (long)W * C), f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] += f[q];
+    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + (long)W * C + C), f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = (a[q] + f[q]) * scale;
+    *reinterpret_cast<uint4*>(y + (((long)b * Ho + oh) * Wo + ow) * C + co * 8) = pack8<T>(a);
+  }
+}
+
+template <typename T>
+__global__ void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, float scale) {
+  const int Ho = H * 2, Wo = W * 2, noct = C / 8;
+  const long total = (long)B * Ho * Wo * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    long t = i / noct;
+    const int ow = t % Wo; t /= Wo;
+    const int oh = t % Ho;
+    const int b = t / Ho;
+    uint4 v = *reinterpret_cast<const uint4*>(x + (((long)b * H + oh / 2) * W + ow / 2) * C + co * 8);
+    if (scale != 1.0f) {
+      float f[8];
+      unpack8<T>(v, f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] *= scale;
+      v = pack8<T>(f);
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = v;
+  }
+}
+
+template <typename T>
+__global__ void copy_channels_kernel(const T* __restrict__ src, long ldsrc, long soff, T* __restrict__ dst, long lddst,
+                                     long doff, long P, int n) {
+  const int noct = n / 8;
+  const long total = P * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    const long p = i / noct;
+    *reinterpret_cast<uint4*>(dst + p * lddst + doff + co * 8) =
+        *reinterpret_cast<const uint4*>(src + p * ldsrc + soff + co * 8);
+  }
+}
+
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ a, float alpha, const float* __restrict__ alpha_dev,
+                             const T* __restrict__ b, float beta, T* __restrict__ y, long n8) {
+  if (alpha_dev) alpha *= *alpha_dev;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float fa[8], fb[8];
+    unpack8<T>(reinterpret_cast<const uint4*>(a)[i], fa);
+    if (b) {
+      unpack8<T>(reinterpret_cast<const uint4*>(b)[i], fb);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fa[q] = alpha * fa[q] + beta * fb[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fa[q] *= alpha;
+    }
+    reinterpret_cast<uint4*>(y)[i] = pack8<T>(fa);
+  }
+}
+
+// ---- attention helpers -----------------------------------------------------------------------
+template <typename T>
+__global__ void transpose_heads_kernel(const T* __restrict__ src, long ldsrc, long coff, long hstride,
+                                       T* __restrict__ dst, int B, int Tn, int nh, int ch) {
+  const int noct = ch / 8;
+  const long total = (long)B * nh * noct * Tn;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int t = i % Tn;  // fastest: 2-byte stores of neighbouring lanes are contiguous
+    long r = i / Tn;
+    const int co = r % noct; r /= noct;
+    const int h = r % nh;
+    const int b = r / nh;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + ((long)b * Tn + t) * ldsrc + coff + h * hstride + co * 8);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint16_t* d = reinterpret_cast<uint16_t*>(dst) + (((long)b * nh + h) * ch + co * 8) * Tn + t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      d[(long)(2 * q) * Tn] = (uint16_t)(w[q] & 0xffffu);
+      d[(long)(2 * q + 1) * Tn] = (uint16_t)(w[q] >> 16);
+    }
+  }
+}
+
+// one wave per row, 4 rows per 256-thread block; T % 4 == 0
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ S, T* __restrict__ P, long rows, int Tn) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* s4 = reinterpret_cast<const float4*>(S + row * Tn);
+  const int n4 = Tn / 4;
+  float mx = -INFINITY;
+  for (int j = lane; j < n4; j += 64) {
+    const float4 v = s4[j];
+    mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n4; j += 64) {
+    const float4 v = s4[j];
+    sum += __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx);
+  }
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;
+  uint2* p2 = reinterpret_cast<uint2*>(P + row * Tn);
+  for (int j = lane; j < n4; j += 64) {
+    const float4 v = s4[j];
+    p2[j] = pack4<T>(__expf(v.x - mx) * inv, __expf(v.y - mx) * inv, __expf(v.z - mx) * inv, __expf(v.w - mx) * inv);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ P, const float* __restrict__ dP,
+                                                          T* __restrict__ dS, long rows, int Tn, float alpha) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* g4 = reinterpret_cast<const float4*>(dP + row * Tn);
+  const uint2* p2 = reinterpret_cast<const uint2*>(P + row * Tn);
+  const int n4 = Tn / 4;
+  float dot = 0.f;
+  for (int j = lane; j < n4; j += 64) {
+    const float4 g = g4[j];
+    float pf[4];
+    unpack4<T>(p2[j], pf);
+    dot += g.x * pf[0] + g.y * pf[1] + g.z * pf[2] + g.w * pf[3];
+  }
+  dot = wave_sum(dot);
+  uint2* o2 = reinterpret_cast<uint2*>(dS + row * Tn);
+  for (int j = lane; j < n4; j += 64) {
+    const float4 g = g4[j];
+    float pf[4];
+    unpack4<T>(p2[j], pf);
+    o2[j] = pack4<T>(alpha * pf[0] * (g.x - dot), alpha * pf[1] * (g.y - dot), alpha * pf[2] * (g.z - dot),
+                     alpha * pf[3] * (g.w - dot));
+  }
+}
+
+// ---- small fp32 linears (embedding path) --------------------------------------------------------
+__device__ __forceinline__ float act_f(float v, int act) { return act == JG_ACT_SILU ? v / (1.0f + expf(-v)) : v; }
+__device__ __forceinline__ float act_grad_f(float v, int act) {
+  if (act != JG_ACT_SILU) return 1.0f;
+  const float s = 1.0f / (1.0f + expf(-v));
+  return s * (1.0f + v * (1.0f - s));
+}
+
+__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                                  float* __restrict__ y, int Bn, int K, int N, int act) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Bn * N) return;
+  const int b = idx / N, n = idx % N;
+  float acc = bias ? bias[n] : 0.f;
+  for (int k = 0; k < K; ++k) acc += act_f(x[(long)b * K + k], act) * W[(long)n * K + k];
+  y[idx] = acc;
+}
+__global__ void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
+                                     float* __restrict__ dx, int Bn, int K, int N, int act) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Bn * K) return;
+  const int b = idx / K, k = idx % K;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc += dy[(long)b * N + n] * W[(long)n * K + k];
+  dx[idx] = acc * act_grad_f(x[idx], act);
+}
+__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
+                                     float* __restrict__ dbias, int Bn, int K, int N, int act) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * (K + 1)) return;
+  const int n = idx / (K + 1), k = idx % (K + 1);
+  float acc = 0.f;
+  if (k < K) {
+    if (!dW) return;
+    for (int b = 0; b < Bn; ++b) acc += dy[(long)b * N + n] * act_f(x[(long)b * K + k], act);
+    dW[(long)n * K + k] += acc;
+  } else {
+    if (!dbias) return;
+    for (int b = 0; b < Bn; ++b) acc += dy[(long)b * N + n];
+    dbias[n] += acc;
+  }
+}
+
+__global__ void gamma_embedding_kernel(const float* __restrict__ gammas, float* __restrict__ emb, int Bn, int dim,
+                                       float neg_log_period) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Bn * dim) return;
+  const int b = idx / dim, j = idx % dim;
+  const int half = dim / 2;
+  if (j >= 2 * half) { emb[idx] = 0.f; return; }
+  const int k = j < half ? j : j - half;
+  const float freq = expf(neg_log_period * (float)k / (float)half);
+  const float arg = gammas[b] * freq;
+  emb[idx] = j < half ? cosf(arg) : sinf(arg);
+}
+
+// ---- DDPM glue ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void ddpm_prepare_kernel(const float* __restrict__ y0, const float* __restrict__ ycond,
+                                    const float* __restrict__ noise, const int64_t* __restrict__ mask,
+                                    const float* __restrict__ gammas, T* __restrict__ xin, int B, int C, int HW, int Cpad) {
+  const long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / HW;
+    const long p = i % HW;
+    const float g = gammas[b];
+    const float sg = sqrtf(g), s1 = sqrtf(1.0f - g);
+    float m = 1.0f;
+    if (mask) {
+      const int64_t mv = mask[i];
+      m = mv < 0 ? 0.f : (mv > 1 ? 1.f : (float)mv);
+    }
+    T* o = xin + i * Cpad;
+    for (int c = 0; c < Cpad; ++c) {
+      float v = 0.f;
+      if (c < C) {
+        v = ycond[((long)b * C + c) * HW + p];
+      } else if (c < 2 * C) {
+        const long q = ((long)b * C + (c - C)) * HW + p;
+        const float yv = y0[q];
+        float yn = sg * yv + s1 * noise[q];
+        if (mask) yn = yn * m + (1.0f - m) * yv;
+        v = yn;
+      }
+      o[c] = from_f32<T>(v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ddpm_mse_loss_kernel(const float* __restrict__ noise, const T* __restrict__ nh,
+                                                            const int64_t* __restrict__ mask, const float* __restrict__ w,
+                                                            float* __restrict__ loss, T* __restrict__ dnh, int B, int C,
+                                                            int HW, int Cpad, float lambda, float grad_scale) {
+  __shared__ float s_part[4];
+  const long total = (long)B * HW;
+  const float invN = 1.0f / ((float)total * (float)C);
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / HW;
+    const long p = i % HW;
+    float wm = w ? w[b] : 1.0f;
+    if (mask) {
+      const int64_t mv = mask[i];
+      wm *= mv < 0 ? 0.f : (mv > 1 ? 1.f : (float)mv);
+    }
+    for (int c = 0; c < Cpad; ++c) {
+      float gout = 0.f;
+      if (c < C) {
+        const float n = noise[((long)b * C + c) * HW + p];
+        const float h = to_f32(nh[i * Cpad + c]);
+        const float d = wm * n - wm * h;
+        acc += d * d;
+        gout = -2.0f * d * wm * invN * lambda * grad_scale;
+      }
+      if (dnh) dnh[i * Cpad + c] = from_f32<T>(gout);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * invN * lambda);
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int HW, int Cpad) {
+  const long total = (long)B * C * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % HW;
+    const long r = i / HW;
+    const int c = r % C;
+    const int b = r / C;
+    y[i] = to_f32(x[((long)b * HW + p) * Cpad + c]);
+  }
+}
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int HW, int Cpad) {
+  const long total = (long)B * HW * Cpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % Cpad;
+    const long r = i / Cpad;
+    const long p = r % HW;
+    const int b = r / HW;
+    y[i] = from_f32<T>(c < C ? x[((long)b * C + c) * HW + p] : 0.f);
+  }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+  long g = (total + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" int jg_pool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s) {
+  if (!x || !y || C % 8 || H % 2 || W % 2 || B < 1) return JG_ERR_BAD_ARG;
+  const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool2x2_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, (T*)y, B, H, W, C, scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_upsample2x(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s) {
+  if (!x || !y || C % 8 || B < 1) return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * 2 * W * 2 * (C / 8);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, (T*)y, B, H, W, C, scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_copy_channels(int dtype, const void* src, int64_t ldsrc, int64_t soff, void* dst, int64_t lddst,
+                                int64_t doff, int64_t P, int n, jg_stream_t s) {
+  if (!src || !dst || n % 8 || ldsrc % 8 || lddst % 8 || soff % 8 || doff % 8 || P < 1) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((copy_channels_kernel<T>), dim3(grid_for(P * (n / 8))), dim3(256), 0,
+                                              (hipStream_t)s, (const T*)src, (long)ldsrc, (long)soff, (T*)dst, (long)lddst,
+                                              (long)doff, (long)P, n););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_axpby(int dtype, const void* a, float alpha, const float* alpha_dev, const void* b, float beta, void* y,
+                        int64_t n, jg_stream_t s) {
+  if (!a || !y || n % 8) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((axpby_kernel<T>), dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)a, alpha, alpha_dev, (const T*)b, beta, (T*)y, (long)(n / 8)););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_transpose_heads(int dtype, const void* src, int64_t ldsrc, int64_t coff, int64_t hstride, void* dst,
+                                  int B, int Tn, int nh, int ch, jg_stream_t s) {
+  if (!src || !dst || ch % 8 || ldsrc % 8 || coff % 8 || hstride % 8) return JG_ERR_BAD_ARG;
+  const long total = (long)B * nh * (ch / 8) * Tn;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((transpose_heads_kernel<T>), dim3(grid_for(total)), dim3(256), 0,
+                                              (hipStream_t)s, (const T*)src, (long)ldsrc, (long)coff, (long)hstride,
+                                              (T*)dst, B, Tn, nh, ch););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_softmax_fwd(int dtype, const float* S, void* P, int64_t rows, int Tn, jg_stream_t s) {
+  if (!S || !P || Tn % 4 || rows < 1) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softmax_fwd_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                              (hipStream_t)s, S, (T*)P, (long)rows, Tn););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_softmax_bwd(int dtype, const void* P, const float* dP, void* dS, int64_t rows, int Tn, float alpha,
+                              jg_stream_t s) {
+  if (!P || !dP || !dS || Tn % 4 || rows < 1) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((softmax_bwd_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                                              (hipStream_t)s, (const T*)P, dP, (T*)dS, (long)rows, Tn, alpha););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_linear_fwd(const float* x, const float* W, const float* bias, float* y, int Bn, int K, int N, int act,
+                             jg_stream_t s) {
+  if (!x || !W || !y || Bn < 1 || K < 1 || N < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((Bn * N + 255) / 256), dim3(256), 0, (hipStream_t)s, x, W, bias, y, Bn, K, N, act);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* dbias, int Bn,
+                             int K, int N, int act, jg_stream_t s) {
+  if (!x || !W || !dy || Bn < 1 || K < 1 || N < 1) return JG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((Bn * K + 255) / 256), dim3(256), 0, st, x, W, dy, dx, Bn, K, N, act);
+  if (dW || dbias)
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((N * (K + 1) + 255) / 256), dim3(256), 0, st, x, dy, dW, dbias, Bn, K, N, act);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_gamma_embedding(const float* gammas, float* emb, int Bn, int dim, float max_period, jg_stream_t s) {
+  if (!gammas || !emb || Bn < 1 || dim < 2) return JG_ERR_BAD_ARG;
+  const float nlp = -(float)log((double)max_period);
+  hipLaunchKernelGGL(gamma_embedding_kernel, dim3((Bn * dim + 255) / 256), dim3(256), 0, (hipStream_t)s, gammas, emb, Bn, dim, nlp);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_ddpm_prepare(int dtype, const float* y0, const float* ycond, const float* noise, const int64_t* mask,
+                               const float* gammas, void* xin, int B, int C, int H, int W, int Cpad, jg_stream_t s) {
+  if (!y0 || !ycond || !noise || !gammas || !xin || Cpad < 2 * C || Cpad % 8) return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ddpm_prepare_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              y0, ycond, noise, mask, gammas, (T*)xin, B, C, H * W, Cpad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
+                                float* loss, void* dnh, int B, int C, int H, int W, int Cpad, float lambda,
+                                float grad_scale, jg_stream_t s) {
+  if (!noise || !noise_hat || !loss || Cpad < C || Cpad % 8) return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ddpm_mse_loss_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0,
+                                              (hipStream_t)s, noise, (const T*)noise_hat, mask, w, loss, (T*)dnh, B, C,
+                                              H * W, Cpad, lambda, grad_scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cpad, jg_stream_t s) {
+  if (!x || !y || Cpad < C) return JG_ERR_BAD_ARG;
+  const long total = (long)B * C * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, y, B, C, H * W, Cpad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cpad, jg_stream_t s) {
+  if (!x || !y || Cpad < C) return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W * Cpad;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              x, (T*)y, B, C, H * W, Cpad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}

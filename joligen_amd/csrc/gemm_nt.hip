@@ -1,0 +1,232 @@
+// Implicit-GEMM convolution / batched "NT" GEMM on gfx950 MFMA (v_mfma_f32_16x16x32_{f16,bf16}).
+//
+//   y[m][n] = alpha * sum_k A[m][k] * Wt[n][k] + bias[n] + res_scale * res[m][n]
+//   A[m][k] = x[b, oh*stride + r - pad, ow*stride + s - pad, ci]   m=(b,oh,ow)  k=(r,s,ci)
+//
+// Data layout: x NHWC (pixel stride ldx), weights KRSC ([Cout][R][S][Cin], row stride ldw),
+// y NHWC.  Both operands are K-contiguous, so every MFMA fragment is one 16-byte read.
+//
+// Tiling: workgroup = 256 threads = 4 waves; block tile BM x BN x 32; each wave owns a 64x64
+// sub-tile = 4x4 MFMA tiles of 16x16 (64 accumulator VGPRs).  Global->register->LDS staging with
+// a register prefetch of the next K-step (loads issued before the MFMAs of the current step) and
+// two LDS buffers: one barrier per K-step.  LDS rows are 64 B (32 k-values); the 16-byte chunk
+// index is XOR-swizzled with bit 3 of the row so that each 16-lane service group of ds_read_b128
+// covers all 64 banks (MI355X_MICROARCH.md, LDS table).
+//
+// The weight fragment is fed as the MFMA "A" operand and the activation fragment as "B", so that
+// the 4 accumulator registers of a lane are 4 consecutive output channels of one pixel: the
+// epilogue stores 8 bytes per lane per tile instead of four 2-byte stores.
+#include "common.h"
+
+namespace {
+
+struct ConvP {
+  const char* x; const char* w; char* y; const float* bias; const char* res;
+  int M, N, K;
+  int H, W, Cin, R, S, pad, stride, Ho, Wo;
+  long ldx, ldw, ldy, ldres;
+  int nh;
+  long sxb, sxh, swb, swh, syb, syh, srb, srh;
+  float alpha, res_scale;
+  int out_f32;
+};
+
+__device__ __forceinline__ int swz64(int row) { return ((row >> 3) & 1) << 1; }
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int A_CH = BM * 4 / 256, B_CH = BN * 4 / 256;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+
+  __shared__ uint4 sm[2][(BM + BN) * 4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int n0 = (blockIdx.x % tilesN) * BN;
+  const int m0 = (blockIdx.x / tilesN) * BM;
+
+  const int z = blockIdx.z;
+  const int zb = z / p.nh, zh = z % p.nh;
+  const T* __restrict__ x = (const T*)p.x + zb * p.sxb + zh * p.sxh;
+  const T* __restrict__ w = (const T*)p.w + zb * p.swb + zh * p.swh;
+
+  // ---- per-thread staging coordinates ---------------------------------------------------
+  const int kc = tid & 3;      // 16-byte chunk (8 k-values) inside the 32-wide K-step
+  const int srow = tid >> 2;   // 0..63, +64 per extra chunk
+  int ih0[A_CH], iw0[A_CH], pb[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int m = m0 + srow + 64 * i;
+    const int ow = m % p.Wo;
+    const int t = m / p.Wo;
+    const int oh = t % p.Ho;
+    const int b = t / p.Ho;
+    ih0[i] = (m < p.M) ? oh * p.stride - p.pad : -(1 << 28);
+    iw0[i] = ow * p.stride - p.pad;
+    pb[i] = b * p.H;
+  }
+  // k-state of this thread's chunk: k = ks*32 + kc*8 -> (r, s, c)
+  int c = (kc * 8) % p.Cin;
+  int rs0 = (kc * 8) / p.Cin;
+  int r = rs0 / p.S, s = rs0 % p.S;
+  long kg = kc * 8;
+
+  uint4 ra[A_CH], rb[B_CH];
+
+  auto load_tiles = [&]() {
+    const bool kvalid = r < p.R;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int ih = ih0[i] + r, iw = iw0[i] + s;
+      const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const long off = ok ? ((long)(pb[i] + ih) * p.W + iw) * p.ldx + c : 0;
+      ra[i] = ldg16(x + off, ok);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int n = n0 + srow + 64 * i;
+      const bool ok = kvalid && n < p.N;
+      rb[i] = ldg16(w + (ok ? (long)n * p.ldw + kg : 0), ok);
+    }
+  };
+  auto advance_k = [&]() {
+    kg += 32;
+    c += 32;
+    while (c >= p.Cin) {
+      c -= p.Cin;
+      if (++s == p.S) { s = 0; ++r; }
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int row = srow + 64 * i;
+      sm[buf][row * 4 + (kc ^ swz64(row))] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int row = srow + 64 * i;
+      sm[buf][BM * 4 + row * 4 + (kc ^ swz64(row))] = rb[i];
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  auto compute = [&](int buf) {
+    uint4 fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int row = wm * WM + i * 16 + frow;
+      fa[i] = sm[buf][row * 4 + (fk ^ swz64(row))];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = wn * WN + j * 16 + frow;
+      fb[j] = sm[buf][BM * 4 + row * 4 + (fk ^ swz64(row))];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[j][i] = Mfma<T>::run(fb[j], fa[i], acc[j][i]);
+  };
+
+  const int nk = (p.K + 31) / 32;
+  load_tiles();
+  store_lds(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    const bool more = ks + 1 < nk;
+    if (more) {
+      advance_k();
+      load_tiles();
+    }
+    compute(cur);
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue --------------------------------------------------------------------------
+  char* yb = p.y + (zb * p.syb + zh * p.syh) * (p.out_f32 ? 4 : 2);
+  const T* resb = p.res ? (const T*)p.res + zb * p.srb + zh * p.srh : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = p.bias[n + q];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WM + i * 16 + (lane & 15);
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[j][i][q] + bv[q];
+      if (resb) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(resb + (long)m * p.ldres + n);
+        float rf[4];
+        unpack4<T>(rv, rf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += p.res_scale * rf[q];
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<float4*>((float*)yb + (long)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        *reinterpret_cast<uint2*>((T*)yb + (long)m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename T>
+int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
+  if (p.N <= 64) {
+    constexpr int BM = 256, BN = 64;
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, nbatch);
+    hipLaunchKernelGGL((conv_nt_kernel<T, BM, BN, 4, 1>), grid, dim3(256), 0, st, p);
+  } else {
+    constexpr int BM = 128, BN = 128;
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, nbatch);
+    hipLaunchKernelGGL((conv_nt_kernel<T, BM, BN, 2, 2>), grid, dim3(256), 0, st, p);
+  }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+}  // namespace
+
+extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream) {
+  if (!a || !a->x || !a->w || !a->y) return JG_ERR_BAD_ARG;
+  if (a->Cin % 8 || a->Cout % 4 || a->ldx % 8 || a->ldw % 8 || a->ldy % 4) return JG_ERR_BAD_ARG;
+  if (a->res && (a->ldres % 4)) return JG_ERR_BAD_ARG;
+  if (a->nbatch < 1 || a->nh < 1 || a->nbatch > 65535) return JG_ERR_BAD_ARG;
+  if (a->R < 1 || a->S < 1 || a->stride < 1) return JG_ERR_BAD_ARG;
+  const long M = (long)a->B * a->Ho * a->Wo;
+  if (M <= 0 || M > (1L << 30)) return JG_ERR_BAD_ARG;
+  ConvP p;
+  p.x = (const char*)a->x; p.w = (const char*)a->w; p.y = (char*)a->y; p.bias = a->bias; p.res = (const char*)a->res;
+  p.M = (int)M; p.N = a->Cout; p.K = a->R * a->S * a->Cin;
+  p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.R = a->R; p.S = a->S; p.pad = a->pad; p.stride = a->stride;
+  p.Ho = a->Ho; p.Wo = a->Wo;
+  p.ldx = a->ldx; p.ldw = a->ldw; p.ldy = a->ldy; p.ldres = a->ldres;
+  p.nh = a->nh;
+  p.sxb = a->sxb; p.sxh = a->sxh; p.swb = a->swb; p.swh = a->swh; p.syb = a->syb; p.syh = a->syh;
+  p.srb = a->srb; p.srh = a->srh;
+  p.alpha = a->alpha; p.res_scale = a->res_scale; p.out_f32 = a->out_f32;
+  JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream););
+}

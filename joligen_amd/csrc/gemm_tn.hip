@@ -1,0 +1,258 @@
+// Weight gradient / batched "TN" GEMM on gfx950 MFMA.
+//
+//   dw[co][(r,s,ci)] (+)= alpha * sum_p dy[p][co] * x[b, oh*stride+r-pad, ow*stride+s-pad, ci]
+//   p = (b,oh,ow) is the reduction ("K") index: both operands are K-STRIDED in memory (NHWC),
+//   while an MFMA fragment wants 8 consecutive k per lane.  Each thread therefore loads a
+//   4-pixel x 8-channel block (4 x 16 B, channel-contiguous), transposes it in registers and
+//   writes 8 x 8 B (4 pixels of one channel) into a [channel][pixel] LDS tile; fragments are
+//   then single ds_read_b128 like in gemm_nt.hip.
+//
+// Tiling: 256 threads = 4 waves (2x2), block tile 128 (co) x 128 (r,s,ci) x 64 pixels per
+// K-step, split-K over the pixel range (gridDim.z = nbatch * splitk), fp32 atomics into the
+// gradient arena (or plain stores for the attention backward).  LDS rows are 128 B (64 pixels);
+// 16-byte chunk index XOR-swizzled with (row >> 1) & 7: conflict-free for both the 16-lane
+// ds_read_b128 groups and the 16-lane ds_write_b64 groups.
+#include "common.h"
+
+namespace {
+
+struct WgP {
+  const char* dy; const char* x; char* dw; float* dbias;
+  int Mpix, Cout, Ktot;  // reduction length, rows, cols (= R*S*Cin)
+  int H, W, Cin, R, S, pad, stride, Ho, Wo;
+  int Cin_out, Cout_out;
+  long lddy, ldx, lddw;
+  int nh, splitk;
+  long sdyb, sdyh, sxb, sxh, sdwb, sdwh;
+  float alpha;
+  int out_mode;
+};
+
+__device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
+
+// 4 pixels x 8 channels (ra[i] = 8 channels of pixel i) -> out[j] = 4 pixels of channel j
+__device__ __forceinline__ void transpose4x8(const uint4* ra, uint2* out) {
+  const uint32_t w[4][4] = {{ra[0].x, ra[0].y, ra[0].z, ra[0].w},
+                            {ra[1].x, ra[1].y, ra[1].z, ra[1].w},
+                            {ra[2].x, ra[2].y, ra[2].z, ra[2].w},
+                            {ra[3].x, ra[3].y, ra[3].z, ra[3].w}};
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    out[2 * d].x = (w[0][d] & 0xffffu) | (w[1][d] << 16);
+    out[2 * d].y = (w[2][d] & 0xffffu) | (w[3][d] << 16);
+    out[2 * d + 1].x = (w[0][d] >> 16) | (w[1][d] & 0xffff0000u);
+    out[2 * d + 1].y = (w[2][d] >> 16) | (w[3][d] & 0xffff0000u);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_tn_kernel(WgP p) {
+  constexpr int BM = 128, BN = 128, BK = 64;
+  __shared__ uint4 sm[2][(BM + BN) * 8];  // rows of 128 B = 8 chunks
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tilesN = (p.Ktot + BN - 1) / BN;
+  const int n0 = (blockIdx.x % tilesN) * BN;
+  const int m0 = (blockIdx.x / tilesN) * BM;
+
+  const int z = blockIdx.z;
+  const int batch = z / p.splitk, split = z % p.splitk;
+  const int zb = batch / p.nh, zh = batch % p.nh;
+  const T* __restrict__ dy = (const T*)p.dy + zb * p.sdyb + zh * p.sdyh;
+  const T* __restrict__ x = (const T*)p.x + zb * p.sxb + zh * p.sxh;
+
+  int per = (p.Mpix + p.splitk - 1) / p.splitk;
+  per = (per + BK - 1) / BK * BK;
+  const int kbeg = split * per;
+  const int kend = min(p.Mpix, kbeg + per);
+  if (kbeg >= kend) return;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // staging coordinates: pixel quad pq (4 consecutive pixels), channel octet co
+  const int pq = tid & 15, co = tid >> 4;
+  const int cm = m0 + co * 8;                 // dy channel of this thread's octet
+  const bool a_ok = cm < p.Cout;
+  const int nn = n0 + co * 8;                 // (r,s,ci) column of this thread's octet
+  const bool b_ok = nn < p.Ktot;
+  const int rs = nn / p.Cin, ci = nn % p.Cin;
+  const int fr = rs / p.S, fs = rs % p.S;
+  const bool quad_row = (p.Wo & 3) == 0;      // a pixel quad never straddles an output row
+
+  uint4 ra[4], rb[4];
+  float bsum[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
+  const bool do_bias = p.dbias != nullptr && (blockIdx.x % tilesN) == 0;
+
+  auto load_tiles = [&](int kbase) {
+    const int p0 = kbase + pq * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = p0 + i;
+      const bool ok = a_ok && pp < kend;
+      ra[i] = ldg16(dy + (ok ? (long)pp * p.lddy + cm : 0), ok);
+    }
+    if (quad_row) {
+      const int ow0 = p0 % p.Wo;
+      const int t = p0 / p.Wo;
+      const int oh = t % p.Ho;
+      const int b = t / p.Ho;
+      const int ih = oh * p.stride + fr - p.pad;
+      const bool row_ok = b_ok && (unsigned)ih < (unsigned)p.H;
+      const long rowoff = ((long)(b * p.H + ih) * p.W) * p.ldx + ci;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iw = (ow0 + i) * p.stride + fs - p.pad;
+        const bool ok = row_ok && (p0 + i) < kend && (unsigned)iw < (unsigned)p.W;
+        rb[i] = ldg16(x + (ok ? rowoff + (long)iw * p.ldx : 0), ok);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pp = p0 + i;
+        const int ow = pp % p.Wo;
+        const int t = pp / p.Wo;
+        const int oh = t % p.Ho;
+        const int b = t / p.Ho;
+        const int ih = oh * p.stride + fr - p.pad;
+        const int iw = ow * p.stride + fs - p.pad;
+        const bool ok = b_ok && pp < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        rb[i] = ldg16(x + (ok ? ((long)(b * p.H + ih) * p.W + iw) * p.ldx + ci : 0), ok);
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+    uint2 ta[8], tb[8];
+    transpose4x8(ra, ta);
+    transpose4x8(rb, tb);
+    uint2* s2 = reinterpret_cast<uint2*>(&sm[buf][0]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = co * 8 + j;
+      const int slot = row * 16 + (((pq >> 1) ^ swz128(row)) << 1) + (pq & 1);
+      s2[slot] = ta[j];
+      s2[BM * 16 + slot] = tb[j];
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack8<T>(ra[i], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bsum[q] += f[q];
+      }
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      uint4 fa[4], fb[4];
+      const int kc = fk + 4 * sub;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = wm * 64 + i * 16 + frow;
+        fa[i] = sm[buf][row * 8 + (kc ^ swz128(row))];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = wn * 64 + j * 16 + frow;
+        fb[j] = sm[buf][BM * 8 + row * 8 + (kc ^ swz128(row))];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  };
+
+  load_tiles(kbeg);
+  store_lds(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    const bool more = ks + 1 < nk;
+    if (more) load_tiles(kbeg + (ks + 1) * BK);
+    compute(cur);
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D row = co index = (lane>>4)*4 + reg, col = (r,s,ci) index = lane & 15 ----
+  const long zoff = zb * p.sdwb + zh * p.sdwh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+    if (n >= p.Ktot) continue;
+    const int ors = n / p.Cin, oci = n % p.Cin;
+    if (oci >= p.Cin_out) continue;
+    const long ocol = (long)ors * p.Cin_out + oci;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
+        if (m >= p.Cout_out) continue;
+        const float v = p.alpha * acc[i][j][q];
+        const long off = zoff + (long)m * p.lddw + ocol;
+        if (p.out_mode == JG_OUT_ATOMIC_F32) {
+          atomicAdd((float*)p.dw + off, v);
+        } else if (p.out_mode == JG_OUT_STORE_F32) {
+          ((float*)p.dw)[off] = v;
+        } else {
+          ((T*)p.dw)[off] = from_f32<T>(v);
+        }
+      }
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = bsum[q];
+      v += __shfl_xor(v, 1);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 8);
+      if (pq == 0 && (cm + q) < p.Cout_out) atomicAdd(p.dbias + cm + q, v);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream) {
+  if (!a || !a->dy || !a->x || !a->dw) return JG_ERR_BAD_ARG;
+  if (a->Cin % 8 || a->Cout % 8 || a->ldx % 8 || a->lddy % 8) return JG_ERR_BAD_ARG;
+  if (a->nbatch < 1 || a->nh < 1 || a->splitk < 1) return JG_ERR_BAD_ARG;
+  if ((long)a->nbatch * a->splitk > 65535) return JG_ERR_BAD_ARG;
+  if (a->out_mode != JG_OUT_ATOMIC_F32 && a->splitk != 1) return JG_ERR_BAD_ARG;
+  if (a->dbias && a->out_mode != JG_OUT_ATOMIC_F32) return JG_ERR_BAD_ARG;
+  const long Mpix = (long)a->B * a->Ho * a->Wo;
+  if (Mpix <= 0 || Mpix > (1L << 30)) return JG_ERR_BAD_ARG;
+  WgP p;
+  p.dy = (const char*)a->dy; p.x = (const char*)a->x; p.dw = (char*)a->dw; p.dbias = a->dbias;
+  p.Mpix = (int)Mpix; p.Cout = a->Cout; p.Ktot = a->R * a->S * a->Cin;
+  p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.R = a->R; p.S = a->S; p.pad = a->pad; p.stride = a->stride;
+  p.Ho = a->Ho; p.Wo = a->Wo;
+  p.Cin_out = a->Cin_out > 0 ? a->Cin_out : a->Cin;
+  p.Cout_out = a->Cout_out > 0 ? a->Cout_out : a->Cout;
+  p.lddy = a->lddy; p.ldx = a->ldx; p.lddw = a->lddw;
+  p.nh = a->nh; p.splitk = a->splitk;
+  p.sdyb = a->sdyb; p.sdyh = a->sdyh; p.sxb = a->sxb; p.sxh = a->sxh; p.sdwb = a->sdwb; p.sdwh = a->sdwh;
+  p.alpha = a->alpha; p.out_mode = a->out_mode;
+  dim3 grid(((p.Cout + 127) / 128) * ((p.Ktot + 127) / 128), 1, a->nbatch * a->splitk);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}

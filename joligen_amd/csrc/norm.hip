@@ -1,0 +1,322 @@
+// GroupNorm (+FiLM) (+SiLU) forward/backward for NHWC 16-bit activations, fp32 statistics.
+//
+// All passes are HBM-bound streaming kernels: a thread owns one 8-channel octet (one 16-byte
+// vector per pixel) and a strided set of pixels, so the per-channel coefficients live in
+// registers and every global access is a coalesced 16-byte load/store.
+//
+//   forward : stats (sum, sum^2 per (b,c))  ->  coef (a,b per (b,c))  ->  apply y = act(a x + b)
+//   backward: reduce (sum du, sum du x)     ->  bwd_coef (P,Q,R)      ->  apply dx = du P + x Q + R
+//
+// Algorithmic bytes (T = 2 B): forward reads x twice and writes y once (6 B/elem), backward
+// reads x,dy twice and writes dx once (10 B/elem).
+#include "common.h"
+
+namespace {
+
+struct Map {
+  int noct, pl, active, chunk;
+};
+__host__ __device__ inline Map make_map(int C) {
+  Map m;
+  m.noct = C / 8;
+  m.pl = 256 / m.noct;
+  if (m.pl < 1) m.pl = 1;
+  m.active = m.pl * m.noct;
+  m.chunk = m.pl * 16;
+  return m;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, int HW, int C) {
+  extern __shared__ float s_acc[];  // [C][2]
+  const Map mp = make_map(C);
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  if (tid < mp.active) {
+    const int co = tid % mp.noct, pl = tid / mp.noct;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s1[q] = s2[q] = 0.f;
+    const int pbeg = blockIdx.x * mp.chunk;
+    const int pend = min(HW, pbeg + mp.chunk);
+    const T* xb = x + ((long)b * HW) * C + co * 8;
+    for (int p = pbeg + pl; p < pend; p += mp.pl) {
+      const uint4 v = *reinterpret_cast<const uint4*>(xb + (long)p * C);
+      float f[8];
+      unpack8<T>(v, f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s1[q] += f[q];
+        s2[q] += f[q] * f[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
+      atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[(long)b * 2 * C + i], s_acc[i]);
+}
+
+__global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ film, long ldfilm,
+                               float* __restrict__ ab, float* __restrict__ mr, int B, int HW, int C, int G, float eps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx % C;
+  const int cpg = C / G, g = c / cpg;
+  float S1 = 0.f, S2 = 0.f;
+  for (int k = 0; k < cpg; ++k) {
+    const long o = ((long)b * C + g * cpg + k) * 2;
+    S1 += sums[o];
+    S2 += sums[o + 1];
+  }
+  const float n = (float)HW * (float)cpg;
+  const float mean = S1 / n;
+  const float var = fmaxf(S2 / n - mean * mean, 0.f);
+  const float rstd = rsqrtf(var + eps);
+  const float a0 = rstd * (gamma ? gamma[c] : 1.f);
+  const float b0 = (beta ? beta[c] : 0.f) - mean * a0;
+  float a = a0, bb = b0;
+  if (film) {
+    const float sc = film[(long)b * ldfilm + c], sh = film[(long)b * ldfilm + C + c];
+    a = a0 * (1.f + sc);
+    bb = b0 * (1.f + sc) + sh;
+  }
+  ab[(long)idx * 2] = a;
+  ab[(long)idx * 2 + 1] = bb;
+  if (c == g * cpg) {
+    mr[((long)b * G + g) * 2] = mean;
+    mr[((long)b * G + g) * 2 + 1] = rstd;
+  }
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ ab,
+                                                       T* __restrict__ y, int HW, int C) {
+  const Map mp = make_map(C);
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid >= mp.active) return;
+  const int co = tid % mp.noct, pl = tid / mp.noct;
+  float a[8], bb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    a[q] = ab[((long)b * C + co * 8 + q) * 2];
+    bb[q] = ab[((long)b * C + co * 8 + q) * 2 + 1];
+  }
+  const int pbeg = blockIdx.x * mp.chunk;
+  const int pend = min(HW, pbeg + mp.chunk);
+  const long base = ((long)b * HW) * C + co * 8;
+  for (int p = pbeg + pl; p < pend; p += mp.pl) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + base + (long)p * C);
+    float f[8];
+    unpack8<T>(v, f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float u = a[q] * f[q] + bb[q];
+      f[q] = ACT == JG_ACT_SILU ? silu_f(u) : u;
+    }
+    *reinterpret_cast<uint4*>(y + base + (long)p * C) = pack8<T>(f);
+  }
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                            const float* __restrict__ ab, float* __restrict__ red,
+                                                            int HW, int C) {
+  extern __shared__ float s_acc[];  // [C][2]
+  const Map mp = make_map(C);
+  const int tid = threadIdx.x, b = blockIdx.y;
+  for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  if (tid < mp.active) {
+    const int co = tid % mp.noct, pl = tid / mp.noct;
+    float a[8], bb[8], s1[8], s2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a[q] = ab[((long)b * C + co * 8 + q) * 2];
+      bb[q] = ab[((long)b * C + co * 8 + q) * 2 + 1];
+      s1[q] = s2[q] = 0.f;
+    }
+    const int pbeg = blockIdx.x * mp.chunk;
+    const int pend = min(HW, pbeg + mp.chunk);
+    const long base = ((long)b * HW) * C + co * 8;
+    for (int p = pbeg + pl; p < pend; p += mp.pl) {
+      const uint4 vx = *reinterpret_cast<const uint4*>(x + base + (long)p * C);
+      const uint4 vg = *reinterpret_cast<const uint4*>(dy + base + (long)p * C);
+      float fx[8], fg[8];
+      unpack8<T>(vx, fx);
+      unpack8<T>(vg, fg);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float du = fg[q];
+        if (ACT == JG_ACT_SILU) du *= silu_grad_f(a[q] * fx[q] + bb[q]);
+        s1[q] += du;
+        s2[q] += du * fx[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
+      atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) atomicAdd(&red[(long)b * 2 * C + i], s_acc[i]);
+}
+
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ red, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ film, long ldfilm,
+                                   const float* __restrict__ mr, float* __restrict__ pqr, float* __restrict__ dgamma,
+                                   float* __restrict__ dbeta, float* __restrict__ dfilm, long lddfilm, int B, int HW,
+                                   int C, int G) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx % C;
+  const int cpg = C / G, g = c / cpg;
+  const float mean = mr[((long)b * G + g) * 2], rstd = mr[((long)b * G + g) * 2 + 1];
+  float SM1 = 0.f, SM2 = 0.f;
+  for (int k = 0; k < cpg; ++k) {
+    const int cc = g * cpg + k;
+    const float gam = gamma ? gamma[cc] : 1.f;
+    const float f = film ? 1.f + film[(long)b * ldfilm + cc] : 1.f;
+    const float A1 = red[((long)b * C + cc) * 2], A2 = red[((long)b * C + cc) * 2 + 1];
+    SM1 += gam * f * A1;
+    SM2 += gam * f * rstd * (A2 - mean * A1);
+  }
+  const float n = (float)HW * (float)cpg;
+  const float M1 = SM1 / n, M2 = SM2 / n;
+  const float gam = gamma ? gamma[c] : 1.f;
+  const float f = film ? 1.f + film[(long)b * ldfilm + c] : 1.f;
+  const float A1 = red[(long)idx * 2], A2 = red[(long)idx * 2 + 1];
+  pqr[(long)idx * 3] = f * gam * rstd;
+  pqr[(long)idx * 3 + 1] = -rstd * rstd * M2;
+  pqr[(long)idx * 3 + 2] = -rstd * M1 + mean * rstd * rstd * M2;
+  if (dgamma) atomicAdd(&dgamma[c], f * rstd * (A2 - mean * A1));
+  if (dbeta) atomicAdd(&dbeta[c], f * A1);
+  if (dfilm) {
+    const float a0 = rstd * gam;
+    const float b0 = (beta ? beta[c] : 0.f) - mean * a0;
+    dfilm[(long)b * lddfilm + c] = a0 * A2 + b0 * A1;
+    dfilm[(long)b * lddfilm + C + c] = A1;
+  }
+}
+
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
+                                                           const float* __restrict__ ab, const float* __restrict__ pqr,
+                                                           T* __restrict__ dx, int HW, int C) {
+  const Map mp = make_map(C);
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid >= mp.active) return;
+  const int co = tid % mp.noct, pl = tid / mp.noct;
+  float a[8], bb[8], P[8], Q[8], R[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const long o = (long)b * C + co * 8 + q;
+    a[q] = ab[o * 2];
+    bb[q] = ab[o * 2 + 1];
+    P[q] = pqr[o * 3];
+    Q[q] = pqr[o * 3 + 1];
+    R[q] = pqr[o * 3 + 2];
+  }
+  const int pbeg = blockIdx.x * mp.chunk;
+  const int pend = min(HW, pbeg + mp.chunk);
+  const long base = ((long)b * HW) * C + co * 8;
+  for (int p = pbeg + pl; p < pend; p += mp.pl) {
+    const uint4 vx = *reinterpret_cast<const uint4*>(x + base + (long)p * C);
+    const uint4 vg = *reinterpret_cast<const uint4*>(dy + base + (long)p * C);
+    float fx[8], fg[8];
+    unpack8<T>(vx, fx);
+    unpack8<T>(vg, fg);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float du = fg[q];
+      if (ACT == JG_ACT_SILU) du *= silu_grad_f(a[q] * fx[q] + bb[q]);
+      fg[q] = du * P[q] + fx[q] * Q[q] + R[q];
+    }
+    *reinterpret_cast<uint4*>(dx + base + (long)p * C) = pack8<T>(fg);
+  }
+}
+
+inline bool bad_shape(int B, int HW, int C) { return B < 1 || HW < 1 || C < 8 || (C % 8) || C > 2048 || B > 65535; }
+
+}  // namespace
+
+extern "C" int jg_gn_stats(int dtype, const void* x, float* sums, int B, int HW, int C, jg_stream_t s) {
+  if (!x || !sums || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 2 * C * sizeof(float), st,
+                                              (const T*)x, sums, HW, C););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_coef(const float* sums, const float* gamma, const float* beta, const float* film, int64_t ldfilm,
+                          float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s) {
+  if (!sums || !ab || !mr || G < 1 || C % G) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, sums, gamma, beta, film,
+                     (long)ldfilm, ab, mr, B, HW, C, G, eps);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_apply(int dtype, const void* x, const float* ab, void* y, int B, int HW, int C, int act,
+                           jg_stream_t s) {
+  if (!x || !ab || !y || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  hipStream_t st = (hipStream_t)s;
+  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0, st,
+                                                                       (const T*)x, ab, (T*)y, HW, C);
+                    else hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x, ab,
+                                            (T*)y, HW, C););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_reduce(int dtype, const void* x, const void* dy, const float* ab, float* red, int B, int HW,
+                                int C, int act, jg_stream_t s) {
+  if (!x || !dy || !ab || !red || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  const size_t shm = 2 * C * sizeof(float);
+  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_SILU>), grid, dim3(256), shm,
+                                                                       st, (const T*)x, (const T*)dy, ab, red, HW, C);
+                    else hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_NONE>), grid, dim3(256), shm, st, (const T*)x,
+                                            (const T*)dy, ab, red, HW, C););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_coef(const float* red, const float* gamma, const float* beta, const float* film,
+                              int64_t ldfilm, const float* mr, float* pqr, float* dgamma, float* dbeta, float* dfilm,
+                              int64_t lddfilm, int B, int HW, int C, int G, jg_stream_t s) {
+  if (!red || !mr || !pqr || G < 1 || C % G) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, red, gamma, beta, film,
+                     (long)ldfilm, mr, pqr, dgamma, dbeta, dfilm, (long)lddfilm, B, HW, C, G);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, const float* pqr, void* dx,
+                               int B, int HW, int C, int act, jg_stream_t s) {
+  if (!x || !dy || !ab || !pqr || !dx || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  hipStream_t st = (hipStream_t)s;
+  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0,
+                                                                       st, (const T*)x, (const T*)dy, ab, pqr, (T*)dx, HW, C);
+                    else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x,
+                                            (const T*)dy, ab, pqr, (T*)dx, HW, C););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}

@@ -1,0 +1,279 @@
+"""Step driver mirroring /root/reference/models/base_model.py for the training hot path:
+`optimize_parameters` (:1302-1377), `compute_step` (:1250-1282), `ema_step` (:1284-1297),
+`set_requires_grad` (:1196-1217), `get_current_losses` (:815-822), `save_networks` (:824-868),
+`load_networks` (:957-1103, plain path), `setup` (:694-723), `parallelize`/`single_gpu`
+(:725-745), `update_learning_rate` (:770-779).
+
+Differences that are the point of this build:
+  * networks keep their parameters in a flat arena; `parallelize()` wraps them in
+    FlatDataParallel (one RCCL all-reduce of the flat gradient per step) instead of DDP;
+  * the optimizer is the fused AdamW(+EMA+zero_grad) kernel; the EMA copy is a flat buffer and
+    `net<name>_ema` is a light module view of it (same state_dict keys);
+  * no GradScaler: bf16 activations need none, fp16 uses a static loss scale.
+Evaluation / visuals / metrics / export (reference :870-938, :1637-2287) are out of scope.
+"""
+from __future__ import annotations
+
+import copy
+import os
+from collections import OrderedDict
+from contextlib import ExitStack
+
+import torch
+
+from .. import parallel
+from ..optim import FusedAdamW
+
+
+class NetworkGroup:
+    """util/network_group.py of the reference."""
+
+    def __init__(self, networks_to_optimize, forward_functions, backward_functions, loss_names_list, optimizer,
+                 loss_backward, networks_to_ema=()):
+        self.networks_to_optimize = networks_to_optimize
+        self.forward_functions = forward_functions
+        self.backward_functions = backward_functions
+        self.loss_names_list = loss_names_list
+        self.optimizer = optimizer
+        self.loss_backward = loss_backward
+        self.networks_to_ema = list(networks_to_ema)
+
+
+class IterCalculator:
+    """util/iter_calculator.py of the reference (loss averaging over train_iter_size)."""
+
+    def __init__(self, loss_names):
+        self.loss_names = loss_names
+        for n in loss_names:
+            setattr(self, "loss_" + n, 0)
+            setattr(self, "loss_" + n + "_cur", 0)
+
+    def compute_last_step(self, loss_names):
+        for n in loss_names:
+            setattr(self, "loss_" + n, getattr(self, "loss_" + n + "_cur"))
+            setattr(self, "loss_" + n + "_cur", 0)
+
+    def compute_step(self, loss_name, value):
+        setattr(self, "loss_" + loss_name + "_cur", getattr(self, "loss_" + loss_name + "_cur") + value)
+
+
+def get_scheduler(optimizer, opt):
+    """models/modules/utils.py:115-157."""
+    from torch.optim import lr_scheduler
+
+    if opt.train_lr_policy == "linear":
+        def lambda_rule(epoch):
+            return 1.0 - max(0, epoch + opt.train_epoch_count - opt.train_n_epochs) / float(opt.train_n_epochs_decay + 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    if opt.train_lr_policy == "step":
+        return lr_scheduler.StepLR(optimizer, step_size=opt.train_lr_decay_iters, gamma=0.1)
+    if opt.train_lr_policy == "multistep":
+        return lr_scheduler.MultiStepLR(optimizer, milestones=opt.train_lr_steps, gamma=0.1)
+    if opt.train_lr_policy == "cosine":
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.train_n_epochs, eta_min=0)
+    raise NotImplementedError(f"learning rate policy [{opt.train_lr_policy}] is not implemented")
+
+
+ACT_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16}
+
+
+class BaseModel:
+    def __init__(self, opt, rank):
+        self.rank = rank
+        self.opt = opt
+        self.gpu_ids = opt.gpu_ids
+        self.isTrain = opt.isTrain
+        self.with_amp = opt.with_amp
+        if not torch.cuda.is_available() or not self.gpu_ids:
+            raise RuntimeError("joligen_amd runs on MI355X GPUs only: no CPU fallback (gpu_ids=%r)" % (opt.gpu_ids,))
+        self.use_cuda = True
+        self.device = torch.device("cuda:{}".format(self.gpu_ids[rank]))
+        self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        self.loss_names, self.model_names, self.visual_names, self.optimizers = [], [], [], []
+        self.niter = 0
+        self.objects_to_update = []
+        self.act_dtype = ACT_DTYPES[getattr(opt, "jg_act_dtype", "bf16")]
+        ls = float(getattr(opt, "jg_loss_scale", 0.0) or 0.0)
+        self.loss_scale = ls if ls > 0 else (65536.0 if self.act_dtype == torch.float16 else 1.0)
+        self._ema_fused_this_iter = set()
+
+    # ---- optimizer factory (train.py:51-62) ------------------------------------------------
+    def make_optimizer(self, net, lr, betas, weight_decay, eps):
+        name = self.opt.train_optim
+        if name not in ("adam", "adamw"):
+            raise NotImplementedError(f"train_optim={name!r}: only adam / adamw have a fused MI355X kernel")
+        arena = net.jg_finalize(self.device, self.act_dtype)
+        opt = FusedAdamW(arena, net.parameters(), lr, betas, weight_decay, eps, decoupled=(name == "adamw"))
+        opt.grad_scale = 1.0 / self.loss_scale
+        return opt
+
+    # ---- setup / parallel --------------------------------------------------------------------
+    def setup(self, opt):
+        if self.isTrain:
+            self.schedulers = [get_scheduler(o, opt) for o in self.optimizers]
+        if not self.isTrain or opt.train_continue or getattr(opt, "train_continue_from", ""):
+            suffix = "iter_%d" % opt.train_load_iter if opt.train_load_iter > 0 else opt.train_epoch
+            self.load_networks(suffix, load_dir=os.path.expanduser(opt.train_continue_from) or None)
+
+    def _net(self, name):
+        net = getattr(self, "net" + name)
+        return net.module if isinstance(net, parallel.FlatDataParallel) else net
+
+    def single_gpu(self):
+        for name in self.model_names:
+            self._net(name).jg_finalize(self.device, self.act_dtype)
+
+    def parallelize(self, rank):
+        """One process per GPU; parameters broadcast from rank 0 (DDP constructor semantics)."""
+        for name in self.model_names:
+            net = self._net(name)
+            arena = net.jg_finalize(self.device, self.act_dtype)
+            self.set_requires_grad(net, True)
+            parallel.broadcast_params(arena, 0)
+            setattr(self, "net" + name, parallel.FlatDataParallel(net))
+
+    def eval(self):
+        for name in self.model_names:
+            getattr(self, "net" + name).eval()
+
+    def update_learning_rate(self):
+        for s in self.schedulers:
+            s.step()
+
+    # ---- requires_grad toggling (:1196-1217) -------------------------------------------------
+    def set_requires_grad(self, nets, requires_grad=False):
+        if not isinstance(nets, list):
+            nets = [nets]
+        for net in nets:
+            if net is None:
+                continue
+            for name, param in net.named_parameters():
+                if "freeze" not in name and "cv_ensemble" not in name:
+                    param.requires_grad = requires_grad
+                else:
+                    param.requires_grad = False
+
+    # ---- step driver (:1302-1377) --------------------------------------------------------------
+    def optimize_parameters(self):
+        self.niter += 1
+        self._ema_fused_this_iter = set()
+        with ExitStack() as stack:
+            if len(self.opt.gpu_ids) > 1 and self.niter % self.opt.train_iter_size != 0:
+                stack.enter_context(parallel.no_sync())
+            for group in self.networks_groups:
+                for network in self.model_names:
+                    self.set_requires_grad(getattr(self, "net" + network), network in group.networks_to_optimize)
+                for forward in group.forward_functions or []:
+                    getattr(self, forward)()
+                for backward in group.backward_functions:
+                    getattr(self, backward)()
+                for loss in group.loss_backward:
+                    ll = getattr(self, loss) / self.opt.train_iter_size
+                    ll.backward()
+                loss_names = []
+                for temp in group.loss_names_list:
+                    loss_names += getattr(self, temp)
+                self.compute_step(group.optimizer, loss_names, group)
+                if self.opt.train_G_ema:
+                    for network in self.model_names:
+                        if network in group.networks_to_ema:
+                            self.ema_step(network)
+            for obj in self.objects_to_update:
+                obj.update(self.niter)
+
+    def compute_step(self, optimizers_names, loss_names, group=None):
+        """:1250-1282.  The EMA update of the group's networks is fused into the optimizer launch
+        when the EMA copy already exists (always, except on the very first step)."""
+        optimizers = [getattr(self, n) for n in optimizers_names]
+        if self.opt.train_iter_size > 1:
+            for n in loss_names:
+                value = getattr(self, "loss_" + n).clone() / self.opt.train_iter_size
+                self.iter_calculator.compute_step(n, value.detach() if torch.is_tensor(value) else value)
+        if self.niter % self.opt.train_iter_size == 0:
+            for optimizer in optimizers:
+                ema_beta = None
+                if self.opt.train_G_ema and group is not None and isinstance(optimizer, FusedAdamW):
+                    owners = [n for n in group.networks_to_ema if self._net(n).arena is optimizer.arena]
+                    if owners and optimizer.arena.ema is not None:
+                        ema_beta = self.opt.train_G_ema_beta
+                        self._ema_fused_this_iter.update(owners)
+                optimizer.step(ema_beta=ema_beta) if isinstance(optimizer, FusedAdamW) else optimizer.step()
+                optimizer.zero_grad() if not isinstance(optimizer, FusedAdamW) else None
+            if self.opt.train_iter_size > 1:
+                self.iter_calculator.compute_last_step(loss_names)
+                for n in loss_names:
+                    setattr(self, "loss_" + n + "_avg", getattr(self.iter_calculator, "loss_" + n))
+
+    def ema_step(self, network_name):
+        """:1284-1297.  First call: the EMA copy is created from the current parameters."""
+        net = self._net(network_name)
+        arena = net.arena
+        if arena.ema is None:
+            arena.ema_create()
+            setattr(self, "net" + network_name + "_ema", _EmaView(net, arena))
+            if network_name in self._ema_fused_this_iter:
+                self._ema_fused_this_iter.discard(network_name)
+        if network_name in self._ema_fused_this_iter:
+            return  # already updated inside the optimizer launch of this iteration
+        arena.ema_update(self.opt.train_G_ema_beta)
+
+    def iter_calculator_init(self):
+        if self.opt.train_iter_size > 1:
+            self.iter_calculator = IterCalculator(self.loss_names)
+            for i, cur in enumerate(self.loss_names):
+                self.loss_names[i] = cur + "_avg"
+                setattr(self, "loss_" + self.loss_names[i], 0)
+
+    def get_current_losses(self):
+        out = OrderedDict()
+        for name in self.loss_names:
+            if isinstance(name, str):
+                out[name] = getattr(self, "loss_" + name)
+        return out
+
+    def get_current_batch_size(self):
+        return self.real_A.shape[0]
+
+    # ---- checkpoints (:824-868, :957-1103) -------------------------------------------------------
+    def save_networks(self, epoch):
+        os.makedirs(self.save_dir, exist_ok=True)
+        for name in self.model_names:
+            net = self._net(name)
+            torch.save(net.state_dict(), os.path.join(self.save_dir, "%s_net_%s.pth" % (epoch, name)))
+            if self.opt.train_G_ema:
+                ema = getattr(self, "net" + name + "_ema", None)
+                if ema is not None:
+                    torch.save(ema.state_dict(), os.path.join(self.save_dir, "%s_net_%s_ema.pth" % (epoch, name)))
+
+    def load_networks(self, epoch, load_dir=None):
+        load_dir = load_dir or self.save_dir
+        for name in self.model_names:
+            path = os.path.join(load_dir, "%s_net_%s.pth" % (epoch, name))
+            state_dict = torch.load(path, map_location="cpu")
+            if hasattr(state_dict, "_metadata"):
+                del state_dict._metadata
+            self._net(name).load_state_dict(state_dict, strict=not getattr(self.opt, "model_load_no_strictness", False))
+
+
+class _EmaView:
+    """`net<name>_ema` of the reference is a deepcopy of the network; here it is a view of the
+    arena's flat EMA buffer that serves `state_dict()` (checkpoint `<suffix>_net_<name>_ema.pth`),
+    `parameters()` and `named_parameters()` with the reference's keys."""
+
+    def __init__(self, net, arena):
+        self._net, self._arena = net, arena
+
+    def named_parameters(self):
+        return list(self._arena.named_views(self._arena.ema).items())
+
+    def parameters(self):
+        return [v for _, v in self.named_parameters()]
+
+    def state_dict(self):
+        sd = self._net.state_dict()
+        for k, v in self._arena.named_views(self._arena.ema).items():
+            sd[k] = v.detach().clone(memory_format=torch.contiguous_format)
+        return sd
+
+    def eval(self):
+        return self

@@ -1,0 +1,111 @@
+"""palette_model (DDPM) training step on MI355X: mirror of /root/reference/models/palette_model.py
+(`__init__` :116-285, `set_input` :287-366 (inpainting / pix2pix, cond_image_creation="y_t"),
+`compute_palette_loss` :558-620) and models/diffusion_networks.py `define_G` (:24-139,361-376)
+for `G_netG="unet_mha"`.
+
+Same public surface as the reference model class: `set_input(data)`,
+`optimize_parameters()`, `get_current_losses()`, `save_networks()`, `netG_A`, `model_names`...
+Inference / sampling (`inference` :622-887) is the first "next" row of SURVEY.md 8(f).
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import ops
+from ..modules.diffusion_generator import DiffusionGenerator, PaletteDenoiseFn
+from ..modules.unet_generator_attn import UNet
+from .base_model import BaseModel, NetworkGroup
+
+
+def define_G(model_type, model_input_nc, model_output_nc, G_netG, data_crop_size, G_diff_n_timestep_train,
+             G_diff_n_timestep_test, G_dropout, G_ngf, G_unet_mha_num_heads, G_unet_mha_num_head_channels,
+             G_unet_mha_res_blocks, G_unet_mha_channel_mults, G_unet_mha_attn_res, G_unet_mha_norm_layer,
+             G_unet_mha_group_norm_size, G_unet_mha_vit_efficient, alg_palette_sampling_method, alg_diffusion_cond_embed,
+             alg_diffusion_cond_embed_dim, alg_diffusion_ref_embed_net="clip", model_prior_321_backwardcompatibility=False,
+             f_s_semantic_nclasses=-1, train_feat_wavelet=False, **unused_options):
+    """models/diffusion_networks.py:24-139,361-376 restricted to palette + unet_mha."""
+    if model_type != "palette":
+        raise NotImplementedError(f"define_G(model_type={model_type!r}) not implemented yet")
+    if G_netG != "unet_mha":
+        raise NotImplementedError(f"G_netG={G_netG!r}: only unet_mha is on the SURVEY.md 8 DDPM path")
+    in_channel = model_input_nc + model_output_nc
+    if "mask" in alg_diffusion_cond_embed:
+        in_channel += alg_diffusion_cond_embed_dim
+    model = UNet(
+        image_size=data_crop_size, in_channel=in_channel, inner_channel=G_ngf, out_channel=model_output_nc,
+        res_blocks=G_unet_mha_res_blocks, attn_res=G_unet_mha_attn_res, num_heads=G_unet_mha_num_heads,
+        num_head_channels=G_unet_mha_num_head_channels, tanh=False, dropout=G_dropout,
+        n_timestep_train=G_diff_n_timestep_train, n_timestep_test=G_diff_n_timestep_test,
+        channel_mults=G_unet_mha_channel_mults, norm=G_unet_mha_norm_layer, group_norm_size=G_unet_mha_group_norm_size,
+        efficient=G_unet_mha_vit_efficient, cond_embed_dim=alg_diffusion_cond_embed_dim, freq_space=train_feat_wavelet,
+    )
+    denoise_fn = PaletteDenoiseFn(model=model, cond_embed_dim=alg_diffusion_cond_embed_dim,
+                                  ref_embed_net=alg_diffusion_ref_embed_net, conditioning=alg_diffusion_cond_embed,
+                                  nclasses=f_s_semantic_nclasses)
+    return DiffusionGenerator(denoise_fn=denoise_fn, sampling_method=alg_palette_sampling_method,
+                              image_size=data_crop_size, G_ngf=G_ngf,
+                              loading_backward_compatibility=model_prior_321_backwardcompatibility)
+
+
+class PaletteModel(BaseModel):
+    def __init__(self, opt, rank):
+        super().__init__(opt, rank)
+        self.task = opt.alg_diffusion_task
+        if self.task not in ("inpainting", "pix2pix"):
+            raise NotImplementedError(f"alg_diffusion_task={self.task!r} is outside the SURVEY.md 8 hot path")
+        if opt.alg_diffusion_cond_image_creation != "y_t":
+            raise NotImplementedError("only alg_diffusion_cond_image_creation='y_t' is implemented")
+        if opt.alg_palette_loss != "MSE":
+            raise NotImplementedError("only alg_palette_loss='MSE' has a fused loss kernel yet")
+        if opt.alg_diffusion_dropout_prob > 0:
+            raise NotImplementedError("alg_diffusion_dropout_prob > 0 (classifier-free guidance) is not implemented")
+        if opt.G_nblocks == 9 and "resnet" not in opt.G_netG:
+            opt.G_nblocks = 2  # palette_model.py:199-203
+
+        self.netG_A = define_G(**vars(opt))
+        self.model_names = ["G_A"]
+        if opt.isTrain:
+            self.optimizer_G = self.make_optimizer(self.netG_A, lr=opt.train_G_lr, betas=(opt.train_beta1, opt.train_beta2),
+                                                   weight_decay=opt.train_optim_weight_decay, eps=opt.train_optim_eps)
+            self.optimizers.append(self.optimizer_G)
+        self.loss_names_G = ["G_tot"]
+        self.loss_names = list(self.loss_names_G)
+        self.group_G = NetworkGroup(networks_to_optimize=["G_A"], forward_functions=[],
+                                    backward_functions=["compute_palette_loss"], loss_names_list=["loss_names_G"],
+                                    optimizer=["optimizer_G"], loss_backward=["loss_G_tot"], networks_to_ema=["G_A"])
+        self.networks_groups = [self.group_G]
+        self.iter_calculator_init()
+        self.rng_injection = None  # parity runs: callable(batch_size) -> (t, u, noise) drawn on the host
+
+    # palette_model.py:287-366 (4-D inputs, no SAM masks, no reference image)
+    def set_input(self, data):
+        a = data["A"].to(self.device, non_blocking=True)
+        if a.dim() != 4:
+            raise NotImplementedError("temporal (5-D) batches are outside the SURVEY.md 8 hot path")
+        if self.task == "inpainting":
+            self.y_t = a
+            self.gt_image = data["B"].to(self.device, non_blocking=True)
+            self.mask = data["B_label_mask"].to(self.device, non_blocking=True)
+        else:  # pix2pix
+            self.y_t = a
+            self.gt_image = data["B"].to(self.device, non_blocking=True)
+            self.mask = None
+        self.cls = None
+        self.cond_image = self.y_t
+        self.batch_size = self.cond_image.shape[0]
+        self.real_A = self.cond_image
+        self.real_B = self.gt_image
+
+    # palette_model.py:558-620
+    def compute_palette_loss(self):
+        y_0, y_cond, mask = self.gt_image, self.cond_image, self.mask
+        t = u = noise = None
+        if self.rng_injection is not None:
+            t, u, noise = self.rng_injection(y_0.shape[0])
+            noise = noise.to(self.device)
+        net = self._net("G_A")
+        noise, noise_hat, min_snr_w, _ = net.forward_nhwc(y_0, y_cond, mask, noise, t, u)
+        w = min_snr_w if self.opt.alg_palette_minsnr else None
+        loss = ops.ddpm_mse_loss(noise_hat, noise.float(), mask, w, lam=self.opt.alg_diffusion_lambda_G,
+                                 grad_scale=self.loss_scale)
+        self.loss_G_tot = loss

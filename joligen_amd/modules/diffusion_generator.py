@@ -1,0 +1,164 @@
+"""DDPM training forward on the HIP ops: mirror of
+/root/reference/models/modules/diffusion_generator.py (`DiffusionGenerator` :23-80, `forward`
+:457-521, `compute_gammas` :526-528), models/modules/palette_denoise_fn.py (`PaletteDenoiseFn`
+:35-115, conditioning off) and models/modules/diffusion_utils.py (`make_beta_schedule` :45-79,
+`set_new_noise_schedule` :81-119).
+
+state_dict keys are the reference's: `denoise_fn.model.<unet...>`, the 14 schedule buffers
+`denoise_fn.model.{gammas,...}_{train,test}` and `cond_embed.{0,2}.{weight,bias}`.
+
+The sampling / restoration loops (reference :83-455) are not part of the training hot path.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..arena import ParamArena
+from ..ops import JG_ACT_NONE, JG_ACT_SILU
+
+
+def make_beta_schedule(schedule, n_timestep, linear_start=1e-6, linear_end=1e-2, cosine_s=8e-3):
+    """diffusion_utils.py:45-79 (float64 numpy)."""
+    if schedule == "quad":
+        return np.linspace(linear_start ** 0.5, linear_end ** 0.5, n_timestep, dtype=np.float64) ** 2
+    if schedule == "linear":
+        return np.linspace(linear_start, linear_end, n_timestep, dtype=np.float64)
+    if schedule == "const":
+        return linear_end * np.ones(n_timestep, dtype=np.float64)
+    if schedule == "jsd":
+        return 1.0 / np.linspace(n_timestep, 1, n_timestep, dtype=np.float64)
+    raise NotImplementedError(schedule)
+
+
+def set_new_noise_schedule(model, phase):
+    """diffusion_utils.py:81-119: registers the 7 schedule buffers of `phase` on `model`."""
+    to_torch = partial(torch.tensor, dtype=torch.float32)
+    betas = make_beta_schedule(**model.beta_schedule[phase])
+    alphas = 1.0 - betas
+    (timesteps,) = betas.shape
+    setattr(model, "num_timesteps_" + phase, int(timesteps))
+    gammas = np.cumprod(alphas, axis=0)
+    gammas_prev = np.append(1.0, gammas[:-1])
+    model.register_buffer("gammas_" + phase, to_torch(gammas))
+    model.register_buffer("gammas_prev_" + phase, to_torch(gammas_prev))
+    model.register_buffer("sqrt_recip_gammas_" + phase, to_torch(np.sqrt(1.0 / gammas)))
+    model.register_buffer("sqrt_recipm1_gammas_" + phase, to_torch(np.sqrt(1.0 / gammas - 1)))
+    posterior_variance = betas * (1.0 - gammas_prev) / (1.0 - gammas)
+    model.register_buffer("posterior_log_variance_clipped_" + phase, to_torch(np.log(np.maximum(posterior_variance, 1e-20))))
+    model.register_buffer("posterior_mean_coef1_" + phase, to_torch(betas * np.sqrt(gammas_prev) / (1.0 - gammas)))
+    model.register_buffer("posterior_mean_coef2_" + phase, to_torch((1.0 - gammas_prev) * np.sqrt(alphas) / (1.0 - gammas)))
+
+
+class PaletteDenoiseFn(nn.Module):
+    """palette_denoise_fn.py:35-115 with `conditioning == ""` (class / mask / ref embeddings are
+    outside SURVEY.md 8: all off in the BASELINE configs)."""
+
+    def __init__(self, model, cond_embed_dim, ref_embed_net, conditioning, nclasses):
+        super().__init__()
+        if conditioning:
+            raise NotImplementedError(f"alg_diffusion_cond_embed={conditioning!r} is not implemented (SURVEY.md 8: off)")
+        self.model = model
+        self.conditioning = conditioning
+        self.cond_embed_dim = cond_embed_dim
+        self.ref_embed_net = ref_embed_net
+
+    def forward(self, input, embed_noise_level, cls=None, mask=None, ref=None):
+        return self.model(input, embed_noise_level)
+
+
+class DiffusionGenerator(nn.Module):
+    def __init__(self, denoise_fn, sampling_method, image_size, G_ngf, loading_backward_compatibility=False):
+        super().__init__()
+        if loading_backward_compatibility:
+            raise NotImplementedError("model_prior_321_backwardcompatibility is not implemented")
+        self.denoise_fn = denoise_fn
+        self.sampling_method = sampling_method
+        self.image_size = image_size
+        cond_embed_dim = self.denoise_fn.cond_embed_dim
+        set_new_noise_schedule(model=self.denoise_fn.model, phase="train")
+        set_new_noise_schedule(model=self.denoise_fn.model, phase="test")
+        self.cond_embed_dim = cond_embed_dim
+        self.cond_embed_gammas = cond_embed_dim
+        self.cond_embed = nn.Sequential(
+            nn.Linear(self.cond_embed_gammas, self.cond_embed_gammas),
+            nn.SiLU(),
+            nn.Linear(self.cond_embed_gammas, self.cond_embed_gammas),
+        )
+        self.cond_embed_gammas_in = self.cond_embed_gammas
+        self.arena = None
+        self.act_dtype = torch.bfloat16
+        self.loss_scale = 1.0
+
+    # ---- MI355X finalisation -------------------------------------------------------------
+    def jg_finalize(self, device, act_dtype=torch.bfloat16):
+        """Move every parameter into a flat device arena and build the 16-bit conv weights.
+        Must be called once, after construction / before the first forward (the model classes'
+        single_gpu()/parallelize() do it)."""
+        if self.arena is not None:
+            return self.arena
+        self.act_dtype = act_dtype
+        self.arena = ParamArena(self, device, act_dtype)
+        self.denoise_fn.model._jg_arena_ref = self.arena
+        return self.arena
+
+    # ---- pieces --------------------------------------------------------------------------
+    def compute_gammas(self, gammas):
+        """reference :526-528: cond_embed(gamma_embedding(gammas, dim))."""
+        emb = ops.gamma_embedding(gammas, self.cond_embed_gammas_in)
+        l0, l2 = self.cond_embed[0], self.cond_embed[2]
+        emb = ops.linear(emb, l0.weight, l0.bias, JG_ACT_NONE)
+        return ops.linear(emb, l2.weight, l2.bias, JG_ACT_SILU)
+
+    def sample_gammas(self, b, device, t=None, u=None):
+        """reference :467-478.  `t`/`u` may be injected (parity runs draw them from a CPU generator)."""
+        model = self.denoise_fn.model
+        if t is None:
+            t = torch.randint(1, model.num_timesteps_train, (b,), device=device).long()
+        else:
+            t = t.to(device).long()
+        if u is None:
+            u = torch.rand((b, 1), device=device)
+        else:
+            u = u.to(device).float().view(b, 1)
+        gammas = model.gammas_train
+        gamma_t1 = gammas.gather(-1, t - 1).view(b, 1)
+        gamma_t2 = gammas.gather(-1, t).view(b, 1)
+        return t, (gamma_t2 - gamma_t1) * u + gamma_t1
+
+    def min_snr_weight(self, t):
+        """reference :502-519."""
+        model = self.denoise_fn.model
+        snr = torch.pow(model.sqrt_recip_gammas_train.gather(-1, t) / model.sqrt_recipm1_gammas_train.gather(-1, t), 2)
+        return (torch.minimum(snr, 5.0 * torch.ones_like(snr)) / snr).view(-1, 1, 1, 1)
+
+    def forward_nhwc(self, y_0, y_cond, mask, noise, t=None, u=None):
+        """The training forward with the UNet output left in NHWC 16-bit (8 channels, 3 valid).
+        Returns (noise fp32 NCHW, noise_hat NHWC 16-bit, min_snr_w [B,1,1,1], t)."""
+        if self.arena is None:
+            raise RuntimeError("DiffusionGenerator.jg_finalize(device) has not been called")
+        if y_0.dim() != 4:
+            raise NotImplementedError("video (5-D) inputs are outside the SURVEY.md 8 hot path")
+        self.arena.ensure_fresh()
+        b = y_0.shape[0]
+        dev = y_0.device
+        t, sample_gammas = self.sample_gammas(b, dev, t, u)
+        if noise is None:
+            noise = torch.randn_like(y_0)
+        emb = self.compute_gammas(sample_gammas)
+        xin = ops.ddpm_prepare(y_0.float(), y_cond.float(), noise.float(), mask, sample_gammas.view(-1).contiguous(),
+                               self.act_dtype, cpad=8)
+        noise_hat = self.denoise_fn(xin, emb, cls=None, mask=mask, ref=None)
+        return noise, noise_hat, self.min_snr_weight(t), t
+
+    def forward(self, y_0, y_cond, mask, noise, cls=None, ref=None, dropout_prob=0.0, t=None, u=None):
+        """reference :457-521 signature; returns (noise, noise_hat, min_snr_loss_weight) NCHW fp32."""
+        noise, nh, w, _ = self.forward_nhwc(y_0, y_cond, mask, noise, t, u)
+        return noise, ops.to_nchw_f32(nh, y_0.shape[1]), w
+
+    def set_new_sampling_method(self, sampling_method):
+        self.sampling_method = sampling_method

@@ -1,0 +1,69 @@
+"""Parameter containers with the reference's state_dict names whose forward runs the HIP ops."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+
+class JGConvNd:
+    """Marker mix-in: a conv layer whose 16-bit working weights are managed by ParamArena."""
+
+    needs_dgrad = True
+    meta = None
+    jg_padding = 0
+    jg_stride = 1
+
+
+class JGConv2d(nn.Conv2d, JGConvNd):
+    """nn.Conv2d parameters/initialisation (so checkpoints and default init match the reference);
+    forward = implicit-GEMM MFMA kernel on NHWC 16-bit activations, with an optional fused
+    residual `y = conv(x) + bias + res_scale * res`."""
+
+    def __init__(self, cin, cout, k, padding=0, stride=1, needs_dgrad=True):
+        super().__init__(cin, cout, k, stride=stride, padding=padding)
+        self.needs_dgrad = needs_dgrad
+        self.jg_padding, self.jg_stride = padding, stride
+
+    def forward(self, x, res=None, res_scale=1.0):
+        if self.meta is None:
+            raise RuntimeError("JGConv2d used before ParamArena finalisation (call net.jg_finalize(device))")
+        return ops.conv2d(x, self.meta, res, res_scale)
+
+
+class JGConv1d(nn.Conv1d, JGConvNd):
+    """nn.Conv1d(k=1) container (attention qkv / proj_out); runs as a 1x1 conv over [B, T, C]."""
+
+    def __init__(self, cin, cout, k=1, needs_dgrad=True):
+        assert k == 1
+        super().__init__(cin, cout, 1)
+        self.needs_dgrad = needs_dgrad
+        self.jg_padding, self.jg_stride = 0, 1
+
+    def forward(self, x, res=None, res_scale=1.0):
+        if self.meta is None:
+            raise RuntimeError("JGConv1d used before ParamArena finalisation")
+        B, T, Cc = x.shape
+        r4 = None if res is None else res.view(B, 1, T, res.shape[-1])
+        y = ops.conv2d(x.view(B, 1, T, Cc), self.meta, r4, res_scale)
+        return y.view(B, T, y.shape[-1])
+
+
+class GroupNorm(nn.Module):
+    """Same attribute layout as the reference wrapper (unet_attn_utils.py:42-48): `.norm` is an
+    nn.GroupNorm that only holds (weight, bias); the computation is ops.group_norm."""
+
+    def __init__(self, group_size, channels):
+        super().__init__()
+        self.norm = nn.GroupNorm(group_size, channels)
+
+    def forward(self, x, film=None, act=ops.JG_ACT_NONE):
+        return ops.group_norm(x, self.norm.num_groups, self.norm.weight, self.norm.bias, film, act, self.norm.eps)
+
+
+def zero_module(module):
+    """unet_attn_utils.py:69-75."""
+    for p in module.parameters():
+        p.detach().zero_()
+    return module

@@ -1,0 +1,596 @@
+"""Host-side operators over libjg355.so: thin launch wrappers, the autograd formulas that chain
+the hand-written forward/backward kernels, and the `torch.ops.jg355.*` registrations.
+
+Conventions
+  * activations: 16-bit (torch.float16 / torch.bfloat16), logical AND physical NHWC
+    `[B, H, W, C]` (or `[B, T, C]`), contiguous, C % 8 == 0;
+  * parameters: fp32 views into a ParamArena (joligen_amd/arena.py); kernels ACCUMULATE parameter
+    gradients straight into `param.grad` (an arena view) -- the autograd Functions return None
+    for parameter inputs, which are passed only so that autograd tracks them;
+  * every kernel is launched on torch's current stream; nothing here synchronises.
+
+PyTorch is used for device memory (caching allocator), streams and the autograd tape only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import JG_ACT_NONE, JG_ACT_SILU, JG_OUT_ATOMIC_F32, JG_OUT_STORE_T, ConvArgs, WgradArgs, check
+
+_DT = {torch.float16: _lib.JG_F16, torch.bfloat16: _lib.JG_BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"joligen_amd activations must be float16/bfloat16, got {t.dtype}") from None
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("joligen_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+
+
+# ======================================================================================
+# raw launchers
+# ======================================================================================
+# bench.py sets this to a list to time every launch of the dominant kernel with HIP events
+# (start/stop recorded on the launch stream); entries: (kernel, ev_start, ev_stop, algorithmic flops)
+KERNEL_TIMING = None
+
+def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
+            ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
+            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None):
+    """jg_conv2d_nt with element offsets into the operand tensors."""
+    a = ConvArgs()
+    es = 2
+    a.x = x.data_ptr() + x_off * es
+    a.w = w.data_ptr() + w_off * es
+    a.y = y.data_ptr() + y_off * (4 if out_f32 else es)
+    a.bias = _p(bias)
+    a.res = _p(res)
+    a.B, a.H, a.W, a.Cin, a.Cout, a.R, a.S, a.pad, a.stride, a.Ho, a.Wo = B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo
+    a.ldx, a.ldw, a.ldy, a.ldres = ldx, ldw, ldy, ldres
+    a.nbatch, a.nh = nbatch, nh
+    a.sxb, a.sxh = sx
+    a.swb, a.swh = sw
+    a.syb, a.syh = sy
+    a.srb, a.srh = sr
+    a.alpha, a.res_scale, a.out_f32 = alpha, res_scale, int(out_f32)
+    if KERNEL_TIMING is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()  # current stream == the stream the kernel is launched on
+    check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
+    if KERNEL_TIMING is not None:
+        ev1.record()
+        KERNEL_TIMING.append(("conv_nt", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin))
+
+
+def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
+             Cout_out=0, splitk=1, nbatch=1, nh=1, sdy=(0, 0), sx=(0, 0), sdw=(0, 0), alpha=1.0,
+             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0):
+    a = WgradArgs()
+    a.dy = dy.data_ptr() + dy_off * 2
+    a.x = x.data_ptr() + x_off * 2
+    a.dw = dw.data_ptr() + dw_off * dw.element_size()
+    a.dbias = _p(dbias)
+    a.B, a.H, a.W, a.Cin, a.Cout, a.R, a.S, a.pad, a.stride, a.Ho, a.Wo = B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo
+    a.Cin_out, a.Cout_out = Cin_out, Cout_out
+    a.lddy, a.ldx, a.lddw = lddy, ldx, lddw
+    a.nbatch, a.nh, a.splitk = nbatch, nh, splitk
+    a.sdyb, a.sdyh = sdy
+    a.sxb, a.sxh = sx
+    a.sdwb, a.sdwh = sdw
+    a.alpha, a.out_mode = alpha, out_mode
+    if KERNEL_TIMING is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(_lib.lib().jg_conv2d_wgrad_tn(_dt(dy), C.byref(a), _st()), "jg_conv2d_wgrad_tn")
+    if KERNEL_TIMING is not None:
+        ev1.record()
+        KERNEL_TIMING.append(("wgrad_tn", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin))
+
+
+def axpby(a, alpha=1.0, b=None, beta=0.0, alpha_dev=None, out=None):
+    y = torch.empty_like(a) if out is None else out
+    check(_lib.lib().jg_axpby(_dt(a), a.data_ptr(), alpha, _p(alpha_dev), _p(b), beta, y.data_ptr(), a.numel(), _st()),
+          "jg_axpby")
+    return y
+
+
+# ======================================================================================
+# convolution
+# ======================================================================================
+class ConvMeta:
+    """Geometry + working weight copies of one conv layer (filled by ParamArena)."""
+
+    __slots__ = ("Cin", "Cout", "Cin_real", "Cout_real", "R", "S", "pad", "stride", "w16", "w16T", "weight", "bias",
+                 "bias_pad")
+
+    def out_hw(self, H, W):
+        return ((H + 2 * self.pad - self.R) // self.stride + 1, (W + 2 * self.pad - self.S) // self.stride + 1)
+
+
+def _wgrad_splitk(tiles, mpix, nbatch=1):
+    want = max(1, (1536 + tiles - 1) // tiles)
+    cap = max(1, mpix // 256)
+    return max(1, min(want, cap, 65535 // max(1, nbatch)))
+
+
+def conv2d_forward(x, m: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
+    _require_cuda(x)
+    B, H, W, Cin = x.shape
+    assert Cin == m.Cin, (Cin, m.Cin)
+    Ho, Wo = m.out_hw(H, W)
+    y = torch.empty((B, Ho, Wo, m.Cout), device=x.device, dtype=x.dtype)
+    conv_nt(x, m.w16, y, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
+            ldx=Cin, ldw=m.R * m.S * Cin, ldy=m.Cout, bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
+            ldres=m.Cout, alpha=alpha, res_scale=res_scale)
+    return y
+
+
+def conv2d_dgrad(dy, m: ConvMeta, x_shape, alpha=1.0):
+    """dx = conv(dy, flipped/transposed weights), stride 1 only (UNet)."""
+    if m.stride != 1:
+        raise NotImplementedError("input-gradient of strided convolutions is not implemented yet")
+    B, H, W, Cin = x_shape
+    _, Ho, Wo, Cout = dy.shape
+    dx = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
+    conv_nt(dy, m.w16T, dx, B=B, H=Ho, W=Wo, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,
+            ldx=Cout, ldw=m.R * m.S * Cout, ldy=Cin, alpha=alpha)
+    return dx
+
+
+def conv2d_wgrad(dy, x, m: ConvMeta, alpha=1.0, want_w=True, want_b=True):
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    wg = m.weight.grad
+    if wg is None:
+        raise RuntimeError("conv weight has no arena-backed .grad (module not finalised by ParamArena)")
+    ktot = m.R * m.S * Cin
+    tiles = ((Cout + 127) // 128) * ((ktot + 127) // 128)
+    splitk = _wgrad_splitk(tiles, B * Ho * Wo)
+    dbias = m.bias.grad if (want_b and m.bias is not None) else None
+    wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
+             lddy=Cout, ldx=Cin, lddw=m.R * m.S * m.Cin_real, dbias=dbias, Cin_out=m.Cin_real, Cout_out=m.Cout_real,
+             splitk=splitk, alpha=alpha)
+
+
+class _Conv2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, meta, res_scale, alpha):
+        y = conv2d_forward(x, meta, res, res_scale, alpha)
+        ctx.save_for_backward(x)
+        ctx.meta, ctx.res_scale, ctx.alpha, ctx.has_res = meta, res_scale, alpha, res is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        m = ctx.meta
+        dy = dy.contiguous()
+        dx = dres = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_dgrad(dy, m, x.shape, ctx.alpha)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            conv2d_wgrad(dy, x, m, ctx.alpha, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
+        if ctx.has_res and ctx.needs_input_grad[3]:
+            dres = dy if ctx.res_scale == 1.0 else axpby(dy, ctx.res_scale)
+        return dx, None, None, dres, None, None, None
+
+
+def conv2d(x, meta: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
+    """y = alpha*conv(x) + bias + res_scale*res   (nn.Conv2d / Conv1d(k=1) of the reference)."""
+    return _Conv2dFn.apply(x, meta.weight, meta.bias, res, meta, res_scale, alpha)
+
+
+# ======================================================================================
+# GroupNorm (+FiLM, +SiLU) / InstanceNorm1d
+# ======================================================================================
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, film, G, act, eps):
+        _require_cuda(x)
+        L = _lib.lib()
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        dev, st, dt = x.device, _st(), _dt(x)
+        sums = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        ab = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        mr = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
+        y = torch.empty_like(x)
+        ldfilm = film.stride(0) if film is not None else 0
+        check(L.jg_gn_stats(dt, x.data_ptr(), sums.data_ptr(), B, HW, C, st), "jg_gn_stats")
+        check(L.jg_gn_coef(sums.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, ab.data_ptr(), mr.data_ptr(), B, HW, C,
+                           G, eps, st), "jg_gn_coef")
+        check(L.jg_gn_apply(dt, x.data_ptr(), ab.data_ptr(), y.data_ptr(), B, HW, C, act, st), "jg_gn_apply")
+        ctx.save_for_backward(x, ab, mr, gamma, beta, film)
+        ctx.G, ctx.act = G, act
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, ab, mr, gamma, beta, film = ctx.saved_tensors
+        L = _lib.lib()
+        dy = dy.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        dev, st, dt = x.device, _st(), _dt(x)
+        red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        pqr = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
+        want_film = film is not None and ctx.needs_input_grad[3]
+        dfilm = torch.empty((B, 2 * C), device=dev, dtype=torch.float32) if want_film else None
+        dgamma = gamma.grad if (gamma is not None and ctx.needs_input_grad[1]) else None
+        dbeta = beta.grad if (beta is not None and ctx.needs_input_grad[2]) else None
+        if (gamma is not None and ctx.needs_input_grad[1] and dgamma is None):
+            raise RuntimeError("norm weight has no arena-backed .grad")
+        ldfilm = film.stride(0) if film is not None else 0
+        check(L.jg_gn_bwd_reduce(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), red.data_ptr(), B, HW, C, ctx.act, st),
+              "jg_gn_bwd_reduce")
+        check(L.jg_gn_bwd_coef(red.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, mr.data_ptr(), pqr.data_ptr(),
+                               _p(dgamma), _p(dbeta), _p(dfilm), 2 * C, B, HW, C, ctx.G, st), "jg_gn_bwd_coef")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.jg_gn_bwd_apply(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), pqr.data_ptr(), dx.data_ptr(), B, HW,
+                                    C, ctx.act, st), "jg_gn_bwd_apply")
+        return dx, None, None, dfilm, None, None, None
+
+
+def group_norm(x, G, gamma=None, beta=None, film=None, act=JG_ACT_NONE, eps=1e-5):
+    """act(GroupNorm_G(x) * gamma + beta [* (1 + scale) + shift]); statistics in fp32."""
+    return _GroupNormFn.apply(x, gamma, beta, film, G, act, eps)
+
+
+# ======================================================================================
+# resampling / concat
+# ======================================================================================
+def _pool(x, scale):
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, H // 2, W // 2, Cc), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_pool2x2(_dt(x), x.data_ptr(), y.data_ptr(), B, H, W, Cc, scale, _st()), "jg_pool2x2")
+    return y
+
+
+def _up(x, scale):
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, H * 2, W * 2, Cc), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_upsample2x(_dt(x), x.data_ptr(), y.data_ptr(), B, H, W, Cc, scale, _st()), "jg_upsample2x")
+    return y
+
+
+class _AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _pool(x, 0.25)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        return _up(dy.contiguous(), 0.25)
+
+
+class _Upsample2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _up(x, 1.0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        return _pool(dy.contiguous(), 1.0)
+
+
+def avg_pool2(x):
+    return _AvgPool2Fn.apply(x)
+
+
+def upsample_nearest2(x):
+    return _Upsample2Fn.apply(x)
+
+
+def copy_channels(src, soff, dst, doff, n):
+    P = src.numel() // src.shape[-1]
+    check(_lib.lib().jg_copy_channels(_dt(src), src.data_ptr(), src.shape[-1], soff, dst.data_ptr(), dst.shape[-1], doff, P,
+                                      n, _st()), "jg_copy_channels")
+
+
+class _CatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        Ca, Cb = a.shape[-1], b.shape[-1]
+        y = torch.empty(a.shape[:-1] + (Ca + Cb,), device=a.device, dtype=a.dtype)
+        copy_channels(a, 0, y, 0, Ca)
+        copy_channels(b, 0, y, Ca, Cb)
+        ctx.Ca, ctx.Cb = Ca, Cb
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(dy.shape[:-1] + (ctx.Ca,), device=dy.device, dtype=dy.dtype)
+            copy_channels(dy, 0, da, 0, ctx.Ca)
+        if ctx.needs_input_grad[1]:
+            db = torch.empty(dy.shape[:-1] + (ctx.Cb,), device=dy.device, dtype=dy.dtype)
+            copy_channels(dy, ctx.Ca, db, 0, ctx.Cb)
+        return da, db
+
+
+def cat_channels(a, b):
+    """torch.cat([a, b], dim=1) of the reference (NCHW) == last-dim concat in NHWC."""
+    return _CatFn.apply(a, b)
+
+
+# ======================================================================================
+# attention core (QKVAttentionLegacy)
+# ======================================================================================
+def _gemm_geom(M, N, K):
+    return dict(B=1, H=1, W=M, Cin=K, Cout=N, R=1, S=1, pad=0, stride=1, Ho=1, Wo=M)
+
+
+def _transpose_heads(qkv, coff, nh, ch):
+    B, T, C3 = qkv.shape
+    out = torch.empty((B * nh, ch, T), device=qkv.device, dtype=qkv.dtype)
+    check(_lib.lib().jg_transpose_heads(_dt(qkv), qkv.data_ptr(), C3, coff, 3 * ch, out.data_ptr(), B, T, nh, ch, _st()),
+          "jg_transpose_heads")
+    return out
+
+
+class _AttnCoreFn(torch.autograd.Function):
+    """qkv [B,T,3C] in the LEGACY head layout (channel = h*3ch + {q: 0..ch, k: ch..2ch, v: 2ch..3ch},
+    unet_generator_attn.py:340) -> a [B,T,C] (channel = h*ch + c)."""
+
+    @staticmethod
+    def forward(ctx, qkv, nh):
+        _require_cuda(qkv)
+        L = _lib.lib()
+        B, T, C3 = qkv.shape
+        Cc = C3 // 3
+        ch = Cc // nh
+        BH = B * nh
+        dev, dt = qkv.device, _dt(qkv)
+        scale2 = 1.0 / math.sqrt(ch)  # (ch^-1/4)^2
+        S = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
+        conv_nt(qkv, qkv, S, **_gemm_geom(T, T, ch), ldx=C3, ldw=C3, ldy=T, alpha=scale2, out_f32=True, nbatch=BH, nh=nh,
+                sx=(T * C3, 3 * ch), sw=(T * C3, 3 * ch), sy=(nh * T * T, T * T), w_off=ch)
+        P = torch.empty((BH, T, T), device=dev, dtype=qkv.dtype)
+        check(L.jg_softmax_fwd(dt, S.data_ptr(), P.data_ptr(), BH * T, T, _st()), "jg_softmax_fwd")
+        del S
+        Vt = _transpose_heads(qkv, 2 * ch, nh, ch)
+        a = torch.empty((B, T, Cc), device=dev, dtype=qkv.dtype)
+        conv_nt(P, Vt, a, **_gemm_geom(T, ch, T), ldx=T, ldw=T, ldy=Cc, nbatch=BH, nh=nh, sx=(nh * T * T, T * T),
+                sw=(nh * ch * T, ch * T), sy=(T * Cc, ch))
+        ctx.save_for_backward(qkv, P)
+        ctx.nh = nh
+        return a
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, da):
+        qkv, P = ctx.saved_tensors
+        L = _lib.lib()
+        nh = ctx.nh
+        da = da.contiguous()
+        B, T, C3 = qkv.shape
+        Cc = C3 // 3
+        ch = Cc // nh
+        BH = B * nh
+        dev, dt = qkv.device, _dt(qkv)
+        scale2 = 1.0 / math.sqrt(ch)
+        # dP = dA V^T
+        dP = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
+        conv_nt(da, qkv, dP, **_gemm_geom(T, T, ch), ldx=Cc, ldw=C3, ldy=T, out_f32=True, nbatch=BH, nh=nh,
+                sx=(T * Cc, ch), sw=(T * C3, 3 * ch), sy=(nh * T * T, T * T), w_off=2 * ch)
+        dS = torch.empty((BH, T, T), device=dev, dtype=qkv.dtype)
+        check(L.jg_softmax_bwd(dt, P.data_ptr(), dP.data_ptr(), dS.data_ptr(), BH * T, T, scale2, _st()), "jg_softmax_bwd")
+        del dP
+        dqkv = torch.empty_like(qkv)
+        # dQ = dS K      (NT with K^T as the "weight" operand)
+        Kt = _transpose_heads(qkv, ch, nh, ch)
+        conv_nt(dS, Kt, dqkv, **_gemm_geom(T, ch, T), ldx=T, ldw=T, ldy=C3, nbatch=BH, nh=nh, sx=(nh * T * T, T * T),
+                sw=(nh * ch * T, ch * T), sy=(T * C3, 3 * ch))
+        # dK = dS^T Q ; dV = P^T dA     (TN: reduction index t is the row index of both operands)
+        geom = dict(B=1, H=1, W=T, Cin=ch, Cout=T, R=1, S=1, pad=0, stride=1, Ho=1, Wo=T)
+        wgrad_tn(dS, qkv, dqkv, **geom, lddy=T, ldx=C3, lddw=C3, nbatch=BH, nh=nh, sdy=(nh * T * T, T * T),
+                 sx=(T * C3, 3 * ch), sdw=(T * C3, 3 * ch), out_mode=JG_OUT_STORE_T, dw_off=ch)
+        wgrad_tn(P, da, dqkv, **geom, lddy=T, ldx=Cc, lddw=C3, nbatch=BH, nh=nh, sdy=(nh * T * T, T * T),
+                 sx=(T * Cc, ch), sdw=(T * C3, 3 * ch), out_mode=JG_OUT_STORE_T, dw_off=2 * ch)
+        return dqkv, None
+
+
+def attention_core(qkv, n_heads):
+    return _AttnCoreFn.apply(qkv, n_heads)
+
+
+# ======================================================================================
+# small fp32 linear (embedding path)
+# ======================================================================================
+class _LinearFn(torch.autograd.Function):
+    """inputs: x, W, b, act, dW, db, *track -- dW/db are the arena gradient views the kernel accumulates
+    into; `track` are the nn.Parameters behind W/b, passed only so that autograd records the node."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, dW, db, *track):
+        _require_cuda(x, W)
+        x = x.contiguous()
+        Bn, K = x.shape
+        N = W.shape[0]
+        y = torch.empty((Bn, N), device=x.device, dtype=torch.float32)
+        check(_lib.lib().jg_linear_fwd(x.data_ptr(), W.data_ptr(), _p(b), y.data_ptr(), Bn, K, N, act, _st()),
+              "jg_linear_fwd")
+        ctx.save_for_backward(x, W)
+        ctx.act, ctx.dW, ctx.db = act, dW, db
+        ctx.want_param = any(t is not None and t.requires_grad for t in track)
+        ctx.ntrack = len(track)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        Bn, K = x.shape
+        N = W.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.want_param:
+            dW, db = ctx.dW, ctx.db
+            if dW is None:
+                raise RuntimeError("linear weight has no arena-backed .grad")
+        if dx is not None or dW is not None:
+            check(_lib.lib().jg_linear_bwd(x.data_ptr(), W.data_ptr(), dy.data_ptr(), _p(dx), _p(dW), _p(db), Bn, K, N,
+                                           ctx.act, _st()), "jg_linear_bwd")
+        return (dx, None, None, None, None, None) + (None,) * ctx.ntrack
+
+
+def linear(x, weight, bias=None, act=JG_ACT_NONE):
+    """y = act(x) @ weight.T + bias in fp32 (nn.Linear preceded by an optional SiLU)."""
+    track = (weight,) if bias is None else (weight, bias)
+    return _LinearFn.apply(x, weight, bias, act, weight.grad, None if bias is None else bias.grad, *track)
+
+
+def linear_stacked(x, W, b, dW, db, act, track):
+    """Several nn.Linear layers that share their input, run as one: W/b/dW/db are stacked arena views."""
+    return _LinearFn.apply(x, W, b, act, dW, db, *track)
+
+
+def gamma_embedding(gammas, dim, max_period=10000.0):
+    """models/modules/diffusion_utils.py:8-42 for gammas [B,1] (or [B])."""
+    g = gammas.reshape(-1).contiguous().float()
+    emb = torch.empty((g.shape[0], dim), device=g.device, dtype=torch.float32)
+    check(_lib.lib().jg_gamma_embedding(g.data_ptr(), emb.data_ptr(), g.shape[0], dim, float(max_period), _st()),
+          "jg_gamma_embedding")
+    return emb
+
+
+# ======================================================================================
+# DDPM glue + layout converters
+# ======================================================================================
+def ddpm_prepare(y0, ycond, noise, mask, gammas, act_dtype, cpad=8):
+    _require_cuda(y0, ycond, noise)
+    B, Cc, H, W = y0.shape
+    xin = torch.empty((B, H, W, cpad), device=y0.device, dtype=act_dtype)
+    m = None
+    if mask is not None:
+        m = mask.contiguous()
+        if m.dtype != torch.int64:
+            m = m.long()
+    check(_lib.lib().jg_ddpm_prepare(_DT[act_dtype], y0.contiguous().data_ptr(), ycond.contiguous().data_ptr(),
+                                     noise.contiguous().data_ptr(), _p(m), gammas.contiguous().data_ptr(), xin.data_ptr(), B,
+                                     Cc, H, W, cpad, _st()), "jg_ddpm_prepare")
+    return xin
+
+
+class _MSELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nh, noise, mask, w, lam, grad_scale, Cc):
+        B, H, W, cpad = nh.shape
+        loss = torch.zeros((), device=nh.device, dtype=torch.float32)
+        dnh = torch.empty_like(nh)
+        check(_lib.lib().jg_ddpm_mse_loss(_dt(nh), noise.data_ptr(), nh.data_ptr(), _p(mask), _p(w), loss.data_ptr(),
+                                          dnh.data_ptr(), B, Cc, H, W, cpad, lam, grad_scale, _st()), "jg_ddpm_mse_loss")
+        ctx.save_for_backward(dnh)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        (dnh,) = ctx.saved_tensors
+        gout = gout.contiguous().float()
+        return axpby(dnh, 1.0, alpha_dev=gout), None, None, None, None, None, None
+
+
+def ddpm_mse_loss(noise_hat_nhwc, noise, mask, w=None, lam=1.0, grad_scale=1.0):
+    """lambda * MSE(w m noise, w m noise_hat) with its gradient produced in the same pass."""
+    m = None
+    if mask is not None:
+        m = mask.contiguous()
+        if m.dtype != torch.int64:
+            m = m.long()
+    wv = None if w is None else w.reshape(-1).contiguous().float()
+    return _MSELossFn.apply(noise_hat_nhwc, noise.contiguous(), m, wv, float(lam), float(grad_scale), noise.shape[1])
+
+
+class _ToNCHWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Cc):
+        B, H, W, cpad = x.shape
+        y = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+        check(_lib.lib().jg_nhwc_to_nchw_f32(_dt(x), x.data_ptr(), y.data_ptr(), B, Cc, H, W, cpad, _st()), "nhwc_to_nchw")
+        ctx.cpad, ctx.dtype = cpad, x.dtype
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        return to_nhwc(dy.contiguous().float(), ctx.dtype, ctx.cpad), None
+
+
+def to_nchw_f32(x, Cc):
+    return _ToNCHWFn.apply(x, Cc)
+
+
+def to_nhwc(x, act_dtype, cpad=None):
+    """NCHW fp32 -> NHWC 16-bit with the channel count padded to `cpad` (multiple of 8). No autograd."""
+    B, Cc, H, W = x.shape
+    cpad = cpad or (Cc + 7) // 8 * 8
+    y = torch.empty((B, H, W, cpad), device=x.device, dtype=act_dtype)
+    check(_lib.lib().jg_nchw_f32_to_nhwc(_DT[act_dtype], x.contiguous().data_ptr(), y.data_ptr(), B, Cc, H, W, cpad, _st()),
+          "nchw_to_nhwc")
+    return y
+
+
+# ======================================================================================
+# torch.ops.jg355.* -- the op surface north_star names (forward kernels; autograd lives above)
+# ======================================================================================
+_TORCH_LIB = None
+
+
+def register_torch_ops():
+    global _TORCH_LIB
+    if _TORCH_LIB is not None:
+        return
+    tl = torch.library.Library("jg355", "DEF")
+    tl.define("conv2d_nt(Tensor x, Tensor w, Tensor? bias, Tensor? res, int pad, int stride, float alpha, float res_scale) -> Tensor")
+    tl.define("group_norm_act(Tensor x, Tensor? gamma, Tensor? beta, Tensor? film, int groups, int act, float eps) -> Tensor")
+    tl.define("attention_core(Tensor qkv, int heads) -> Tensor")
+    tl.define("avg_pool2(Tensor x) -> Tensor")
+    tl.define("upsample_nearest2(Tensor x) -> Tensor")
+
+    def _conv(x, w, bias, res, pad, stride, alpha, res_scale):
+        B, H, W, Cin = x.shape
+        Cout, R, S, _ = w.shape
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
+        conv_nt(x, w, y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, pad=pad, stride=stride, Ho=Ho, Wo=Wo, ldx=Cin,
+                ldw=R * S * Cin, ldy=Cout, bias=bias, res=res, ldres=Cout, alpha=alpha, res_scale=res_scale)
+        return y
+
+    tl.impl("conv2d_nt", _conv, "CUDA")
+    tl.impl("group_norm_act", lambda x, g, b, f, G, act, eps: _GroupNormFn.apply(x, g, b, f, G, act, eps), "CUDA")
+    tl.impl("attention_core", lambda qkv, h: _AttnCoreFn.apply(qkv, h), "CUDA")
+    tl.impl("avg_pool2", lambda x: _pool(x, 0.25), "CUDA")
+    tl.impl("upsample_nearest2", lambda x: _up(x, 1.0), "CUDA")
+    _TORCH_LIB = tl
+
+
+register_torch_ops()

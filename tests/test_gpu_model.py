@@ -1,0 +1,234 @@
+"""GPU parity tests, model level: the HIP UNet / DiffusionGenerator / PaletteModel step against
+(1) the golden fixtures produced by the unmodified reference and (2) the CPU oracle on larger
+seeded inputs.  All calls go through the C ABI (libjg355.so via ctypes)."""
+import os
+
+import pytest
+import torch
+
+import jg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CFGS = ["tiny_eff", "tiny_noeff", "tiny_attn"]
+# model-level tolerances (norm-wise relative): errors of ~60 16-bit layers compound
+TOL_OUT = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+TOL_GRAD = {torch.float16: 1.5e-2, torch.bfloat16: 8e-2}
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def overrides_of(c, **extra):
+    d = dict(G_ngf=c["ngf"], G_unet_mha_channel_mults=c["mults"], G_unet_mha_res_blocks=c["res_blocks"],
+             G_unet_mha_attn_res=c["attn_res"], G_unet_mha_vit_efficient=c["efficient"], data_crop_size=c["S"],
+             train_batch_size=c["B"])
+    d.update(extra)
+    return d
+
+
+def cfg_of(c):
+    return O.UNetCfg(in_channel=6, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"],
+                     attn_res=c["attn_res"], channel_mults=c["mults"], efficient=c["efficient"])
+
+
+def build_net(c, dtype, golden_dir):
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    opt = opt_from_json({}, overrides_of(c))
+    net = define_G(**vars(opt))
+    sched = load(golden_dir, "schedule.pt")
+    sd = net.state_dict()
+    for k in sd:  # schedule buffers of this implementation == the reference's, bit for bit
+        if O._is_buffer(k):
+            assert torch.equal(sd[k], sched[k.split(".")[-1]]), k
+    syn = O.synth_state_dict(sd, seed=0)
+    net.load_state_dict(syn)
+    net.jg_finalize(torch.device("cuda:0"), dtype)
+    return net, syn
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", CFGS)
+def test_unet_vs_reference_golden(golden_dir, name, dtype):
+    """UNet forward/backward against the reference's own outputs (tests/golden/unet_*.pt)."""
+    from joligen_amd import ops
+
+    g = load(golden_dir, f"unet_{name}.pt")
+    net, _ = build_net(g["cfg"], dtype, golden_dir)
+    unet = net.denoise_fn.model
+    net.arena.ensure_fresh()
+    d = torch.device("cuda:0")
+    x = ops.to_nhwc(g["x"].to(d), dtype, 8).requires_grad_(True)
+    emb = g["emb"].to(d).requires_grad_(True)
+    out = unet(x, emb)
+    e_out = relerr(ops.to_nchw_f32(out, 3), g["out"])
+    assert e_out < TOL_OUT[dtype], ("out", name, e_out)
+    R8 = ops.to_nhwc(g["R"].to(d), dtype, 8)
+    out.backward(R8)
+    torch.cuda.synchronize()
+    e_dx = relerr(x.grad.permute(0, 3, 1, 2)[:, :6], g["dx"])
+    e_demb = relerr(emb.grad, g["demb"])
+    assert e_dx < TOL_GRAD[dtype], ("dx", name, e_dx)
+    assert e_demb < TOL_GRAD[dtype], ("demb", name, e_demb)
+    bad = []
+    for k, ref in g["grad_checks"].items():
+        v = dict(unet.named_parameters())[k].grad.detach().float().cpu()
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        tol = TOL_GRAD[dtype] * float(ref[0]) + 1e-6
+        if abs(float(mine[0] - ref[0])) > tol or abs(float(mine[1] - ref[1])) > 2 * tol:
+            bad.append((k, mine.tolist(), ref.tolist()))
+    assert not bad, bad[:6]
+
+
+@pytest.mark.parametrize("name", CFGS)
+def test_diffusion_generator_vs_reference_golden(golden_dir, name):
+    g = load(golden_dir, f"diffgen_{name}.pt")
+    dtype = torch.float16
+    net, _ = build_net(g["cfg"], dtype, golden_dir)
+    d = torch.device("cuda:0")
+    with torch.no_grad():
+        noise, noise_hat, w = net(g["B"].to(d), g["A"].to(d), g["mask"].to(d), g["noise"].to(d), t=g["t"], u=g["u"])
+    assert torch.equal(noise.cpu(), g["noise"])
+    e = relerr(noise_hat, g["noise_hat"])
+    assert e < TOL_OUT[dtype], e
+    assert relerr(w, g["min_snr_w"]) < 1e-6
+
+
+class _Opt:
+    pass
+
+
+def make_model(c, dtype_name, golden_dir, hp=None, **extra):
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    ov = overrides_of(c, model_type="palette", gpu_ids="0", jg_act_dtype=dtype_name, train_optim="adamw",
+                      train_G_ema=True, train_iter_size=1, checkpoints_dir="/tmp/jg_amd_ckpt/", name="t")
+    if hp:
+        ov.update(train_G_lr=hp["lr"], train_beta1=hp["beta1"], train_beta2=hp["beta2"], train_optim_eps=hp["eps"],
+                  train_optim_weight_decay=hp["weight_decay"], train_G_ema_beta=hp["ema_beta"],
+                  alg_diffusion_lambda_G=hp["lambda_G"], train_optim=hp["optim"])
+    ov.update(extra)
+    opt = opt_from_json({}, ov)
+    model = create_model(opt, 0)
+    sd = model.netG_A.state_dict()
+    model.netG_A.load_state_dict(O.synth_state_dict(sd, seed=0))
+    model.setup(opt)
+    model.single_gpu()
+    return model
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", CFGS)
+def test_palette_three_steps_vs_reference_golden(golden_dir, name, dtype_name):
+    """3 x optimize_parameters() (AdamW + EMA) with the reference's injected (t, u, noise):
+    loss per step and per-parameter checksums after steps 1 and 3."""
+    g = load(golden_dir, f"palette_step_{name}.pt")
+    model = make_model(g["cfg"], dtype_name, golden_dir, g["hp"])
+    dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
+    for it, s in enumerate(g["steps"]):
+        model.rng_injection = lambda b, s=s: (s["t"], s["u"], s["noise"])
+        model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "A_img_paths": ["x"]})
+        model.optimize_parameters()
+        loss = float(model.get_current_losses()["G_tot"])
+        # Adam's first steps are sign-like (|update| ~ lr for every weight), so 16-bit gradient noise on
+        # near-zero gradients moves a few weights the other way: compare losses with a loose bound
+        assert abs(loss - float(s["loss"])) < (0.02 if dtype == torch.float16 else 0.06) * abs(float(s["loss"])), (it, loss, float(s["loss"]))
+        if "param_checks" in s:
+            params = dict(model.netG_A.named_parameters())
+            ema = dict(model.netG_A_ema.named_parameters())
+            for k, ref in s["param_checks"].items():
+                v = params[k].detach().float().cpu()
+                assert abs(float(v.norm() - ref[0])) < 2e-3 * float(ref[0]) + 1e-5, (it, k)
+                ve = ema[k].detach().float().cpu()
+                assert abs(float(ve.norm() - s["ema_checks"][k][0])) < 2e-3 * float(s["ema_checks"][k][0]) + 1e-5, (it, k)
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16"])
+def test_first_step_gradients_vs_oracle_medium(golden_dir, dtype_name):
+    """A larger seeded case than the fixtures (64x64, B=2, ngf 32, 3 levels) against the CPU oracle:
+    loss, noise_hat and every parameter gradient of the first step."""
+    c = dict(ngf=32, mults=[1, 2, 4], res_blocks=[2, 2, 1], attn_res=[16], efficient=True, S=64, B=2)
+    model = make_model(c, dtype_name, golden_dir, train_G_ema=False)
+    net = model.netG_A
+    g = torch.Generator().manual_seed(5)
+    Bimg = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    mask = torch.zeros(2, 1, 64, 64, dtype=torch.int64)
+    mask[:, :, 10:40, 20:50] = 1
+    A = Bimg * (1 - mask) + torch.randn(2, 3, 64, 64, generator=g) * mask
+    t, u, noise = O.draw_step_randomness(torch.Generator().manual_seed(9), Bimg, 2000)
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    tr = O.OraclePaletteTrainer(sd, cfg_of(c), ema_beta=None)
+    loss_ref, grads_ref, nh_ref = tr.loss_and_grads(Bimg, A, mask, noise, t, u)
+    model.rng_injection = lambda b: (t, u, noise)
+    model.set_input({"A": A, "B": Bimg, "B_label_mask": mask})
+    model.compute_palette_loss()
+    model.loss_G_tot.backward()
+    torch.cuda.synchronize()
+    assert abs(float(model.loss_G_tot) - float(loss_ref)) < 5e-3 * float(loss_ref)
+    scale = model.loss_scale
+    worst = []
+    for k, p in net.named_parameters():
+        gr = grads_ref[k]
+        if float(gr.norm()) < 1e-12:
+            continue
+        e = relerr(p.grad / scale, gr)
+        worst.append((e, k))
+    worst.sort(reverse=True)
+    assert worst[0][0] < 6e-2, worst[:8]
+    med = sorted(e for e, _ in worst)[len(worst) // 2]
+    assert med < 1.5e-2, med
+
+
+def test_checkpoint_roundtrip_reference_layout(golden_dir, tmp_path):
+    """save_networks writes `<suffix>_net_G_A.pth` with the reference's keys, plain contiguous
+    fp32 tensors in the reference's logical (OIHW) layout, loadable by both sides."""
+    g = load(golden_dir, "palette_step_tiny_eff.pt")
+    model = make_model(g["cfg"], "bf16", golden_dir, checkpoints_dir=str(tmp_path) + "/", name="ck")
+    s = g["steps"][0]
+    model.rng_injection = lambda b: (s["t"], s["u"], s["noise"])
+    model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"]})
+    model.optimize_parameters()
+    model.save_networks("latest")
+    sd = torch.load(os.path.join(str(tmp_path), "ck", "latest_net_G_A.pth"), map_location="cpu")
+    assert list(sd.keys()) == g["keys"]
+    for k, v in sd.items():
+        assert tuple(v.shape) == g["shapes"][k] and v.is_contiguous() and v.dtype in (torch.float32,), k
+    ema = torch.load(os.path.join(str(tmp_path), "ck", "latest_net_G_A_ema.pth"), map_location="cpu")
+    assert list(ema.keys()) == g["keys"]
+    model2 = make_model(g["cfg"], "bf16", golden_dir, checkpoints_dir=str(tmp_path) + "/", name="ck")
+    model2.load_networks("latest")
+    for (k, a), (_, b) in zip(model.netG_A.state_dict().items(), model2.netG_A.state_dict().items()):
+        assert torch.equal(a, b), k
+    # the oracle consumes the checkpoint as is
+    tr = O.OraclePaletteTrainer(sd, cfg_of(g["cfg"]))
+    assert set(tr.P) == set(g["keys"])
+
+
+def test_full_size_properties():
+    """BASELINE config-2 layer sizes (B=4 instead of 32 to bound test time): properties that do not
+    need the CPU oracle -- linearity of the conv kernels and agreement of the MFMA conv with
+    PyTorch's own fp32 GPU convolution at 256x256."""
+    import torch.nn.functional as F
+
+    from joligen_amd import ops
+
+    d = torch.device("cuda:0")
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(3)
+    for (B, S, Cin, Cout) in [(4, 256, 64, 64), (4, 128, 128, 128), (4, 32, 512, 512)]:
+        x = torch.randn(B, S, S, Cin, generator=g).to(dtype).to(d)
+        w = (torch.randn(Cout, 3, 3, Cin, generator=g) / (3 * Cin ** 0.5)).to(dtype).to(d)
+        y = torch.ops.jg355.conv2d_nt(x, w, None, None, 1, 1, 1.0, 0.0)
+        y2 = torch.ops.jg355.conv2d_nt(x, w, None, None, 1, 1, 2.0, 0.0)
+        assert relerr(y2.float(), 2 * y.float()) < 4e-3          # linearity in alpha
+        ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+        assert relerr(y.float(), ref) < 8e-3, (B, S, Cin, Cout)

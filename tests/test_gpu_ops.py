@@ -1,0 +1,410 @@
+"""GPU parity tests, op level: every HIP kernel through the C ABI (ctypes) against a plain PyTorch
+fp32 reference of the same op on the same (16-bit-rounded) inputs.
+
+Tolerances (norm-wise relative error ||a-b|| / ||b||):
+  fp16: 1e-3  (BASELINE.json north_star: "within 1e-3 rel fp16")
+  bf16: 8e-3  (8-bit mantissa: one output rounding is 2^-9 = 2e-3 per element)
+Index / mask / layout ops (copy, concat, pool-of-exact-values, transposes) are checked bit-exact.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, pad, stride
+    (2, 16, 16, 32, 64, 3, 1, 1),
+    (1, 10, 12, 64, 128, 3, 1, 1),     # ragged M (120 pixels), 128-wide N tile
+    (2, 8, 8, 256, 512, 3, 1, 1),      # multi N-tile, long K
+    (2, 16, 16, 8, 64, 3, 1, 1),       # stem-like: Cin 8 (K = 72, not a multiple of 32)
+    (2, 16, 16, 64, 8, 3, 1, 1),       # head-like: Cout 8
+    (2, 12, 12, 64, 192, 1, 0, 1),     # 1x1
+    (2, 16, 16, 24, 40, 3, 1, 1),      # odd channel counts (multiples of 8)
+    (2, 16, 16, 32, 64, 3, 1, 2),      # stride 2 forward
+    (1, 9, 9, 16, 32, 4, 1, 1),        # 4x4 kernel
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_forward(case, dtype):
+    from joligen_amd import ops
+
+    B, H, W, Cin, Cout, k, pad, stride = case
+    x = rnd((B, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, k, k), dtype, 2, 1.0 / math.sqrt(Cin * k * k))
+    bias = rnd((Cout,), torch.float32, 3)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = rnd((B, Cout, Ho, Wo), dtype, 4)
+    ref = 0.5 * F.conv2d(x.float(), w.float(), None, stride, pad) + bias.view(1, -1, 1, 1) + 0.7 * res.float()
+    d = dev()
+    y = torch.ops.jg355.conv2d_nt(nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d), bias.to(d), nhwc(res).to(d),
+                                  pad, stride, 0.5, 0.7)
+    torch.cuda.synchronize()
+    e = relerr(nchw(y), ref)
+    assert e < TOL[dtype], (case, dtype, e)
+    # no bias / no residual path
+    y2 = torch.ops.jg355.conv2d_nt(nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d), None, None, pad, stride, 1.0, 0.0)
+    e2 = relerr(nchw(y2), F.conv2d(x.float(), w.float(), None, stride, pad))
+    assert e2 < TOL[dtype], (case, dtype, e2)
+
+
+def _make_conv_module(Cin, Cout, k, pad, dtype, real_cin=None, real_cout=None, needs_dgrad=True):
+    """A JGConv2d inside a tiny module finalised by a ParamArena (exercises padding + refresh)."""
+    import torch.nn as nn
+
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.modules.layers import JGConv2d
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = JGConv2d(real_cin or Cin, real_cout or Cout, k, padding=pad, needs_dgrad=needs_dgrad)
+
+    m = M()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        m.c.weight.copy_((torch.randn(m.c.weight.shape, generator=g) / math.sqrt(Cin * k * k)).to(dtype).float())
+        m.c.bias.copy_(torch.randn(m.c.bias.shape, generator=g) * 0.1)
+    w_ref, b_ref = m.c.weight.detach().clone(), m.c.bias.detach().clone()
+    arena = ParamArena(m, dev(), dtype, priority=())
+    arena.refresh()
+    return m, arena, w_ref, b_ref
+
+
+BWD_CASES = [
+    (2, 16, 16, 32, 64, 3, 1),
+    (1, 10, 12, 64, 128, 3, 1),   # Wo % 4 == 0 but ragged pixel count (120)
+    (2, 9, 7, 32, 32, 3, 1),      # Wo % 4 != 0 -> per-pixel decomposition path of wgrad
+    (2, 8, 8, 256, 512, 3, 1),
+    (3, 16, 16, 64, 64, 1, 0),
+    (2, 32, 32, 64, 64, 3, 1),    # several split-K slices
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", BWD_CASES)
+def test_conv_backward(case, dtype):
+    from joligen_amd import ops
+
+    B, H, W, Cin, Cout, k, pad = case
+    m, arena, w_ref, b_ref = _make_conv_module(Cin, Cout, k, pad, dtype)
+    x = rnd((B, Cin, H, W), dtype, 11)
+    gy = rnd((B, Cout, H + 2 * pad - k + 1, W + 2 * pad - k + 1), dtype, 12)
+    xr = x.float().requires_grad_(True)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b_ref.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, 1, pad)
+    yr.backward(gy.float())
+    xd = nhwc(x).to(dev()).requires_grad_(True)
+    y = m.c(xd)
+    assert relerr(nchw(y), yr.detach()) < TOL[dtype]
+    y.backward(nhwc(gy).to(dev()))
+    torch.cuda.synchronize()
+    e_dx = relerr(nchw(xd.grad), xr.grad)
+    e_dw = relerr(m.c.weight.grad, wr.grad)
+    e_db = relerr(m.c.bias.grad, br.grad)
+    assert e_dx < TOL[dtype], ("dx", case, e_dx)
+    assert e_dw < TOL[dtype], ("dw", case, e_dw)
+    assert e_db < TOL[dtype], ("db", case, e_db)
+    # gradient accumulation: a second backward adds into the arena
+    y2 = m.c(xd)
+    y2.backward(nhwc(gy).to(dev()))
+    assert relerr(m.c.weight.grad, 2 * wr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_padded_channels(dtype):
+    """stem (Cin 6 -> 8) and head (Cout 3 -> 8): padded working copies, unpadded master grads."""
+    B, H, W = 2, 16, 16
+    # stem
+    m, arena, w_ref, b_ref = _make_conv_module(8, 64, 3, 1, dtype, real_cin=6, needs_dgrad=False)
+    x6 = rnd((B, 6, H, W), dtype, 21)
+    x8 = torch.cat([x6, torch.zeros(B, 2, H, W, dtype=dtype)], 1)
+    gy = rnd((B, 64, H, W), dtype, 22)
+    wr = w_ref.clone().requires_grad_(True)
+    yr = F.conv2d(x6.float(), wr, b_ref, 1, 1)
+    yr.backward(gy.float())
+    xd = nhwc(x8).to(dev())
+    y = m.c(xd)
+    assert relerr(nchw(y), yr.detach()) < TOL[dtype]
+    y.backward(nhwc(gy).to(dev()))
+    assert tuple(m.c.weight.grad.shape) == (64, 6, 3, 3)
+    assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype]
+    # head
+    m, arena, w_ref, b_ref = _make_conv_module(64, 8, 3, 1, dtype, real_cout=3)
+    x = rnd((B, 64, H, W), dtype, 23)
+    gy3 = rnd((B, 3, H, W), dtype, 24)
+    gy8 = torch.cat([gy3, torch.zeros(B, 5, H, W, dtype=dtype)], 1)
+    xr = x.float().requires_grad_(True)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b_ref.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, 1, 1)
+    yr.backward(gy3.float())
+    xd = nhwc(x).to(dev()).requires_grad_(True)
+    y = m.c(xd)
+    assert y.shape[-1] == 8
+    assert relerr(nchw(y)[:, :3], yr.detach()) < TOL[dtype]
+    assert float(nchw(y)[:, 3:].float().abs().max()) == 0.0
+    y.backward(nhwc(gy8).to(dev()))
+    assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype]
+    assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype]
+    assert relerr(m.c.bias.grad, br.grad) < TOL[dtype]
+
+
+GN_CASES = [(2, 16, 16, 64, 32), (2, 8, 8, 512, 32), (3, 5, 7, 32, 32), (2, 16, 16, 192, 32), (2, 64, 1, 96, 96)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("film", [False, True])
+@pytest.mark.parametrize("case", GN_CASES)
+def test_group_norm_forward_backward(case, film, dtype):
+    from joligen_amd import ops
+
+    B, H, W, Cc, G = case
+    d = dev()
+    x = rnd((B, Cc, H, W), dtype, 31) * 1.5 + 0.3
+    gamma = (1 + 0.2 * rnd((Cc,), torch.float32, 32)).to(d).requires_grad_(True)
+    beta = (0.1 * rnd((Cc,), torch.float32, 33)).to(d).requires_grad_(True)
+    gamma.grad = torch.zeros_like(gamma)
+    beta.grad = torch.zeros_like(beta)
+    emb = (0.3 * rnd((B, 2 * Cc + 8), torch.float32, 34)).to(d)
+    gy = rnd((B, Cc, H, W), dtype, 35)
+    act = ops.JG_ACT_SILU
+    # reference
+    xr = x.float().requires_grad_(True)
+    gr = gamma.detach().cpu().clone().requires_grad_(True)
+    br = beta.detach().cpu().clone().requires_grad_(True)
+    er = emb.detach().cpu().clone().requires_grad_(True)
+    h = F.group_norm(xr, G, gr, br, eps=1e-5)
+    if film:
+        sc, sh = er[:, 4:4 + Cc], er[:, 4 + Cc:4 + 2 * Cc]
+        h = h * (1 + sc[:, :, None, None]) + sh[:, :, None, None]
+    yr = F.silu(h)
+    yr.backward(gy.float())
+    # HIP
+    xd = nhwc(x).to(d).requires_grad_(True)
+    ed = emb.clone().requires_grad_(True)
+    fslice = ed[:, 4:4 + 2 * Cc] if film else None   # strided view, like the stacked embedding slices
+    y = ops.group_norm(xd, G, gamma, beta, fslice, act, 1e-5)
+    y.backward(nhwc(gy).to(d))
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), yr.detach()) < TOL[dtype], ("y", case)
+    assert relerr(nchw(xd.grad), xr.grad) < 3 * TOL[dtype], ("dx", case, relerr(nchw(xd.grad), xr.grad))
+    assert relerr(gamma.grad, gr.grad) < 3 * TOL[dtype], ("dgamma", case)
+    assert relerr(beta.grad, br.grad) < 3 * TOL[dtype], ("dbeta", case)
+    if film:
+        assert relerr(ed.grad[:, 4:4 + 2 * Cc], er.grad[:, 4:4 + 2 * Cc]) < 3 * TOL[dtype], ("dfilm", case)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_instance_norm1d(dtype):
+    from joligen_amd import ops
+
+    B, T, Cc = 2, 64, 64
+    x = rnd((B, Cc, T), dtype, 41) * 2 + 0.5
+    gy = rnd((B, Cc, T), dtype, 42)
+    xr = x.float().requires_grad_(True)
+    yr = F.instance_norm(xr, eps=1e-5)
+    yr.backward(gy.float())
+    xd = x.permute(0, 2, 1).contiguous().to(dev()).requires_grad_(True)
+    y = ops.group_norm(xd, Cc, None, None, None, ops.JG_ACT_NONE, 1e-5)
+    y.backward(gy.permute(0, 2, 1).contiguous().to(dev()))
+    assert relerr(y.permute(0, 2, 1), yr.detach()) < TOL[dtype]
+    assert relerr(xd.grad.permute(0, 2, 1), xr.grad) < 3 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resample_and_concat_bit_exact(dtype):
+    from joligen_amd import ops
+
+    d = dev()
+    B, H, W, Cc = 2, 8, 12, 24
+    x = rnd((B, Cc, H, W), dtype, 51)
+    xd = nhwc(x).to(d).requires_grad_(True)
+    up = ops.upsample_nearest2(xd)
+    assert torch.equal(nchw(up).cpu(), F.interpolate(x.float(), scale_factor=2, mode="nearest").to(dtype))
+    gy = rnd((B, Cc, 2 * H, 2 * W), dtype, 52)
+    up.backward(nhwc(gy).to(d))
+    ref = (F.avg_pool2d(gy.float(), 2) * 4)
+    assert relerr(nchw(xd.grad), ref) < TOL[dtype]
+    xd2 = nhwc(x).to(d).requires_grad_(True)
+    pl = ops.avg_pool2(xd2)
+    assert relerr(nchw(pl), F.avg_pool2d(x.float(), 2)) < TOL[dtype]
+    gp = rnd((B, Cc, H // 2, W // 2), dtype, 53)
+    pl.backward(nhwc(gp).to(d))
+    assert relerr(nchw(xd2.grad), F.interpolate(gp.float(), scale_factor=2, mode="nearest") * 0.25) < TOL[dtype]
+    a = rnd((B, H, W, 16), dtype, 54).to(d).requires_grad_(True)
+    b = rnd((B, H, W, 40), dtype, 55).to(d).requires_grad_(True)
+    c = ops.cat_channels(a, b)
+    assert torch.equal(c, torch.cat([a, b], -1))
+    gc = rnd((B, H, W, 56), dtype, 56).to(d)
+    c.backward(gc)
+    assert torch.equal(a.grad, gc[..., :16]) and torch.equal(b.grad, gc[..., 16:])
+
+
+def _attn_ref(qkv_bct, nh):
+    """QKVAttentionLegacy.forward (reference unet_generator_attn.py:331-347) in fp32."""
+    bs, width, length = qkv_bct.shape
+    ch = width // (3 * nh)
+    q, k, v = qkv_bct.reshape(bs * nh, ch * 3, length).split(ch, dim=1)
+    scale = 1 / math.sqrt(math.sqrt(ch))
+    w = torch.einsum("bct,bcs->bts", q * scale, k * scale)
+    w = torch.softmax(w.float(), dim=-1)
+    a = torch.einsum("bts,bcs->bct", w, v)
+    return a.reshape(bs, -1, length)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 64, 64, 2), (1, 256, 128, 4), (2, 96, 64, 2)])
+def test_attention_core(shape, dtype):
+    from joligen_amd import ops
+
+    B, T, Cc, nh = shape
+    if T % 8:
+        pytest.skip("T must be a multiple of 8")
+    qkv = rnd((B, 3 * Cc, T), dtype, 61)
+    ga = rnd((B, Cc, T), dtype, 62)
+    qr = qkv.float().requires_grad_(True)
+    ar = _attn_ref(qr, nh)
+    ar.backward(ga.float())
+    qd = qkv.permute(0, 2, 1).contiguous().to(dev()).requires_grad_(True)
+    a = ops.attention_core(qd, nh)
+    a.backward(ga.permute(0, 2, 1).contiguous().to(dev()))
+    torch.cuda.synchronize()
+    assert relerr(a.permute(0, 2, 1), ar.detach()) < 2 * TOL[dtype], relerr(a.permute(0, 2, 1), ar.detach())
+    assert relerr(qd.grad.permute(0, 2, 1), qr.grad) < 4 * TOL[dtype], relerr(qd.grad.permute(0, 2, 1), qr.grad)
+
+
+def test_linear_and_gamma_embedding():
+    import jg_oracle as O
+    from joligen_amd import ops
+
+    d = dev()
+    B, K, N = 4, 32, 96
+    x = rnd((B, K), torch.float32, 71).to(d).requires_grad_(True)
+    Wt = rnd((N, K), torch.float32, 72).to(d).requires_grad_(True)
+    b = rnd((N,), torch.float32, 73).to(d).requires_grad_(True)
+    Wt.grad, b.grad = torch.zeros_like(Wt), torch.zeros_like(b)
+    gy = rnd((B, N), torch.float32, 74).to(d)
+    y = ops.linear(x, Wt, b, ops.JG_ACT_SILU)
+    y.backward(gy)
+    xr = x.detach().cpu().requires_grad_(True)
+    wr = Wt.detach().cpu().requires_grad_(True)
+    br = b.detach().cpu().requires_grad_(True)
+    yr = F.linear(F.silu(xr), wr, br)
+    yr.backward(gy.cpu())
+    assert relerr(y, yr.detach()) < 1e-5
+    assert relerr(x.grad, xr.grad) < 1e-5
+    assert relerr(Wt.grad, wr.grad) < 1e-5
+    assert relerr(b.grad, br.grad) < 1e-5
+    g = torch.rand(5, 1)
+    e = ops.gamma_embedding(g.to(d), 32)
+    assert relerr(e, O.gamma_embedding(g, 32)) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_ddpm_prepare_and_loss(dtype):
+    import jg_oracle as O
+    from joligen_amd import ops
+
+    d = dev()
+    B, S = 3, 16
+    g = torch.Generator().manual_seed(81)
+    y0 = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    yc = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    noise = torch.randn(B, 3, S, S, generator=g)
+    mask = torch.zeros(B, 1, S, S, dtype=torch.int64)
+    mask[:, :, 3:11, 2:9] = 2      # class ids > 1 must clamp to 1 (bit-exact mask semantics)
+    mask[0, :, 0, 0] = 1
+    gam = torch.rand(B, generator=g) * 0.9 + 0.05
+    xin = ops.ddpm_prepare(y0.to(d), yc.to(d), noise.to(d), mask.to(d), gam.to(d), dtype)
+    sg = gam.view(-1, 1, 1, 1)
+    yn = sg.sqrt() * y0 + (1 - sg).sqrt() * noise
+    m = mask.clamp(0, 1).float()
+    yn = yn * m + (1 - m) * y0
+    ref = torch.cat([yc, yn, torch.zeros(B, 2, S, S)], 1)
+    assert relerr(nchw(xin), ref.to(dtype)) < 2e-3 if dtype == torch.bfloat16 else relerr(nchw(xin), ref.to(dtype)) < 3e-4
+    assert float(xin[..., 6:].float().abs().max()) == 0.0
+    # exactly-unmasked pixels are exact copies of y0 (mask semantics are bit-exact)
+    keep = (m == 0).expand(B, 3, S, S)
+    assert torch.equal(nchw(xin)[:, 3:6].cpu()[keep], y0.to(dtype)[keep])
+    # loss + gradient
+    nh = rnd((B, S, S, 8), dtype, 82)
+    w = torch.rand(B, generator=g) + 0.5
+    nhd = nh.to(d).requires_grad_(True)
+    loss = ops.ddpm_mse_loss(nhd, noise.to(d), mask.to(d), w.to(d), lam=1.5, grad_scale=64.0)
+    (loss / 2).backward()
+    nhr = nh.float()[..., :3].permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    lr = O.palette_loss(noise, nhr, mask, w.view(-1, 1, 1, 1), 1.5)
+    (lr / 2).backward()
+    assert abs(float(loss) - float(lr)) < 1e-4 * abs(float(lr)) + 1e-7
+    gd = nhd.grad[..., :3].permute(0, 3, 1, 2).float().cpu() / 64.0
+    assert relerr(gd, nhr.grad) < TOL[dtype]
+    assert float(nhd.grad[..., 3:].float().abs().max()) == 0.0
+
+
+def test_adamw_ema_matches_torch_optim():
+    import jg_oracle as O
+    from joligen_amd import _lib
+
+    d = dev()
+    n = 100003
+    g = torch.Generator().manual_seed(91)
+    p0 = torch.randn(n, generator=g)
+    for decoupled, wd in ((1, 0.0), (1, 0.05), (0, 0.05)):
+        p = p0.clone().to(d)
+        m = torch.zeros(n, device=d)
+        v = torch.zeros(n, device=d)
+        ema = p.clone()
+        pr, mr, vr, er = p0.clone(), torch.zeros(n), torch.zeros(n), p0.clone()
+        for step in range(1, 4):
+            gr = torch.randn(n, generator=g)
+            gd = (gr * 8.0).to(d)  # scaled gradient, undone by grad_scale
+            _lib.check(_lib.lib().jg_adamw_ema(p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n,
+                                               2e-3, 0.9, 0.999, 1e-8, wd, decoupled, step, 0.125, 0.99, 1,
+                                               torch.cuda.current_stream().cuda_stream))
+            O.adamw_step([pr], [gr], [mr], [vr], step, 2e-3, 0.9, 0.999, 1e-8, wd, bool(decoupled))
+            O.ema_step([er], [pr], 0.99)
+            assert float(gd.abs().max()) == 0.0  # fused zero_grad
+        assert relerr(p, pr) < 1e-6 and relerr(ema, er) < 1e-6 and relerr(v, vr) < 1e-5
+
+
+def test_c_abi_rejects_bad_arguments():
+    from joligen_amd import _lib
+
+    L = _lib.lib()
+    assert L.jg_version() >= 100
+    assert L.jg_gn_stats(_lib.JG_BF16, None, None, 1, 1, 8, None) == -1
+    assert L.jg_pool2x2(_lib.JG_BF16, 1, 1, 1, 3, 4, 8, 1.0, None) == -1  # odd H
+    assert b"bad argument" in L.jg_strerror(-1)

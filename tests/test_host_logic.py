@@ -1,0 +1,177 @@
+"""CPU: host-side logic that needs no GPU -- the C ABI library loads and exports every symbol
+include/jg355.h declares, module trees reproduce the reference's state_dict keys/shapes, the flat
+parameter arena's views/layout, options flattening, checkpoint hooks."""
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+import jg_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from joligen_amd import _lib
+
+    path = _lib.build()
+    header = open(os.path.join(ROOT, "include", "jg355.h")).read()
+    declared = set(re.findall(r"\b(jg_[a-z0-9_]+)\s*\(", header))
+    declared -= {"jg_stream_t"}
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    nm = subprocess.run(["nm", "-D", path], check=True, capture_output=True, text=True).stdout
+    for name in declared:
+        assert f" T {name}" in nm, name
+    L = _lib.lib()  # dlopen + argtypes; no compute call (no GPU here)
+    assert L.jg_version() >= 100
+    assert b"bad argument" in L.jg_strerror(-1)
+
+
+def test_struct_layout_matches_header():
+    """ctypes mirrors of jg_conv_args / jg_wgrad_args: field order and sizes as in the header."""
+    import ctypes as C
+
+    from joligen_amd._lib import ConvArgs, WgradArgs
+
+    assert C.sizeof(ConvArgs) == 5 * 8 + 11 * 4 + 4 + 4 * 8 + 2 * 4 + 8 * 8 + 3 * 4 + 4  # with natural padding
+    assert ConvArgs.ldx.offset % 8 == 0 and ConvArgs.sxb.offset % 8 == 0
+    assert WgradArgs.lddy.offset % 8 == 0 and WgradArgs.sdyb.offset % 8 == 0
+    hdr = open(os.path.join(ROOT, "include", "jg355.h")).read()
+    body = hdr[hdr.index("typedef struct {"):hdr.index("} jg_conv_args;")]
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
+    assert names == [f[0] for f in ConvArgs._fields_], names
+    body = hdr[hdr.index("} jg_conv_args;"):]
+    body = body[body.index("typedef struct {"):body.index("} jg_wgrad_args;")]
+    names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
+    assert names == [f[0] for f in WgradArgs._fields_], names
+
+
+@pytest.mark.parametrize("name", ["tiny_eff", "tiny_noeff", "tiny_attn"])
+def test_module_tree_has_reference_state_dict(golden_dir, name):
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    g = torch.load(os.path.join(golden_dir, f"palette_step_{name}.pt"), weights_only=False)
+    c = g["cfg"]
+    opt = opt_from_json({}, dict(G_ngf=c["ngf"], G_unet_mha_channel_mults=c["mults"], G_unet_mha_res_blocks=c["res_blocks"],
+                                 G_unet_mha_attn_res=c["attn_res"], G_unet_mha_vit_efficient=c["efficient"],
+                                 data_crop_size=c["S"]))
+    net = define_G(**vars(opt))
+    sd = net.state_dict()
+    assert list(sd.keys()) == g["keys"]
+    for k, v in sd.items():
+        assert tuple(v.shape) == g["shapes"][k], k
+    sched = torch.load(os.path.join(golden_dir, "schedule.pt"), weights_only=False)
+    for k, v in sd.items():
+        if O._is_buffer(k):
+            assert torch.equal(v, sched[k.split(".")[-1]]), k
+    # zero-initialised layers of the reference (zero_module) are zero here too
+    for k, v in sd.items():
+        if k.endswith("out_layers.3.weight") or k.endswith("proj_out.weight") or k.endswith("out.2.weight"):
+            assert float(v.abs().max()) == 0.0, k
+
+
+def test_full_size_network_matches_survey_counts():
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    net = define_G(**vars(opt_from_json({}, dict(data_crop_size=256))))
+    assert sum(p.numel() for p in net.parameters()) == 59346627 + 2112
+    assert len(net.state_dict()) == 338 and len(list(net.parameters())) == 324
+
+
+def test_options_flatten_reference_json_layout():
+    from joligen_amd.options import opt_from_json
+
+    cfg = {"G": {"netG": "unet_mha", "ngf": 32, "unet_mha_vit_efficient": True},
+           "alg": {"diffusion": {"lambda_G": 2.0, "task": "inpainting"}, "palette": {"loss": "MSE"}},
+           "train": {"batch_size": 4, "iter_size": 16, "G_ema": True, "optim": "adamw"},
+           "data": {"crop_size": 128, "online_creation": {"crop_size_A": 128}}, "gpu_ids": "0,1", "model_type": "palette"}
+    opt = opt_from_json(cfg, {"train_iter_size": 1})
+    assert opt.G_ngf == 32 and opt.G_unet_mha_vit_efficient is True and opt.alg_diffusion_lambda_G == 2.0
+    assert opt.train_batch_size == 4 and opt.train_iter_size == 1 and opt.train_G_ema is True
+    assert opt.data_online_creation_crop_size_A == 128 and opt.gpu_ids == [0, 1] and opt.isTrain
+    assert opt_from_json({}, {"gpu_ids": "-1"}).gpu_ids == []
+
+
+def test_param_arena_layout_on_cpu():
+    """The arena itself is plain tensor-view bookkeeping and can be exercised on the CPU device
+    (only refresh()/adamw_step() launch kernels)."""
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    opt = opt_from_json({}, dict(G_ngf=32, G_unet_mha_channel_mults=[1, 2], G_unet_mha_res_blocks=[1, 1], data_crop_size=16))
+    net = define_G(**vars(opt))
+    ref = {k: v.clone() for k, v in net.state_dict().items()}
+    arena = ParamArena(net, "cpu", torch.bfloat16)
+    # values preserved, logical shapes unchanged, conv weights physically KRSC
+    for k, p in net.named_parameters():
+        assert torch.equal(p.detach(), ref[k]), k
+        assert p.grad is not None and p.grad.shape == p.shape
+        off, n = arena.slices[k]
+        assert p.data_ptr() == arena.p.data_ptr() + 4 * off
+        assert p.grad.data_ptr() == arena.g.data_ptr() + 4 * off
+        if p.dim() == 4:
+            O_, I, R, S = p.shape
+            assert p.stride() == (R * S * I, 1, S * I, I), (k, p.stride())
+            flat = arena.p[off:off + n].view(O_, R, S, I)
+            assert torch.equal(flat, ref[k].permute(0, 2, 3, 1))
+    # the stacked embedding projection is one contiguous [sum(2C), emb] block in module order
+    unet = net.denoise_fn.model
+    Wall = arena.group_view("emb_layers.1.weight").view(unet.emb_total, unet.cond_embed_dim)
+    off = 0
+    for m in unet.modules():
+        if hasattr(m, "emb_slice") and m.emb_slice is not None:
+            assert m.emb_slice[0] == off
+            assert torch.equal(Wall[off:off + m.emb_slice[1]], m.emb_layers[1].weight.detach())
+            off += m.emb_slice[1]
+    assert off == unet.emb_total
+    # state_dict() hands out plain contiguous tensors in the reference layout
+    sd = net.state_dict()
+    for k, v in sd.items():
+        assert v.is_contiguous() and torch.equal(v, ref[k]), k
+        assert v.untyped_storage().nbytes() <= max(v.numel(), 1) * v.element_size() + 64
+    # load_state_dict writes through the views and marks the 16-bit copies stale
+    arena.dirty = False
+    net.load_state_dict(O.synth_state_dict(sd, seed=3))
+    assert arena.dirty
+    k0 = "denoise_fn.model.input_blocks.1.0.in_layers.2.weight"
+    off, n = arena.slices[k0]
+    assert torch.equal(arena.p[off:off + n].view(32, 3, 3, 32), O.synth_state_dict(sd, seed=3)[k0].permute(0, 2, 3, 1))
+    # working-copy descriptors: padded shapes and offsets are consistent
+    desc = arena.desc.tolist()
+    tot = 0
+    for src, dst, dstT, cout, rs, cin, coutp, cinp in desc:
+        assert dst == tot and coutp % 8 == 0 and cinp % 8 == 0 and coutp >= cout and cinp >= cin
+        tot += coutp * rs * cinp
+    assert tot <= arena.w16.numel()
+    stem = net.denoise_fn.model.input_blocks[0][0].meta
+    assert (stem.Cin, stem.Cin_real, stem.Cout) == (8, 6, 32)
+    head = net.denoise_fn.model.out[2].meta
+    assert (head.Cout, head.Cout_real) == (8, 3) and head.bias_pad is not None
+
+
+def test_ops_refuse_cpu_tensors():
+    """No CPU / eager fallback: the product path fails loudly without a GPU."""
+    from joligen_amd import ops
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    with pytest.raises(RuntimeError, match="GPU only|no CPU"):
+        ops.group_norm(torch.zeros(1, 4, 4, 8, dtype=torch.bfloat16), 1)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            create_model(opt_from_json({}, {"gpu_ids": "0"}), 0)
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "joligen_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "jg_oracle" not in src and "ref_shim" not in src and "/root/reference" not in src.replace(
+                    "/root/reference/models", "").replace("/root/reference/", "REF/"), os.path.join(dirpath, f)
