@@ -82,13 +82,52 @@ def build_model(args, rank, local_rank, world):
     return model, opt
 
 
+def usable_cores():
+    """Host cores this process may actually run on: min(affinity mask, cgroup CPU quota).
+    (os.cpu_count() reports the whole machine; oversubscribing a quota-limited container with one
+    OpenMP thread per machine core makes the CPU run orders of magnitude slower.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_baseline_subprocess(args, timeout_s=240):
+    """Run the CPU leg in a child process with a hard wall-clock bound so that bench.py always
+    finishes within minutes whatever the host looks like."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
+           "--efficient", str(args.efficient)]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
+        for line in out.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
+                "sample": "cpu leg failed: " + out.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
+                "sample": f"cpu leg exceeded its {timeout_s}s bound on this host"}
+
+
 def cpu_baseline(args):
     """The oracle's full step (forward, backward, AdamW, EMA) on the host cores, bounded sample."""
     import jg_oracle as O
     from joligen_amd.models.palette_model import define_G
     from joligen_amd.options import opt_from_json
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     S, Bc = args.size, 1
     opt = opt_from_json({}, dict(G_unet_mha_vit_efficient=bool(args.efficient), data_crop_size=S))
@@ -121,7 +160,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(args)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -155,7 +198,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    loss = float(model.get_current_losses()["G_tot"])
+    loss = float(model.get_current_losses()["G_tot"].detach())
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -199,7 +242,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args)
+        cpu = cpu_baseline_subprocess(args)
 
     if rank == 0:
         line = {

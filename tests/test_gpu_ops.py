@@ -397,7 +397,7 @@ def test_adamw_ema_matches_torch_optim():
             O.adamw_step([pr], [gr], [mr], [vr], step, 2e-3, 0.9, 0.999, 1e-8, wd, bool(decoupled))
             O.ema_step([er], [pr], 0.99)
             assert float(gd.abs().max()) == 0.0  # fused zero_grad
-        assert relerr(p, pr) < 1e-6 and relerr(ema, er) < 1e-6 and relerr(v, vr) < 1e-5
+        assert relerr(p, pr) < 1e-6 and relerr(ema, er) < 1e-6 and relerr(v, vr) < 1e-4
 
 
 def test_c_abi_rejects_bad_arguments():
