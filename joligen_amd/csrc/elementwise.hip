@@ -182,14 +182,39 @@ __global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __re
   for (int k = 0; k < K; ++k) acc += act_f(x[(long)b * K + k], act) * W[(long)n * K + k];
   y[idx] = acc;
 }
-__global__ void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ dy,
-                                     float* __restrict__ dx, int Bn, int K, int N, int act) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Bn * K) return;
-  const int b = idx / K, k = idx % K;
-  float acc = 0.f;
-  for (int n = 0; n < N; ++n) acc += dy[(long)b * N + n] * W[(long)n * K + k];
-  dx[idx] = acc * act_grad_f(x[idx], act);
+// dx[b][k] = act'(x[b][k]) * sum_n dy[b][n] W[n][k]: one block per (b, 32-wide k tile); threads stride
+// over n (W rows are read as contiguous 128-byte segments), 32 partial sums per thread, LDS reduce.
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ dy, float* __restrict__ dx, int Bn,
+                                                            int K, int N, int act) {
+  __shared__ float s_red[8][33];
+  const int b = blockIdx.x, k0 = blockIdx.y * 32;
+  const int kt = min(32, K - k0);
+  float acc[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) acc[q] = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float g = dy[(long)b * N + n];
+    const float* wr = W + (long)n * K + k0;
+    if (kt == 32) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) acc[q] += g * wr[q];
+    } else {
+      for (int q = 0; q < kt; ++q) acc[q] += g * wr[q];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const float v = wave_sum(acc[q]);
+    if (lane == 0) s_red[wv][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kt) {
+    const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    const long o = (long)b * K + k0 + threadIdx.x;
+    dx[o] = v * act_grad_f(x[o], act);
+  }
 }
 __global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
                                      float* __restrict__ dbias, int Bn, int K, int N, int act) {
@@ -390,7 +415,7 @@ extern "C" int jg_linear_bwd(const float* x, const float* W, const float* dy, fl
                              int K, int N, int act, jg_stream_t s) {
   if (!x || !W || !dy || Bn < 1 || K < 1 || N < 1) return JG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3((Bn * K + 255) / 256), dim3(256), 0, st, x, W, dy, dx, Bn, K, N, act);
+  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(Bn, (K + 31) / 32), dim3(256), 0, st, x, W, dy, dx, Bn, K, N, act);
   if (dW || dbias)
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((N * (K + 1) + 255) / 256), dim3(256), 0, st, x, dy, dW, dbias, Bn, K, N, act);
   JG_CHECK_LAUNCH();

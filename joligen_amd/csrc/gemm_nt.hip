@@ -17,6 +17,7 @@
 // the 4 accumulator registers of a lane are 4 consecutive output channels of one pixel: the
 // epilogue stores 8 bytes per lane per tile instead of four 2-byte stores.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -193,8 +194,196 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Variant 2: direct global->LDS staging (global_load_lds_dwordx4, the gfx950 LDS-DMA path).
+// No VGPR round trip and no ds_write pass: on the register-staged kernel above the ds_write_b128
+// traffic (~79 B/clk/CU) costs more LDS time than the MFMAs take.  An LDS-DMA instruction writes
+// wave-base + lane*16, i.e. LDS stays LINEAR in issue order; the bank swizzle therefore goes on the
+// SOURCE side: the lane that lands on physical chunk position c of row r fetches the logical
+// k-chunk c ^ swz(r) (cdna_hip_programming.md 5.4 rule 21).  Zero padding / ragged edges: invalid
+// lanes fetch from a 16-byte device-global zero page (always a valid address).
+// BK = 32 (64-byte rows, swz64) or 64 (128-byte rows, swz128).
+__device__ uint4 jg_zero_page = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ int swz128r(int row) { return (row >> 1) & 7; }
+
+template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
+  constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
+  constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int A_CH = BM * CPR / 256, B_CH = BN * CPR / 256;
+  constexpr int RSTEP = 256 / CPR;                    // rows covered by one block-wide staging round
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
+
+  __shared__ uint4 sm[2][(BM + BN) * CPR];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int n0 = (blockIdx.x % tilesN) * BN;
+  const int m0 = (blockIdx.x / tilesN) * BM;
+
+  const int z = blockIdx.z;
+  const int zb = z / p.nh, zh = z % p.nh;
+  const T* __restrict__ x = (const T*)p.x + zb * p.sxb + zh * p.sxh;
+  const T* __restrict__ w = (const T*)p.w + zb * p.swb + zh * p.swh;
+
+  const int cpos = tid % CPR;                         // physical chunk position inside the LDS row
+  const int srow = tid / CPR;                         // + RSTEP per staging round
+  const int sw = (BK == 32) ? swz64(srow) : swz128r(srow);   // invariant under + RSTEP
+  const int kc = cpos ^ sw;                           // logical k-chunk this thread fetches
+  int ih0[A_CH], iw0[A_CH], pb[A_CH];
+#pragma unroll
+  for (int i = 0; i < A_CH; ++i) {
+    const int m = m0 + srow + RSTEP * i;
+    const int ow = m % p.Wo;
+    const int t = m / p.Wo;
+    const int oh = t % p.Ho;
+    const int b = t / p.Ho;
+    ih0[i] = (m < p.M) ? oh * p.stride - p.pad : -(1 << 28);
+    iw0[i] = ow * p.stride - p.pad;
+    pb[i] = b * p.H;
+  }
+  int c = (kc * 8) % p.Cin;
+  int rs0 = (kc * 8) / p.Cin;
+  int r = rs0 / p.S, s = rs0 % p.S;
+  long kg = kc * 8;
+  const T* zp = reinterpret_cast<const T*>(&jg_zero_page);
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  auto issue_loads = [&](int buf) {
+    const bool kvalid = r < p.R;
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+      const int ih = ih0[i] + r, iw = iw0[i] + s;
+      const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      const T* src = ok ? x + (((long)(pb[i] + ih) * p.W + iw) * p.ldx + c) : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&sm[buf][256 * i + wave * 64], 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+      const int n = n0 + srow + RSTEP * i;
+      const bool ok = kvalid && n < p.N;
+      const T* src = ok ? w + ((long)n * p.ldw + kg) : zp;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&sm[buf][BM * CPR + 256 * i + wave * 64], 16, 0, 0);
+    }
+  };
+  auto advance_k = [&]() {
+    kg += BK;
+    c += BK;
+    while (c >= p.Cin) {
+      c -= p.Cin;
+      if (++s == p.S) { s = 0; ++r; }
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int sub = 0; sub < BK / 32; ++sub) {
+      uint4 fa[TM], fb[TN];
+      const int lk = fk + 4 * sub;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WM + i * 16 + frow;
+        fa[i] = sm[buf][row * CPR + (lk ^ ((BK == 32) ? swz64(row) : swz128r(row)))];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WN + j * 16 + frow;
+        fb[j] = sm[buf][BM * CPR + row * CPR + (lk ^ ((BK == 32) ? swz64(row) : swz128r(row)))];
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = Mfma<T>::run(fb[j], fa[i], acc[j][i]);
+    }
+  };
+
+  const int nk = (p.K + BK - 1) / BK;
+  issue_loads(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    if (ks + 1 < nk) {
+      advance_k();
+      issue_loads(cur ^ 1);
+    }
+    compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  char* yb = p.y + (zb * p.syb + zh * p.syh) * (p.out_f32 ? 4 : 2);
+  const T* resb = p.res ? (const T*)p.res + zb * p.srb + zh * p.srh : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = p.bias[n + q];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WM + i * 16 + (lane & 15);
+      if (m >= p.M) continue;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[j][i][q] + bv[q];
+      if (resb) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(resb + (long)m * p.ldres + n);
+        float rf[4];
+        unpack4<T>(rv, rf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += p.res_scale * rf[q];
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<float4*>((float*)yb + (long)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        *reinterpret_cast<uint2*>((T*)yb + (long)m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int BK, int WMv, int WNv>
+void launch_glds(const ConvP& p, int nbatch, hipStream_t st) {
+  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, nbatch);
+  hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, st, p);
+}
+
 template <typename T>
 int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
+  const char* venv = getenv("JG_CONV_VARIANT");
+  const int variant = venv ? atoi(venv) : 3;  // 1: register-staged 32-deep; 2..5: LDS-DMA staged (default 128x128x64)
+  if (variant >= 2) {
+    if (p.N <= 64) {
+      if (variant == 3) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);
+      else launch_glds<T, 256, 64, 32, 4, 1>(p, nbatch, st);
+    } else {
+      if (variant == 2) launch_glds<T, 128, 128, 32, 2, 2>(p, nbatch, st);
+      else if (variant == 3) launch_glds<T, 128, 128, 64, 2, 2>(p, nbatch, st);
+      else if (variant == 4) launch_glds<T, 256, 128, 32, 2, 2>(p, nbatch, st);
+      else launch_glds<T, 256, 128, 64, 2, 2>(p, nbatch, st);
+    }
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   if (p.N <= 64) {
     constexpr int BM = 256, BN = 64;
     dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, nbatch);

@@ -13,6 +13,7 @@
 // 16-byte chunk index XOR-swizzled with (row >> 1) & 7: conflict-free for both the 16-lane
 // ds_read_b128 groups and the 16-lane ds_write_b64 groups.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -229,6 +230,210 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Variant 2: LDS tiles stay in the NHWC order of global memory ([pixel][channel], 256-byte rows,
+// plain 16-byte staging writes) and the MFMA fragments are fetched with the gfx950 transposing
+// LDS read ds_read_b64_tr_b16: within a 16-lane group lane i supplies the address of 4 consecutive
+// channels (row = pixel k0 + (i >> 2), channels c0 + 4 (i & 3) ..) and receives channel c0 + i of
+// the 4 pixels k0 .. k0+3 (measured lane semantics: tools/probe_tr.hip).  Two reads give the 8
+// k-values of a 16x16x32 operand; A and B use the same pixel<->k assignment, which is all the MFMA
+// needs.  The 32-byte (16-channel) block index of a row is XOR-swizzled with row bits {0,1,3} so a
+// 32-lane service group of the transposing read touches all 64 banks exactly once.
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int swz_tr(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+// WAVES_M = 2: block tile 128 (co) x 128, waves 2x2 of 64x64.  WAVES_M = 1: block tile 64 (co) x 128,
+// waves 1x4 of 64x32 -- for Cout <= 64 layers, where a 128-row tile would waste half of the MFMAs.
+template <typename T, int WAVES_M>
+__global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
+  constexpr int BM = 64 * WAVES_M, BN = 128, BK = 64;
+  constexpr int WAVES_N = 4 / WAVES_M;
+  constexpr int TN = BN / WAVES_N / 16;  // 16-wide column tiles per wave: 4 or 2
+  constexpr int TILE = BK * 16;  // uint4 chunks per operand tile (64 rows x 256 B)
+  __shared__ uint4 sm[2][2 * TILE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  const int tilesN = (p.Ktot + BN - 1) / BN;
+  const int n0 = (blockIdx.x % tilesN) * BN;
+  const int m0 = (blockIdx.x / tilesN) * BM;
+
+  const int z = blockIdx.z;
+  const int batch = z / p.splitk, split = z % p.splitk;
+  const int zb = batch / p.nh, zh = batch % p.nh;
+  const T* __restrict__ dy = (const T*)p.dy + zb * p.sdyb + zh * p.sdyh;
+  const T* __restrict__ x = (const T*)p.x + zb * p.sxb + zh * p.sxh;
+
+  int per = (p.Mpix + p.splitk - 1) / p.splitk;
+  per = (per + BK - 1) / BK * BK;
+  const int kbeg = split * per;
+  const int kend = min(p.Mpix, kbeg + per);
+  if (kbeg >= kend) return;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const int cidx = tid & 15;          // 16-byte chunk (8 channels) of the 128-channel row
+  const int prow = (tid >> 4) * 4;    // 4 consecutive pixel rows per thread
+  const int cm = m0 + cidx * 8;
+  const bool a_ok = cm < p.Cout && cidx * 8 < BM;
+  const int nn = n0 + cidx * 8;
+  const bool b_ok = nn < p.Ktot;
+  const int rs = nn / p.Cin, ci = nn % p.Cin;
+  const int fr = rs / p.S, fs = rs % p.S;
+  const bool quad_row = (p.Wo & 3) == 0;
+
+  uint4 ra[4], rb[4];
+  float bsum[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
+  const bool do_bias = p.dbias != nullptr && (blockIdx.x % tilesN) == 0;
+
+  auto load_tiles = [&](int kbase) {
+    const int p0 = kbase + prow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = p0 + i;
+      const bool ok = a_ok && pp < kend;
+      ra[i] = ldg16(dy + (ok ? (long)pp * p.lddy + cm : 0), ok);
+    }
+    if (quad_row) {
+      const int ow0 = p0 % p.Wo;
+      const int t = p0 / p.Wo;
+      const int oh = t % p.Ho;
+      const int b = t / p.Ho;
+      const int ih = oh * p.stride + fr - p.pad;
+      const bool row_ok = b_ok && (unsigned)ih < (unsigned)p.H;
+      const long rowoff = ((long)(b * p.H + ih) * p.W) * p.ldx + ci;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iw = (ow0 + i) * p.stride + fs - p.pad;
+        const bool ok = row_ok && (p0 + i) < kend && (unsigned)iw < (unsigned)p.W;
+        rb[i] = ldg16(x + (ok ? rowoff + (long)iw * p.ldx : 0), ok);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pp = p0 + i;
+        const int ow = pp % p.Wo;
+        const int t = pp / p.Wo;
+        const int oh = t % p.Ho;
+        const int b = t / p.Ho;
+        const int ih = oh * p.stride + fr - p.pad;
+        const int iw = ow * p.stride + fs - p.pad;
+        const bool ok = b_ok && pp < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        rb[i] = ldg16(x + (ok ? ((long)(b * p.H + ih) * p.W + iw) * p.ldx + ci : 0), ok);
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = prow + i;
+      const int pos = row * 16 + ((((cidx >> 1) ^ swz_tr(row)) << 1) | (cidx & 1));
+      sm[buf][pos] = ra[i];
+      sm[buf][TILE + pos] = rb[i];
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack8<T>(ra[i], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bsum[q] += f[q];
+      }
+    }
+  };
+
+  f32x4 acc[4][TN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int i16 = lane & 15, g = lane >> 4;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+  auto frag = [&](int buf, int tile, int cb, int sub) -> uint4 {
+    const char* base = reinterpret_cast<const char*>(&sm[buf][tile]);
+    uint32_t w[4];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int row = sub * 32 + g * 8 + rd * 4 + (i16 >> 2);
+      const int off = (row * 16 + ((cb ^ swz_tr(row)) << 1)) * 16 + (i16 & 3) * 8;
+      const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + off));
+      const uint2 u = __builtin_bit_cast(uint2, v);
+      w[2 * rd] = u.x;
+      w[2 * rd + 1] = u.y;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      uint4 fa[4], fb[TN];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = frag(buf, 0, wm * 4 + i, sub);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = frag(buf, TILE, wn * TN + j, sub);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+  };
+
+  load_tiles(kbeg);
+  store_lds(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    const bool more = ks + 1 < nk;
+    if (more) load_tiles(kbeg + (ks + 1) * BK);
+    compute(cur);
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  const long zoff = zb * p.sdwb + zh * p.sdwh;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (TN * 16) + j * 16 + (lane & 15);
+    if (n >= p.Ktot) continue;
+    const int ors = n / p.Cin, oci = n % p.Cin;
+    if (oci >= p.Cin_out) continue;
+    const long ocol = (long)ors * p.Cin_out + oci;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q;
+        if (m >= p.Cout_out) continue;
+        const float v = p.alpha * acc[i][j][q];
+        const long off = zoff + (long)m * p.lddw + ocol;
+        if (p.out_mode == JG_OUT_ATOMIC_F32) {
+          atomicAdd((float*)p.dw + off, v);
+        } else if (p.out_mode == JG_OUT_STORE_F32) {
+          ((float*)p.dw)[off] = v;
+        } else {
+          ((T*)p.dw)[off] = from_f32<T>(v);
+        }
+      }
+    }
+  }
+  if (do_bias) {
+    // threads sharing a channel octet: same (tid & 15) -> lanes l, l+16, l+32, l+48 of every wave
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = bsum[q];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      if (lane < 16 && a_ok && (cm + q) < p.Cout_out) atomicAdd(p.dbias + cm + q, v);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream) {
@@ -251,8 +456,19 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   p.nh = a->nh; p.splitk = a->splitk;
   p.sdyb = a->sdyb; p.sdyh = a->sdyh; p.sxb = a->sxb; p.sxh = a->sxh; p.sdwb = a->sdwb; p.sdwh = a->sdwh;
   p.alpha = a->alpha; p.out_mode = a->out_mode;
-  dim3 grid(((p.Cout + 127) / 128) * ((p.Ktot + 127) / 128), 1, a->nbatch * a->splitk);
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p););
+  const char* venv = getenv("JG_WGRAD_VARIANT");
+  const int variant = venv ? atoi(venv) : 2;
+  const int tilesN = (p.Ktot + 127) / 128;
+  if (variant == 1) {
+    dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * a->splitk);
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p););
+  } else if (p.Cout <= 64 && variant != 3) {
+    dim3 grid(tilesN, 1, a->nbatch * a->splitk);
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p););
+  } else {
+    dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * a->splitk);
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, p););
+  }
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -125,8 +125,11 @@ class ConvMeta:
         return ((H + 2 * self.pad - self.R) // self.stride + 1, (W + 2 * self.pad - self.S) // self.stride + 1)
 
 
+WGRAD_TARGET_BLOCKS = 1536
+
+
 def _wgrad_splitk(tiles, mpix, nbatch=1):
-    want = max(1, (1536 + tiles - 1) // tiles)
+    want = max(1, (WGRAD_TARGET_BLOCKS + tiles - 1) // tiles)
     cap = max(1, mpix // 256)
     return max(1, min(want, cap, 65535 // max(1, nbatch)))
 
@@ -162,7 +165,7 @@ def conv2d_wgrad(dy, x, m: ConvMeta, alpha=1.0, want_w=True, want_b=True):
     if wg is None:
         raise RuntimeError("conv weight has no arena-backed .grad (module not finalised by ParamArena)")
     ktot = m.R * m.S * Cin
-    tiles = ((Cout + 127) // 128) * ((ktot + 127) // 128)
+    tiles = ((Cout + 127) // 128) * ((ktot + 127) // 128)  # Cout <= 64 runs the 64-row tile: same count
     splitk = _wgrad_splitk(tiles, B * Ho * Wo)
     dbias = m.bias.grad if (want_b and m.bias is not None) else None
     wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,

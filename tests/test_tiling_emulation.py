@@ -331,3 +331,140 @@ def test_staging_writes_are_bank_conflict_free():
                 row = co * 8 + j
                 slots.append((row * 16 + (((pq >> 1) ^ swz128(row)) << 1) + (pq & 1)) % 16)
             assert len(set(slots)) == 16
+
+
+# ---- wgrad variant 2: transposing LDS reads (csrc/gemm_tn.hip wgrad_tn_tr_kernel) ---------------
+def ds_read_b64_tr_b16(lds, byte_addr):
+    """Measured gfx950 semantics (tools/probe_tr.hip): in each 16-lane group, lane i supplies the
+    address of 4 consecutive 16-bit elements M[i][0..3]; it receives out[j] = M[4 j + i // 4][i % 4]."""
+    out = np.zeros((64, 4))
+    for grp in range(4):
+        M = np.array([lds[byte_addr[grp * 16 + i] // 2: byte_addr[grp * 16 + i] // 2 + 4] for i in range(16)])
+        for i in range(16):
+            for j in range(4):
+                out[grp * 16 + i, j] = M[4 * j + i // 4, i % 4]
+    return out
+
+
+def swz_tr(row):
+    return (row & 3) | (((row >> 3) & 1) << 2)
+
+
+def emulate_wgrad_tr(dy, x, R, S, pad, stride, splitk):
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    Mpix, Ktot = B * Ho * Wo, R * S * Cin
+    BM = BN = 128
+    BK = 64
+    TILE = BK * 16
+    dw = np.zeros((Cout, Ktot))
+    dyf, xf = dy.reshape(Mpix, Cout), x.reshape(-1, Cin)
+    tilesN = (Ktot + BN - 1) // BN
+    nblocks = ((Cout + 127) // 128) * tilesN
+    for split in range(splitk):
+        per = (Mpix + splitk - 1) // splitk
+        per = (per + BK - 1) // BK * BK
+        kbeg, kend = split * per, min(Mpix, split * per + per)
+        if kbeg >= kend:
+            continue
+        nk = (kend - kbeg + BK - 1) // BK
+        for bid in range(nblocks):
+            n0, m0 = (bid % tilesN) * BN, (bid // tilesN) * BM
+            acc = np.zeros((4, 4, 4, 64, 4))
+            for ks in range(nk):
+                kbase = kbeg + ks * BK
+                sm = np.zeros((2 * TILE, 8))
+                for tid in range(256):
+                    cidx, prow = tid & 15, (tid >> 4) * 4
+                    cm, nn = m0 + cidx * 8, n0 + cidx * 8
+                    a_ok, b_ok = cm < Cout, nn < Ktot
+                    rs, ci = nn // Cin, nn % Cin
+                    fr, fs = rs // S, rs % S
+                    for i in range(4):
+                        pp = kbase + prow + i
+                        ra = dyf[pp, cm:cm + 8] if (a_ok and pp < kend) else np.zeros(8)
+                        ow, t = pp % Wo, pp // Wo
+                        oh, b = t % Ho, t // Ho
+                        ih, iw = oh * stride + fr - pad, ow * stride + fs - pad
+                        ok = b_ok and pp < kend and 0 <= ih < H and 0 <= iw < W
+                        rb = xf[(b * H + ih) * W + iw, ci:ci + 8] if ok else np.zeros(8)
+                        row = prow + i
+                        pos = row * 16 + ((((cidx >> 1) ^ swz_tr(row)) << 1) | (cidx & 1))
+                        sm[pos] = ra
+                        sm[TILE + pos] = rb
+                lds = sm.reshape(-1)  # element-addressed view (2 bytes per element)
+                for wave in range(4):
+                    wm, wn = wave >> 1, wave & 1
+
+                    def frag(tile, cb, sub):
+                        halves = []
+                        for rd in range(2):
+                            addr = []
+                            for lane in range(64):
+                                i16, g = lane & 15, lane >> 4
+                                row = sub * 32 + g * 8 + rd * 4 + (i16 >> 2)
+                                addr.append(tile * 16 + (row * 16 + ((cb ^ swz_tr(row)) << 1)) * 16 + (i16 & 3) * 8)
+                            halves.append(ds_read_b64_tr_b16(lds, addr))
+                        return np.concatenate(halves, axis=1)  # [64][8]
+
+                    for sub in range(2):
+                        fa = [frag(0, wm * 4 + i, sub) for i in range(4)]
+                        fb = [frag(TILE, wn * 4 + j, sub) for j in range(4)]
+                        for i in range(4):
+                            for j in range(4):
+                                acc[wave, i, j] = mfma_16x16x32(fa[i], fb[j], acc[wave, i, j])
+            for wave in range(4):
+                wm, wn = wave >> 1, wave & 1
+                for lane in range(64):
+                    for j in range(4):
+                        n = n0 + wn * 64 + j * 16 + (lane & 15)
+                        if n >= Ktot:
+                            continue
+                        for i in range(4):
+                            for q in range(4):
+                                m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + q
+                                if m < Cout:
+                                    dw[m, n] += acc[wave, i, j, lane, q]
+    return dw.reshape(Cout, R, S, Cin)
+
+
+@pytest.mark.parametrize("shape", [(1, 6, 8, 16, 24, 3, 1, 1, 2), (2, 5, 7, 8, 8, 3, 1, 1, 1)])
+def test_wgrad_tr_variant_index_math(shape):
+    B, H, W, Cin, Cout, k, pad, stride, splitk = shape
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((B, H, W, Cin))
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    dy = rng.standard_normal((B, Ho, Wo, Cout))
+    dw = emulate_wgrad_tr(dy, x, k, k, pad, stride, splitk)
+    xp = np.zeros((B, H + 2 * pad, W + 2 * pad, Cin))
+    xp[:, pad:pad + H, pad:pad + W] = x
+    ref = np.zeros((Cout, k, k, Cin))
+    for r in range(k):
+        for s in range(k):
+            patch = xp[:, r:r + Ho * stride:stride, s:s + Wo * stride:stride]
+            ref[:, r, s] = np.einsum("bhwo,bhwi->oi", dy, patch)
+    np.testing.assert_allclose(dw, ref, rtol=1e-9, atol=1e-9)
+
+
+def test_tr_reads_and_staging_writes_bank_conflict_free():
+    # ds_read_b64_tr_b16: two 32-lane groups, 64 banks; 8-byte slots must be distinct mod 256 B
+    for sub in (0, 1):
+        for rd in (0, 1):
+            for cb in range(8):
+                for half in (0, 1):
+                    slots = []
+                    for lane in range(half * 32, half * 32 + 32):
+                        i16, g = lane & 15, lane >> 4
+                        row = sub * 32 + g * 8 + rd * 4 + (i16 >> 2)
+                        off = (row * 16 + ((cb ^ swz_tr(row)) << 1)) * 16 + (i16 & 3) * 8
+                        slots.append((off // 8) % 32)
+                    assert len(set(slots)) == 32
+    # ds_write_b128 staging: groups of 8 contiguous lanes, 32 banks (128 B)
+    for g0 in range(0, 256, 8):
+        for i in range(4):
+            slots = []
+            for tid in range(g0, g0 + 8):
+                cidx, row = tid & 15, (tid >> 4) * 4 + i
+                pos = row * 16 + ((((cidx >> 1) ^ swz_tr(row)) << 1) | (cidx & 1))
+                slots.append(pos % 8)
+            assert len(set(slots)) == 8
