@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dump-kernel-timing", default="", help="write the per-shape conv kernel timing table here")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
@@ -218,7 +219,16 @@ def main():
         recs = ops.KERNEL_TIMING
         ops.KERNEL_TIMING = None
         per = {}
-        for name, e0, e1, fl in recs:
+        if args.dump_kernel_timing:
+            agg = {}
+            for name, e0, e1, fl, geo in recs:
+                a = agg.setdefault((name, geo), [0, 0.0, fl])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+            with open(args.dump_kernel_timing, "w") as f:
+                for (name, geo), (n_, t_, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                    f.write(f"{name:9s} {str(geo):48s} calls/step {n_ / 2:5.1f} ms/step {t_ / 2:8.3f} avg_us {t_ / n_ * 1e3:9.1f} TF {fl / (t_ / n_ * 1e-3) / 1e12:7.1f}\n")
+        for name, e0, e1, fl, _geo in recs:
             d = per.setdefault(name, [0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1) * 1e-3

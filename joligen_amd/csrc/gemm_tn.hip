@@ -423,14 +423,20 @@ __global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
     }
   }
   if (do_bias) {
-    // threads sharing a channel octet: same (tid & 15) -> lanes l, l+16, l+32, l+48 of every wave
+    // threads sharing a channel octet: same (tid & 15) -> lanes l, l+16, l+32, l+48 of every wave;
+    // then across the 4 waves through LDS, so that a block issues ONE atomic per channel (the
+    // bias gradient has only Cout addresses: per-lane atomics serialise thousands deep).
+    float* s_b = reinterpret_cast<float*>(&sm[0][0]);  // all waves are past the last barrier of the K loop
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float v = bsum[q];
       v += __shfl_xor(v, 16);
       v += __shfl_xor(v, 32);
-      if (lane < 16 && a_ok && (cm + q) < p.Cout_out) atomicAdd(p.dbias + cm + q, v);
+      if (lane < 16) s_b[wave * 128 + cidx * 8 + q] = v;
     }
+    __syncthreads();
+    if (tid < BM && (m0 + tid) < p.Cout_out)
+      atomicAdd(p.dbias + m0 + tid, s_b[tid] + s_b[128 + tid] + s_b[256 + tid] + s_b[384 + tid]);
   }
 }
 

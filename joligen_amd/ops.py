@@ -77,7 +77,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append(("conv_nt", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin))
+        KERNEL_TIMING.append(("conv_nt", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
 
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
@@ -102,7 +102,7 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     check(_lib.lib().jg_conv2d_wgrad_tn(_dt(dy), C.byref(a), _st()), "jg_conv2d_wgrad_tn")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append(("wgrad_tn", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin))
+        KERNEL_TIMING.append(("wgrad_tn", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk)))
 
 
 def axpby(a, alpha=1.0, b=None, beta=0.0, alpha_dev=None, out=None):
@@ -126,12 +126,13 @@ class ConvMeta:
 
 
 WGRAD_TARGET_BLOCKS = 1536
+WGRAD_MAX_SPLITK = 512  # deeper splits only add atomic traffic on a tiny output
 
 
 def _wgrad_splitk(tiles, mpix, nbatch=1):
     want = max(1, (WGRAD_TARGET_BLOCKS + tiles - 1) // tiles)
     cap = max(1, mpix // 256)
-    return max(1, min(want, cap, 65535 // max(1, nbatch)))
+    return max(1, min(want, cap, WGRAD_MAX_SPLITK, 65535 // max(1, nbatch)))
 
 
 def conv2d_forward(x, m: ConvMeta, res=None, res_scale=1.0, alpha=1.0):

@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--only", default="")
     ap.add_argument("--target-blocks", type=int, default=0)
+    ap.add_argument("--bias", type=int, default=0)
+    ap.add_argument("--rotate", type=int, default=1, help="cycle through this many operand sets (defeats the 256 MB MALL)")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     if args.target_blocks:
@@ -49,10 +51,17 @@ def main():
     print(f"{'Cin':>5} {'Cout':>5} k {'S':>4} cnt | {'fwd ms':>8} {'TF':>6} | {'dgrad ms':>8} {'TF':>6} | {'wgv1 ms':>8} {'TF':>6} | {'wgv2 ms':>8} {'TF':>6} splitk")
     for Cin, Cout, k, S, cnt in SHAPES:
         pad = k // 2
-        x = torch.randn(B, S, S, Cin, device=d).to(dt)
+        xs = [torch.randn(B, S, S, Cin, device=d).to(dt) for _ in range(args.rotate)]
+        ys = [torch.randn(B, S, S, Cout, device=d).to(dt) for _ in range(args.rotate)]
+        cnt_box = [0]
+
+        def nxt():
+            cnt_box[0] += 1
+            return xs[cnt_box[0] % args.rotate], ys[cnt_box[0] % args.rotate]
+        x, y = xs[0], ys[0]
+        db = torch.zeros(Cout, device=d, dtype=torch.float32) if args.bias else None
         w = (torch.randn(Cout, k, k, Cin, device=d) / (k * Cin ** 0.5)).to(dt)
         wT = (torch.randn(Cin, k, k, Cout, device=d) / (k * Cout ** 0.5)).to(dt)
-        y = torch.empty(B, S, S, Cout, device=d, dtype=dt)
         dx = torch.empty(B, S, S, Cin, device=d, dtype=dt)
         dw = torch.zeros(Cout, k, k, Cin, device=d, dtype=torch.float32)
         geo = dict(B=B, H=S, W=S, R=k, S=k, pad=pad, stride=1, Ho=S, Wo=S)
@@ -71,8 +80,11 @@ def main():
             splitk = ops._wgrad_splitk(tiles, B * S * S)
             for var in ("3", "2"):
                 os.environ["JG_WGRAD_VARIANT"] = var
-                t = timeit(lambda: ops.wgrad_tn(y, x, dw, Cin=Cin, Cout=Cout, lddy=Cout, ldx=Cin, lddw=ktot, splitk=splitk,
-                                                out_mode=JG_OUT_ATOMIC_F32, **geo))
+                def run():
+                    xx, yy = nxt()
+                    ops.wgrad_tn(yy, xx, dw, Cin=Cin, Cout=Cout, lddy=Cout, ldx=Cin, lddw=ktot, splitk=splitk,
+                                 out_mode=JG_OUT_ATOMIC_F32, dbias=db, **geo)
+                t = timeit(run)
                 res["wgrad" if var == "2" else "wgrad_v1"] = t
         line = f"{Cin:5d} {Cout:5d} {k} {S:4d} {cnt:3d} |"
         for key in ("fwd", "dgrad", "wgrad_v1", "wgrad"):
