@@ -233,17 +233,19 @@ def main():
             d[0] += 1
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += fl
-        n, tsum, fsum = per["conv_nt"]
+        dom = max((k for k in per if k.startswith("conv_nt")), key=lambda k: per[k][1])
+        n, tsum, fsum = per[dom]
         achieved = fsum / tsum / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_nt_kernel", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                     "launches_per_step": n // 2, "avg_launch_us": round(tsum / n * 1e6, 2),
-                    "avg_flops_per_launch": round(fsum / n, 1), "time_per_step_ms": round(tsum / 2 * 1e3, 3)}
-        if "wgrad_tn" in per:
-            n2, t2, f2 = per["wgrad_tn"]
-            roofline["wgrad_tn_kernel"] = {"achieved": round(f2 / t2 / 1e12, 2), "frac": round(f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                           "launches_per_step": n2 // 2, "avg_launch_us": round(t2 / n2 * 1e6, 2),
-                                           "time_per_step_ms": round(t2 / 2 * 1e3, 3)}
+                    "avg_flops_per_launch": round(fsum / n, 1), "time_per_step_ms": round(tsum / 2 * 1e3, 3),
+                    "other_kernels": {}}
+        for k, (n2, t2, f2) in per.items():
+            if k != dom:
+                roofline["other_kernels"][k] = {"achieved": round(f2 / t2 / 1e12, 2), "frac": round(f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                "launches_per_step": n2 // 2, "avg_launch_us": round(t2 / n2 * 1e6, 2),
+                                                "time_per_step_ms": round(t2 / 2 * 1e3, 3)}
         gf = FWD_GFLOP_PER_IMG.get((args.size, bool(args.efficient)))
         if gf:
             step_tflop = 3 * gf * args.batch / 1e3

@@ -77,7 +77,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append(("conv_nt", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
+        KERNEL_TIMING.append(("conv_nt_glds_kernel<256,64,64,4,1>" if Cout <= 64 else "conv_nt_glds_kernel<128,128,64,2,2>", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
 
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
@@ -102,7 +102,7 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     check(_lib.lib().jg_conv2d_wgrad_tn(_dt(dy), C.byref(a), _st()), "jg_conv2d_wgrad_tn")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append(("wgrad_tn", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk)))
+        KERNEL_TIMING.append(("wgrad_tn_tr_kernel<1>" if Cout <= 64 else "wgrad_tn_tr_kernel<2>", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk)))
 
 
 def axpby(a, alpha=1.0, b=None, beta=0.0, alpha_dev=None, out=None):
