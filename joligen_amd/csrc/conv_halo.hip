@@ -1,0 +1,280 @@
+// Halo-resident implicit-GEMM 3x3 convolution (stride 1, pad 1) on gfx950 MFMA.
+//
+//   y[b,oh,ow,n] = alpha * sum_{r,s,ci} x[b,oh+r-1,ow+s-1,ci] * w[n][r][s][ci] + bias[n] + res_scale*res
+//
+// A workgroup owns a 16x16 tile of output pixels of ONE image and BN output channels.  The K loop
+// runs over 64-channel chunks; for each chunk the 18x18-pixel input HALO of the tile (324 pixels x
+// 128 B = 40.5 KB) is brought into LDS ONCE by LDS-DMA and all 9 filter taps read their MFMA
+// operand fragments from it at shifted pixel positions.  Compared with re-fetching a 256x64 im2col
+// tile per tap (gemm_nt.hip) this divides the activation traffic L2->LDS by 9/1.27 = 7 and removes
+// every per-tap bounds check / address computation from the loop: the padding is materialised once,
+// when the halo is loaded (out-of-image pixels fetch a zero page).
+//
+// The weight tile of a (tap, chunk) K-step (BN rows x 128 B) is streamed through an NBBUF-deep LDS
+// ring with counted `s_waitcnt vmcnt(N)` so that its loads stay in flight across the one raw
+// `s_barrier` per K-step; the halo of the NEXT chunk is prefetched one LDS-DMA round per tap.
+//
+// LDS images are lane-linear (LDS-DMA writes wave_base + lane*16), so the bank swizzle lives on the
+// SOURCE side: the 16-byte chunk landing at physical position c of a 128-byte row fetches logical
+// k-chunk c ^ ((row >> 1) & 7), and fragment reads apply the same XOR (row = halo pixel index /
+// weight row).  MFMA: v_mfma_f32_16x16x32, weights as operand A so that a lane's 4 accumulators are
+// 4 consecutive output channels of one pixel (8-byte epilogue stores).
+#include "conv_params.h"
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ uint4 jg_halo_zero_page = {0u, 0u, 0u, 0u};
+
+constexpr int HW_ = 18;                 // halo width / height
+constexpr int HALO_PX = HW_ * HW_;      // 324
+constexpr int HALO_CH = HALO_PX * 8;    // 16-byte chunks per halo buffer
+
+// LDS-DMA issued from inline asm: hipcc does not model it, so it neither drains it with a
+// vmcnt(0) before the next ds_read (what it does for __builtin_amdgcn_global_load_lds) nor counts
+// it -- every wait on these loads is an explicit wait_vmcnt<N>() below.  M0 (the LDS destination
+// base) is compiler-reserved: saved, written and restored inside the one statement
+// (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BN, int NT, int WAVES_M, int WAVES_N, int NABUF, int NBBUF, int MINB>
+__global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
+  constexpr int NWAVES = NT / 64;
+  static_assert(WAVES_M * WAVES_N == NWAVES, "wave grid");
+  constexpr int TM = 16 / WAVES_M;                 // 16-pixel tile rows per wave
+  constexpr int WN = BN / WAVES_N, TN = WN / 16;   // output channels per wave
+  constexpr int A_ROUNDS = (HALO_CH + NT - 1) / NT;
+  constexpr int B_ROUNDS = BN * 8 / NT;
+  constexpr int B_BUF = BN * 8;
+  static_assert(B_ROUNDS >= 1 && BN * 8 % NT == 0, "weight tile vs block size");
+  static_assert(NABUF == 1 || A_ROUNDS <= 9, "halo prefetch is spread over the 9 taps");
+  static_assert(NBBUF == 2 || NBBUF == 3, "weight ring depth");
+
+  __shared__ uint4 sm[NABUF * HALO_CH + NBBUF * B_BUF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- block -> (image, tile row, tile col, channel tile); XCD-aware: consecutive ids share an L2 ----
+  const int nwg = gridDim.x;
+  int id;
+  {
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  }
+  const int tilesN = (p.N + BN - 1) / BN;
+  const int n0 = (id % tilesN) * BN;
+  const int sp = id / tilesN;
+  const int tw = p.W >> 4, th = p.H >> 4;
+  const int ow0 = (sp % tw) << 4;
+  const int oh0 = ((sp / tw) % th) << 4;
+  const int b = sp / (tw * th);
+
+  const T* __restrict__ x = (const T*)p.x;
+  const T* __restrict__ w = (const T*)p.w;
+  const T* zp = reinterpret_cast<const T*>(&jg_halo_zero_page);
+  typedef __attribute__((address_space(3))) char* lds_cptr;
+  const unsigned lds0 = (unsigned)(size_t)(lds_cptr)(char*)&sm[0];   // LDS byte address of sm
+  const char* smb = reinterpret_cast<const char*>(&sm[0]);
+
+  // ---- per-thread LDS-DMA source offsets (elements), fixed for the whole kernel --------------------
+  int aoff[A_ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < A_ROUNDS; ++rd) {
+    const int pos = rd * NT + tid;
+    const int hp = pos >> 3, cpos = pos & 7;
+    const int hy = hp / HW_, hx = hp - hy * HW_;
+    const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+    const bool ok = pos < HALO_CH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+    const int kc = cpos ^ ((hx >> 1) & 7);   // swizzle by the COLUMN inside the halo row: the same for every row
+    aoff[rd] = ok ? (int)((((long)b * p.H + ih) * p.W + iw) * p.ldx) + kc * 8 : -1;
+  }
+  int boff[B_ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < B_ROUNDS; ++rd) {
+    const int row = (tid >> 3) + rd * (NT / 8);
+    const int cpos = tid & 7;
+    const int kc = cpos ^ ((row >> 1) & 7);
+    const int n = n0 + row;
+    boff[rd] = (n < p.N) ? (int)((long)n * p.ldw) + kc * 8 : -1;
+  }
+
+  auto issue_a_round = [&](int abuf, int cc, int rd) {
+    const int pos = rd * NT + tid;
+    if (pos < HALO_CH) {
+      const T* src = aoff[rd] >= 0 ? x + aoff[rd] + cc * 64 : zp;
+      glds16(src, lds0 + (abuf * HALO_CH + rd * NT + wave * 64) * 16);
+    }
+  };
+  auto issue_b = [&](int bbuf, int koff) {
+#pragma unroll
+    for (int rd = 0; rd < B_ROUNDS; ++rd) {
+      const T* src = boff[rd] >= 0 ? w + boff[rd] + koff : zp;
+      glds16(src, lds0 + (NABUF * HALO_CH + bbuf * B_BUF + rd * NT + wave * 64) * 16);
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int l15 = lane & 15, lk = lane >> 4;
+  // weight fragment byte offsets inside a ring slot, per N-tile (k-half 1 = this ^ 64)
+  int bfrag[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int row = wn * WN + j * 16 + l15;
+    bfrag[j] = row * 128 + ((lk ^ ((row >> 1) & 7)) << 4);
+  }
+  // halo fragment byte offsets for the three horizontal tap shifts s (tile row 0 of this wave, k-half 0);
+  // tile row i and vertical shift r add the constant (i + r) * 18 * 128, k-half 1 is ^ 64
+  int afrag[3];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int hx = l15 + s3;
+    afrag[s3] = ((wm * TM) * HW_ + hx) * 128 + ((lk ^ ((hx >> 1) & 7)) << 4);
+  }
+
+  auto compute = [&](int abyte, int bbyte, int r, int s3) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      uint4 fa[TM], fb[TN];
+      const int a0 = (afrag[s3] ^ (sub * 64)) + abyte;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(smb + a0 + (i + r) * (HW_ * 128));
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const uint4*>(smb + (bfrag[j] ^ (sub * 64)) + bbyte);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = Mfma<T>::run(fb[j], fa[i], acc[j][i]);
+    }
+  };
+
+  const int nch = p.Cin >> 6;       // 64-channel chunks
+  const int nk = nch * 9;
+
+  // ---- prologue: halo of chunk 0, first NBBUF-1 weight tiles -----------------------------------------
+#pragma unroll
+  for (int rd = 0; rd < A_ROUNDS; ++rd) issue_a_round(0, 0, rd);
+  issue_b(0, 0);
+  if (NBBUF == 3) issue_b(1, p.Cin);   // tap 1 of chunk 0 (nk >= 9 always)
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int kpre = NBBUF - 1;             // K-step whose weight tile is issued next
+  int pre_tap = NBBUF - 1, pre_cc = 0;
+  int bslot = 0;                    // ring slot of the current K-step
+  for (int cc = 0; cc < nch; ++cc) {
+    const int abyte = (NABUF == 2 ? (cc & 1) : 0) * (HALO_CH * 16);
+    const bool next_chunk = cc + 1 < nch;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // 1. prefetch: weight tile of K-step k + NBBUF - 1 into the slot freed at the previous barrier
+      const bool b_iss = kpre < nk;
+      if (b_iss) {
+        int slot = bslot + NBBUF - 1;
+        if (slot >= NBBUF) slot -= NBBUF;
+        issue_b(slot, pre_tap * p.Cin + pre_cc * 64);
+        ++kpre;
+        if (++pre_tap == 9) { pre_tap = 0; ++pre_cc; }
+      }
+      // 2. one LDS-DMA round of the next chunk's halo per tap
+      bool a_iss = false;
+      if (NABUF == 2 && tap < A_ROUNDS && next_chunk && tap * NT + wave * 64 < HALO_CH) {  // wave-uniform
+        issue_a_round((cc + 1) & 1, cc + 1, tap);
+        a_iss = true;
+      }
+      // 3. MFMAs of this K-step
+      compute(abyte, (NABUF * HALO_CH + bslot * B_BUF) * 16, tap / 3, tap % 3);
+      // 4. the weight tile of the NEXT K-step (and, at tap 8, the whole next halo) must have landed;
+      //    what was issued in this step may stay in flight (NBBUF == 3)
+      if (NBBUF == 3 && b_iss) {
+        if (a_iss) wait_vmcnt<B_ROUNDS + 1>(); else wait_vmcnt<B_ROUNDS>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      __builtin_amdgcn_s_barrier();
+      if (++bslot == NBBUF) bslot = 0;
+    }
+    if (NABUF == 1 && next_chunk) {
+      // single halo buffer: reload between chunks (all waves are past their reads of it)
+#pragma unroll
+      for (int rd = 0; rd < A_ROUNDS; ++rd) issue_a_round(0, cc + 1, rd);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------
+  char* yb = p.y;
+  const T* resb = (const T*)p.res;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 16 + lk * 4;
+    if (n >= p.N) continue;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = p.bias[n + q];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const long m = ((long)b * p.H + oh0 + wm * TM + i) * p.W + ow0 + l15;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[j][i][q] + bv[q];
+      if (resb) {
+        const uint2 rv = *reinterpret_cast<const uint2*>(resb + m * p.ldres + n);
+        float rf[4];
+        unpack4<T>(rv, rf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += p.res_scale * rf[q];
+      }
+      if (p.out_f32) {
+        *reinterpret_cast<float4*>((float*)yb + m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        *reinterpret_cast<uint2*>((T*)yb + m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int NT, int WMv, int WNv, int NABUF, int NBBUF, int MINB>
+void launch_halo(const ConvP& p, hipStream_t st) {
+  const int tiles = p.B * (p.H >> 4) * (p.W >> 4) * ((p.N + BN - 1) / BN);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NT, WMv, WNv, NABUF, NBBUF, MINB>), dim3(tiles), dim3(NT), 0, st, p);
+}
+
+template <typename T>
+void dispatch_halo(const ConvP& p, hipStream_t st) {
+  if (p.N % 256 == 0) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
+  else if (p.N % 128 == 0) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
+  else launch_halo<T, 64, 256, 4, 1, 1, 3, 2>(p, st);
+}
+
+}  // namespace
+
+bool jg_conv_halo_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
+  if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1) return false;
+  if (p.Cin % 64 || p.N % 64 || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
+  if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return false;
+  if (dtype == JG_F16) dispatch_halo<f16_t>(p, st);
+  else if (dtype == JG_BF16) dispatch_halo<bf16_t>(p, st);
+  else return false;
+  return true;
+}

@@ -17,20 +17,12 @@
 // the 4 accumulator registers of a lane are 4 consecutive output channels of one pixel: the
 // epilogue stores 8 bytes per lane per tile instead of four 2-byte stores.
 #include "common.h"
+#include "conv_params.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
-struct ConvP {
-  const char* x; const char* w; char* y; const float* bias; const char* res;
-  int M, N, K;
-  int H, W, Cin, R, S, pad, stride, Ho, Wo;
-  long ldx, ldw, ldy, ldres;
-  int nh;
-  long sxb, sxh, swb, swh, syb, syh, srb, srh;
-  float alpha, res_scale;
-  int out_f32;
-};
 
 __device__ __forceinline__ int swz64(int row) { return ((row >> 3) & 1) << 1; }
 
@@ -370,14 +362,18 @@ void launch_glds(const ConvP& p, int nbatch, hipStream_t st) {
 template <typename T>
 int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
   const char* venv = getenv("JG_CONV_VARIANT");
-  const int variant = venv ? atoi(venv) : 3;  // 1: register-staged 32-deep; 2..5: LDS-DMA staged (default 128x128x64)
+  const int variant = venv ? atoi(venv) : 6;  // 1: register-staged 32-deep; 2..5: LDS-DMA staged (128x128x64 = 3); 6: + halo-resident 3x3
+  if (variant >= 6 && jg_conv_halo_try(sizeof(T) == 2 && std::is_same<T, f16_t>::value ? JG_F16 : JG_BF16, p, nbatch, st)) {
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   if (variant >= 2) {
     if (p.N <= 64) {
-      if (variant == 3) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);
+      if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);
       else launch_glds<T, 256, 64, 32, 4, 1>(p, nbatch, st);
     } else {
       if (variant == 2) launch_glds<T, 128, 128, 32, 2, 2>(p, nbatch, st);
-      else if (variant == 3) launch_glds<T, 128, 128, 64, 2, 2>(p, nbatch, st);
+      else if (variant == 3 || variant >= 6) launch_glds<T, 128, 128, 64, 2, 2>(p, nbatch, st);
       else if (variant == 4) launch_glds<T, 256, 128, 32, 2, 2>(p, nbatch, st);
       else launch_glds<T, 256, 128, 64, 2, 2>(p, nbatch, st);
     }
@@ -417,5 +413,6 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.sxb = a->sxb; p.sxh = a->sxh; p.swb = a->swb; p.swh = a->swh; p.syb = a->syb; p.syh = a->syh;
   p.srb = a->srb; p.srh = a->srh;
   p.alpha = a->alpha; p.res_scale = a->res_scale; p.out_f32 = a->out_f32;
+  p.B = a->B; p.stats = nullptr;
   JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream););
 }
