@@ -52,6 +52,12 @@ CONV_CASES = [
     (2, 16, 16, 24, 40, 3, 1, 1),      # odd channel counts (multiples of 8)
     (2, 16, 16, 32, 64, 3, 1, 2),      # stride 2 forward
     (1, 9, 9, 16, 32, 4, 1, 1),        # 4x4 kernel
+    # halo-resident 3x3 kernel (conv_halo.hip): H, W multiples of 16, Cin and Cout multiples of 64
+    (2, 32, 32, 64, 64, 3, 1, 1),      # 64-wide channel tile, one chunk, image borders on every side
+    (1, 16, 48, 128, 128, 3, 1, 1),    # 128-wide channel tile, two chunks (halo double buffer), non-square
+    (2, 16, 16, 192, 256, 3, 1, 1),    # 256-wide channel tile, three chunks, 2-deep weight ring
+    (1, 32, 16, 128, 192, 3, 1, 1),    # 64-wide tile with several chunks (single halo buffer reload), 3 channel tiles
+    (3, 16, 16, 64, 384, 3, 1, 1),     # 128-wide tile, 3 channel tiles
 ]
 
 
@@ -108,7 +114,8 @@ BWD_CASES = [
     (2, 9, 7, 32, 32, 3, 1),      # Wo % 4 != 0 -> per-pixel decomposition path of wgrad
     (2, 8, 8, 256, 512, 3, 1),
     (3, 16, 16, 64, 64, 1, 0),
-    (2, 32, 32, 64, 64, 3, 1),    # several split-K slices
+    (2, 32, 32, 64, 64, 3, 1),    # several split-K slices; halo kernel for forward and input gradient
+    (2, 16, 32, 128, 256, 3, 1),  # halo kernel: 256-wide forward, 128-wide input gradient
 ]
 
 
