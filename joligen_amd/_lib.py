@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libjg355.so")
-SOURCES = ["gemm_nt.hip", "conv_halo.hip", "gemm_tn.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
+SOURCES = ["gemm_nt.hip", "conv_halo.hip", "gemm_tn.hip", "wgrad_halo.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 JG_F16, JG_BF16 = 0, 1
@@ -81,7 +81,7 @@ SIGNATURES = {
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source into csrc/libjg355.so for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(os.path.dirname(_HERE), "include", "jg355.h")]
+    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "wgrad_params.h"), os.path.join(os.path.dirname(_HERE), "include", "jg355.h")]
     if not force and os.path.exists(LIB_PATH):
         if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
             return LIB_PATH

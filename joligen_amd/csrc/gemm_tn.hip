@@ -13,21 +13,11 @@
 // 16-byte chunk index XOR-swizzled with (row >> 1) & 7: conflict-free for both the 16-lane
 // ds_read_b128 groups and the 16-lane ds_write_b64 groups.
 #include "common.h"
+#include "wgrad_params.h"
 #include <cstdlib>
 
 namespace {
 
-struct WgP {
-  const char* dy; const char* x; char* dw; float* dbias;
-  int Mpix, Cout, Ktot;  // reduction length, rows, cols (= R*S*Cin)
-  int H, W, Cin, R, S, pad, stride, Ho, Wo;
-  int Cin_out, Cout_out;
-  long lddy, ldx, lddw;
-  int nh, splitk;
-  long sdyb, sdyh, sxb, sxh, sdwb, sdwh;
-  float alpha;
-  int out_mode;
-};
 
 __device__ __forceinline__ int swz128(int row) { return (row >> 1) & 7; }
 
@@ -461,9 +451,13 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   p.lddy = a->lddy; p.ldx = a->ldx; p.lddw = a->lddw;
   p.nh = a->nh; p.splitk = a->splitk;
   p.sdyb = a->sdyb; p.sdyh = a->sdyh; p.sxb = a->sxb; p.sxh = a->sxh; p.sdwb = a->sdwb; p.sdwh = a->sdwh;
-  p.alpha = a->alpha; p.out_mode = a->out_mode;
+  p.alpha = a->alpha; p.out_mode = a->out_mode; p.B = a->B;
   const char* venv = getenv("JG_WGRAD_VARIANT");
-  const int variant = venv ? atoi(venv) : 2;
+  const int variant = venv ? atoi(venv) : 4;  // 1: register transpose; 2: transposing LDS reads; 3: 2 with 128-row tiles only; 4: + halo-resident 3x3
+  if (variant >= 4 && jg_wgrad_halo_try(dtype, p, a->nbatch, (hipStream_t)stream)) {
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   const int tilesN = (p.Ktot + 127) / 128;
   if (variant == 1) {
     dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * a->splitk);

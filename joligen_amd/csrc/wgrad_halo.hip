@@ -1,0 +1,281 @@
+// Halo-resident weight gradient of a 3x3 / stride 1 / pad 1 convolution on gfx950 MFMA.
+//
+//   dw[co][r][s][ci] += alpha * sum_{b,oh,ow} dy[b,oh,ow,co] * x[b,oh+r-1,ow+s-1,ci]
+//   dbias[co]        +=         sum_{b,oh,ow} dy[b,oh,ow,co]
+//
+// The reduction index is the PIXEL index.  A workgroup owns BCO output channels x one 64-channel
+// input chunk x ALL 9 taps, and walks over a slice of TH x 16 spatial tiles (split-K over tiles,
+// fp32 atomics into the gradient arena at the end).  Per tile it brings the dy tile
+// [TH*16 px][BCO] and the x HALO [(TH+2) x 18 px][64] into LDS once (LDS-DMA, double buffered across
+// tiles) and every tap multiplies the same dy fragments with the halo read at a shifted position:
+// 9 x fewer L2->LDS bytes per MFMA than one im2col tile per tap (gemm_tn.hip), no address math or
+// bounds checks in the MFMA loop.
+//
+// Both operands are pixel-major in LDS (the NHWC order of global memory) while an MFMA fragment
+// wants 8 consecutive k (= pixels) per lane: fragments come from the transposing LDS read
+// ds_read_b64_tr_b16 (lane i of a 16-lane group addresses 4 channels of pixel k0 + i/4 and receives
+// channel c0 + i of pixels k0..k0+3).  A 32-lane service group of that read touches 8 pixels
+// {h..h+3, h+8..h+11} x 32 B; the 32-byte block index of a pixel row is XOR-swizzled with a function
+// of the pixel COLUMN (so that vertical tap shifts are plain address offsets) that is injective on
+// every such set: conflict-free for every tap.  LDS-DMA writes lane-linearly, so the swizzle is
+// applied to the SOURCE chunk index (cdna_hip_programming.md 5.4 rule 21).
+#include "wgrad_params.h"
+#include <cstdlib>
+
+namespace {
+
+__device__ uint4 jg_wg_zero_page = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+
+// 2-bit swizzle of a 128-byte pixel row (4 blocks of 32 B), by pixel column c
+__device__ __forceinline__ int f4(int c) { return ((c >> 1) & 1) | (((c >> 3) & 1) << 1); }
+// 3-bit swizzle of a 256-byte pixel row (8 blocks of 32 B)
+__device__ __forceinline__ int f8(int c) { return (c & 3) | (((c >> 3) & 1) << 2); }
+
+template <typename T, int TH, int CPW>
+__global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles, int per, int npairs, int ncot) {
+  constexpr int NT = 512;
+  constexpr int BCO = 2 * CPW * 16;            // output channels per block (2 wave rows x CPW tiles)
+  constexpr int HW_ = 18, HPX = (TH + 2) * HW_;
+  constexpr int HALO_CH = HPX * 8;             // 16-byte chunks of the halo (64 channels = 128 B / pixel)
+  constexpr int CPP = BCO / 8;                 // chunks per dy pixel row
+  constexpr int DY_ROWB = BCO * 2;
+  constexpr int DY_CH = TH * 16 * CPP;
+  constexpr int A_ROUNDS = (HALO_CH + NT - 1) / NT;
+  constexpr int A_FULL = HALO_CH / NT;         // rounds every wave takes part in
+  constexpr int D_ROUNDS = DY_CH / NT;
+  constexpr int BUF_CH = HALO_CH + DY_CH;
+  constexpr int NSUB = TH / 2;                 // K-steps of 32 pixels (2 tile rows) per tile
+  static_assert(DY_CH % NT == 0, "dy tile vs block size");
+  static_assert(A_ROUNDS - A_FULL <= 1, "at most one partial halo round");
+
+  __shared__ uint4 sm[2 * BUF_CH];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  int id;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  }
+  const int pair = id % npairs, slice = id / npairs;
+  const int co0 = (pair % ncot) * BCO, ci0 = (pair / ncot) * 64;
+  const int t0 = slice * per;
+  const int t1 = min(ntiles, t0 + per);
+  if (t0 >= t1) return;
+
+  const T* __restrict__ xg = (const T*)p.x + ci0;
+  const T* __restrict__ dyg = (const T*)p.dy + co0;
+  const T* zp = reinterpret_cast<const T*>(&jg_wg_zero_page);
+  typedef __attribute__((address_space(3))) char* lds_cptr;
+  const unsigned lds0 = (unsigned)(size_t)(lds_cptr)(char*)&sm[0];
+  const char* smb = reinterpret_cast<const char*>(&sm[0]);
+  const int tw = p.W >> 4, th = p.H / TH;
+
+  // ---- per-thread LDS-DMA source coordinates relative to the tile origin ---------------------------
+  int a_rel[A_ROUNDS], a_yx[A_ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < A_ROUNDS; ++rd) {
+    const int pos = rd * NT + tid;
+    const int hp = pos >> 3, cpos = pos & 7;
+    const int hy = hp / HW_, hx = hp - hy * HW_;
+    const int chunk = (((cpos >> 1) ^ f4(hx)) << 1) | (cpos & 1);
+    a_rel[rd] = ((hy - 1) * p.W + (hx - 1)) * (int)p.ldx + chunk * 8;
+    a_yx[rd] = (pos < HALO_CH) ? ((hy << 8) | hx) : -1;
+  }
+  int d_rel[D_ROUNDS];
+#pragma unroll
+  for (int rd = 0; rd < D_ROUNDS; ++rd) {
+    const int pos = rd * NT + tid;
+    const int px = pos / CPP, cpos = pos % CPP;
+    const int ty = px >> 4, xx = px & 15;
+    const int blk = (cpos >> 1) ^ (BCO == 64 ? f4(xx) : f8(xx));
+    d_rel[rd] = (ty * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8;
+  }
+
+  auto issue_tile = [&](int t, int buf) {
+    const int tx = t % tw;
+    const int r2 = t / tw;
+    const int ty = r2 % th;
+    const int b = r2 / th;
+    const int oh0 = ty * TH, ow0 = tx << 4;
+    const long pix = ((long)b * p.H + oh0) * p.W + ow0;
+    const T* xb = xg + pix * p.ldx;
+    const T* db = dyg + pix * p.lddy;
+    const unsigned l0 = lds0 + (buf * BUF_CH + wave * 64) * 16;
+#pragma unroll
+    for (int rd = 0; rd < D_ROUNDS; ++rd) glds16(db + d_rel[rd], l0 + (HALO_CH + rd * NT) * 16);
+#pragma unroll
+    for (int rd = 0; rd < A_ROUNDS; ++rd) {
+      if (a_yx[rd] >= 0) {
+        const int ih = oh0 - 1 + (a_yx[rd] >> 8), iw = ow0 - 1 + (a_yx[rd] & 255);
+        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        glds16(ok ? xb + a_rel[rd] : zp, l0 + rd * NT * 16);
+      }
+    }
+  };
+  // LDS-DMA instructions a wave issues per tile (wave-uniform): the count its vmcnt wait leaves in flight
+  const bool partial = (A_ROUNDS > A_FULL) && (A_FULL * NT + wave * 64 < HALO_CH);
+
+  // ---- fragment byte offsets inside a buffer ------------------------------------------------------------
+  const int i16 = lane & 15, g = lane >> 4;
+  const int trow = g >> 1;
+  int abase[CPW][2], bbase[3][2];
+#pragma unroll
+  for (int rd = 0; rd < 2; ++rd) {
+    const int xq = (g & 1) * 8 + rd * 4 + (i16 >> 2);
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int cb = wm * CPW + i;
+      abase[i][rd] = HALO_CH * 16 + (trow * 16 + xq) * DY_ROWB + ((cb ^ (BCO == 64 ? f4(xq) : f8(xq))) << 5) + (i16 & 3) * 8;
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      const int hx = xq + s3;
+      bbase[s3][rd] = (trow * HW_ + hx) * 128 + ((wn ^ f4(hx)) << 5) + (i16 & 3) * 8;
+    }
+  }
+  auto tr_frag = [&](int off0, int off1) -> uint4 {
+    const uint2 u0 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(smb + off0)));
+    const uint2 u1 = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(smb + off1)));
+    return make_uint4(u0.x, u0.y, u1.x, u1.y);
+  };
+
+  f32x4 acc[9][CPW], accb[CPW];
+#pragma unroll
+  for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) acc[t9][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.dbias != nullptr && ci0 == 0 && wn == 0;
+  // eight 1.0 values: bf16 0x3F80, fp16 0x3C00
+  const uint32_t one1 = to_bits<T>(from_f32<T>(1.0f));
+  const uint32_t one2 = one1 | (one1 << 16);
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
+
+  issue_tile(t0, 0);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    const bool more = t + 1 < t1;
+    if (more) issue_tile(t + 1, buf ^ 1);
+    if (more) {
+      if (partial) wait_vmcnt<D_ROUNDS + A_FULL + 1>(); else wait_vmcnt<D_ROUNDS + A_FULL>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const int boff = buf * (BUF_CH * 16);
+#pragma unroll
+    for (int sub = 0; sub < NSUB; ++sub) {
+      uint4 fa[CPW];
+#pragma unroll
+      for (int i = 0; i < CPW; ++i)
+        fa[i] = tr_frag(boff + abase[i][0] + sub * 32 * DY_ROWB, boff + abase[i][1] + sub * 32 * DY_ROWB);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) accb[i] = Mfma<T>::run(fa[i], ones, accb[i]);
+      }
+#pragma unroll
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int r = t9 / 3, s3 = t9 % 3;
+        const uint4 fb = tr_frag(boff + bbase[s3][0] + (2 * sub + r) * (HW_ * 128), boff + bbase[s3][1] + (2 * sub + r) * (HW_ * 128));
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) acc[t9][i] = Mfma<T>::run(fa[i], fb, acc[t9][i]);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+
+  // ---- epilogue: D row = co = g*4 + q, col = ci = i16 ----------------------------------------------------
+  float* dw = (float*)p.dw;
+  const int ci = ci0 + wn * 16 + i16;
+  if (ci < p.Cin_out) {
+#pragma unroll
+    for (int t9 = 0; t9 < 9; ++t9) {
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = co0 + (wm * CPW + i) * 16 + g * 4 + q;
+          if (co < p.Cout_out) atomicAdd(dw + (long)co * p.lddw + (long)t9 * p.Cin_out + ci, p.alpha * acc[t9][i][q]);
+        }
+      }
+    }
+  }
+  if (do_bias && i16 == 0) {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = co0 + (wm * CPW + i) * 16 + g * 4 + q;
+        if (co < p.Cout_out) atomicAdd(p.dbias + co, accb[i][q]);
+      }
+  }
+}
+
+// Split-K choice: one workgroup per CU (LDS), so the launch runs in rounds of 256 blocks; every block
+// walks `per` tiles and pays a fixed prologue + atomic epilogue worth about OVH tiles.
+static void pick_split(int npairs, int ntiles, int ovh, int* per_out, int* splitk_out) {
+  long best = -1;
+  int bper = ntiles, bsk = 1;
+  const int skmax = ntiles < 2048 / npairs + 1 ? ntiles : 2048 / npairs + 1;
+  for (int sk = 1; sk <= skmax; ++sk) {
+    const int per = (ntiles + sk - 1) / sk;
+    const int ske = (ntiles + per - 1) / per;
+    const long blocks = (long)npairs * ske;
+    const long rounds = (blocks + 255) / 256;
+    const long cost = (long)(per + ovh) * rounds;
+    if (best < 0 || cost < best) { best = cost; bper = per; bsk = ske; }
+  }
+  *per_out = bper; *splitk_out = bsk;
+}
+
+template <typename T, int TH, int CPW>
+void launch_wg(const WgP& p, hipStream_t st) {
+  constexpr int BCO = 2 * CPW * 16;
+  const int ncot = p.Cout / BCO, npairs = ncot * (p.Cin / 64);
+  const int ntiles = p.B * (p.H / TH) * (p.W >> 4);
+  int per, splitk;
+  pick_split(npairs, ntiles, TH == 16 ? 6 : 10, &per, &splitk);
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW>), dim3(npairs * splitk), dim3(512), 0, st, p, ntiles, per, npairs, ncot);
+}
+
+template <typename T>
+void dispatch_wg(const WgP& p, hipStream_t st) {
+  const char* e = getenv("JG_WGRAD_HALO_CFG");
+  const int cfg = e ? atoi(e) : 0;   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co
+  // the 128-channel x 8-row configuration halves the L2->LDS bytes per MFMA but doubles the atomic
+  // volume: it pays once a block has >= 64 (16-row) tiles to walk
+  const long per1 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.Cout / 64) * (p.Cin / 64) / 256;
+  const bool big = cfg == 2 || (cfg == 0 && per1 >= 64);
+  if (big && p.Cout % 128 == 0) launch_wg<T, 8, 4>(p, st);
+  else launch_wg<T, 16, 2>(p, st);
+}
+
+}  // namespace
+
+bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st) {
+  if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_mode != JG_OUT_ATOMIC_F32) return false;
+  if (p.Cin % 64 || p.Cout % 64 || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
+  if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.B * p.H * p.W * p.lddy >= (1L << 31)) return false;
+  if (dtype == JG_F16) dispatch_wg<f16_t>(p, st);
+  else if (dtype == JG_BF16) dispatch_wg<bf16_t>(p, st);
+  else return false;
+  return true;
+}

@@ -1,0 +1,19 @@
+// Kernel-side parameter block shared by the weight-gradient kernels (gemm_tn.hip, wgrad_halo.hip).
+#pragma once
+#include "common.h"
+
+struct WgP {
+  const char* dy; const char* x; char* dw; float* dbias;
+  int Mpix, Cout, Ktot;  // reduction length, rows, cols (= R*S*Cin)
+  int H, W, Cin, R, S, pad, stride, Ho, Wo;
+  int Cin_out, Cout_out;
+  long lddy, ldx, lddw;
+  int nh, splitk;
+  long sdyb, sdyh, sxb, sxh, sdwb, sdwh;
+  float alpha;
+  int out_mode;
+  int B;
+};
+
+// wgrad_halo.hip: returns true when the shape was handled by the halo-resident 3x3 kernel.
+bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st);
