@@ -233,7 +233,7 @@ def main():
             d[0] += 1
             d[1] += e0.elapsed_time(e1) * 1e-3
             d[2] += fl
-        dom = max((k for k in per if k.startswith("conv_nt")), key=lambda k: per[k][1])
+        dom = max(per, key=lambda k: per[k][1])
         n, tsum, fsum = per[dom]
         achieved = fsum / tsum / 1e12
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,

@@ -49,6 +49,14 @@ typedef struct {
   int64_t sxb, sxh, swb, swh, syb, syh, srb, srh;
   float alpha, res_scale;
   int32_t out_f32;
+  /* optional fused GroupNorm statistics of the OUTPUT (the consumer's jg_gn_stats pass folded into
+   * this epilogue): stats[(b * ldstats + n) * 2 + {0,1}] += (sum, sum of squares) over the pixels of
+   * image b, fp32 atomics, computed from the fp32 values before the 16-bit rounding.  The caller
+   * zeroes the buffer.  Needs nbatch == 1, out_f32 == 0, Ho*Wo % 256 == 0, Cout % 64 == 0
+   * (JG_ERR_UNSUPPORTED otherwise).  ldstats = channel count of the statistics row (>= Cout: lets
+   * two producers fill the halves of a channel-concatenated consumer); 0 means Cout. */
+  float* stats;
+  int64_t ldstats;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 
@@ -69,6 +77,7 @@ typedef struct {
   int64_t sdyb, sdyh, sxb, sxh, sdwb, sdwh;
   float alpha;
   int32_t out_mode;
+  float dbias_scale; /* dbias[co] += dbias_scale * sum_p dy[p][co]; 0 means 1 (a skip-path conv fed with skipw*dy) */
 } jg_wgrad_args;
 int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream);
 
@@ -95,6 +104,26 @@ int jg_gn_bwd_coef(const float* red, const float* gamma, const float* beta, cons
                    int B, int HW, int C, int G, jg_stream_t s);
 int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, const float* pqr, void* dx,
                     int B, int HW, int C, int act, jg_stream_t s);
+/* Strided forms of the three streaming passes: every tensor carries its own pixel stride (elements,
+ * multiple of 8, >= C), so they run on channel slices of a concatenated buffer without a copy
+ * (torch.cat of the UNet skip connections, unet_generator_attn.py:692-693, and its backward split).
+ * bwd_apply_ld additionally folds the gradient accumulation of the OTHER consumers of x into the
+ * same pass: dx = GN-backward(...) + scale1*add1 + scale2*add2 (each optional) -- the residual /
+ * skip-connection / concat fan-out sums that autograd would run as separate add kernels. */
+/* stats_ld ACCUMULATES into sums (the caller zeroes), x pixel stride ldx, statistics row stride ldsums channels. */
+int jg_gn_stats_ld(int dtype, const void* x, int64_t ldx, float* sums, int64_t ldsums, int B, int HW, int C, jg_stream_t s);
+/* coef_ld: the statistics row of image b starts at sums + b*ldsums*2 (channel slice of a wider row);
+ * HW is the pixel count the sums were taken over (a nearest-upsampled tensor reuses the sums of
+ * its source with the source's HW: mean and variance are unchanged). */
+int jg_gn_coef_ld(const float* sums, int64_t ldsums, const float* gamma, const float* beta, const float* film,
+                  int64_t ldfilm, float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s);
+int jg_gn_apply_ld(int dtype, const void* x, int64_t ldx, const float* ab, void* y, int64_t ldy,
+                   int B, int HW, int C, int act, jg_stream_t s);
+int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
+                        float* red, int B, int HW, int C, int act, jg_stream_t s);
+int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
+                       const float* pqr, void* dx, int64_t lddx, const void* add1, int64_t ldadd1, float scale1,
+                       const void* add2, int64_t ldadd2, float scale2, int B, int HW, int C, int act, jg_stream_t s);
 
 /* 2x2 sum-pool * scale and nearest x2 upsample * scale, NHWC.  Forward/backward of
  * nn.AvgPool2d(2,2) (pool scale .25 / upsample scale .25) and of
@@ -102,6 +131,11 @@ int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, c
  * (unet_generator_attn.py:81-96,121-140). */
 int jg_pool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s);
 int jg_upsample2x(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s);
+/* the same with explicit pixel strides (channel slices of a concatenated buffer) */
+int jg_pool2x2_ld(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, float scale,
+                  jg_stream_t s);
+int jg_upsample2x_ld(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C, float scale,
+                     jg_stream_t s);
 /* dst[p][doff:doff+n] = src[p][soff:soff+n] for p < P (channel-block copy; torch.cat(dim=1) and its
  * backward split in NHWC; unet_generator_attn.py:687). */
 int jg_copy_channels(int dtype, const void* src, int64_t ldsrc, int64_t soff, void* dst, int64_t lddst, int64_t doff,

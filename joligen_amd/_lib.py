@@ -30,7 +30,7 @@ class ConvArgs(C.Structure):
         + [(n, c_i64) for n in ("ldx", "ldw", "ldy", "ldres")]
         + [(n, c_i32) for n in ("nbatch", "nh")]
         + [(n, c_i64) for n in ("sxb", "sxh", "swb", "swh", "syb", "syh", "srb", "srh")]
-        + [("alpha", c_f32), ("res_scale", c_f32), ("out_f32", c_i32)]
+        + [("alpha", c_f32), ("res_scale", c_f32), ("out_f32", c_i32), ("stats", c_p), ("ldstats", c_i64)]
     )
 
 
@@ -42,7 +42,7 @@ class WgradArgs(C.Structure):
         + [(n, c_i64) for n in ("lddy", "ldx", "lddw")]
         + [(n, c_i32) for n in ("nbatch", "nh", "splitk")]
         + [(n, c_i64) for n in ("sdyb", "sdyh", "sxb", "sxh", "sdwb", "sdwh")]
-        + [("alpha", c_f32), ("out_mode", c_i32)]
+        + [("alpha", c_f32), ("out_mode", c_i32), ("dbias_scale", c_f32)]
     )
 
 
@@ -58,8 +58,16 @@ SIGNATURES = {
     "jg_gn_bwd_reduce": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_gn_bwd_coef": [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_gn_bwd_apply": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_stats_ld": [c_i32, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_coef_ld": [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
+    "jg_gn_apply_ld": [c_i32, c_p, c_i64, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_bwd_reduce_ld": [c_i32, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_bwd_apply_ld": [c_i32, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_f32, c_p, c_i64, c_f32,
+                           c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_pool2x2": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_upsample2x": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
+    "jg_pool2x2_ld": [c_i32, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
+    "jg_upsample2x_ld": [c_i32, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_copy_channels": [c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_i32, c_p],
     "jg_axpby": [c_i32, c_p, c_f32, c_p, c_p, c_f32, c_p, c_i64, c_p],
     "jg_transpose_heads": [c_i32, c_p, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p],

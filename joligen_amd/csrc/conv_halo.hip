@@ -232,6 +232,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[q] = p.bias[n + q];
     }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const long m = ((long)b * p.H + oh0 + wm * TM + i) * p.W + ow0 + l15;
@@ -250,7 +251,13 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
       } else {
         *reinterpret_cast<uint2*>((T*)yb + m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s1[q] += v[q];
+        s2[q] += v[q] * v[q];
+      }
     }
+    if (p.stats) jg_stats_flush(p.stats, (long)b * p.ldstats, n, s1, s2, lane);
   }
 }
 

@@ -12,8 +12,27 @@ struct ConvP {
   float alpha, res_scale;
   int out_f32;
   int B;
-  float* stats;   // optional [B][N][2] fp32 (sum, sum of squares) of the stored output, accumulated atomically
+  float* stats;   // optional fp32 (sum, sum of squares) per (image, output channel) of the output, accumulated
+  long ldstats;   //   atomically at stats[(b * ldstats + n) * 2 + {0,1}] (GroupNorm statistics of the consumer)
 };
+
+// Per-wave reduction of the epilogue's (sum, sum^2) partials over the 16 pixel lanes of an MFMA tile
+// column group, then one atomic pair per channel from lane (l & 15) == 0.
+__device__ __forceinline__ void jg_stats_flush(float* stats, long row, int n, const float* s1, const float* s2, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float a = s1[q], b = s2[q];
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      a += __shfl_xor(a, o);
+      b += __shfl_xor(b, o);
+    }
+    if ((lane & 15) == 0) {
+      atomicAdd(stats + (row + n + q) * 2, a);
+      atomicAdd(stats + (row + n + q) * 2 + 1, b);
+    }
+  }
+}
 
 // conv_halo.hip: returns true when the shape was handled by the halo-resident 3x3 kernel.
 bool jg_conv_halo_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);

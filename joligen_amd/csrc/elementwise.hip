@@ -8,7 +8,8 @@ namespace {
 
 // ---- 2x2 sum pool / nearest upsample --------------------------------------------------------
 template <typename T>
-__global__ void pool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, float scale) {
+__global__ void pool2x2_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int B, int H, int W, int C,
+                               float scale) {
   const int Ho = H / 2, Wo = W / 2, noct = C / 8;
   const long total = (long)B * Ho * Wo * noct;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -17,24 +18,25 @@ __global__ void pool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int B
     const int ow = t % Wo; t /= Wo;
     const int oh = t % Ho;
     const int b = t / Ho;
-    const T* p00 = x + (((long)b * H + oh * 2) * W + ow * 2) * C + co * 8;
+    const T* p00 = x + (((long)b * H + oh * 2) * W + ow * 2) * ldx + co * 8;
     float f[8], a[8];
     unpack8<T>(*reinterpret_cast<const uint4*>(p00), a);
-    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + C), f);
+    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + ldx), f);
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] += f[q];
-    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + (long)W * C), f);
+    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + (long)W * ldx), f);
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] += f[q];
-    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + (long)W * C + C), f);
+    unpack8<T>(*reinterpret_cast<const uint4*>(p00 + (long)W * ldx + ldx), f);
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = (a[q] + f[q]) * scale;
-    *reinterpret_cast<uint4*>(y + (((long)b * Ho + oh) * Wo + ow) * C + co * 8) = pack8<T>(a);
+    *reinterpret_cast<uint4*>(y + (((long)b * Ho + oh) * Wo + ow) * ldy + co * 8) = pack8<T>(a);
   }
 }
 
 template <typename T>
-__global__ void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, float scale) {
+__global__ void upsample2x_kernel(const T* __restrict__ x, long ldx, T* __restrict__ y, long ldy, int B, int H, int W, int C,
+                                  float scale) {
   const int Ho = H * 2, Wo = W * 2, noct = C / 8;
   const long total = (long)B * Ho * Wo * noct;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -43,7 +45,7 @@ __global__ void upsample2x_kernel(const T* __restrict__ x, T* __restrict__ y, in
     const int ow = t % Wo; t /= Wo;
     const int oh = t % Ho;
     const int b = t / Ho;
-    uint4 v = *reinterpret_cast<const uint4*>(x + (((long)b * H + oh / 2) * W + ow / 2) * C + co * 8);
+    uint4 v = *reinterpret_cast<const uint4*>(x + (((long)b * H + oh / 2) * W + ow / 2) * ldx + co * 8);
     if (scale != 1.0f) {
       float f[8];
       unpack8<T>(v, f);
@@ -346,21 +348,29 @@ inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
 
 }  // namespace
 
-extern "C" int jg_pool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s) {
-  if (!x || !y || C % 8 || H % 2 || W % 2 || B < 1) return JG_ERR_BAD_ARG;
+extern "C" int jg_pool2x2_ld(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C,
+                             float scale, jg_stream_t s) {
+  if (!x || !y || C % 8 || H % 2 || W % 2 || B < 1 || ldx < C || ldy < C || ldx % 8 || ldy % 8) return JG_ERR_BAD_ARG;
   const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((pool2x2_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
-                                              (const T*)x, (T*)y, B, H, W, C, scale););
+                                              (const T*)x, (long)ldx, (T*)y, (long)ldy, B, H, W, C, scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_pool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s) {
+  return jg_pool2x2_ld(dtype, x, C, y, C, B, H, W, C, scale, s);
+}
+extern "C" int jg_upsample2x_ld(int dtype, const void* x, int64_t ldx, void* y, int64_t ldy, int B, int H, int W, int C,
+                                float scale, jg_stream_t s) {
+  if (!x || !y || C % 8 || B < 1 || ldx < C || ldy < C || ldx % 8 || ldy % 8) return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * 2 * W * 2 * (C / 8);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, (long)ldx, (T*)y, (long)ldy, B, H, W, C, scale););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
 extern "C" int jg_upsample2x(int dtype, const void* x, void* y, int B, int H, int W, int C, float scale, jg_stream_t s) {
-  if (!x || !y || C % 8 || B < 1) return JG_ERR_BAD_ARG;
-  const long total = (long)B * H * 2 * W * 2 * (C / 8);
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((upsample2x_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
-                                              (const T*)x, (T*)y, B, H, W, C, scale););
-  JG_CHECK_LAUNCH();
-  return JG_OK;
+  return jg_upsample2x_ld(dtype, x, C, y, C, B, H, W, C, scale, s);
 }
 extern "C" int jg_copy_channels(int dtype, const void* src, int64_t ldsrc, int64_t soff, void* dst, int64_t lddst,
                                 int64_t doff, int64_t P, int n, jg_stream_t s) {

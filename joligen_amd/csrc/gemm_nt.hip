@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) bv[q] = p.bias[n + q];
     }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * WM + i * 16 + (lane & 15);
@@ -349,7 +350,14 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
       } else {
         *reinterpret_cast<uint2*>((T*)yb + (long)m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        s1[q] += v[q];
+        s2[q] += v[q] * v[q];
+      }
     }
+    // host guarantees (Ho*Wo) % BM == 0 when stats != nullptr: the whole tile belongs to one image
+    if (p.stats) jg_stats_flush(p.stats, (long)(m0 / (p.Ho * p.Wo)) * p.ldstats, n, s1, s2, lane);
   }
 }
 
@@ -363,6 +371,7 @@ template <typename T>
 int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
   const char* venv = getenv("JG_CONV_VARIANT");
   const int variant = venv ? atoi(venv) : 6;  // 1: register-staged 32-deep; 2..5: LDS-DMA staged (128x128x64 = 3); 6: + halo-resident 3x3
+  if (p.stats && variant < 2) return JG_ERR_UNSUPPORTED;
   if (variant >= 6 && jg_conv_halo_try(sizeof(T) == 2 && std::is_same<T, f16_t>::value ? JG_F16 : JG_BF16, p, nbatch, st)) {
     JG_CHECK_LAUNCH();
     return JG_OK;
@@ -413,6 +422,11 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.sxb = a->sxb; p.sxh = a->sxh; p.swb = a->swb; p.swh = a->swh; p.syb = a->syb; p.syh = a->syh;
   p.srb = a->srb; p.srh = a->srh;
   p.alpha = a->alpha; p.res_scale = a->res_scale; p.out_f32 = a->out_f32;
-  p.B = a->B; p.stats = nullptr;
+  p.B = a->B; p.stats = a->stats; p.ldstats = a->ldstats > 0 ? a->ldstats : a->Cout;
+  if (p.stats) {
+    // fused GroupNorm statistics: single conv, whole tiles inside one image, LDS-DMA kernels only
+    const long hw = (long)a->Ho * a->Wo;
+    if (a->nbatch != 1 || a->out_f32 || hw % 256 || a->Cout % 64) return JG_ERR_UNSUPPORTED;
+  }
   JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream););
 }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(WgP p) {
       v += __shfl_xor(v, 2);
       v += __shfl_xor(v, 4);
       v += __shfl_xor(v, 8);
-      if (pq == 0 && (cm + q) < p.Cout_out) atomicAdd(p.dbias + cm + q, v);
+      if (pq == 0 && (cm + q) < p.Cout_out) atomicAdd(p.dbias + cm + q, p.dbias_scale * v);
     }
   }
 }
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
     }
     __syncthreads();
     if (tid < BM && (m0 + tid) < p.Cout_out)
-      atomicAdd(p.dbias + m0 + tid, s_b[tid] + s_b[128 + tid] + s_b[256 + tid] + s_b[384 + tid]);
+      atomicAdd(p.dbias + m0 + tid, p.dbias_scale * (s_b[tid] + s_b[128 + tid] + s_b[256 + tid] + s_b[384 + tid]));
   }
 }
 
@@ -452,6 +452,7 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   p.nh = a->nh; p.splitk = a->splitk;
   p.sdyb = a->sdyb; p.sdyh = a->sdyh; p.sxb = a->sxb; p.sxh = a->sxh; p.sdwb = a->sdwb; p.sdwh = a->sdwh;
   p.alpha = a->alpha; p.out_mode = a->out_mode; p.B = a->B;
+  p.dbias_scale = a->dbias_scale != 0.f ? a->dbias_scale : 1.f;
   const char* venv = getenv("JG_WGRAD_VARIANT");
   const int variant = venv ? atoi(venv) : 4;  // 1: register transpose; 2: transposing LDS reads; 3: 2 with 128-row tiles only; 4: + halo-resident 3x3
   if (variant >= 4 && jg_wgrad_halo_try(dtype, p, a->nbatch, (hipStream_t)stream)) {

@@ -27,7 +27,8 @@ __host__ __device__ inline Map make_map(int C) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, float* __restrict__ sums, int HW, int C) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, long ldx, float* __restrict__ sums, long ldsums,
+                                                       int HW, int C) {
   extern __shared__ float s_acc[];  // [C][2]
   const Map mp = make_map(C);
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -40,9 +41,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     for (int q = 0; q < 8; ++q) s1[q] = s2[q] = 0.f;
     const int pbeg = blockIdx.x * mp.chunk;
     const int pend = min(HW, pbeg + mp.chunk);
-    const T* xb = x + ((long)b * HW) * C + co * 8;
+    const T* xb = x + ((long)b * HW) * ldx + co * 8;
     for (int p = pbeg + pl; p < pend; p += mp.pl) {
-      const uint4 v = *reinterpret_cast<const uint4*>(xb + (long)p * C);
+      const uint4 v = *reinterpret_cast<const uint4*>(xb + (long)p * ldx);
       float f[8];
       unpack8<T>(v, f);
 #pragma unroll
@@ -58,10 +59,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     }
   }
   __syncthreads();
-  for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[(long)b * 2 * C + i], s_acc[i]);
+  for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[(long)b * 2 * ldsums + i], s_acc[i]);
 }
 
-__global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+__global__ void gn_coef_kernel(const float* __restrict__ sums, long ldsums, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ film, long ldfilm,
                                float* __restrict__ ab, float* __restrict__ mr, int B, int HW, int C, int G, float eps) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,7 +71,7 @@ __global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __re
   const int cpg = C / G, g = c / cpg;
   float S1 = 0.f, S2 = 0.f;
   for (int k = 0; k < cpg; ++k) {
-    const long o = ((long)b * C + g * cpg + k) * 2;
+    const long o = ((long)b * ldsums + g * cpg + k) * 2;
     S1 += sums[o];
     S2 += sums[o + 1];
   }
@@ -95,8 +96,8 @@ __global__ void gn_coef_kernel(const float* __restrict__ sums, const float* __re
 }
 
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, const float* __restrict__ ab,
-                                                       T* __restrict__ y, int HW, int C) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ ab,
+                                                       T* __restrict__ y, long ldy, int HW, int C) {
   const Map mp = make_map(C);
   const int tid = threadIdx.x, b = blockIdx.y;
   if (tid >= mp.active) return;
@@ -109,9 +110,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
   const int pbeg = blockIdx.x * mp.chunk;
   const int pend = min(HW, pbeg + mp.chunk);
-  const long base = ((long)b * HW) * C + co * 8;
+  const long row0 = (long)b * HW;
   for (int p = pbeg + pl; p < pend; p += mp.pl) {
-    const uint4 v = *reinterpret_cast<const uint4*>(x + base + (long)p * C);
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
     float f[8];
     unpack8<T>(v, f);
 #pragma unroll
@@ -119,14 +120,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       const float u = a[q] * f[q] + bb[q];
       f[q] = ACT == JG_ACT_SILU ? silu_f(u) : u;
     }
-    *reinterpret_cast<uint4*>(y + base + (long)p * C) = pack8<T>(f);
+    *reinterpret_cast<uint4*>(y + (row0 + p) * ldy + co * 8) = pack8<T>(f);
   }
 }
 
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                            const float* __restrict__ ab, float* __restrict__ red,
-                                                            int HW, int C) {
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+                                                            long lddy, const float* __restrict__ ab,
+                                                            float* __restrict__ red, int HW, int C) {
   extern __shared__ float s_acc[];  // [C][2]
   const Map mp = make_map(C);
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     }
     const int pbeg = blockIdx.x * mp.chunk;
     const int pend = min(HW, pbeg + mp.chunk);
-    const long base = ((long)b * HW) * C + co * 8;
+    const long row0 = (long)b * HW;
     for (int p = pbeg + pl; p < pend; p += mp.pl) {
-      const uint4 vx = *reinterpret_cast<const uint4*>(x + base + (long)p * C);
-      const uint4 vg = *reinterpret_cast<const uint4*>(dy + base + (long)p * C);
+      const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
+      const uint4 vg = *reinterpret_cast<const uint4*>(dy + (row0 + p) * lddy + co * 8);
       float fx[8], fg[8];
       unpack8<T>(vx, fx);
       unpack8<T>(vg, fg);
@@ -206,9 +207,12 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ red, const float* _
 }
 
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy,
-                                                           const float* __restrict__ ab, const float* __restrict__ pqr,
-                                                           T* __restrict__ dx, int HW, int C) {
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+                                                           long lddy, const float* __restrict__ ab,
+                                                           const float* __restrict__ pqr, T* __restrict__ dx, long lddx,
+                                                           const T* __restrict__ add1, long ldadd1, float sc1,
+                                                           const T* __restrict__ add2, long ldadd2, float sc2, int HW,
+                                                           int C) {
   const Map mp = make_map(C);
   const int tid = threadIdx.x, b = blockIdx.y;
   if (tid >= mp.active) return;
@@ -225,10 +229,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   }
   const int pbeg = blockIdx.x * mp.chunk;
   const int pend = min(HW, pbeg + mp.chunk);
-  const long base = ((long)b * HW) * C + co * 8;
+  const long row0 = (long)b * HW;
   for (int p = pbeg + pl; p < pend; p += mp.pl) {
-    const uint4 vx = *reinterpret_cast<const uint4*>(x + base + (long)p * C);
-    const uint4 vg = *reinterpret_cast<const uint4*>(dy + base + (long)p * C);
+    const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
+    const uint4 vg = *reinterpret_cast<const uint4*>(dy + (row0 + p) * lddy + co * 8);
     float fx[8], fg[8];
     unpack8<T>(vx, fx);
     unpack8<T>(vg, fg);
@@ -238,7 +242,19 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
       if (ACT == JG_ACT_SILU) du *= silu_grad_f(a[q] * fx[q] + bb[q]);
       fg[q] = du * P[q] + fx[q] * Q[q] + R[q];
     }
-    *reinterpret_cast<uint4*>(dx + base + (long)p * C) = pack8<T>(fg);
+    if (add1) {   // fused gradient accumulation of the other consumers of x (residual / skip / concat paths)
+      float fa[8];
+      unpack8<T>(*reinterpret_cast<const uint4*>(add1 + (row0 + p) * ldadd1 + co * 8), fa);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fg[q] += sc1 * fa[q];
+    }
+    if (add2) {
+      float fa[8];
+      unpack8<T>(*reinterpret_cast<const uint4*>(add2 + (row0 + p) * ldadd2 + co * 8), fa);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) fg[q] += sc2 * fa[q];
+    }
+    *reinterpret_cast<uint4*>(dx + (row0 + p) * lddx + co * 8) = pack8<T>(fg);
   }
 }
 
@@ -246,55 +262,75 @@ inline bool bad_shape(int B, int HW, int C) { return B < 1 || HW < 1 || C < 8 ||
 
 }  // namespace
 
-extern "C" int jg_gn_stats(int dtype, const void* x, float* sums, int B, int HW, int C, jg_stream_t s) {
-  if (!x || !sums || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)s;
-  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
+extern "C" int jg_gn_stats_ld(int dtype, const void* x, int64_t ldx, float* sums, int64_t ldsums, int B, int HW, int C,
+                              jg_stream_t s) {
+  if (!x || !sums || bad_shape(B, HW, C) || ldx < C || (ldx % 8) || ldsums < C) return JG_ERR_BAD_ARG;
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 2 * C * sizeof(float), st,
-                                              (const T*)x, sums, HW, C););
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s,
+                                              (const T*)x, (long)ldx, sums, (long)ldsums, HW, C););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_stats(int dtype, const void* x, float* sums, int B, int HW, int C, jg_stream_t s) {
+  if (!x || !sums || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
+  if (hipMemsetAsync(sums, 0, sizeof(float) * 2 * B * C, (hipStream_t)s) != hipSuccess) return JG_ERR_LAUNCH;
+  return jg_gn_stats_ld(dtype, x, C, sums, C, B, HW, C, s);
+}
+
+extern "C" int jg_gn_coef_ld(const float* sums, int64_t ldsums, const float* gamma, const float* beta, const float* film,
+                             int64_t ldfilm, float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s) {
+  if (!sums || !ab || !mr || G < 1 || C % G || ldsums < C) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, sums, (long)ldsums, gamma, beta,
+                     film, (long)ldfilm, ab, mr, B, HW, C, G, eps);
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
 
 extern "C" int jg_gn_coef(const float* sums, const float* gamma, const float* beta, const float* film, int64_t ldfilm,
                           float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s) {
-  if (!sums || !ab || !mr || G < 1 || C % G) return JG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, sums, gamma, beta, film,
-                     (long)ldfilm, ab, mr, B, HW, C, G, eps);
+  return jg_gn_coef_ld(sums, C, gamma, beta, film, ldfilm, ab, mr, B, HW, C, G, eps, s);
+}
+
+extern "C" int jg_gn_apply_ld(int dtype, const void* x, int64_t ldx, const float* ab, void* y, int64_t ldy, int B, int HW,
+                              int C, int act, jg_stream_t s) {
+  if (!x || !ab || !y || bad_shape(B, HW, C) || ldx < C || ldy < C || (ldx % 8) || (ldy % 8)) return JG_ERR_BAD_ARG;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  hipStream_t st = (hipStream_t)s;
+  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0, st,
+                                                                       (const T*)x, (long)ldx, ab, (T*)y, (long)ldy, HW, C);
+                    else hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x, (long)ldx,
+                                            ab, (T*)y, (long)ldy, HW, C););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
 
 extern "C" int jg_gn_apply(int dtype, const void* x, const float* ab, void* y, int B, int HW, int C, int act,
                            jg_stream_t s) {
-  if (!x || !ab || !y || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
-  const Map mp = make_map(C);
-  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  hipStream_t st = (hipStream_t)s;
-  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0, st,
-                                                                       (const T*)x, ab, (T*)y, HW, C);
-                    else hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x, ab,
-                                            (T*)y, HW, C););
-  JG_CHECK_LAUNCH();
-  return JG_OK;
+  return jg_gn_apply_ld(dtype, x, C, ab, y, C, B, HW, C, act, s);
 }
 
-extern "C" int jg_gn_bwd_reduce(int dtype, const void* x, const void* dy, const float* ab, float* red, int B, int HW,
-                                int C, int act, jg_stream_t s) {
-  if (!x || !dy || !ab || !red || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
+extern "C" int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
+                                   float* red, int B, int HW, int C, int act, jg_stream_t s) {
+  if (!x || !dy || !ab || !red || bad_shape(B, HW, C) || ldx < C || lddy < C || (ldx % 8) || (lddy % 8)) return JG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   if (hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   const size_t shm = 2 * C * sizeof(float);
   JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_SILU>), grid, dim3(256), shm,
-                                                                       st, (const T*)x, (const T*)dy, ab, red, HW, C);
+                                                                       st, (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C);
                     else hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_NONE>), grid, dim3(256), shm, st, (const T*)x,
-                                            (const T*)dy, ab, red, HW, C););
+                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C););
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_reduce(int dtype, const void* x, const void* dy, const float* ab, float* red, int B, int HW,
+                                int C, int act, jg_stream_t s) {
+  return jg_gn_bwd_reduce_ld(dtype, x, C, dy, C, ab, red, B, HW, C, act, s);
 }
 
 extern "C" int jg_gn_bwd_coef(const float* red, const float* gamma, const float* beta, const float* film,
@@ -307,16 +343,28 @@ extern "C" int jg_gn_bwd_coef(const float* red, const float* gamma, const float*
   return JG_OK;
 }
 
-extern "C" int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, const float* pqr, void* dx,
-                               int B, int HW, int C, int act, jg_stream_t s) {
+extern "C" int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
+                                  const float* pqr, void* dx, int64_t lddx, const void* add1, int64_t ldadd1, float scale1,
+                                  const void* add2, int64_t ldadd2, float scale2, int B, int HW, int C, int act,
+                                  jg_stream_t s) {
   if (!x || !dy || !ab || !pqr || !dx || bad_shape(B, HW, C)) return JG_ERR_BAD_ARG;
+  if (ldx < C || lddy < C || lddx < C || (ldx % 8) || (lddy % 8) || (lddx % 8)) return JG_ERR_BAD_ARG;
+  if ((add1 && (ldadd1 < C || ldadd1 % 8)) || (add2 && (ldadd2 < C || ldadd2 % 8))) return JG_ERR_BAD_ARG;
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   hipStream_t st = (hipStream_t)s;
   JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0,
-                                                                       st, (const T*)x, (const T*)dy, ab, pqr, (T*)dx, HW, C);
-                    else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x,
-                                            (const T*)dy, ab, pqr, (T*)dx, HW, C););
+                                                                       st, (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, pqr,
+                                                                       (T*)dx, (long)lddx, (const T*)add1, (long)ldadd1, scale1,
+                                                                       (const T*)add2, (long)ldadd2, scale2, HW, C);
+                    else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x, (long)ldx,
+                                            (const T*)dy, (long)lddy, ab, pqr, (T*)dx, (long)lddx, (const T*)add1,
+                                            (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2, HW, C););
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, const float* pqr, void* dx,
+                               int B, int HW, int C, int act, jg_stream_t s) {
+  return jg_gn_bwd_apply_ld(dtype, x, C, dy, C, ab, pqr, dx, C, nullptr, 0, 0.f, nullptr, 0, 0.f, B, HW, C, act, s);
 }

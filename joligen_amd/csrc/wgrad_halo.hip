@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = co0 + (wm * CPW + i) * 16 + g * 4 + q;
-        if (co < p.Cout_out) atomicAdd(p.dbias + co, accb[i][q]);
+        if (co < p.Cout_out) atomicAdd(p.dbias + co, p.dbias_scale * accb[i][q]);
       }
   }
 }

@@ -13,6 +13,7 @@ struct WgP {
   float alpha;
   int out_mode;
   int B;
+  float dbias_scale;
 };
 
 // wgrad_halo.hip: returns true when the shape was handled by the halo-resident 3x3 kernel.

@@ -1,0 +1,452 @@
+"""Fused forward/backward schedule of the DDPM UNet (the training hot path of SURVEY.md 8 a10-a14).
+
+`UNet.forward` (unet_generator_attn.py here) mirrors the reference module by module on top of
+per-op autograd Functions.  This executor runs the SAME modules and the SAME kernels as ONE
+autograd node with a hand-written backward, which is what lets the step shed its HBM-bound glue:
+
+  * GroupNorm statistics come out of the PRODUCING convolution's epilogue (fp32 atomics on
+    (image, channel) sums) -- the separate statistics pass over every activation is gone;
+  * `torch.cat([h, hs.pop()], 1)` (reference unet_generator_attn.py:692-693) is never executed: both
+    producers store straight into the halves of a pre-allocated concat buffer (strided epilogue
+    stores) and every consumer kernel takes explicit pixel strides; the backward split is a view;
+  * every gradient fan-in (ResBlock skip, attention residual, UNet skip connections) is folded into
+    the GroupNorm-backward pass of the consumer (`jg_gn_bwd_apply_ld` addends) or into the epilogue
+    of the 1x1 skip-convolution's input-gradient, instead of autograd's add kernels.
+
+Parameter gradients are accumulated by the kernels straight into the arena (`param.grad` views).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from .._lib import JG_ACT_NONE, JG_ACT_SILU, check
+from ..ops import _dt, _p, _st, attn_core_bwd, attn_core_fwd, conv_nt, wgrad_tn
+
+
+class Act:
+    """An activation of the schedule: NHWC view `t` (any pixel stride), fp32 statistics view
+    `st` [B, C, 2] (sum, sum^2 per image and channel, any row stride) taken over `hw` pixels."""
+
+    __slots__ = ("t", "st", "hw", "pid", "hs_j")
+
+    def __init__(self, t, st, hw, pid, hs_j=None):
+        self.t, self.st, self.hw, self.pid, self.hs_j = t, st, hw, pid, hs_j
+
+
+def _ld(t):
+    assert t.stride(-1) == 1
+    return t.stride(-2)
+
+
+def _stats_fusable(B, Ho, Wo, Cout):
+    return (Ho * Wo) % 256 == 0 and Cout % 64 == 0
+
+
+class _Pool:
+    """Zero-initialised fp32 scratch for the statistics rows of one forward (one fill kernel)."""
+
+    def __init__(self, n, device):
+        self.buf = torch.zeros(n, device=device, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, B, C):
+        n = B * C * 2
+        if self.off + n > self.buf.numel():
+            raise RuntimeError("statistics pool exhausted")
+        v = self.buf[self.off:self.off + n].view(B, C, 2)
+        self.off += n
+        return v
+
+
+# ---------------------------------------------------------------------------------------------------
+# raw launches (no autograd): every tensor may be a channel slice of a wider buffer
+# ---------------------------------------------------------------------------------------------------
+def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None):
+    B, H, W, Cin = x.shape
+    Ho, Wo = m.out_hw(H, W)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, m.Cout), device=x.device, dtype=x.dtype)
+    fuse = stats is not None and _stats_fusable(B, Ho, Wo, m.Cout)
+    conv_nt(x, m.w16, out, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
+            ldx=_ld(x), ldw=m.R * m.S * Cin, ldy=_ld(out), bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
+            ldres=_ld(res) if res is not None else 0, alpha=alpha, res_scale=res_scale,
+            stats=stats if fuse else None, ldstats=stats.stride(0) // 2 if fuse else 0)
+    if stats is not None and not fuse:   # shapes the fused epilogue does not cover: separate statistics pass
+        check(_lib.lib().jg_gn_stats_ld(_dt(out), out.data_ptr(), _ld(out), stats.data_ptr(), stats.stride(0) // 2, B, Ho * Wo,
+                                        m.Cout, _st()), "jg_gn_stats_ld")
+    return out
+
+
+def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0):
+    if m.stride != 1:
+        raise NotImplementedError("input-gradient of strided convolutions is not implemented")
+    B, H, W, Cin = x_shape
+    _, Ho, Wo, Cout = dy.shape
+    if out is None:
+        out = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
+    conv_nt(dy, m.w16T, out, B=B, H=Ho, W=Wo, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,
+            ldx=_ld(dy), ldw=m.R * m.S * Cout, ldy=_ld(out), alpha=alpha, res=res, ldres=_ld(res) if res is not None else 0,
+            res_scale=1.0)
+    return out
+
+
+def conv_wgrad(dy, x, m, alpha=1.0, dbias_scale=0.0):
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    wg = m.weight.grad
+    if wg is None:
+        raise RuntimeError("conv weight has no arena-backed .grad")
+    ktot = m.R * m.S * Cin
+    tiles = ((Cout + 127) // 128) * ((ktot + 127) // 128)
+    splitk = ops._wgrad_splitk(tiles, B * Ho * Wo)
+    wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
+             lddy=_ld(dy), ldx=_ld(x), lddw=m.R * m.S * m.Cin_real, dbias=m.bias.grad if m.bias is not None else None,
+             Cin_out=m.Cin_real, Cout_out=m.Cout_real, splitk=splitk, alpha=alpha, dbias_scale=dbias_scale)
+
+
+def gn_coef(st, hw, gamma, beta, film, G, eps):
+    B, C, _ = st.shape
+    ab = torch.empty((B, C, 2), device=st.device, dtype=torch.float32)
+    mr = torch.empty((B, G, 2), device=st.device, dtype=torch.float32)
+    check(_lib.lib().jg_gn_coef_ld(st.data_ptr(), st.stride(0) // 2, _p(gamma), _p(beta), _p(film),
+                                   film.stride(0) if film is not None else 0, ab.data_ptr(), mr.data_ptr(), B, hw, C, G, eps,
+                                   _st()), "jg_gn_coef_ld")
+    return ab, mr
+
+
+def gn_apply(x, ab, act):
+    B, H, W, C = x.shape
+    y = torch.empty((B, H, W, C), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_gn_apply_ld(_dt(x), x.data_ptr(), _ld(x), ab.data_ptr(), y.data_ptr(), C, B, H * W, C, act, _st()),
+          "jg_gn_apply_ld")
+    return y
+
+
+def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=()):
+    """dx = GroupNorm-backward(x, dy) + sum_i scale_i * add_i  (at most two addends, fused)."""
+    L = _lib.lib()
+    B, H, W, C = x.shape
+    HW = H * W
+    dev, dt = x.device, _dt(x)
+    red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+    pqr = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
+    check(L.jg_gn_bwd_reduce_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), red.data_ptr(), B, HW, C, act,
+                                _st()), "jg_gn_bwd_reduce_ld")
+    dgamma = gamma.grad if gamma is not None else None
+    dbeta = beta.grad if beta is not None else None
+    if gamma is not None and dgamma is None:
+        raise RuntimeError("norm weight has no arena-backed .grad")
+    check(L.jg_gn_bwd_coef(red.data_ptr(), _p(gamma), _p(beta), _p(film), film.stride(0) if film is not None else 0,
+                           mr.data_ptr(), pqr.data_ptr(), _p(dgamma), _p(dbeta), _p(dfilm),
+                           dfilm.stride(0) if dfilm is not None else 0, B, HW, C, G, _st()), "jg_gn_bwd_coef")
+    if out is None:
+        out = torch.empty((B, H, W, C), device=dev, dtype=x.dtype)
+    adds = list(adds)
+    if len(adds) > 2:
+        raise RuntimeError("at most two fused gradient addends")
+    a1, s1 = adds[0] if len(adds) > 0 else (None, 0.0)
+    a2, s2 = adds[1] if len(adds) > 1 else (None, 0.0)
+    check(L.jg_gn_bwd_apply_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), pqr.data_ptr(), out.data_ptr(),
+                               _ld(out), _p(a1), _ld(a1) if a1 is not None else 0, s1, _p(a2),
+                               _ld(a2) if a2 is not None else 0, s2, B, HW, C, act, _st()), "jg_gn_bwd_apply_ld")
+    return out
+
+
+def pool2(x, scale):
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_pool2x2_ld(_dt(x), x.data_ptr(), _ld(x), y.data_ptr(), C, B, H, W, C, scale, _st()), "jg_pool2x2_ld")
+    return y
+
+
+def up2(x, scale):
+    B, H, W, C = x.shape
+    y = torch.empty((B, H * 2, W * 2, C), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_upsample2x_ld(_dt(x), x.data_ptr(), _ld(x), y.data_ptr(), C, B, H, W, C, scale, _st()),
+          "jg_upsample2x_ld")
+    return y
+
+
+# ---------------------------------------------------------------------------------------------------
+# the schedule
+# ---------------------------------------------------------------------------------------------------
+class UNetExecutor:
+    def __init__(self, unet):
+        from .unet_generator_attn import AttentionBlock, ResBlock
+
+        self.u = unet
+        self.ResBlock, self.AttentionBlock = ResBlock, AttentionBlock
+        n_in = len(unet.input_blocks)
+        chans = []
+        for j, blk in enumerate(unet.input_blocks):
+            last = list(blk)[-1]
+            if j == 0:
+                chans.append(last.out_channels)
+            else:
+                chans.append(last.out_channel if isinstance(last, ResBlock) else last.channels)
+        self.n_in = n_in
+        self.cat_ch = []   # j -> (Ctot, Ca, Cb): output_blocks[n_in-1-j] consumes cat(h[Ca], hs[j][Cb])
+        for j in range(n_in):
+            ctot = list(unet.output_blocks[n_in - 1 - j])[0].channels
+            self.cat_ch.append((ctot, ctot - chans[j], chans[j]))
+        self.tape = None
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, xin, emb):
+        u = self.u
+        B, H, W, _ = xin.shape
+        dev = xin.device
+        self.emb = emb
+        self.pool = _Pool(B * 2 * 65536, dev)
+        self.tape = []
+        self.cats = {}
+        tape = self.tape
+
+        def cat_slot(j, half):
+            def make(Bq, Hq, Wq, Cq):
+                ctot, ca, cb = self.cat_ch[j]
+                if j not in self.cats:
+                    self.cats[j] = (torch.empty((Bq, Hq, Wq, ctot), device=dev, dtype=xin.dtype), self.pool.take(Bq, ctot))
+                buf, st = self.cats[j]
+                assert buf.shape[1] == Hq and buf.shape[2] == Wq, "concat halves disagree on the spatial size"
+                lo, hi = (0, ca) if half == "a" else (ca, ctot)
+                assert hi - lo == Cq, (j, half, Cq, lo, hi)
+                return buf[..., lo:hi], st[:, lo:hi, :]
+            return make
+
+        def fresh(Bq, Hq, Wq, Cq):
+            return torch.empty((Bq, Hq, Wq, Cq), device=dev, dtype=xin.dtype), self.pool.take(Bq, Cq)
+
+        # stem
+        stem = list(u.input_blocks[0])[0].meta
+        t, st = cat_slot(0, "b")(B, H, W, stem.Cout)
+        conv_fwd(xin, stem, out=t, stats=st)
+        tape.append(dict(kind="stem", xin=xin, m=stem, add_hs=None, cat_j=None, in_id=None))
+        h = Act(t, st, H * W, 0, hs_j=0)
+
+        def run_layers(layers, h, last_dest, hs_j):
+            for li, layer in enumerate(layers):
+                is_last = li == len(layers) - 1
+                dest = last_dest if is_last else fresh
+                if isinstance(layer, self.ResBlock):
+                    h = self.res_fwd(layer, h, dest)
+                elif isinstance(layer, self.AttentionBlock):
+                    h = self.attn_fwd(layer, h, dest)
+                else:
+                    raise NotImplementedError(type(layer))
+                if is_last:
+                    h.hs_j = hs_j
+            return h
+
+        for j in range(1, self.n_in):
+            h = run_layers(list(u.input_blocks[j]), h, cat_slot(j, "b"), j)
+        h = run_layers(list(u.middle_block), h, cat_slot(self.n_in - 1, "a"), None)
+        n_out = len(u.output_blocks)
+        for k, blk in enumerate(u.output_blocks):
+            j = self.n_in - 1 - k
+            buf, st = self.cats[j]
+            X = Act(buf, st, buf.shape[1] * buf.shape[2], ("cat", j, h.pid))
+            h = run_layers(list(blk), X, cat_slot(j - 1, "a") if k < n_out - 1 else fresh, None)
+        # head
+        gn, head = u.out[0].norm, u.out[2].meta
+        ab, mr = gn_coef(h.st, h.hw, gn.weight, gn.bias, None, gn.num_groups, gn.eps)
+        hn = gn_apply(h.t, ab, JG_ACT_SILU)
+        out = conv_fwd(hn, head)
+        tape.append(dict(kind="head", x=h.t, ab=ab, mr=mr, hn=hn, gn=gn, m=head, in_id=h.pid, add_hs=h.hs_j, cat_j=None))
+        self.cats = None
+        self.pool = None
+        return out
+
+    def _in_fields(self, X):
+        if isinstance(X.pid, tuple):
+            _, j, a_id = X.pid
+            return dict(in_id=None, add_hs=None, cat_j=j, cat_a_id=a_id, Ca=self.cat_ch[j][1])
+        return dict(in_id=X.pid, add_hs=X.hs_j, cat_j=None)
+
+    def res_fwd(self, rb, X, dest):
+        if rb.dropout and rb.training:
+            raise NotImplementedError("dropout > 0 inside ResBlock is not implemented")
+        x = X.t
+        B, H, W, Cin = x.shape
+        Cout = rb.out_channel
+        gn1, c1m = rb.in_layers[0].norm, rb.in_layers[2].meta
+        gn2, c2m = rb.out_layers[0].norm, rb.out_layers[3].meta
+        ab1, mr1 = gn_coef(X.st, X.hw, gn1.weight, gn1.bias, None, gn1.num_groups, gn1.eps)
+        h1 = gn_apply(x, ab1, JG_ACT_SILU)
+        st1 = self.pool.take(B, Cout)
+        Ho, Wo = H, W
+        if rb.updown:
+            Ho, Wo = (H * 2, W * 2) if rb.up else (H // 2, W // 2)
+            if rb.up and rb.efficient:     # conv before the upsample (reference :239-242)
+                a1 = h1
+                c1 = up2(conv_fwd(h1, c1m, stats=st1), 1.0)
+                hw1 = H * W                # statistics of the source: same mean / variance
+            else:
+                a1 = up2(h1, 1.0) if rb.up else pool2(h1, 0.25)
+                c1 = conv_fwd(a1, c1m, stats=st1)
+                hw1 = Ho * Wo
+            xs = up2(x, 1.0) if rb.up else pool2(x, 0.25)
+        else:
+            a1, xs, hw1 = h1, x, H * W
+            c1 = conv_fwd(h1, c1m, stats=st1)
+        off, n = rb.emb_slice
+        film = self.emb[:, off:off + n]
+        ab2, mr2 = gn_coef(st1, hw1, gn2.weight, gn2.bias, film, gn2.num_groups, gn2.eps)
+        h2 = gn_apply(c1, ab2, JG_ACT_SILU)
+        skipw = 1.0 / math.sqrt(2) if rb.efficient else 1.0
+        identity = isinstance(rb.skip_connection, nn.Identity)
+        sk = xs if identity else conv_fwd(xs, rb.skip_connection.meta)
+        out_t, out_st = dest(B, Ho, Wo, Cout)
+        conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st)
+        rec = dict(kind="res", rb=rb, x=x, ab1=ab1, mr1=mr1, a1=a1, c1=c1, ab2=ab2, mr2=mr2, h2=h2, film=film,
+                   xs=None if identity else xs, skipw=skipw, identity=identity)
+        rec.update(self._in_fields(X))
+        self.tape.append(rec)
+        return Act(out_t, out_st, Ho * Wo, len(self.tape) - 1)
+
+    def attn_fwd(self, blk, X, dest):
+        x = X.t
+        B, H, W, C = x.shape
+        T = H * W
+        ab, mr = gn_coef(X.st, X.hw, None, None, None, C, 1e-5)      # InstanceNorm1d over T, no affine
+        xn = gn_apply(x, ab, JG_ACT_NONE)
+        qkv = conv_fwd(xn.view(B, 1, T, C), blk.qkv.meta)
+        a, P = attn_core_fwd(qkv.view(B, T, 3 * C), blk.num_heads)
+        out_t, out_st = dest(B, H, W, C)
+        conv_fwd(a.view(B, 1, T, C), blk.proj_out.meta, out=out_t.view(B, 1, T, C), res=x.view(B, 1, T, C), res_scale=1.0,
+                 stats=out_st)
+        rec = dict(kind="attn", blk=blk, x=x, ab=ab, mr=mr, xn=xn, qkv=qkv, P=P, a=a)
+        rec.update(self._in_fields(X))
+        self.tape.append(rec)
+        return Act(out_t, out_st, T, len(self.tape) - 1)
+
+    # ---- backward ----------------------------------------------------------------------------------
+    def backward(self, dout, need_dx=False):
+        tape, self.tape = self.tape, None
+        self.dxin = None
+        if tape is None:
+            raise RuntimeError("UNetExecutor.backward without a forward")
+        self.demb = torch.empty_like(self.emb)
+        dacts, dhs = {}, {}
+        for idx in range(len(tape) - 1, -1, -1):
+            rec = tape[idx]
+            tape[idx] = None
+            dO = dout if rec["kind"] == "head" else dacts.pop(idx)
+            if rec["kind"] == "stem":
+                conv_wgrad(dO, rec["xin"], rec["m"])
+                if need_dx:
+                    self.dxin = conv_dgrad(dO, rec["m"], rec["xin"].shape)
+                continue
+            adds = []
+            if rec.get("add_hs") is not None:
+                adds.append((dhs.pop(rec["add_hs"]), 1.0))
+            if rec["kind"] == "head":
+                dX = self.head_bwd(rec, dO, adds)
+            elif rec["kind"] == "res":
+                dX = self.res_bwd(rec, dO, adds)
+            else:
+                dX = self.attn_bwd(rec, dO, adds)
+            if rec["cat_j"] is not None:
+                ca = rec["Ca"]
+                dacts[rec["cat_a_id"]] = dX[..., :ca]
+                dhs[rec["cat_j"]] = dX[..., ca:]
+            else:
+                dacts[rec["in_id"]] = dX
+        assert not dacts and not dhs, (list(dacts), list(dhs))
+        demb, self.demb, self.emb = self.demb, None, None
+        return demb
+
+    def head_bwd(self, rec, dO, adds):
+        gn, m = rec["gn"], rec["m"]
+        dhn = conv_dgrad(dO, m, rec["hn"].shape)
+        conv_wgrad(dO, rec["hn"], m)
+        return gn_bwd(rec["x"], dhn, rec["ab"], rec["mr"], gn.weight, gn.bias, None, gn.num_groups, JG_ACT_SILU, adds=adds)
+
+    def res_bwd(self, rec, dO, adds):
+        rb = rec["rb"]
+        x = rec["x"]
+        gn1, c1m = rb.in_layers[0].norm, rb.in_layers[2].meta
+        gn2, c2m = rb.out_layers[0].norm, rb.out_layers[3].meta
+        skipw = rec["skipw"]
+        # conv2
+        dh2 = conv_dgrad(dO, c2m, rec["h2"].shape)
+        conv_wgrad(dO, rec["h2"], c2m)
+        # GroupNorm 2 (+FiLM +SiLU)
+        off, n = rb.emb_slice
+        dc1 = gn_bwd(rec["c1"], dh2, rec["ab2"], rec["mr2"], gn2.weight, gn2.bias, rec["film"], gn2.num_groups, JG_ACT_SILU,
+                     dfilm=self.demb[:, off:off + n])
+        del dh2
+        if rb.up and rb.efficient:
+            dc1 = pool2(dc1, 1.0)          # backward of the nearest upsample that follows conv1
+        # conv1
+        da1 = conv_dgrad(dc1, c1m, rec["a1"].shape)
+        conv_wgrad(dc1, rec["a1"], c1m)
+        del dc1
+        if rb.down:
+            dh1 = up2(da1, 0.25)
+        elif rb.up and not rb.efficient:
+            dh1 = pool2(da1, 1.0)
+        else:
+            dh1 = da1
+        # skip path + GroupNorm 1
+        adds = list(adds)
+        if rec["identity"]:
+            if not rb.updown:
+                adds.append((dO, skipw))
+            elif rb.down:
+                adds.append((up2(dO, skipw * 0.25), 1.0))
+            else:
+                adds.append((pool2(dO, skipw), 1.0))
+            return gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds)
+        if rb.updown:
+            raise NotImplementedError("resampling ResBlock with a 1x1 skip convolution")
+        skm = rb.skip_connection.meta
+        conv_wgrad(dO, rec["xs"], skm, alpha=skipw, dbias_scale=skipw)
+        dxg = gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds)
+        return conv_dgrad(dO, skm, x.shape, res=dxg, alpha=skipw)   # skipw * (dO . Wskip) + dxg in one epilogue
+
+    def attn_bwd(self, rec, dO, adds):
+        blk = rec["blk"]
+        x = rec["x"]
+        B, H, W, C = x.shape
+        T = H * W
+        dO4 = dO.view(B, 1, T, C) if dO.dim() == 4 else dO
+        a4 = rec["a"].view(B, 1, T, C)
+        da = conv_dgrad(dO4, blk.proj_out.meta, a4.shape)
+        conv_wgrad(dO4, a4, blk.proj_out.meta)
+        dqkv = attn_core_bwd(rec["qkv"].view(B, T, 3 * C), rec["P"], da.view(B, T, C), blk.num_heads)
+        xn4 = rec["xn"].view(B, 1, T, C)
+        dxn = conv_dgrad(dqkv.view(B, 1, T, 3 * C), blk.qkv.meta, xn4.shape)
+        conv_wgrad(dqkv.view(B, 1, T, 3 * C), xn4, blk.qkv.meta)
+        adds = list(adds) + [(dO, 1.0)]
+        return gn_bwd(x, dxn.view(B, H, W, C), rec["ab"], rec["mr"], None, None, None, C, JG_ACT_NONE, adds=adds)
+
+
+class _FusedUNetFn(torch.autograd.Function):
+    """(xin, emb_all) -> UNet output; `exe` carries the tape between forward and backward."""
+
+    @staticmethod
+    def forward(ctx, xin, emb, exe):
+        ctx.exe = exe
+        out = exe.forward(xin, emb)
+        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            exe.tape = exe.emb = None   # inference: nothing to keep
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        demb = ctx.exe.backward(dout.contiguous(), ctx.needs_input_grad[0])
+        dx, ctx.exe.dxin = ctx.exe.dxin, None
+        return dx, demb, None
+
+
+def fused_unet(unet, xin, emb_all):
+    exe = getattr(unet, "_jg_executor", None)
+    if exe is None:
+        exe = unet._jg_executor = UNetExecutor(unet)
+    return _FusedUNetFn.apply(xin, emb_all, exe)

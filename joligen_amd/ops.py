@@ -52,9 +52,27 @@ def _require_cuda(*ts):
 # (start/stop recorded on the launch stream); entries: (kernel, ev_start, ev_stop, algorithmic flops)
 KERNEL_TIMING = None
 
+def _halo_ok(nbatch, H, W, Cin, Cout, R, S, pad, stride):
+    """mirror of the dispatch conditions of conv_halo.hip / wgrad_halo.hip (labels for bench.py only)"""
+    return (nbatch == 1 and R == 3 and S == 3 and pad == 1 and stride == 1 and Cin % 64 == 0 and Cout % 64 == 0
+            and H % 16 == 0 and W % 16 == 0)
+
+
+def _conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride):
+    if _halo_ok(nbatch, H, W, Cin, Cout, R, S, pad, stride):
+        return "conv3x3_halo_kernel<BN=%d>" % (256 if Cout % 256 == 0 else 128 if Cout % 128 == 0 else 64)
+    return "conv_nt_glds_kernel<256,64,64,4,1>" if Cout <= 64 else "conv_nt_glds_kernel<128,128,64,2,2>"
+
+
+def _wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode):
+    if out_mode == JG_OUT_ATOMIC_F32 and _halo_ok(nbatch, H, W, Cin, Cout, R, S, pad, stride):
+        return "wgrad3x3_halo_kernel"
+    return "wgrad_tn_tr_kernel<1>" if Cout <= 64 else "wgrad_tn_tr_kernel<2>"
+
+
 def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
             ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
-            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None):
+            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0):
     """jg_conv2d_nt with element offsets into the operand tensors."""
     a = ConvArgs()
     es = 2
@@ -71,18 +89,20 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     a.syb, a.syh = sy
     a.srb, a.srh = sr
     a.alpha, a.res_scale, a.out_f32 = alpha, res_scale, int(out_f32)
+    a.stats, a.ldstats = _p(stats), ldstats
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()  # current stream == the stream the kernel is launched on
     check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append(("conv_nt_glds_kernel<256,64,64,4,1>" if Cout <= 64 else "conv_nt_glds_kernel<128,128,64,2,2>", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
+        KERNEL_TIMING.append((_conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride), ev0, ev1,
+                              2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
 
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
              Cout_out=0, splitk=1, nbatch=1, nh=1, sdy=(0, 0), sx=(0, 0), sdw=(0, 0), alpha=1.0,
-             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0):
+             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0, dbias_scale=0.0):
     a = WgradArgs()
     a.dy = dy.data_ptr() + dy_off * 2
     a.x = x.data_ptr() + x_off * 2
@@ -95,14 +115,15 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.sdyb, a.sdyh = sdy
     a.sxb, a.sxh = sx
     a.sdwb, a.sdwh = sdw
-    a.alpha, a.out_mode = alpha, out_mode
+    a.alpha, a.out_mode, a.dbias_scale = alpha, out_mode, dbias_scale
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
     check(_lib.lib().jg_conv2d_wgrad_tn(_dt(dy), C.byref(a), _st()), "jg_conv2d_wgrad_tn")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append(("wgrad_tn_tr_kernel<1>" if Cout <= 64 else "wgrad_tn_tr_kernel<2>", ev0, ev1, 2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk)))
+        KERNEL_TIMING.append((_wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode), ev0, ev1,
+                              2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk)))
 
 
 def axpby(a, alpha=1.0, b=None, beta=0.0, alpha_dev=None, out=None):
@@ -359,30 +380,65 @@ def _transpose_heads(qkv, coff, nh, ch):
     return out
 
 
-class _AttnCoreFn(torch.autograd.Function):
+def attn_core_fwd(qkv, nh):
     """qkv [B,T,3C] in the LEGACY head layout (channel = h*3ch + {q: 0..ch, k: ch..2ch, v: 2ch..3ch},
-    unet_generator_attn.py:340) -> a [B,T,C] (channel = h*ch + c)."""
+    unet_generator_attn.py:340) -> (a [B,T,C] with channel = h*ch + c, P [B*nh,T,T] softmax probabilities)."""
+    _require_cuda(qkv)
+    L = _lib.lib()
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    ch = Cc // nh
+    BH = B * nh
+    dev, dt = qkv.device, _dt(qkv)
+    scale2 = 1.0 / math.sqrt(ch)  # (ch^-1/4)^2
+    S = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
+    conv_nt(qkv, qkv, S, **_gemm_geom(T, T, ch), ldx=C3, ldw=C3, ldy=T, alpha=scale2, out_f32=True, nbatch=BH, nh=nh,
+            sx=(T * C3, 3 * ch), sw=(T * C3, 3 * ch), sy=(nh * T * T, T * T), w_off=ch)
+    P = torch.empty((BH, T, T), device=dev, dtype=qkv.dtype)
+    check(L.jg_softmax_fwd(dt, S.data_ptr(), P.data_ptr(), BH * T, T, _st()), "jg_softmax_fwd")
+    del S
+    Vt = _transpose_heads(qkv, 2 * ch, nh, ch)
+    a = torch.empty((B, T, Cc), device=dev, dtype=qkv.dtype)
+    conv_nt(P, Vt, a, **_gemm_geom(T, ch, T), ldx=T, ldw=T, ldy=Cc, nbatch=BH, nh=nh, sx=(nh * T * T, T * T),
+            sw=(nh * ch * T, ch * T), sy=(T * Cc, ch))
+    return a, P
 
+
+def attn_core_bwd(qkv, P, da, nh):
+    """Gradient of attn_core_fwd with respect to qkv."""
+    L = _lib.lib()
+    da = da.contiguous()
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    ch = Cc // nh
+    BH = B * nh
+    dev, dt = qkv.device, _dt(qkv)
+    scale2 = 1.0 / math.sqrt(ch)
+    # dP = dA V^T
+    dP = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
+    conv_nt(da, qkv, dP, **_gemm_geom(T, T, ch), ldx=Cc, ldw=C3, ldy=T, out_f32=True, nbatch=BH, nh=nh,
+            sx=(T * Cc, ch), sw=(T * C3, 3 * ch), sy=(nh * T * T, T * T), w_off=2 * ch)
+    dS = torch.empty((BH, T, T), device=dev, dtype=qkv.dtype)
+    check(L.jg_softmax_bwd(dt, P.data_ptr(), dP.data_ptr(), dS.data_ptr(), BH * T, T, scale2, _st()), "jg_softmax_bwd")
+    del dP
+    dqkv = torch.empty_like(qkv)
+    # dQ = dS K      (NT with K^T as the "weight" operand)
+    Kt = _transpose_heads(qkv, ch, nh, ch)
+    conv_nt(dS, Kt, dqkv, **_gemm_geom(T, ch, T), ldx=T, ldw=T, ldy=C3, nbatch=BH, nh=nh, sx=(nh * T * T, T * T),
+            sw=(nh * ch * T, ch * T), sy=(T * C3, 3 * ch))
+    # dK = dS^T Q ; dV = P^T dA     (TN: reduction index t is the row index of both operands)
+    geom = dict(B=1, H=1, W=T, Cin=ch, Cout=T, R=1, S=1, pad=0, stride=1, Ho=1, Wo=T)
+    wgrad_tn(dS, qkv, dqkv, **geom, lddy=T, ldx=C3, lddw=C3, nbatch=BH, nh=nh, sdy=(nh * T * T, T * T),
+             sx=(T * C3, 3 * ch), sdw=(T * C3, 3 * ch), out_mode=JG_OUT_STORE_T, dw_off=ch)
+    wgrad_tn(P, da, dqkv, **geom, lddy=T, ldx=Cc, lddw=C3, nbatch=BH, nh=nh, sdy=(nh * T * T, T * T),
+             sx=(T * Cc, ch), sdw=(T * C3, 3 * ch), out_mode=JG_OUT_STORE_T, dw_off=2 * ch)
+    return dqkv
+
+
+class _AttnCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, nh):
-        _require_cuda(qkv)
-        L = _lib.lib()
-        B, T, C3 = qkv.shape
-        Cc = C3 // 3
-        ch = Cc // nh
-        BH = B * nh
-        dev, dt = qkv.device, _dt(qkv)
-        scale2 = 1.0 / math.sqrt(ch)  # (ch^-1/4)^2
-        S = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
-        conv_nt(qkv, qkv, S, **_gemm_geom(T, T, ch), ldx=C3, ldw=C3, ldy=T, alpha=scale2, out_f32=True, nbatch=BH, nh=nh,
-                sx=(T * C3, 3 * ch), sw=(T * C3, 3 * ch), sy=(nh * T * T, T * T), w_off=ch)
-        P = torch.empty((BH, T, T), device=dev, dtype=qkv.dtype)
-        check(L.jg_softmax_fwd(dt, S.data_ptr(), P.data_ptr(), BH * T, T, _st()), "jg_softmax_fwd")
-        del S
-        Vt = _transpose_heads(qkv, 2 * ch, nh, ch)
-        a = torch.empty((B, T, Cc), device=dev, dtype=qkv.dtype)
-        conv_nt(P, Vt, a, **_gemm_geom(T, ch, T), ldx=T, ldw=T, ldy=Cc, nbatch=BH, nh=nh, sx=(nh * T * T, T * T),
-                sw=(nh * ch * T, ch * T), sy=(T * Cc, ch))
+        a, P = attn_core_fwd(qkv, nh)
         ctx.save_for_backward(qkv, P)
         ctx.nh = nh
         return a
@@ -391,34 +447,7 @@ class _AttnCoreFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, da):
         qkv, P = ctx.saved_tensors
-        L = _lib.lib()
-        nh = ctx.nh
-        da = da.contiguous()
-        B, T, C3 = qkv.shape
-        Cc = C3 // 3
-        ch = Cc // nh
-        BH = B * nh
-        dev, dt = qkv.device, _dt(qkv)
-        scale2 = 1.0 / math.sqrt(ch)
-        # dP = dA V^T
-        dP = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
-        conv_nt(da, qkv, dP, **_gemm_geom(T, T, ch), ldx=Cc, ldw=C3, ldy=T, out_f32=True, nbatch=BH, nh=nh,
-                sx=(T * Cc, ch), sw=(T * C3, 3 * ch), sy=(nh * T * T, T * T), w_off=2 * ch)
-        dS = torch.empty((BH, T, T), device=dev, dtype=qkv.dtype)
-        check(L.jg_softmax_bwd(dt, P.data_ptr(), dP.data_ptr(), dS.data_ptr(), BH * T, T, scale2, _st()), "jg_softmax_bwd")
-        del dP
-        dqkv = torch.empty_like(qkv)
-        # dQ = dS K      (NT with K^T as the "weight" operand)
-        Kt = _transpose_heads(qkv, ch, nh, ch)
-        conv_nt(dS, Kt, dqkv, **_gemm_geom(T, ch, T), ldx=T, ldw=T, ldy=C3, nbatch=BH, nh=nh, sx=(nh * T * T, T * T),
-                sw=(nh * ch * T, ch * T), sy=(T * C3, 3 * ch))
-        # dK = dS^T Q ; dV = P^T dA     (TN: reduction index t is the row index of both operands)
-        geom = dict(B=1, H=1, W=T, Cin=ch, Cout=T, R=1, S=1, pad=0, stride=1, Ho=1, Wo=T)
-        wgrad_tn(dS, qkv, dqkv, **geom, lddy=T, ldx=C3, lddw=C3, nbatch=BH, nh=nh, sdy=(nh * T * T, T * T),
-                 sx=(T * C3, 3 * ch), sdw=(T * C3, 3 * ch), out_mode=JG_OUT_STORE_T, dw_off=ch)
-        wgrad_tn(P, da, dqkv, **geom, lddy=T, ldx=Cc, lddw=C3, nbatch=BH, nh=nh, sdy=(nh * T * T, T * T),
-                 sx=(T * Cc, ch), sdw=(T * C3, 3 * ch), out_mode=JG_OUT_STORE_T, dw_off=2 * ch)
-        return dqkv, None
+        return attn_core_bwd(qkv, P, da, ctx.nh), None
 
 
 def attention_core(qkv, n_heads):

@@ -261,3 +261,45 @@ def test_full_size_properties():
         assert relerr(y2.float(), 2 * y.float()) < 4e-3          # linearity in alpha
         ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
         assert relerr(y.float(), ref) < 8e-3, (B, S, Cin, Cout)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("efficient", [True, False])
+def test_fused_schedule_matches_module_graph(golden_dir, efficient, dtype):
+    """unet_exec.py (one autograd node: conv-epilogue statistics, concat-free skip connections, fused
+    gradient fan-in, halo-resident 3x3 kernels) against the module-by-module autograd graph of the
+    same network at a size where every fused path is live (C % 64 == 0, H % 16 == 0)."""
+    from joligen_amd import ops
+
+    c = dict(ngf=64, mults=[1, 2], res_blocks=[1, 1], attn_res=[2], efficient=efficient, S=64, B=2)
+    net, _ = build_net(c, dtype, golden_dir)
+    unet = net.denoise_fn.model
+    net.arena.ensure_fresh()
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    x0 = ops.to_nhwc(torch.randn(c["B"], 6, c["S"], c["S"], generator=g).to(d), dtype, 8)
+    emb0 = torch.randn(c["B"], unet.cond_embed_dim, generator=g).to(d)
+    R = ops.to_nhwc(torch.randn(c["B"], 3, c["S"], c["S"], generator=g).to(d), dtype, 8)
+    res = {}
+    for fused in (False, True):
+        unet.jg_fused = fused
+        net.arena.g.zero_()
+        x = x0.clone().requires_grad_(True)
+        emb = emb0.clone().requires_grad_(True)
+        out = unet(x, emb)
+        out.backward(R)
+        torch.cuda.synchronize()
+        res[fused] = (out.detach().float(), x.grad.float(), emb.grad.clone(), net.arena.g.clone())
+    tol = 4 * TOL_OUT[dtype]
+    assert relerr(res[True][0], res[False][0]) < tol, ("out", relerr(res[True][0], res[False][0]))
+    assert relerr(res[True][1], res[False][1]) < 2 * tol, ("dx", relerr(res[True][1], res[False][1]))
+    assert relerr(res[True][2], res[False][2]) < 2 * tol, ("demb", relerr(res[True][2], res[False][2]))
+    assert relerr(res[True][3], res[False][3]) < 2 * tol, ("flat grad", relerr(res[True][3], res[False][3]))
+    bad = []
+    for name, p in unet.named_parameters():
+        if name.endswith(".weight") and p.dim() == 4:
+            off, n = net.arena.slices["denoise_fn.model." + name]
+            a, b = res[True][3][off:off + n], res[False][3][off:off + n]
+            if float(b.norm()) > 0 and relerr(a, b) > 2 * tol:
+                bad.append((name, relerr(a, b)))
+    assert not bad, bad[:8]
