@@ -57,6 +57,11 @@ typedef struct {
    * two producers fill the halves of a channel-concatenated consumer); 0 means Cout. */
   float* stats;
   int64_t ldstats;
+  /* stats_slots > 1: the statistics row of image b is replicated stats_slots times
+   * (stats[((b * stats_slots + slot) * ldstats + n) * 2 + ...], slot = tile index % stats_slots) so that
+   * the same-address atomic chains of a high-resolution layer are stats_slots times shorter; the
+   * consumer (jg_gn_coef_ld) sums the slots. */
+  int32_t stats_slots;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 
@@ -112,10 +117,10 @@ int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, c
  * skip-connection / concat fan-out sums that autograd would run as separate add kernels. */
 /* stats_ld ACCUMULATES into sums (the caller zeroes), x pixel stride ldx, statistics row stride ldsums channels. */
 int jg_gn_stats_ld(int dtype, const void* x, int64_t ldx, float* sums, int64_t ldsums, int B, int HW, int C, jg_stream_t s);
-/* coef_ld: the statistics row of image b starts at sums + b*ldsums*2 (channel slice of a wider row);
+/* coef_ld: the statistics rows of image b start at sums + b*nslots*ldsums*2 (nslots replicas that are summed; channel slice of a wider row);
  * HW is the pixel count the sums were taken over (a nearest-upsampled tensor reuses the sums of
  * its source with the source's HW: mean and variance are unchanged). */
-int jg_gn_coef_ld(const float* sums, int64_t ldsums, const float* gamma, const float* beta, const float* film,
+int jg_gn_coef_ld(const float* sums, int64_t ldsums, int nslots, const float* gamma, const float* beta, const float* film,
                   int64_t ldfilm, float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s);
 int jg_gn_apply_ld(int dtype, const void* x, int64_t ldx, const float* ab, void* y, int64_t ldy,
                    int B, int HW, int C, int act, jg_stream_t s);

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
         s2[q] += v[q] * v[q];
       }
     }
-    if (p.stats) jg_stats_flush(p.stats, (long)b * p.ldstats, n, s1, s2, lane);
+    if (p.stats) jg_stats_flush(p.stats, ((long)b * p.nslots + sp % p.nslots) * p.ldstats, n, s1, s2, lane);
   }
 }
 

@@ -13,7 +13,8 @@ struct ConvP {
   int out_f32;
   int B;
   float* stats;   // optional fp32 (sum, sum of squares) per (image, output channel) of the output, accumulated
-  long ldstats;   //   atomically at stats[(b * ldstats + n) * 2 + {0,1}] (GroupNorm statistics of the consumer)
+  long ldstats;   //   atomically at stats[((b * nslots + slot) * ldstats + n) * 2 + {0,1}] (GroupNorm statistics of the consumer);
+  int nslots;     //   slot = tile index % nslots spreads the same-address atomic chains (the consumer sums the slots)
 };
 
 // Per-wave reduction of the epilogue's (sum, sum^2) partials over the 16 pixel lanes of an MFMA tile

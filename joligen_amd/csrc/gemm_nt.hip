@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
       }
     }
     // host guarantees (Ho*Wo) % BM == 0 when stats != nullptr: the whole tile belongs to one image
-    if (p.stats) jg_stats_flush(p.stats, (long)(m0 / (p.Ho * p.Wo)) * p.ldstats, n, s1, s2, lane);
+    if (p.stats) jg_stats_flush(p.stats, ((long)(m0 / (p.Ho * p.Wo)) * p.nslots + (m0 / BM) % p.nslots) * p.ldstats, n, s1, s2, lane);
   }
 }
 
@@ -423,6 +423,7 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.srb = a->srb; p.srh = a->srh;
   p.alpha = a->alpha; p.res_scale = a->res_scale; p.out_f32 = a->out_f32;
   p.B = a->B; p.stats = a->stats; p.ldstats = a->ldstats > 0 ? a->ldstats : a->Cout;
+  p.nslots = a->stats_slots > 0 ? a->stats_slots : 1;
   if (p.stats) {
     // fused GroupNorm statistics: single conv, whole tiles inside one image, LDS-DMA kernels only
     const long hw = (long)a->Ho * a->Wo;

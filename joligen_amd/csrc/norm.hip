@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[(long)b * 2 * ldsums + i], s_acc[i]);
 }
 
-__global__ void gn_coef_kernel(const float* __restrict__ sums, long ldsums, const float* __restrict__ gamma,
+__global__ void gn_coef_kernel(const float* __restrict__ sums, long ldsums, int nslots, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ film, long ldfilm,
                                float* __restrict__ ab, float* __restrict__ mr, int B, int HW, int C, int G, float eps) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,10 +70,12 @@ __global__ void gn_coef_kernel(const float* __restrict__ sums, long ldsums, cons
   const int b = idx / C, c = idx % C;
   const int cpg = C / G, g = c / cpg;
   float S1 = 0.f, S2 = 0.f;
-  for (int k = 0; k < cpg; ++k) {
-    const long o = ((long)b * ldsums + g * cpg + k) * 2;
-    S1 += sums[o];
-    S2 += sums[o + 1];
+  for (int sl = 0; sl < nslots; ++sl) {
+    for (int k = 0; k < cpg; ++k) {
+      const long o = (((long)b * nslots + sl) * ldsums + g * cpg + k) * 2;
+      S1 += sums[o];
+      S2 += sums[o + 1];
+    }
   }
   const float n = (float)HW * (float)cpg;
   const float mean = S1 / n;
@@ -279,10 +281,11 @@ extern "C" int jg_gn_stats(int dtype, const void* x, float* sums, int B, int HW,
   return jg_gn_stats_ld(dtype, x, C, sums, C, B, HW, C, s);
 }
 
-extern "C" int jg_gn_coef_ld(const float* sums, int64_t ldsums, const float* gamma, const float* beta, const float* film,
-                             int64_t ldfilm, float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s) {
-  if (!sums || !ab || !mr || G < 1 || C % G || ldsums < C) return JG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, sums, (long)ldsums, gamma, beta,
+extern "C" int jg_gn_coef_ld(const float* sums, int64_t ldsums, int nslots, const float* gamma, const float* beta,
+                             const float* film, int64_t ldfilm, float* ab, float* mr, int B, int HW, int C, int G, float eps,
+                             jg_stream_t s) {
+  if (!sums || !ab || !mr || G < 1 || C % G || ldsums < C || nslots < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, sums, (long)ldsums, nslots, gamma, beta,
                      film, (long)ldfilm, ab, mr, B, HW, C, G, eps);
   JG_CHECK_LAUNCH();
   return JG_OK;
@@ -290,7 +293,7 @@ extern "C" int jg_gn_coef_ld(const float* sums, int64_t ldsums, const float* gam
 
 extern "C" int jg_gn_coef(const float* sums, const float* gamma, const float* beta, const float* film, int64_t ldfilm,
                           float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s) {
-  return jg_gn_coef_ld(sums, C, gamma, beta, film, ldfilm, ab, mr, B, HW, C, G, eps, s);
+  return jg_gn_coef_ld(sums, C, 1, gamma, beta, film, ldfilm, ab, mr, B, HW, C, G, eps, s);
 }
 
 extern "C" int jg_gn_apply_ld(int dtype, const void* x, int64_t ldx, const float* ab, void* y, int64_t ldy, int B, int HW,

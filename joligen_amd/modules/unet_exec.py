@@ -29,7 +29,7 @@ from ..ops import _dt, _p, _st, attn_core_bwd, attn_core_fwd, conv_nt, wgrad_tn
 
 class Act:
     """An activation of the schedule: NHWC view `t` (any pixel stride), fp32 statistics view
-    `st` [B, C, 2] (sum, sum^2 per image and channel, any row stride) taken over `hw` pixels."""
+    `st` [B, NSLOT, C, 2] (sum, sum^2 per image and channel, NSLOT partial replicas, any row stride) taken over `hw` pixels."""
 
     __slots__ = ("t", "st", "hw", "pid", "hs_j")
 
@@ -46,6 +46,11 @@ def _stats_fusable(B, Ho, Wo, Cout):
     return (Ho * Wo) % 256 == 0 and Cout % 64 == 0
 
 
+# replicas of every statistics row: a conv tile adds into replica (tile index % NSLOT), which keeps the
+# same-address fp32 atomic chains of the full-resolution layers short (256 tiles per image at 256x256)
+NSLOT = 16
+
+
 class _Pool:
     """Zero-initialised fp32 scratch for the statistics rows of one forward (one fill kernel)."""
 
@@ -54,10 +59,10 @@ class _Pool:
         self.off = 0
 
     def take(self, B, C):
-        n = B * C * 2
+        n = B * NSLOT * C * 2
         if self.off + n > self.buf.numel():
             raise RuntimeError("statistics pool exhausted")
-        v = self.buf[self.off:self.off + n].view(B, C, 2)
+        v = self.buf[self.off:self.off + n].view(B, NSLOT, C, 2)
         self.off += n
         return v
 
@@ -74,9 +79,9 @@ def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None):
     conv_nt(x, m.w16, out, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
             ldx=_ld(x), ldw=m.R * m.S * Cin, ldy=_ld(out), bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
             ldres=_ld(res) if res is not None else 0, alpha=alpha, res_scale=res_scale,
-            stats=stats if fuse else None, ldstats=stats.stride(0) // 2 if fuse else 0)
+            stats=stats if fuse else None, ldstats=stats.stride(1) // 2 if fuse else 0, stats_slots=NSLOT)
     if stats is not None and not fuse:   # shapes the fused epilogue does not cover: separate statistics pass
-        check(_lib.lib().jg_gn_stats_ld(_dt(out), out.data_ptr(), _ld(out), stats.data_ptr(), stats.stride(0) // 2, B, Ho * Wo,
+        check(_lib.lib().jg_gn_stats_ld(_dt(out), out.data_ptr(), _ld(out), stats.data_ptr(), stats.stride(0) // 2, B, Ho * Wo,  # replica 0
                                         m.Cout, _st()), "jg_gn_stats_ld")
     return out
 
@@ -109,10 +114,10 @@ def conv_wgrad(dy, x, m, alpha=1.0, dbias_scale=0.0):
 
 
 def gn_coef(st, hw, gamma, beta, film, G, eps):
-    B, C, _ = st.shape
+    B, ns, C, _ = st.shape
     ab = torch.empty((B, C, 2), device=st.device, dtype=torch.float32)
     mr = torch.empty((B, G, 2), device=st.device, dtype=torch.float32)
-    check(_lib.lib().jg_gn_coef_ld(st.data_ptr(), st.stride(0) // 2, _p(gamma), _p(beta), _p(film),
+    check(_lib.lib().jg_gn_coef_ld(st.data_ptr(), st.stride(1) // 2, ns, _p(gamma), _p(beta), _p(film),
                                    film.stride(0) if film is not None else 0, ab.data_ptr(), mr.data_ptr(), B, hw, C, G, eps,
                                    _st()), "jg_gn_coef_ld")
     return ab, mr
@@ -194,6 +199,7 @@ class UNetExecutor:
             ctot = list(unet.output_blocks[n_in - 1 - j])[0].channels
             self.cat_ch.append((ctot, ctot - chans[j], chans[j]))
         self.tape = None
+        self._pool_need = {}
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, xin, emb):
@@ -201,7 +207,8 @@ class UNetExecutor:
         B, H, W, _ = xin.shape
         dev = xin.device
         self.emb = emb
-        self.pool = _Pool(B * 2 * 65536, dev)
+        key = (B, H, W)
+        self.pool = _Pool(self._pool_need.get(key, B * NSLOT * 2 * 40000), dev)
         self.tape = []
         self.cats = {}
         tape = self.tape
@@ -215,7 +222,7 @@ class UNetExecutor:
                 assert buf.shape[1] == Hq and buf.shape[2] == Wq, "concat halves disagree on the spatial size"
                 lo, hi = (0, ca) if half == "a" else (ca, ctot)
                 assert hi - lo == Cq, (j, half, Cq, lo, hi)
-                return buf[..., lo:hi], st[:, lo:hi, :]
+                return buf[..., lo:hi], st[:, :, lo:hi, :]
             return make
 
         def fresh(Bq, Hq, Wq, Cq):
@@ -257,6 +264,7 @@ class UNetExecutor:
         hn = gn_apply(h.t, ab, JG_ACT_SILU)
         out = conv_fwd(hn, head)
         tape.append(dict(kind="head", x=h.t, ab=ab, mr=mr, hn=hn, gn=gn, m=head, in_id=h.pid, add_hs=h.hs_j, cat_j=None))
+        self._pool_need[key] = self.pool.off   # exact size from the second forward of a shape on
         self.cats = None
         self.pool = None
         return out
