@@ -223,6 +223,12 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   // ---- epilogue ----------------------------------------------------------------------------------------
   char* yb = p.y;
   const T* resb = (const T*)p.res;
+  // fused GroupNorm statistics: wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block
+  float* sred = reinterpret_cast<float*>(&sm[0]);   // every wave is past its last LDS read (K-loop barrier)
+  if (p.stats) {
+    for (int i = tid; i < BN * 2; i += NT) sred[i] = 0.f;
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + lk * 4;
@@ -257,7 +263,26 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
         s2[q] += v[q] * v[q];
       }
     }
-    if (p.stats) jg_stats_flush(p.stats, ((long)b * p.nslots + sp % p.nslots) * p.ldstats, n, s1, s2, lane);
+    if (p.stats) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = s1[q], c2 = s2[q];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o);
+          c2 += __shfl_xor(c2, o);
+        }
+        if (l15 == 0) {
+          atomicAdd(&sred[(n - n0 + q) * 2], a);
+          atomicAdd(&sred[(n - n0 + q) * 2 + 1], c2);
+        }
+      }
+    }
+  }
+  if (p.stats) {
+    __syncthreads();
+    float* dst = p.stats + (((long)b * p.nslots + sp % p.nslots) * p.ldstats + n0) * 2;
+    for (int i = tid; i < BN * 2; i += NT) atomicAdd(dst + i, sred[i]);
   }
 }
 

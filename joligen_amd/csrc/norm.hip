@@ -62,21 +62,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
   for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[(long)b * 2 * ldsums + i], s_acc[i]);
 }
 
-__global__ void gn_coef_kernel(const float* __restrict__ sums, long ldsums, int nslots, const float* __restrict__ gamma,
-                               const float* __restrict__ beta, const float* __restrict__ film, long ldfilm,
-                               float* __restrict__ ab, float* __restrict__ mr, int B, int HW, int C, int G, float eps) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * C) return;
+// One 16-lane group per (b, c): the lanes split the (slot, channel-of-group) statistics between them and
+// combine with xor-shuffles (the slot loop is nslots * cpg long: serial it took 17 us per call).
+__global__ __launch_bounds__(256) void gn_coef_kernel(const float* __restrict__ sums, long ldsums, int nslots,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ film, long ldfilm, float* __restrict__ ab,
+                                                      float* __restrict__ mr, int B, int HW, int C, int G, float eps) {
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int sub = threadIdx.x & 15;
+  if (idx >= B * C) return;   // whole 16-lane groups leave together
   const int b = idx / C, c = idx % C;
   const int cpg = C / G, g = c / cpg;
   float S1 = 0.f, S2 = 0.f;
-  for (int sl = 0; sl < nslots; ++sl) {
-    for (int k = 0; k < cpg; ++k) {
-      const long o = (((long)b * nslots + sl) * ldsums + g * cpg + k) * 2;
-      S1 += sums[o];
-      S2 += sums[o + 1];
-    }
+  const int total = nslots * cpg;
+  for (int i = sub; i < total; i += 16) {
+    const int sl = i / cpg, k = i - sl * cpg;
+    const long o = (((long)b * nslots + sl) * ldsums + g * cpg + k) * 2;
+    S1 += sums[o];
+    S2 += sums[o + 1];
   }
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    S1 += __shfl_xor(S1, o);
+    S2 += __shfl_xor(S2, o);
+  }
+  if (sub != 0) return;
   const float n = (float)HW * (float)cpg;
   const float mean = S1 / n;
   const float var = fmaxf(S2 / n - mean * mean, 0.f);
@@ -285,7 +295,7 @@ extern "C" int jg_gn_coef_ld(const float* sums, int64_t ldsums, int nslots, cons
                              const float* film, int64_t ldfilm, float* ab, float* mr, int B, int HW, int C, int G, float eps,
                              jg_stream_t s) {
   if (!sums || !ab || !mr || G < 1 || C % G || ldsums < C || nslots < 1) return JG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, sums, (long)ldsums, nslots, gamma, beta,
+  hipLaunchKernelGGL(gn_coef_kernel, dim3((B * C + 15) / 16), dim3(256), 0, (hipStream_t)s, sums, (long)ldsums, nslots, gamma, beta,
                      film, (long)ldfilm, ab, mr, B, HW, C, G, eps);
   JG_CHECK_LAUNCH();
   return JG_OK;
