@@ -1,0 +1,85 @@
+// Coalesced convolution epilogue through LDS (16-bit outputs).
+//
+// The MFMA accumulator layout (lane = pixel l & 15 x 4 consecutive channels) turns a direct store
+// into 8-byte pieces scattered over 16 pixel rows per instruction: 32-byte segments, store-issue
+// bound (cdna_hip_programming.md T21).  Here every wave transposes its 64-pixel x 64-channel slab
+// through a private 16 KB fp32 LDS scratch and leaves it row-wise: a lane owns 8 consecutive
+// channels (16 bytes) of a pixel, 8 lanes cover a 128-byte line, so the residual read, the output
+// store and the bias / statistics bookkeeping are all full-line 16-byte accesses.
+//
+//   y = alpha * acc + bias + res_scale * res         (fp32, one rounding)
+//   statistics (optional): per-channel (sum, sum^2) of y over the wave's pixels, reduced over the
+//   lanes that share a channel octet, handed to `flush(channel_octet_base, s1[8], s2[8])`.
+//
+// 16-byte scratch chunks are XOR-swizzled with (pixel & 15): the ds_write_b128 of a 16-lane group
+// (16 pixels, one chunk column) and the two ds_read_b128 of the row-wise pass are conflict-free.
+#pragma once
+#include "conv_params.h"
+
+// acc[TN][TM]: TN = 4 channel tiles (64 channels), TM = 4 or 8 pixel tiles.  pix(lp) maps the local
+// pixel index (0 .. TM*16-1) of this wave to the global pixel row (long, -1 = out of range).
+template <typename T, int TM, typename PixFn, typename FlushFn>
+__device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][TM], char* scratch, int lane, int nbase,
+                                                PixFn pix, FlushFn flush) {
+  static_assert(TM % 4 == 0, "slabs of 4 pixel tiles");
+  const int l15 = lane & 15, lk = lane >> 4;
+  const int c8 = lane & 7, prow = lane >> 3;
+  const bool nok = nbase + c8 * 8 < p.N;   // channel octet inside the tensor (N % 8 == 0)
+  float bias[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bias[q] = (p.bias && nok) ? p.bias[nbase + c8 * 8 + q] : 0.f;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s1[q] = s2[q] = 0.f;
+  T* y = (T*)p.y;
+  const T* res = (const T*)p.res;
+#pragma unroll
+  for (int slab = 0; slab < TM / 4; ++slab) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int pl = ii * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int chunk = (j * 4 + lk) ^ l15;   // pl & 15 == l15
+        float4 v = make_float4(p.alpha * acc[j][slab * 4 + ii][0], p.alpha * acc[j][slab * 4 + ii][1],
+                               p.alpha * acc[j][slab * 4 + ii][2], p.alpha * acc[j][slab * 4 + ii][3]);
+        *reinterpret_cast<float4*>(scratch + pl * 256 + chunk * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int pl = it * 8 + prow;
+      const float4 a = *reinterpret_cast<const float4*>(scratch + pl * 256 + (((2 * c8) ^ (pl & 15)) << 4));
+      const float4 b = *reinterpret_cast<const float4*>(scratch + pl * 256 + (((2 * c8 + 1) ^ (pl & 15)) << 4));
+      float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      const long m = nok ? pix(slab * 64 + pl) : -1L;
+      if (m >= 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += bias[q];
+        if (res) {
+          float rf[8];
+          unpack8<T>(*reinterpret_cast<const uint4*>(res + m * p.ldres + nbase + c8 * 8), rf);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] += p.res_scale * rf[q];
+        }
+        *reinterpret_cast<uint4*>(y + m * p.ldy + nbase + c8 * 8) = pack8<T>(v);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          s1[q] += v[q];
+          s2[q] += v[q] * v[q];
+        }
+      }
+    }
+  }
+  if (p.stats) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) {
+        s1[q] += __shfl_xor(s1[q], o);
+        s2[q] += __shfl_xor(s2[q], o);
+      }
+    }
+    if (prow == 0 && nok) flush(nbase + c8 * 8, s1, s2);
+  }
+}

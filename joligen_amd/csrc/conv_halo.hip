@@ -20,6 +20,7 @@
 // weight row).  MFMA: v_mfma_f32_16x16x32, weights as operand A so that a lane's 4 accumulators are
 // 4 consecutive output channels of one pixel (8-byte epilogue stores).
 #include "conv_params.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -220,65 +221,27 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     }
   }
 
-  // ---- epilogue ----------------------------------------------------------------------------------------
-  char* yb = p.y;
-  const T* resb = (const T*)p.res;
-  // fused GroupNorm statistics: wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block
-  float* sred = reinterpret_cast<float*>(&sm[0]);   // every wave is past its last LDS read (K-loop barrier)
+  // ---- epilogue: LDS-transposed, full-line stores (conv_epilogue.h) ---------------------------------------
+  static_assert(TN == 4, "the shared epilogue works on 64-channel wave tiles");
+  static_assert(sizeof(sm) >= NWAVES * 16384 + BN * 8, "epilogue scratch");
+  char* smc = reinterpret_cast<char*>(&sm[0]);          // every wave is past its last LDS read (K-loop barrier)
+  float* sred = reinterpret_cast<float*>(smc + NWAVES * 16384);
   if (p.stats) {
     for (int i = tid; i < BN * 2; i += NT) sred[i] = 0.f;
     __syncthreads();
   }
+  const long mrow0 = ((long)b * p.H + oh0 + wm * TM) * p.W + ow0;
+  jg_epilogue_lds<T, TM>(
+      p, acc, smc + wave * 16384, lane, n0 + wn * WN,
+      [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
+      [&](int nch, const float* s1, const float* s2) {
+        // wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 16 + lk * 4;
-    if (n >= p.N) continue;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bv[q] = p.bias[n + q];
-    }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const long m = ((long)b * p.H + oh0 + wm * TM + i) * p.W + ow0 + l15;
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[j][i][q] + bv[q];
-      if (resb) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(resb + m * p.ldres + n);
-        float rf[4];
-        unpack4<T>(rv, rf);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += p.res_scale * rf[q];
-      }
-      if (p.out_f32) {
-        *reinterpret_cast<float4*>((float*)yb + m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        *reinterpret_cast<uint2*>((T*)yb + m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        s1[q] += v[q];
-        s2[q] += v[q] * v[q];
-      }
-    }
-    if (p.stats) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float a = s1[q], c2 = s2[q];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o);
-          c2 += __shfl_xor(c2, o);
+        for (int q = 0; q < 8; ++q) {
+          atomicAdd(&sred[(nch - n0 + q) * 2], s1[q]);
+          atomicAdd(&sred[(nch - n0 + q) * 2 + 1], s2[q]);
         }
-        if (l15 == 0) {
-          atomicAdd(&sred[(n - n0 + q) * 2], a);
-          atomicAdd(&sred[(n - n0 + q) * 2 + 1], c2);
-        }
-      }
-    }
-  }
+      });
   if (p.stats) {
     __syncthreads();
     float* dst = p.stats + (((long)b * p.nslots + sp % p.nslots) * p.ldstats + n0) * 2;
@@ -302,7 +265,7 @@ void dispatch_halo(const ConvP& p, hipStream_t st) {
 }  // namespace
 
 bool jg_conv_halo_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
-  if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1) return false;
+  if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_f32) return false;
   if (p.Cin % 64 || p.N % 64 || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return false;
   if (dtype == JG_F16) dispatch_halo<f16_t>(p, st);

@@ -18,6 +18,7 @@
 // epilogue stores 8 bytes per lane per tile instead of four 2-byte stores.
 #include "common.h"
 #include "conv_params.h"
+#include "conv_epilogue.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -319,6 +320,28 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
     __syncthreads();
   }
 
+  if constexpr (sizeof(sm) >= 4 * 16384 && TN == 4 && TM == 4) {
+    if (!p.out_f32 && (p.N & 7) == 0) {
+      // LDS-transposed epilogue with full-line residual reads / stores (conv_epilogue.h); all waves are past the
+      // last barrier of the K loop, each uses a private 16 KB scratch
+      ConvP q = p;
+      q.y = p.y + (zb * p.syb + zh * p.syh) * 2;
+      q.res = p.res ? p.res + (zb * p.srb + zh * p.srh) * 2 : nullptr;
+      const long srow = p.stats ? ((long)(m0 / (p.Ho * p.Wo)) * p.nslots + (m0 / BM) % p.nslots) * p.ldstats : 0;
+      const int mw = m0 + wm * WM;
+      jg_epilogue_lds<T, TM>(
+          q, acc, reinterpret_cast<char*>(&sm[0][0]) + wave * 16384, lane, n0 + wn * WN,
+          [&](int lp) -> long { return (mw + lp < p.M) ? (long)(mw + lp) : -1L; },
+          [&](int nch, const float* s1, const float* s2) {
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+              atomicAdd(p.stats + (srow + nch + qq) * 2, s1[qq]);
+              atomicAdd(p.stats + (srow + nch + qq) * 2 + 1, s2[qq]);
+            }
+          });
+      return;
+    }
+  }
   char* yb = p.y + (zb * p.syb + zh * p.syh) * (p.out_f32 ? 4 : 2);
   const T* resb = p.res ? (const T*)p.res + zb * p.srb + zh * p.srh : nullptr;
 #pragma unroll
