@@ -21,6 +21,7 @@
 // 4 consecutive output channels of one pixel (8-byte epilogue stores).
 #include "conv_params.h"
 #include "conv_epilogue.h"
+#include <cstdlib>
 
 namespace {
 
@@ -257,8 +258,14 @@ void launch_halo(const ConvP& p, hipStream_t st) {
 
 template <typename T>
 void dispatch_halo(const ConvP& p, hipStream_t st) {
-  if (p.N % 256 == 0) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
-  else if (p.N % 128 == 0) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
+  const char* e = getenv("JG_HALO_CFG");
+  const int cfg = e ? atoi(e) : 0;   // 0: auto; 1: never the 256-wide tile; 2: 8-wave 128-wide tile (A/B experiments)
+  // 256-wide tiles run one 8-wave workgroup per CU: worth it only when the grid fills whole rounds of 256
+  const long b256 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.N / 256);
+  const bool fill256 = p.N % 256 == 0 && (double)b256 / (double)(((b256 + 255) / 256) * 256) >= 0.85;
+  if (fill256 && cfg == 0) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
+  else if (p.N % 128 == 0 && cfg == 2) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
+  else if (p.N % 128 == 0) launch_halo<T, 128, 256, 2, 2, 1, 2, 2>(p, st);   // 4 waves x (128 px x 64 ch), 2 workgroups / CU
   else launch_halo<T, 64, 256, 4, 1, 1, 3, 2>(p, st);
 }
 

@@ -60,7 +60,7 @@ def _halo_ok(nbatch, H, W, Cin, Cout, R, S, pad, stride):
 
 def _conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride):
     if _halo_ok(nbatch, H, W, Cin, Cout, R, S, pad, stride):
-        return "conv3x3_halo_kernel<BN=%d>" % (256 if Cout % 256 == 0 else 128 if Cout % 128 == 0 else 64)
+        return "conv3x3_halo_kernel"
     return "conv_nt_glds_kernel<256,64,64,4,1>" if Cout <= 64 else "conv_nt_glds_kernel<128,128,64,2,2>"
 
 

@@ -16,6 +16,7 @@ from tools.conv_bench import SHAPES, timeit
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 VARIANTS = args[0].split(",") if args else ["3", "6"]
 QUICK = "--quick" in sys.argv
+ONLY = [tuple(int(v) for v in a[7:].split("x")) for a in sys.argv if a.startswith("--only=")]  # --only=CinxCoutxS
 B = 32
 dt = torch.bfloat16
 d = torch.device("cuda:0")
@@ -37,6 +38,8 @@ for Cin, Cout, k, S, cnt in shapes:
         allshapes.append([ci, co, k, S, cnt])
 if QUICK:
     allshapes = allshapes[:6]
+if ONLY:
+    allshapes = [s for s in allshapes if (s[0], s[1], s[3]) in ONLY]
 print("  Cin  Cout k    S cnt | " + " | ".join(f"v{v:>2} ms    TF  relerr" for v in VARIANTS))
 for Cin, Cout, k, S, cnt in allshapes:
     g = torch.Generator(device=d).manual_seed(Cin * 7 + Cout)
@@ -49,7 +52,9 @@ for Cin, Cout, k, S, cnt in allshapes:
     line = f"{Cin:5d} {Cout:5d} {k} {S:4d} {cnt:3d} |"
     ref = None
     for v in VARIANTS:
-        os.environ["JG_CONV_VARIANT"] = v
+        vv = v.split(":")
+        os.environ["JG_CONV_VARIANT"] = vv[0]
+        os.environ["JG_HALO_CFG"] = vv[1] if len(vv) > 1 else "0"
         y = torch.zeros(B, S, S, Cout, device=d, dtype=dt)
         ops.conv_nt(x, w, y, Cin=Cin, Cout=Cout, ldx=Cin, ldw=k * k * Cin, ldy=Cout, bias=bias, res=res, ldres=Cout,
                     res_scale=0.7071, **geo)
