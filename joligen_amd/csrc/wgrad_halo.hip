@@ -43,10 +43,10 @@ __device__ __forceinline__ int f4(int c) { return ((c >> 1) & 1) | (((c >> 3) & 
 // 3-bit swizzle of a 256-byte pixel row (8 blocks of 32 B)
 __device__ __forceinline__ int f8(int c) { return (c & 3) | (((c >> 3) & 1) << 2); }
 
-template <typename T, int TH, int CPW>
-__global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles, int per, int npairs, int ncot) {
-  constexpr int NT = 512;
-  constexpr int BCO = 2 * CPW * 16;            // output channels per block (2 wave rows x CPW tiles)
+template <typename T, int TH, int CPW, int WMR>
+__global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p, int ntiles, int per, int npairs, int ncot) {
+  constexpr int NT = WMR * 256;                // WMR wave rows (output-channel groups) x 4 wave columns (16-channel ci tiles)
+  constexpr int BCO = WMR * CPW * 16;          // output channels per block
   constexpr int HW_ = 18, HPX = (TH + 2) * HW_;
   constexpr int HALO_CH = HPX * 8;             // 16-byte chunks of the halo (64 channels = 128 B / pixel)
   constexpr int CPP = BCO / 8;                 // chunks per dy pixel row
@@ -60,12 +60,13 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles
   static_assert(DY_CH % NT == 0, "dy tile vs block size");
   static_assert(A_ROUNDS - A_FULL <= 1, "at most one partial halo round");
 
+  static_assert(2 * BUF_CH * 16 * (3 - WMR) <= 163840, "LDS per CU");
   __shared__ uint4 sm[2 * BUF_CH];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave >> 2, wn = wave & 3;   // wm < WMR
 
   int id;
   {
@@ -87,8 +88,12 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles
   const char* smb = reinterpret_cast<const char*>(&sm[0]);
   const int tw = p.W >> 4, th = p.H / TH;
 
+  // Two forms of the per-tile LDS-DMA issue; which one keeps the MFMA loop spill-free depends on the
+  // configuration (hipcc hoists the recomputed coordinates of the 8-wave form back into registers).
+  constexpr bool RECOMP = (WMR == 1);
   // ---- per-thread LDS-DMA source coordinates relative to the tile origin ---------------------------
   int a_rel[A_ROUNDS], a_yx[A_ROUNDS];
+  if constexpr (!RECOMP) {
 #pragma unroll
   for (int rd = 0; rd < A_ROUNDS; ++rd) {
     const int pos = rd * NT + tid;
@@ -98,7 +103,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles
     a_rel[rd] = ((hy - 1) * p.W + (hx - 1)) * (int)p.ldx + chunk * 8;
     a_yx[rd] = (pos < HALO_CH) ? ((hy << 8) | hx) : -1;
   }
+  }
   int d_rel[D_ROUNDS];
+  if constexpr (!RECOMP) {
 #pragma unroll
   for (int rd = 0; rd < D_ROUNDS; ++rd) {
     const int pos = rd * NT + tid;
@@ -107,26 +114,61 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles
     const int blk = (cpos >> 1) ^ (BCO == 64 ? f4(xx) : f8(xx));
     d_rel[rd] = (ty * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8;
   }
+  }
 
   auto issue_tile = [&](int t, int buf) {
-    const int tx = t % tw;
-    const int r2 = t / tw;
-    const int ty = r2 % th;
-    const int b = r2 / th;
-    const int oh0 = ty * TH, ow0 = tx << 4;
-    const long pix = ((long)b * p.H + oh0) * p.W + ow0;
-    const T* xb = xg + pix * p.ldx;
-    const T* db = dyg + pix * p.lddy;
-    const unsigned l0 = lds0 + (buf * BUF_CH + wave * 64) * 16;
-#pragma unroll
-    for (int rd = 0; rd < D_ROUNDS; ++rd) glds16(db + d_rel[rd], l0 + (HALO_CH + rd * NT) * 16);
-#pragma unroll
-    for (int rd = 0; rd < A_ROUNDS; ++rd) {
-      if (a_yx[rd] >= 0) {
-        const int ih = oh0 - 1 + (a_yx[rd] >> 8), iw = ow0 - 1 + (a_yx[rd] & 255);
-        const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-        glds16(ok ? xb + a_rel[rd] : zp, l0 + rd * NT * 16);
+    if constexpr (RECOMP) {
+      const int tx = t % tw;
+      const int r2 = t / tw;
+      const int ty = r2 % th;
+      const int b = r2 / th;
+      const int oh0 = ty * TH, ow0 = tx << 4;
+      const long pix = ((long)b * p.H + oh0) * p.W + ow0;
+      const T* xb = xg + pix * p.ldx;
+      const T* db = dyg + pix * p.lddy;
+      const unsigned l0 = lds0 + (buf * BUF_CH + wave * 64) * 16;
+  #pragma unroll
+      for (int rd = 0; rd < D_ROUNDS; ++rd) {
+        const int pos = rd * NT + tid;
+        const int px = pos / CPP, cpos = pos % CPP;
+        const int yy = px >> 4, xx = px & 15;
+        const int blk = (cpos >> 1) ^ (BCO == 64 ? f4(xx) : f8(xx));
+        glds16(db + (yy * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8, l0 + (HALO_CH + rd * NT) * 16);
       }
+  #pragma unroll
+      for (int rd = 0; rd < A_ROUNDS; ++rd) {
+        const int pos = rd * NT + tid;
+        if (pos < HALO_CH) {
+          const int hp = pos >> 3, cpos = pos & 7;
+          const int hy = hp / HW_, hx = hp - hy * HW_;
+          const int chunk = (((cpos >> 1) ^ f4(hx)) << 1) | (cpos & 1);
+          const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+          const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          glds16(ok ? xb + ((hy - 1) * p.W + (hx - 1)) * (int)p.ldx + chunk * 8 : zp, l0 + rd * NT * 16);
+        }
+      }
+    
+    } else {
+      const int tx = t % tw;
+      const int r2 = t / tw;
+      const int ty = r2 % th;
+      const int b = r2 / th;
+      const int oh0 = ty * TH, ow0 = tx << 4;
+      const long pix = ((long)b * p.H + oh0) * p.W + ow0;
+      const T* xb = xg + pix * p.ldx;
+      const T* db = dyg + pix * p.lddy;
+      const unsigned l0 = lds0 + (buf * BUF_CH + wave * 64) * 16;
+  #pragma unroll
+      for (int rd = 0; rd < D_ROUNDS; ++rd) glds16(db + d_rel[rd], l0 + (HALO_CH + rd * NT) * 16);
+  #pragma unroll
+      for (int rd = 0; rd < A_ROUNDS; ++rd) {
+        if (a_yx[rd] >= 0) {
+          const int ih = oh0 - 1 + (a_yx[rd] >> 8), iw = ow0 - 1 + (a_yx[rd] & 255);
+          const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+          glds16(ok ? xb + a_rel[rd] : zp, l0 + rd * NT * 16);
+        }
+      }
+    
     }
   };
   // LDS-DMA instructions a wave issues per tile (wave-uniform): the count its vmcnt wait leaves in flight
@@ -229,9 +271,9 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_halo_kernel(WgP p, int ntiles
   }
 }
 
-// Split-K choice: one workgroup per CU (LDS), so the launch runs in rounds of 256 blocks; every block
+// Split-K choice: `slots` workgroups run at a time (1 or 2 per CU by LDS), so the launch runs in rounds; every block
 // walks `per` tiles and pays a fixed prologue + atomic epilogue worth about OVH tiles.
-static void pick_split(int npairs, int ntiles, int ovh, int* per_out, int* splitk_out) {
+static void pick_split(int npairs, int ntiles, int ovh, int slots, int* per_out, int* splitk_out) {
   long best = -1;
   int bper = ntiles, bsk = 1;
   const int skmax = ntiles < 2048 / npairs + 1 ? ntiles : 2048 / npairs + 1;
@@ -239,33 +281,34 @@ static void pick_split(int npairs, int ntiles, int ovh, int* per_out, int* split
     const int per = (ntiles + sk - 1) / sk;
     const int ske = (ntiles + per - 1) / per;
     const long blocks = (long)npairs * ske;
-    const long rounds = (blocks + 255) / 256;
+    const long rounds = (blocks + slots - 1) / slots;
     const long cost = (long)(per + ovh) * rounds;
     if (best < 0 || cost < best) { best = cost; bper = per; bsk = ske; }
   }
   *per_out = bper; *splitk_out = bsk;
 }
 
-template <typename T, int TH, int CPW>
+template <typename T, int TH, int CPW, int WMR>
 void launch_wg(const WgP& p, hipStream_t st) {
-  constexpr int BCO = 2 * CPW * 16;
+  constexpr int BCO = WMR * CPW * 16;
   const int ncot = p.Cout / BCO, npairs = ncot * (p.Cin / 64);
   const int ntiles = p.B * (p.H / TH) * (p.W >> 4);
   int per, splitk;
-  pick_split(npairs, ntiles, TH == 16 ? 6 : 10, &per, &splitk);
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW>), dim3(npairs * splitk), dim3(512), 0, st, p, ntiles, per, npairs, ncot);
+  pick_split(npairs, ntiles, TH == 16 ? 6 : 10, WMR == 1 ? 512 : 256, &per, &splitk);
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot);
 }
 
 template <typename T>
 void dispatch_wg(const WgP& p, hipStream_t st) {
   const char* e = getenv("JG_WGRAD_HALO_CFG");
-  const int cfg = e ? atoi(e) : 0;   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co
+  const int cfg = e ? atoi(e) : 0;   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co; 3: 8x16 x 64 co, 4 waves
   // the 128-channel x 8-row configuration halves the L2->LDS bytes per MFMA but doubles the atomic
   // volume: it pays once a block has >= 64 (16-row) tiles to walk
   const long per1 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.Cout / 64) * (p.Cin / 64) / 256;
   const bool big = cfg == 2 || (cfg == 0 && per1 >= 64);
-  if (big && p.Cout % 128 == 0) launch_wg<T, 8, 4>(p, st);
-  else launch_wg<T, 16, 2>(p, st);
+  if (cfg == 3) launch_wg<T, 8, 4, 1>(p, st);   // 4 waves, 64 co x 8-row tiles, 2 workgroups / CU
+  else if (big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2>(p, st);
+  else launch_wg<T, 16, 2, 2>(p, st);
 }
 
 }  // namespace
