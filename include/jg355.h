@@ -62,6 +62,15 @@ typedef struct {
    * the same-address atomic chains of a high-resolution layer are stats_slots times shorter; the
    * consumer (jg_gn_coef_ld) sums the slots. */
   int32_t stats_slots;
+  /* stats_mode 1: instead of (sum y, sum y^2) the epilogue accumulates the GroupNorm-BACKWARD reductions
+   * of the norm whose output-gradient this call computes (y = dL/d act(a*gx+b), i.e. this is the
+   * input-gradient convolution of the layer that consumed the norm's output):
+   *   stats[..][0] += sum du,  stats[..][1] += sum du * gx,   du = y * act'(a*gx + b)
+   * with gn_x the norm's INPUT [B,Ho,Wo,Cout] (pixel stride gn_ldx), gn_ab its (a, b) coefficients
+   * [B][Cout][2] from jg_gn_coef, gn_act its activation: the separate jg_gn_bwd_reduce pass over
+   * (x, dy) is folded into this epilogue (one extra 16-byte read of x per output row). */
+  int32_t stats_mode;
+  const void* gn_x; int64_t gn_ldx; const float* gn_ab; int32_t gn_act;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 
@@ -109,6 +118,11 @@ int jg_gn_bwd_coef(const float* red, const float* gamma, const float* beta, cons
                    int B, int HW, int C, int G, jg_stream_t s);
 int jg_gn_bwd_apply(int dtype, const void* x, const void* dy, const float* ab, const float* pqr, void* dx,
                     int B, int HW, int C, int act, jg_stream_t s);
+/* bwd_coef on reductions that were accumulated by a convolution epilogue (jg_conv_args.stats_mode 1):
+ * red rows are replicated nslots times, [(b*nslots + slot)*C + c][2], and summed here. */
+int jg_gn_bwd_coef_slots(const float* red, int nslots, const float* gamma, const float* beta, const float* film,
+                         int64_t ldfilm, const float* mr, float* pqr, float* dgamma, float* dbeta, float* dfilm,
+                         int64_t lddfilm, int B, int HW, int C, int G, jg_stream_t s);
 /* Strided forms of the three streaming passes: every tensor carries its own pixel stride (elements,
  * multiple of 8, >= C), so they run on channel slices of a concatenated buffer without a copy
  * (torch.cat of the UNet skip connections, unet_generator_attn.py:692-693, and its backward split).

@@ -20,7 +20,7 @@
 // pixel index (0 .. TM*16-1) of this wave to the global pixel row (long, -1 = out of range).
 template <typename T, int TM, typename PixFn, typename FlushFn>
 __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][TM], char* scratch, int lane, int nbase,
-                                                PixFn pix, FlushFn flush) {
+                                                int gimg, PixFn pix, FlushFn flush) {
   static_assert(TM % 4 == 0, "slabs of 4 pixel tiles");
   const int l15 = lane & 15, lk = lane >> 4;
   const int c8 = lane & 7, prow = lane >> 3;
@@ -31,6 +31,18 @@ __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][
   float s1[8], s2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) s1[q] = s2[q] = 0.f;
+  // GroupNorm-backward reduction mode: per-lane (a, b) of its 8 channels; gimg = image index of this tile
+  float ga[8], gb[8];
+  const bool gnr = p.stats && p.stats_mode == 1;
+  if (gnr) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long o = ((long)gimg * p.N + nbase + c8 * 8 + q) * 2;
+      ga[q] = nok ? p.gab[o] : 0.f;
+      gb[q] = nok ? p.gab[o + 1] : 0.f;
+    }
+  }
+  const T* gx = (const T*)p.gx;
   T* y = (T*)p.y;
   const T* res = (const T*)p.res;
 #pragma unroll
@@ -63,10 +75,22 @@ __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][
           for (int q = 0; q < 8; ++q) v[q] += p.res_scale * rf[q];
         }
         *reinterpret_cast<uint4*>(y + m * p.ldy + nbase + c8 * 8) = pack8<T>(v);
+        if (gnr) {
+          float xf[8];
+          unpack8<T>(*reinterpret_cast<const uint4*>(gx + m * p.gldx + nbase + c8 * 8), xf);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          s1[q] += v[q];
-          s2[q] += v[q] * v[q];
+          for (int q = 0; q < 8; ++q) {
+            float du = v[q];
+            if (p.gact == JG_ACT_SILU) du *= silu_grad_f(ga[q] * xf[q] + gb[q]);
+            s1[q] += du;
+            s2[q] += du * xf[q];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            s1[q] += v[q];
+            s2[q] += v[q] * v[q];
+          }
         }
       }
     }

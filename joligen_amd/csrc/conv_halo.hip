@@ -233,7 +233,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   }
   const long mrow0 = ((long)b * p.H + oh0 + wm * TM) * p.W + ow0;
   jg_epilogue_lds<T, TM>(
-      p, acc, smc + wave * 16384, lane, n0 + wn * WN,
+      p, acc, smc + wave * 16384, lane, n0 + wn * WN, b,
       [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
       [&](int nch, const float* s1, const float* s2) {
         // wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block

@@ -15,6 +15,11 @@ struct ConvP {
   float* stats;   // optional fp32 (sum, sum of squares) per (image, output channel) of the output, accumulated
   long ldstats;   //   atomically at stats[((b * nslots + slot) * ldstats + n) * 2 + {0,1}] (GroupNorm statistics of the consumer);
   int nslots;     //   slot = tile index % nslots spreads the same-address atomic chains (the consumer sums the slots)
+  // stats_mode 1: the epilogue accumulates the GroupNorm-BACKWARD reductions of the norm whose output
+  // gradient this convolution produces (y = dL/d act(a*x+b)):  (sum du, sum du*x), du = y * act'(a*gx + b),
+  // gx = the norm's input (pixel stride gldx), gab = its [B][N][2] (a, b) coefficients.
+  int stats_mode;
+  const char* gx; long gldx; const float* gab; int gact;
 };
 
 // Per-wave reduction of the epilogue's (sum, sum^2) partials over the 16 pixel lanes of an MFMA tile

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
       const long srow = p.stats ? ((long)(m0 / (p.Ho * p.Wo)) * p.nslots + (m0 / BM) % p.nslots) * p.ldstats : 0;
       const int mw = m0 + wm * WM;
       jg_epilogue_lds<T, TM>(
-          q, acc, reinterpret_cast<char*>(&sm[0][0]) + wave * 16384, lane, n0 + wn * WN,
+          q, acc, reinterpret_cast<char*>(&sm[0][0]) + wave * 16384, lane, n0 + wn * WN, p.stats ? m0 / (p.Ho * p.Wo) : 0,
           [&](int lp) -> long { return (mw + lp < p.M) ? (long)(mw + lp) : -1L; },
           [&](int nch, const float* s1, const float* s2) {
 #pragma unroll
@@ -447,6 +447,8 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.alpha = a->alpha; p.res_scale = a->res_scale; p.out_f32 = a->out_f32;
   p.B = a->B; p.stats = a->stats; p.ldstats = a->ldstats > 0 ? a->ldstats : a->Cout;
   p.nslots = a->stats_slots > 0 ? a->stats_slots : 1;
+  p.stats_mode = a->stats_mode; p.gx = (const char*)a->gn_x; p.gldx = a->gn_ldx; p.gab = a->gn_ab; p.gact = a->gn_act;
+  if (p.stats && p.stats_mode == 1 && (!p.gx || !p.gab || p.gldx < a->Cout || (a->Cout & 7))) return JG_ERR_BAD_ARG;
   if (p.stats) {
     // fused GroupNorm statistics: single conv, whole tiles inside one image, LDS-DMA kernels only
     const long hw = (long)a->Ho * a->Wo;

@@ -181,7 +181,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
   for (int i = tid; i < 2 * C; i += 256) atomicAdd(&red[(long)b * 2 * C + i], s_acc[i]);
 }
 
-__global__ void gn_bwd_coef_kernel(const float* __restrict__ red, const float* __restrict__ gamma,
+__device__ __forceinline__ float red_sum(const float* __restrict__ red, int nslots, int b, int C, int c, int j) {
+  float s = 0.f;
+  for (int sl = 0; sl < nslots; ++sl) s += red[(((long)b * nslots + sl) * C + c) * 2 + j];
+  return s;
+}
+
+__global__ void gn_bwd_coef_kernel(const float* __restrict__ red, int nslots, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, const float* __restrict__ film, long ldfilm,
                                    const float* __restrict__ mr, float* __restrict__ pqr, float* __restrict__ dgamma,
                                    float* __restrict__ dbeta, float* __restrict__ dfilm, long lddfilm, int B, int HW,
@@ -196,7 +202,7 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ red, const float* _
     const int cc = g * cpg + k;
     const float gam = gamma ? gamma[cc] : 1.f;
     const float f = film ? 1.f + film[(long)b * ldfilm + cc] : 1.f;
-    const float A1 = red[((long)b * C + cc) * 2], A2 = red[((long)b * C + cc) * 2 + 1];
+    const float A1 = red_sum(red, nslots, b, C, cc, 0), A2 = red_sum(red, nslots, b, C, cc, 1);
     SM1 += gam * f * A1;
     SM2 += gam * f * rstd * (A2 - mean * A1);
   }
@@ -204,7 +210,7 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ red, const float* _
   const float M1 = SM1 / n, M2 = SM2 / n;
   const float gam = gamma ? gamma[c] : 1.f;
   const float f = film ? 1.f + film[(long)b * ldfilm + c] : 1.f;
-  const float A1 = red[(long)idx * 2], A2 = red[(long)idx * 2 + 1];
+  const float A1 = red_sum(red, nslots, b, C, c, 0), A2 = red_sum(red, nslots, b, C, c, 1);
   pqr[(long)idx * 3] = f * gam * rstd;
   pqr[(long)idx * 3 + 1] = -rstd * rstd * M2;
   pqr[(long)idx * 3 + 2] = -rstd * M1 + mean * rstd * rstd * M2;
@@ -346,14 +352,20 @@ extern "C" int jg_gn_bwd_reduce(int dtype, const void* x, const void* dy, const 
   return jg_gn_bwd_reduce_ld(dtype, x, C, dy, C, ab, red, B, HW, C, act, s);
 }
 
-extern "C" int jg_gn_bwd_coef(const float* red, const float* gamma, const float* beta, const float* film,
-                              int64_t ldfilm, const float* mr, float* pqr, float* dgamma, float* dbeta, float* dfilm,
-                              int64_t lddfilm, int B, int HW, int C, int G, jg_stream_t s) {
-  if (!red || !mr || !pqr || G < 1 || C % G) return JG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, red, gamma, beta, film,
+extern "C" int jg_gn_bwd_coef_slots(const float* red, int nslots, const float* gamma, const float* beta, const float* film,
+                                    int64_t ldfilm, const float* mr, float* pqr, float* dgamma, float* dbeta, float* dfilm,
+                                    int64_t lddfilm, int B, int HW, int C, int G, jg_stream_t s) {
+  if (!red || !mr || !pqr || G < 1 || C % G || nslots < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, red, nslots, gamma, beta, film,
                      (long)ldfilm, mr, pqr, dgamma, dbeta, dfilm, (long)lddfilm, B, HW, C, G);
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_coef(const float* red, const float* gamma, const float* beta, const float* film,
+                              int64_t ldfilm, const float* mr, float* pqr, float* dgamma, float* dbeta, float* dfilm,
+                              int64_t lddfilm, int B, int HW, int C, int G, jg_stream_t s) {
+  return jg_gn_bwd_coef_slots(red, 1, gamma, beta, film, ldfilm, mr, pqr, dgamma, dbeta, dfilm, lddfilm, B, HW, C, G, s);
 }
 
 extern "C" int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,

@@ -18,6 +18,7 @@ Parameter gradients are accumulated by the kernels straight into the arena (`par
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -49,6 +50,10 @@ def _stats_fusable(B, Ho, Wo, Cout):
 # replicas of every statistics row: a conv tile adds into replica (tile index % NSLOT), which keeps the
 # same-address fp32 atomic chains of the full-resolution layers short (256 tiles per image at 256x256)
 NSLOT = 16
+# GroupNorm-backward reductions inside the producing dgrad convolution (jg_conv_args.stats_mode 1).  Measured on
+# MI355X (profiles/r01_notes.md): the separate reduction pass disappears (-5.4 ms/step) but the un-overlapped epilogue
+# reads of x cost the convolutions +4.8 ms and the slot-summing bwd_coef +1.8 ms: OFF by default.
+FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 
 
 class _Pool:
@@ -86,17 +91,27 @@ def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None):
     return out
 
 
-def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0):
+def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0, gn=None, pool=None):
+    """Input gradient of a stride-1 convolution.  `gn = (x, ab, act)`: the result is the output-gradient of a
+    GroupNorm with input x / coefficients ab; its backward reductions (sum du, sum du*x) are then taken in
+    this epilogue and returned as `red` [B, NSLOT, C, 2] (None when the shape is not covered: the caller
+    runs the separate reduction pass)."""
     if m.stride != 1:
         raise NotImplementedError("input-gradient of strided convolutions is not implemented")
     B, H, W, Cin = x_shape
     _, Ho, Wo, Cout = dy.shape
     if out is None:
         out = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
+    red = None
+    kw = {}
+    if gn is not None and pool is not None and res is None and _stats_fusable(B, H, W, Cin) and FUSE_GN_REDUCE:
+        gx, gab, gact = gn
+        red = pool.take(B, Cin)
+        kw = dict(stats=red, ldstats=Cin, stats_slots=NSLOT, gn_reduce=(gx, _ld(gx), gab, gact))
     conv_nt(dy, m.w16T, out, B=B, H=Ho, W=Wo, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,
             ldx=_ld(dy), ldw=m.R * m.S * Cout, ldy=_ld(out), alpha=alpha, res=res, ldres=_ld(res) if res is not None else 0,
-            res_scale=1.0)
-    return out
+            res_scale=1.0, **kw)
+    return (out, red) if gn is not None else out
 
 
 def conv_wgrad(dy, x, m, alpha=1.0, dbias_scale=0.0):
@@ -131,23 +146,28 @@ def gn_apply(x, ab, act):
     return y
 
 
-def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=()):
-    """dx = GroupNorm-backward(x, dy) + sum_i scale_i * add_i  (at most two addends, fused)."""
+def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=(), red=None):
+    """dx = GroupNorm-backward(x, dy) + sum_i scale_i * add_i  (at most two addends, fused).
+    `red`: reductions already accumulated by the convolution that produced dy ([B, NSLOT, C, 2])."""
     L = _lib.lib()
     B, H, W, C = x.shape
     HW = H * W
     dev, dt = x.device, _dt(x)
-    red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
     pqr = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
-    check(L.jg_gn_bwd_reduce_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), red.data_ptr(), B, HW, C, act,
-                                _st()), "jg_gn_bwd_reduce_ld")
+    nslots = NSLOT
+    if red is None:
+        nslots = 1
+        red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        check(L.jg_gn_bwd_reduce_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), red.data_ptr(), B, HW, C,
+                                    act, _st()), "jg_gn_bwd_reduce_ld")
     dgamma = gamma.grad if gamma is not None else None
     dbeta = beta.grad if beta is not None else None
     if gamma is not None and dgamma is None:
         raise RuntimeError("norm weight has no arena-backed .grad")
-    check(L.jg_gn_bwd_coef(red.data_ptr(), _p(gamma), _p(beta), _p(film), film.stride(0) if film is not None else 0,
-                           mr.data_ptr(), pqr.data_ptr(), _p(dgamma), _p(dbeta), _p(dfilm),
-                           dfilm.stride(0) if dfilm is not None else 0, B, HW, C, G, _st()), "jg_gn_bwd_coef")
+    check(L.jg_gn_bwd_coef_slots(red.data_ptr(), nslots, _p(gamma), _p(beta), _p(film),
+                                 film.stride(0) if film is not None else 0, mr.data_ptr(), pqr.data_ptr(), _p(dgamma),
+                                 _p(dbeta), _p(dfilm), dfilm.stride(0) if dfilm is not None else 0, B, HW, C, G, _st()),
+          "jg_gn_bwd_coef_slots")
     if out is None:
         out = torch.empty((B, H, W, C), device=dev, dtype=x.dtype)
     adds = list(adds)
@@ -265,6 +285,7 @@ class UNetExecutor:
         out = conv_fwd(hn, head)
         tape.append(dict(kind="head", x=h.t, ab=ab, mr=mr, hn=hn, gn=gn, m=head, in_id=h.pid, add_hs=h.hs_j, cat_j=None))
         self._pool_need[key] = self.pool.off   # exact size from the second forward of a shape on
+        self._key = key
         self.cats = None
         self.pool = None
         return out
@@ -339,6 +360,8 @@ class UNetExecutor:
         if tape is None:
             raise RuntimeError("UNetExecutor.backward without a forward")
         self.demb = torch.empty_like(self.emb)
+        bkey = ("bwd",) + self._key
+        self.bpool = _Pool(self._pool_need.get(bkey, 2 * self._pool_need[self._key] + 65536), self.demb.device)
         dacts, dhs = {}, {}
         for idx in range(len(tape) - 1, -1, -1):
             rec = tape[idx]
@@ -365,14 +388,17 @@ class UNetExecutor:
             else:
                 dacts[rec["in_id"]] = dX
         assert not dacts and not dhs, (list(dacts), list(dhs))
+        self._pool_need[bkey] = max(self.bpool.off, 64)
+        self.bpool = None
         demb, self.demb, self.emb = self.demb, None, None
         return demb
 
     def head_bwd(self, rec, dO, adds):
         gn, m = rec["gn"], rec["m"]
-        dhn = conv_dgrad(dO, m, rec["hn"].shape)
+        dhn, red = conv_dgrad(dO, m, rec["hn"].shape, gn=(rec["x"], rec["ab"], JG_ACT_SILU), pool=self.bpool)
         conv_wgrad(dO, rec["hn"], m)
-        return gn_bwd(rec["x"], dhn, rec["ab"], rec["mr"], gn.weight, gn.bias, None, gn.num_groups, JG_ACT_SILU, adds=adds)
+        return gn_bwd(rec["x"], dhn, rec["ab"], rec["mr"], gn.weight, gn.bias, None, gn.num_groups, JG_ACT_SILU, adds=adds,
+                      red=red)
 
     def res_bwd(self, rec, dO, adds):
         rb = rec["rb"]
@@ -381,17 +407,21 @@ class UNetExecutor:
         gn2, c2m = rb.out_layers[0].norm, rb.out_layers[3].meta
         skipw = rec["skipw"]
         # conv2
-        dh2 = conv_dgrad(dO, c2m, rec["h2"].shape)
+        dh2, red2 = conv_dgrad(dO, c2m, rec["h2"].shape, gn=(rec["c1"], rec["ab2"], JG_ACT_SILU), pool=self.bpool)
         conv_wgrad(dO, rec["h2"], c2m)
         # GroupNorm 2 (+FiLM +SiLU)
         off, n = rb.emb_slice
         dc1 = gn_bwd(rec["c1"], dh2, rec["ab2"], rec["mr2"], gn2.weight, gn2.bias, rec["film"], gn2.num_groups, JG_ACT_SILU,
-                     dfilm=self.demb[:, off:off + n])
+                     dfilm=self.demb[:, off:off + n], red=red2)
         del dh2
         if rb.up and rb.efficient:
             dc1 = pool2(dc1, 1.0)          # backward of the nearest upsample that follows conv1
         # conv1
-        da1 = conv_dgrad(dc1, c1m, rec["a1"].shape)
+        direct = (not rb.updown) or (rb.up and rb.efficient)   # da1 IS the output-gradient of GroupNorm 1
+        if direct:
+            da1, red1 = conv_dgrad(dc1, c1m, rec["a1"].shape, gn=(x, rec["ab1"], JG_ACT_SILU), pool=self.bpool)
+        else:
+            da1, red1 = conv_dgrad(dc1, c1m, rec["a1"].shape), None
         conv_wgrad(dc1, rec["a1"], c1m)
         del dc1
         if rb.down:
@@ -409,12 +439,14 @@ class UNetExecutor:
                 adds.append((up2(dO, skipw * 0.25), 1.0))
             else:
                 adds.append((pool2(dO, skipw), 1.0))
-            return gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds)
+            return gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
+                          red=red1)
         if rb.updown:
             raise NotImplementedError("resampling ResBlock with a 1x1 skip convolution")
         skm = rb.skip_connection.meta
         conv_wgrad(dO, rec["xs"], skm, alpha=skipw, dbias_scale=skipw)
-        dxg = gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds)
+        dxg = gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
+                     red=red1)
         return conv_dgrad(dO, skm, x.shape, res=dxg, alpha=skipw)   # skipw * (dO . Wskip) + dxg in one epilogue
 
     def attn_bwd(self, rec, dO, adds):
@@ -428,10 +460,11 @@ class UNetExecutor:
         conv_wgrad(dO4, a4, blk.proj_out.meta)
         dqkv = attn_core_bwd(rec["qkv"].view(B, T, 3 * C), rec["P"], da.view(B, T, C), blk.num_heads)
         xn4 = rec["xn"].view(B, 1, T, C)
-        dxn = conv_dgrad(dqkv.view(B, 1, T, 3 * C), blk.qkv.meta, xn4.shape)
+        dxn, red = conv_dgrad(dqkv.view(B, 1, T, 3 * C), blk.qkv.meta, xn4.shape, gn=(x.view(B, 1, T, C), rec["ab"], JG_ACT_NONE),
+                              pool=self.bpool)
         conv_wgrad(dqkv.view(B, 1, T, 3 * C), xn4, blk.qkv.meta)
         adds = list(adds) + [(dO, 1.0)]
-        return gn_bwd(x, dxn.view(B, H, W, C), rec["ab"], rec["mr"], None, None, None, C, JG_ACT_NONE, adds=adds)
+        return gn_bwd(x, dxn.view(B, H, W, C), rec["ab"], rec["mr"], None, None, None, C, JG_ACT_NONE, adds=adds, red=red)
 
 
 class _FusedUNetFn(torch.autograd.Function):

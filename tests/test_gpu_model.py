@@ -280,9 +280,12 @@ def test_fused_schedule_matches_module_graph(golden_dir, efficient, dtype):
     x0 = ops.to_nhwc(torch.randn(c["B"], 6, c["S"], c["S"], generator=g).to(d), dtype, 8)
     emb0 = torch.randn(c["B"], unet.cond_embed_dim, generator=g).to(d)
     R = ops.to_nhwc(torch.randn(c["B"], 3, c["S"], c["S"], generator=g).to(d), dtype, 8)
+    from joligen_amd.modules import unet_exec
+
     res = {}
-    for fused in (False, True):
-        unet.jg_fused = fused
+    for fused in (False, True, "no_reduce_fusion"):
+        unet.jg_fused = bool(fused)
+        unet_exec.FUSE_GN_REDUCE = fused is True
         net.arena.g.zero_()
         x = x0.clone().requires_grad_(True)
         emb = emb0.clone().requires_grad_(True)
@@ -290,6 +293,9 @@ def test_fused_schedule_matches_module_graph(golden_dir, efficient, dtype):
         out.backward(R)
         torch.cuda.synchronize()
         res[fused] = (out.detach().float(), x.grad.float(), emb.grad.clone(), net.arena.g.clone())
+    unet_exec.FUSE_GN_REDUCE = True
+    # GroupNorm-backward reductions in the dgrad epilogue vs the separate reduction pass: same sums
+    assert relerr(res[True][3], res["no_reduce_fusion"][3]) < TOL_OUT[dtype], relerr(res[True][3], res["no_reduce_fusion"][3])
     tol = 4 * TOL_OUT[dtype]
     assert relerr(res[True][0], res[False][0]) < tol, ("out", relerr(res[True][0], res[False][0]))
     assert relerr(res[True][1], res[False][1]) < 2 * tol, ("dx", relerr(res[True][1], res[False][1]))
