@@ -174,6 +174,16 @@ int jg_transpose_heads(int dtype, const void* src, int64_t ldsrc, int64_t coff, 
 int jg_softmax_fwd(int dtype, const float* S, void* P, int64_t rows, int T, jg_stream_t s);
 int jg_softmax_bwd(int dtype, const void* P, const float* dP, void* dS, int64_t rows, int T, float alpha, jg_stream_t s);
 
+/* Fused self-attention (flash style, head_dim 32, T % 128 == 0; JG_ERR_UNSUPPORTED otherwise -> use the
+ * jg_conv2d_nt + jg_softmax pipeline above).  qkv [B,T,3C] in the legacy layout of QKVAttentionLegacy
+ * (channel = h*3*ch + {q,k,v}*ch + c, unet_generator_attn.py:340); a [B,T,C] (channel = h*ch + c);
+ * L [B*heads, T] fp32 = logsumexp of the scaled logits (kept for the backward instead of the T x T matrix).
+ * Replaces QKVAttentionLegacy.forward (:331-347) and its autograd: the logits never reach HBM.
+ * bwd: o = the forward output, da its gradient; dqkv fully written; Dq [B*heads, T] fp32 scratch. */
+int jg_attention_fwd(int dtype, const void* qkv, void* a, float* L, int B, int T, int heads, int head_dim, jg_stream_t s);
+int jg_attention_bwd(int dtype, const void* qkv, const void* o, const float* L, const void* da, void* dqkv, float* Dq,
+                     int B, int T, int heads, int head_dim, jg_stream_t s);
+
 /* Small fp32 linear layers on the embedding path (nn.Linear in ResBlock.emb_layers and
  * DiffusionGenerator.cond_embed; unet_generator_attn.py:201-207, diffusion_generator.py:74-78).
  *   fwd: y[b][n] = sum_k act(x[b][k]) W[n][k] + bias[n]

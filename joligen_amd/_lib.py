@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libjg355.so")
-SOURCES = ["gemm_nt.hip", "conv_halo.hip", "gemm_tn.hip", "wgrad_halo.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
+SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "gemm_tn.hip", "wgrad_halo.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 JG_F16, JG_BF16 = 0, 1
@@ -74,6 +74,8 @@ SIGNATURES = {
     "jg_transpose_heads": [c_i32, c_p, c_i64, c_i64, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_softmax_fwd": [c_i32, c_p, c_p, c_i64, c_i32, c_p],
     "jg_softmax_bwd": [c_i32, c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
+    "jg_attention_fwd": [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_attention_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_linear_fwd": [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_linear_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_gamma_embedding": [c_p, c_p, c_i32, c_i32, c_f32, c_p],

@@ -458,7 +458,7 @@ class UNetExecutor:
         a4 = rec["a"].view(B, 1, T, C)
         da = conv_dgrad(dO4, blk.proj_out.meta, a4.shape)
         conv_wgrad(dO4, a4, blk.proj_out.meta)
-        dqkv = attn_core_bwd(rec["qkv"].view(B, T, 3 * C), rec["P"], da.view(B, T, C), blk.num_heads)
+        dqkv = attn_core_bwd(rec["qkv"].view(B, T, 3 * C), rec["P"], da.view(B, T, C), blk.num_heads, rec["a"])
         xn4 = rec["xn"].view(B, 1, T, C)
         dxn, red = conv_dgrad(dqkv.view(B, 1, T, 3 * C), blk.qkv.meta, xn4.shape, gn=(x.view(B, 1, T, C), rec["ab"], JG_ACT_NONE),
                               pool=self.bpool)

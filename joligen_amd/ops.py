@@ -51,6 +51,8 @@ def _require_cuda(*ts):
 # bench.py sets this to a list to time every launch of the dominant kernel with HIP events
 # (start/stop recorded on the launch stream); entries: (kernel, ev_start, ev_stop, algorithmic flops)
 KERNEL_TIMING = None
+# fused (flash-style) attention kernel for head dim 32; JG_FLASH_ATTENTION=0 selects the GEMM + softmax pipeline
+FLASH_ATTENTION = __import__("os").environ.get("JG_FLASH_ATTENTION", "1") != "0"
 
 def _halo_ok(nbatch, H, W, Cin, Cout, R, S, pad, stride):
     """mirror of the dispatch conditions of conv_halo.hip / wgrad_halo.hip (labels for bench.py only)"""
@@ -393,6 +395,12 @@ def attn_core_fwd(qkv, nh):
     ch = Cc // nh
     BH = B * nh
     dev, dt = qkv.device, _dt(qkv)
+    if FLASH_ATTENTION and ch == 32 and T % 128 == 0:
+        # fused kernel (attention.hip): the T x T logits stay on chip; aux = per-query logsumexp
+        a = torch.empty((B, T, Cc), device=dev, dtype=qkv.dtype)
+        lse = torch.empty((BH, T), device=dev, dtype=torch.float32)
+        check(L.jg_attention_fwd(dt, qkv.data_ptr(), a.data_ptr(), lse.data_ptr(), B, T, nh, ch, _st()), "jg_attention_fwd")
+        return a, lse
     scale2 = 1.0 / math.sqrt(ch)  # (ch^-1/4)^2
     S = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
     conv_nt(qkv, qkv, S, **_gemm_geom(T, T, ch), ldx=C3, ldw=C3, ldy=T, alpha=scale2, out_f32=True, nbatch=BH, nh=nh,
@@ -407,8 +415,9 @@ def attn_core_fwd(qkv, nh):
     return a, P
 
 
-def attn_core_bwd(qkv, P, da, nh):
-    """Gradient of attn_core_fwd with respect to qkv."""
+def attn_core_bwd(qkv, P, da, nh, a=None):
+    """Gradient of attn_core_fwd with respect to qkv.  `P` is the second result of attn_core_fwd (the
+    probabilities [B*nh,T,T], or the logsumexp [B*nh,T] of the fused kernel, which also needs the output `a`)."""
     L = _lib.lib()
     da = da.contiguous()
     B, T, C3 = qkv.shape
@@ -416,6 +425,14 @@ def attn_core_bwd(qkv, P, da, nh):
     ch = Cc // nh
     BH = B * nh
     dev, dt = qkv.device, _dt(qkv)
+    if P.dim() == 2:
+        if a is None:
+            raise RuntimeError("the fused attention backward needs the forward output")
+        dqkv = torch.empty_like(qkv)
+        dq_rows = torch.empty((BH, T), device=dev, dtype=torch.float32)
+        check(L.jg_attention_bwd(dt, qkv.data_ptr(), a.data_ptr(), P.data_ptr(), da.data_ptr(), dqkv.data_ptr(),
+                                 dq_rows.data_ptr(), B, T, nh, ch, _st()), "jg_attention_bwd")
+        return dqkv
     scale2 = 1.0 / math.sqrt(ch)
     # dP = dA V^T
     dP = torch.empty((BH, T, T), device=dev, dtype=torch.float32)
@@ -442,15 +459,15 @@ class _AttnCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, nh):
         a, P = attn_core_fwd(qkv, nh)
-        ctx.save_for_backward(qkv, P)
+        ctx.save_for_backward(qkv, P, a)
         ctx.nh = nh
         return a
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, da):
-        qkv, P = ctx.saved_tensors
-        return attn_core_bwd(qkv, P, da, ctx.nh), None
+        qkv, P, a = ctx.saved_tensors
+        return attn_core_bwd(qkv, P, da, ctx.nh, a), None
 
 
 def attention_core(qkv, n_heads):

@@ -293,10 +293,14 @@ def _attn_ref(qkv_bct, nh):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 64, 64, 2), (1, 256, 128, 4), (2, 96, 64, 2)])
-def test_attention_core(shape, dtype):
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("shape", [(2, 64, 64, 2), (1, 256, 128, 4), (2, 96, 64, 2), (2, 1024, 128, 4), (1, 128, 64, 2)])
+def test_attention_core(shape, dtype, flash, monkeypatch):
+    """flash=True: fused kernel (attention.hip) where it applies (head dim 32, T % 128 == 0);
+    flash=False: MFMA GEMMs + fp32 softmax with the T x T matrices in HBM."""
     from joligen_amd import ops
 
+    monkeypatch.setattr(ops, "FLASH_ATTENTION", flash)
     B, T, Cc, nh = shape
     if T % 8:
         pytest.skip("T must be a multiple of 8")
