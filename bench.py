@@ -14,7 +14,8 @@ G_unet_mha_vit_efficient true).  A step = set_input(device-resident batch) + opt
 (forward, backward, gradient all-reduce, fused AdamW + EMA, refresh of the bf16 weights).
 
 Extra objects on the JSON line:
-  roofline     -- dominant kernel = conv_nt_kernel (implicit-GEMM conv forward + input-gradient):
+  roofline     -- dominant kernel = the one with the largest summed time (conv3x3_halo_kernel: halo-resident
+                  implicit-GEMM 3x3 convolution, forward + input-gradient):
                   achieved = algorithmic FLOPs per launch (2*M*N*K) / average launch duration, both
                   from HIP events recorded around EVERY launch on the launch stream during a
                   separate instrumented pass of 2 steps (the timed region carries no events);
@@ -236,8 +237,17 @@ def main():
         dom = max(per, key=lambda k: per[k][1])
         n, tsum, fsum = per[dom]
         achieved = fsum / tsum / 1e12
+        # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+        # profiles/r01_pmc_hbm_traffic.md) of this same command, committed as profiles/r01_pmc.json
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            traffic = round(pmc[dom.split("<")[0]]["bytes_per_launch"], 1)
+        except Exception:
+            pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
                     "launches_per_step": n // 2, "avg_launch_us": round(tsum / n * 1e6, 2),
                     "avg_flops_per_launch": round(fsum / n, 1), "time_per_step_ms": round(tsum / 2 * 1e3, 3),
                     "other_kernels": {}}

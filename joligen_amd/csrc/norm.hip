@@ -10,6 +10,7 @@
 // Algorithmic bytes (T = 2 B): forward reads x twice and writes y once (6 B/elem), backward
 // reads x,dy twice and writes dx once (10 B/elem).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -24,6 +25,19 @@ __host__ __device__ inline Map make_map(int C) {
   m.active = m.pl * m.noct;
   m.chunk = m.pl * 16;
   return m;
+}
+
+// reductions: 4x more pixels per block than the streaming passes (4x fewer global atomics per channel)
+__host__ __device__ inline Map make_map_red(int C, int mult) {
+  Map m = make_map(C);
+  m.chunk = m.pl * mult;   // mult in {16, 32, 64}: chosen by the host so that small tensors still fill the chip
+  return m;
+}
+inline int red_mult(int B, int HW, int C) {
+  const Map m = make_map(C);
+  for (int mult = 64; mult > 16; mult >>= 1)
+    if ((long)B * ((HW + m.pl * mult - 1) / (m.pl * mult)) >= 2048) return mult;
+  return 16;
 }
 
 template <typename T>
@@ -139,9 +153,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                             long lddy, const float* __restrict__ ab,
-                                                            float* __restrict__ red, int HW, int C) {
+                                                            float* __restrict__ red, int HW, int C, int mult) {
   extern __shared__ float s_acc[];  // [C][2]
-  const Map mp = make_map(C);
+  const Map mp = make_map_red(C, mult);
   const int tid = threadIdx.x, b = blockIdx.y;
   for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.f;
   __syncthreads();
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const int pbeg = blockIdx.x * mp.chunk;
     const int pend = min(HW, pbeg + mp.chunk);
     const long row0 = (long)b * HW;
+#pragma unroll 4
     for (int p = pbeg + pl; p < pend; p += mp.pl) {
       const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
       const uint4 vg = *reinterpret_cast<const uint4*>(dy + (row0 + p) * lddy + co * 8);
@@ -171,10 +186,24 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         s2[q] += du * fx[q];
       }
     }
+    // lanes of a wave that share the channel octet (tid % noct, noct a power of two < 64) combine by xor-shuffle
+    // first: one LDS atomic per wave and channel instead of up to 32 colliding ones
+    const bool p2 = (mp.noct & (mp.noct - 1)) == 0 && mp.noct < 64;
+    if (p2) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
-      atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
+      for (int q = 0; q < 8; ++q) {
+        for (int o = mp.noct; o < 64; o <<= 1) {
+          s1[q] += __shfl_xor(s1[q], o);
+          s2[q] += __shfl_xor(s2[q], o);
+        }
+      }
+    }
+    if (!p2 || (tid & 63) < mp.noct) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
+        atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
+      }
     }
   }
   __syncthreads();
@@ -230,9 +259,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ pqr, T* __restrict__ dx, long lddx,
                                                            const T* __restrict__ add1, long ldadd1, float sc1,
                                                            const T* __restrict__ add2, long ldadd2, float sc2, int HW,
-                                                           int C) {
+                                                           int C, int rev) {
   const Map mp = make_map(C);
-  const int tid = threadIdx.x, b = blockIdx.y;
+  // reversed traversal: the pass runs right behind gn_bwd_reduce over the same (x, dy); walking from the END
+  // re-reads what the reduction touched last and is still resident in the 256 MB Infinity Cache
+  const int tid = threadIdx.x, b = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
   if (tid >= mp.active) return;
   const int co = tid % mp.noct, pl = tid / mp.noct;
   float a[8], bb[8], P[8], Q[8], R[8];
@@ -245,7 +276,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     Q[q] = pqr[o * 3 + 1];
     R[q] = pqr[o * 3 + 2];
   }
-  const int pbeg = blockIdx.x * mp.chunk;
+  const int pbeg = (rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * mp.chunk;
   const int pend = min(HW, pbeg + mp.chunk);
   const long row0 = (long)b * HW;
   for (int p = pbeg + pl; p < pend; p += mp.pl) {
@@ -336,13 +367,14 @@ extern "C" int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const 
   if (!x || !dy || !ab || !red || bad_shape(B, HW, C) || ldx < C || lddy < C || (ldx % 8) || (lddy % 8)) return JG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   if (hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
-  const Map mp = make_map(C);
+  const int mult = red_mult(B, HW, C);
+  const Map mp = make_map_red(C, mult);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   const size_t shm = 2 * C * sizeof(float);
   JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_SILU>), grid, dim3(256), shm,
-                                                                       st, (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C);
+                                                                       st, (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult);
                     else hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_NONE>), grid, dim3(256), shm, st, (const T*)x,
-                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C););
+                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -378,13 +410,14 @@ extern "C" int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const v
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   hipStream_t st = (hipStream_t)s;
+  static const int rev = [] { const char* e = getenv("JG_GN_REVERSE"); return e ? atoi(e) : 1; }();
   JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0,
                                                                        st, (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, pqr,
                                                                        (T*)dx, (long)lddx, (const T*)add1, (long)ldadd1, scale1,
-                                                                       (const T*)add2, (long)ldadd2, scale2, HW, C);
+                                                                       (const T*)add2, (long)ldadd2, scale2, HW, C, rev);
                     else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x, (long)ldx,
                                             (const T*)dy, (long)lddy, ab, pqr, (T*)dx, (long)lddx, (const T*)add1,
-                                            (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2, HW, C););
+                                            (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2, HW, C, rev););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

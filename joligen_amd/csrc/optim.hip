@@ -39,29 +39,41 @@ __global__ __launch_bounds__(256) void ema_update_kernel(float* __restrict__ ema
   }
 }
 
+// One block = one 64 (co) x 64 (ci) tile of one filter tap of one layer, staged through LDS so that the fp32
+// master is read in full 256-byte rows (ci fastest) and BOTH 16-bit images are written in full rows: the
+// straight copy [CoutP][RS][CinP] (ci fastest) and the flipped + transposed one [CinP][RS][CoutP] (co
+// fastest).  (A direct gather for the transposed image read 20x the parameter bytes: 4-byte accesses at
+// a stride of RS*Cin floats.)
 template <typename T>
 __global__ __launch_bounds__(256) void refresh_weights_kernel(const float* __restrict__ p, T* __restrict__ w16,
                                                               T* __restrict__ w16T, const int64_t* __restrict__ desc) {
+  __shared__ float tile[64][65];
   const int64_t* d = desc + (long)blockIdx.y * 8;
   const long src = d[0], dst = d[1], dstT = d[2];
   const int Cout = (int)d[3], RS = (int)d[4], Cin = (int)d[5], CoutP = (int)d[6], CinP = (int)d[7];
-  const long total = (long)CoutP * RS * CinP;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    {  // straight copy [CoutP][RS][CinP]
-      const int ci = i % CinP;
-      const long t = i / CinP;
-      const int rs = t % RS;
-      const int co = t / RS;
+  const int tci = (CinP + 63) / 64, tco = (CoutP + 63) / 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int t0 = blockIdx.x; t0 < tci * tco * RS; t0 += gridDim.x) {   // block-uniform trip count
+    int t = t0;
+    const int ci0 = (t % tci) * 64;
+    t /= tci;
+    const int co0 = (t % tco) * 64;
+    const int rs = t / tco;
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+      const int co = co0 + r, ci = ci0 + tx;
       const float v = (co < Cout && ci < Cin) ? p[src + ((long)co * RS + rs) * Cin + ci] : 0.f;
-      w16[dst + i] = from_f32<T>(v);
+      tile[r][tx] = v;
+      if (co < CoutP && ci < CinP) w16[dst + ((long)co * RS + rs) * CinP + ci] = from_f32<T>(v);
     }
-    if (dstT >= 0) {  // flipped + transposed [CinP][RS][CoutP]
-      const int co = i % CoutP;
-      const long t = i / CoutP;
-      const int rs = t % RS;
-      const int ci = t / RS;
-      const float v = (co < Cout && ci < Cin) ? p[src + ((long)co * RS + (RS - 1 - rs)) * Cin + ci] : 0.f;
-      w16T[dstT + i] = from_f32<T>(v);
+    if (dstT >= 0) {
+      __syncthreads();
+#pragma unroll 4
+      for (int r = ty; r < 64; r += 4) {
+        const int ci = ci0 + r, co = co0 + tx;
+        if (ci < CinP && co < CoutP) w16T[dstT + ((long)ci * RS + (RS - 1 - rs)) * CoutP + co] = from_f32<T>(tile[tx][r]);
+      }
+      __syncthreads();
     }
   }
 }
@@ -94,7 +106,7 @@ extern "C" int jg_ema_update(float* ema, const float* p, int64_t n, float beta, 
 extern "C" int jg_refresh_weights(int dtype, const float* p, void* w16, void* w16T, const int64_t* desc, int nlayers,
                                   jg_stream_t s) {
   if (!p || !w16 || !desc || nlayers < 1 || nlayers > 65535) return JG_ERR_BAD_ARG;
-  dim3 grid(128, nlayers);
+  dim3 grid(1152, nlayers);   // 64x64 tiles of a 1024 x 512 x 3x3 layer; larger layers loop, smaller ones exit
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((refresh_weights_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, p, (T*)w16,
                                               (T*)w16T, desc););
   JG_CHECK_LAUNCH();
