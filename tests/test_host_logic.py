@@ -29,23 +29,39 @@ def test_c_abi_exports_every_declared_symbol():
     assert b"bad argument" in L.jg_strerror(-1)
 
 
-def test_struct_layout_matches_header():
-    """ctypes mirrors of jg_conv_args / jg_wgrad_args: field order and sizes as in the header."""
+def test_struct_layout_matches_header(tmp_path):
+    """ctypes mirrors of jg_conv_args / jg_wgrad_args: field order as in the header, and sizes / offsets equal
+    to what a C compiler makes of include/jg355.h (gcc)."""
     import ctypes as C
+    import subprocess
 
     from joligen_amd._lib import ConvArgs, WgradArgs
 
-    assert C.sizeof(ConvArgs) == 5 * 8 + 11 * 4 + 4 + 4 * 8 + 2 * 4 + 8 * 8 + 3 * 4 + 4  # with natural padding
-    assert ConvArgs.ldx.offset % 8 == 0 and ConvArgs.sxb.offset % 8 == 0
-    assert WgradArgs.lddy.offset % 8 == 0 and WgradArgs.sdyb.offset % 8 == 0
     hdr = open(os.path.join(ROOT, "include", "jg355.h")).read()
-    body = hdr[hdr.index("typedef struct {"):hdr.index("} jg_conv_args;")]
+    nocomment = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    body = nocomment[nocomment.index("typedef struct {"):nocomment.index("} jg_conv_args;")]
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
     assert names == [f[0] for f in ConvArgs._fields_], names
-    body = hdr[hdr.index("} jg_conv_args;"):]
+    body = nocomment[nocomment.index("} jg_conv_args;"):]
     body = body[body.index("typedef struct {"):body.index("} jg_wgrad_args;")]
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
     assert names == [f[0] for f in WgradArgs._fields_], names
+    # the compiler's view of the two structs
+    probe = ["stats", "ldstats", "gn_x", "gn_act", "ldx", "sxb", "alpha"]
+    wprobe = ["lddy", "sdyb", "alpha", "dbias_scale"]
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "jg355.h"\nint main(void) {\n'
+        '  printf("%zu %zu", sizeof(jg_conv_args), sizeof(jg_wgrad_args));\n'
+        + "".join(f'  printf(" %zu", offsetof(jg_conv_args, {n}));\n' for n in probe)
+        + "".join(f'  printf(" %zu", offsetof(jg_wgrad_args, {n}));\n' for n in wprobe)
+        + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    vals = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    mine = [C.sizeof(ConvArgs), C.sizeof(WgradArgs)] + [getattr(ConvArgs, n).offset for n in probe] \
+        + [getattr(WgradArgs, n).offset for n in wprobe]
+    assert vals == mine, (vals, mine)
 
 
 @pytest.mark.parametrize("name", ["tiny_eff", "tiny_noeff", "tiny_attn"])
