@@ -18,7 +18,14 @@
 
 // acc[TN][TM]: TN = 4 channel tiles (64 channels), TM = 4 or 8 pixel tiles.  pix(lp) maps the local
 // pixel index (0 .. TM*16-1) of this wave to the global pixel row (long, -1 = out of range).
-template <typename T, int TM, typename PixFn, typename FlushFn>
+// MFMA row r of a pixel tile <-> pixel column jg_pixperm(r) (PERM kernels): rows {0-3, 12-15} take the even
+// columns, rows {4-11} the odd ones.  A ds_read_b128 service group mixes rows {0-3, 12-15} of k-chunk c with
+// rows {4-11} of chunk c+1; with this assignment the two sets sit in different 128-byte halves of the bank
+// row for EVERY horizontal tap shift, and the 8 same-parity pixels of a set get 8 distinct XOR swizzles:
+// the shifted-tap fragment reads of conv_halo.hip become conflict-free (they were 2-way for s = 1, 2).
+__device__ __forceinline__ int jg_pixperm(int r) { return r < 4 ? 2 * r : (r < 12 ? 2 * (r - 4) + 1 : 2 * (r - 8)); }
+
+template <typename T, int TM, bool PERM = false, typename PixFn, typename FlushFn>
 __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][TM], char* scratch, int lane, int nbase,
                                                 int gimg, PixFn pix, FlushFn flush) {
   static_assert(TM % 4 == 0, "slabs of 4 pixel tiles");
@@ -49,10 +56,11 @@ __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][
   for (int slab = 0; slab < TM / 4; ++slab) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) {
-      const int pl = ii * 16 + l15;
+      const int pc = PERM ? jg_pixperm(l15) : l15;
+      const int pl = ii * 16 + pc;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int chunk = (j * 4 + lk) ^ l15;   // pl & 15 == l15
+        const int chunk = (j * 4 + lk) ^ pc;   // pl & 15 == pc
         float4 v = make_float4(p.alpha * acc[j][slab * 4 + ii][0], p.alpha * acc[j][slab * 4 + ii][1],
                                p.alpha * acc[j][slab * 4 + ii][2], p.alpha * acc[j][slab * 4 + ii][3]);
         *reinterpret_cast<float4*>(scratch + pl * 256 + chunk * 16) = v;

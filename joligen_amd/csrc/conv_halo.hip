@@ -147,7 +147,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   int afrag[3];
 #pragma unroll
   for (int s3 = 0; s3 < 3; ++s3) {
-    const int hx = l15 + s3;
+    const int hx = jg_pixperm(l15) + s3;   // MFMA row l15 <-> pixel column jg_pixperm(l15) (conv_epilogue.h)
     afrag[s3] = ((wm * TM) * HW_ + hx) * 128 + ((lk ^ ((hx >> 1) & 7)) << 4);
   }
 
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     __syncthreads();
   }
   const long mrow0 = ((long)b * p.H + oh0 + wm * TM) * p.W + ow0;
-  jg_epilogue_lds<T, TM>(
+  jg_epilogue_lds<T, TM, true>(
       p, acc, smc + wave * 16384, lane, n0 + wn * WN, b,
       [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
       [&](int nch, const float* s1, const float* s2) {
