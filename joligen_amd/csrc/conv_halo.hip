@@ -60,7 +60,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   constexpr int B_BUF = BN * 8;
   static_assert(B_ROUNDS >= 1 && BN * 8 % NT == 0, "weight tile vs block size");
   static_assert(NABUF == 1 || A_ROUNDS <= 9, "halo prefetch is spread over the 9 taps");
-  static_assert(NBBUF == 2 || NBBUF == 3, "weight ring depth");
+  static_assert(NBBUF >= 2 && NBBUF <= 5, "weight ring depth");
 
   __shared__ uint4 sm[NABUF * HALO_CH + NBBUF * B_BUF];
 
@@ -171,10 +171,12 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   const int nk = nch * 9;
 
   // ---- prologue: halo of chunk 0, first NBBUF-1 weight tiles -----------------------------------------
+  if (!(p.dbg & 4)) {
 #pragma unroll
-  for (int rd = 0; rd < A_ROUNDS; ++rd) issue_a_round(0, 0, rd);
-  issue_b(0, 0);
-  if (NBBUF == 3) issue_b(1, p.Cin);   // tap 1 of chunk 0 (nk >= 9 always)
+    for (int rd = 0; rd < A_ROUNDS; ++rd) issue_a_round(0, 0, rd);
+  }
+#pragma unroll
+  for (int pb = 0; pb < NBBUF - 1; ++pb) issue_b(pb, pb * p.Cin);   // taps 0 .. NBBUF-2 of chunk 0 (nk >= 9 always)
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
@@ -202,11 +204,13 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
         a_iss = true;
       }
       // 3. MFMAs of this K-step
-      compute(abyte, (NABUF * HALO_CH + bslot * B_BUF) * 16, tap / 3, tap % 3);
+      if (!(p.dbg & 2)) compute(abyte, (NABUF * HALO_CH + bslot * B_BUF) * 16, tap / 3, tap % 3);
       // 4. the weight tile of the NEXT K-step (and, at tap 8, the whole next halo) must have landed;
       //    what was issued in this step may stay in flight (NBBUF == 3)
-      if (NBBUF == 3 && b_iss) {
-        if (a_iss) wait_vmcnt<B_ROUNDS + 1>(); else wait_vmcnt<B_ROUNDS>();
+      if (NBBUF >= 3 && b_iss) {
+        // in flight: the weight tiles of K-steps k+2 .. k+NBBUF-1 (+ the halo round issued in this step; halo rounds
+        // of earlier steps are older than the tile that must land, so they are covered)
+        if (a_iss) wait_vmcnt<(NBBUF - 2) * B_ROUNDS + 1>(); else wait_vmcnt<(NBBUF - 2) * B_ROUNDS>();
       } else {
         wait_vmcnt<0>();
       }
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     }
   }
 
+  if (p.dbg & 1) return;
   // ---- epilogue: LDS-transposed, full-line stores (conv_epilogue.h) ---------------------------------------
   static_assert(TN == 4, "the shared epilogue works on 64-channel wave tiles");
   static_assert(sizeof(sm) >= NWAVES * 16384 + BN * 8, "epilogue scratch");
@@ -266,12 +271,16 @@ void dispatch_halo(const ConvP& p, hipStream_t st) {
   if (fill256 && cfg == 0) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
   else if (p.N % 128 == 0 && cfg == 2) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
   else if (p.N % 128 == 0) launch_halo<T, 128, 256, 2, 2, 1, 2, 2>(p, st);   // 4 waves x (128 px x 64 ch), 2 workgroups / CU
+  else if (cfg == 4) launch_halo<T, 64, 256, 4, 1, 1, 4, 2>(p, st);
   else launch_halo<T, 64, 256, 4, 1, 1, 3, 2>(p, st);
 }
 
 }  // namespace
 
-bool jg_conv_halo_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
+bool jg_conv_halo_try(int dtype, const ConvP& p0, int nbatch, hipStream_t st) {
+  ConvP p = p0;
+  static const int dbg = [] { const char* e = getenv("JG_HALO_DBG"); return e ? atoi(e) : 0; }();
+  p.dbg = dbg;
   if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_f32) return false;
   if (p.Cin % 64 || p.N % 64 || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return false;

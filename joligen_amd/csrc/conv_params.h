@@ -19,6 +19,7 @@ struct ConvP {
   // gradient this convolution produces (y = dL/d act(a*x+b)):  (sum du, sum du*x), du = y * act'(a*gx + b),
   // gx = the norm's input (pixel stride gldx), gab = its [B][N][2] (a, b) coefficients.
   int stats_mode;
+  int dbg;        // ablation switches of the dev tools (JG_HALO_DBG): 1 = no epilogue, 2 = no MFMA/LDS reads, 4 = no halo DMA
   const char* gx; long gldx; const float* gab; int gact;
 };
 

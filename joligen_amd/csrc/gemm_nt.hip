@@ -447,7 +447,7 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.alpha = a->alpha; p.res_scale = a->res_scale; p.out_f32 = a->out_f32;
   p.B = a->B; p.stats = a->stats; p.ldstats = a->ldstats > 0 ? a->ldstats : a->Cout;
   p.nslots = a->stats_slots > 0 ? a->stats_slots : 1;
-  p.stats_mode = a->stats_mode; p.gx = (const char*)a->gn_x; p.gldx = a->gn_ldx; p.gab = a->gn_ab; p.gact = a->gn_act;
+  p.dbg = 0; p.stats_mode = a->stats_mode; p.gx = (const char*)a->gn_x; p.gldx = a->gn_ldx; p.gab = a->gn_ab; p.gact = a->gn_act;
   if (p.stats && p.stats_mode == 1 && (!p.gx || !p.gab || p.gldx < a->Cout || (a->Cout & 7))) return JG_ERR_BAD_ARG;
   if (p.stats) {
     // fused GroupNorm statistics: single conv, whole tiles inside one image, LDS-DMA kernels only

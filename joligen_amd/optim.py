@@ -28,7 +28,7 @@ class FusedAdamW(torch.optim.Optimizer):
         a.step += 1
         hp = dict(lr=float(g["lr"]), beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"],
                   weight_decay=g["weight_decay"], decoupled=self.decoupled, ema_beta=ema_beta, zero_grad=True)
-        if parallel.world_size() > 1 and not parallel.in_no_sync():
+        if parallel.exchange_active():
             parallel.allreduce_and_step(a, hp, self.grad_scale, self.n_chunks)
         else:
             a.adamw_step(grad_scale=self.grad_scale, **hp)

@@ -12,6 +12,8 @@ import torch
 import torch.distributed as dist
 
 _NO_SYNC = 0
+# run the chunked all-reduce + optimizer pipeline even with a single rank (tests exercise the RCCL path on a 1-GPU box)
+FORCE_EXCHANGE = False
 
 
 def world_size():
@@ -24,6 +26,11 @@ def rank():
 
 def in_no_sync():
     return _NO_SYNC > 0
+
+
+def exchange_active():
+    """True when optimizer steps must all-reduce the flat gradient first."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_EXCHANGE) and not in_no_sync()
 
 
 @contextlib.contextmanager

@@ -309,3 +309,65 @@ def test_fused_schedule_matches_module_graph(golden_dir, efficient, dtype):
             if float(b.norm()) > 0 and relerr(a, b) > 2 * tol:
                 bad.append((name, relerr(a, b)))
     assert not bad, bad[:8]
+
+
+_RCCL_SCRIPT = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "oracle")); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import jg_oracle as O
+from joligen_amd import parallel
+from joligen_amd.models import create_model
+from joligen_amd.options import opt_from_json
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29731")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+c = dict(ngf=32, mults=[1, 2], res_blocks=[1, 1], attn_res=[16], efficient=True, S=32, B=2)
+ov = dict(G_ngf=32, G_unet_mha_channel_mults=[1, 2], G_unet_mha_res_blocks=[1, 1], G_unet_mha_attn_res=[16],
+          G_unet_mha_vit_efficient=True, data_crop_size=32, train_batch_size=2, model_type="palette", gpu_ids="0",
+          jg_act_dtype="fp16", train_optim="adamw", train_G_ema=True, train_iter_size=1, checkpoints_dir="/tmp/jg_rccl/", name="t")
+g = torch.Generator().manual_seed(5)
+Bimg = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+mask = torch.zeros(2, 1, 32, 32, dtype=torch.int64); mask[:, :, 8:24, 4:20] = 1
+A = Bimg * (1 - mask) + torch.randn(Bimg.shape, generator=g) * mask
+draws = [O.draw_step_randomness(torch.Generator().manual_seed(10 + i), Bimg, 2000) for i in range(3)]
+out = []
+for mode in ("single", "rccl"):
+    opt = opt_from_json({{}}, ov)
+    model = create_model(opt, 0)
+    model.netG_A.load_state_dict(O.synth_state_dict(model.netG_A.state_dict(), seed=0))
+    model.setup(opt)
+    if mode == "single":
+        model.single_gpu()
+    else:
+        parallel.FORCE_EXCHANGE = True
+        model.parallelize(0)          # broadcast + FlatDataParallel wrapper
+    losses = []
+    for d in draws:
+        model.rng_injection = lambda b, d=d: d
+        model.set_input({{"A": A, "B": Bimg, "B_label_mask": mask}})
+        model.optimize_parameters()
+        losses.append(float(model.get_current_losses()["G_tot"]))
+    net = model.netG_A.module if hasattr(model.netG_A, "module") else model.netG_A
+    out.append((losses, float(net.arena.p.double().norm()), float(net.arena.ema.double().norm())))
+    parallel.FORCE_EXCHANGE = False
+dist.destroy_process_group()
+(l0, p0, e0), (l1, p1, e1) = out
+# fp32 atomics (split-K, statistics) make two runs differ at the 1e-5 level even in the same mode
+assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+assert abs(p0 - p1) <= 1e-4 * p0 and abs(e0 - e1) <= 1e-4 * e0, (p0, p1, e0, e1)
+print("RCCL_PATH_OK", l1)
+"""
+
+
+def test_rccl_exchange_path_single_rank():
+    """The multi-GPU code path on the one GPU of the test box: a 1-rank RCCL process group, parameters broadcast,
+    FlatDataParallel wrapper, chunked async all-reduce of the flat gradient with the fused optimizer pipelined
+    behind it -- three steps must reproduce the single-GPU path (sum over one rank, mean over one rank)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
