@@ -139,11 +139,16 @@ def cpu_baseline(args):
     batch = synth_batch(Bc, S, 99, "cpu")
     gen = torch.Generator().manual_seed(3)
     times = []
-    for it in range(3):  # first call is the warm-up
+    budget_s, t_start = 15.0, time.perf_counter()   # bounded sample: ~15 s of CPU work after the warm-up call
+    for it in range(33):  # first call is the warm-up
         t, u, noise = O.draw_step_randomness(gen, batch["B"], 2000)
         t0 = time.perf_counter()
         tr.optimize_parameters(batch["B"], batch["A"], batch["B_label_mask"], noise, t, u)
         times.append(time.perf_counter() - t0)
+        if it == 0:
+            t_start = time.perf_counter()
+        elif time.perf_counter() - t_start > budget_s:
+            break
     per_step = sum(times[1:]) / len(times[1:])
     return {"value": round(Bc / per_step, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": f"oracle/jg_oracle.py OraclePaletteTrainer, {len(times) - 1} timed full steps (fwd+bwd+AdamW+EMA) "

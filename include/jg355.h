@@ -207,6 +207,23 @@ int jg_ddpm_prepare(int dtype, const float* y0, const float* ycond, const float*
 int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
                      float* loss, void* dnh, int B, int C, int H, int W, int Cpad, float lambda, float grad_scale,
                      jg_stream_t s);
+/* Consistency-model (cm_model) glue around the UNet, models/modules/cm_generator.py / models/cm_model.py.
+ *   cm_noisy   : noisy = x + sigma[b]*noise, blended with clamp(mask,0,1) (forward :452-460); written as fp32 NCHW
+ *                and as the 16-bit NHWC UNet input [cond | noisy | 0-pad] (= torch.cat([x_cond, x], 1) of :377-381)
+ *   cm_combine : c_skip[b]*noisy + c_out[b]*F  (cm_forward :383-385), fp32 NCHW
+ *   cm_loss    : lambda * mean(w[b] * pseudo_huber(mask*pred, mask*target)) with pred/target formed on the fly from
+ *                the two UNet outputs, and dL/dF_next in the same pass (compute_cm_loss cm_model.py:353-375,
+ *                pseudo_huber_loss :27-43; the mask multiplies AS IS, like the reference); loss accumulates (zero it)
+ *   noise_level_embedding : [sin | cos](sigma * W * 2 pi)  (NoiseLevelEmbedding.forward :276-280) */
+int jg_cm_noisy(int dtype, const float* x, const float* noise, const float* sigma, const int64_t* mask, const float* cond,
+                float* out_nchw, void* out_nhwc, int B, int C, int Ccond, int H, int W, int Cpad, jg_stream_t s);
+int jg_cm_combine(int dtype, const float* noisy, const void* F, const float* cskip, const float* cout, float* out, int B,
+                  int C, int H, int W, int Cpad, jg_stream_t s);
+int jg_cm_loss(int dtype, const void* Fn, const void* Fc, const float* noisy_n, const float* noisy_c, const float* cs_n,
+               const float* co_n, const float* cs_c, const float* co_c, const int64_t* mask, const float* w, float* loss,
+               void* dFn, int B, int C, int H, int W, int Cpad, float c_huber, float lambda, float grad_scale, jg_stream_t s);
+int jg_noise_level_embedding(const float* sigma, const float* W, float* emb, int Bn, int half, jg_stream_t s);
+
 /* NHWC(T, Cpad) <-> NCHW(fp32, C) layout converters at the module boundary. */
 int jg_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);
 int jg_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);

@@ -81,6 +81,11 @@ SIGNATURES = {
     "jg_gamma_embedding": [c_p, c_p, c_i32, c_i32, c_f32, c_p],
     "jg_ddpm_prepare": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_ddpm_mse_loss": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_p],
+    "jg_cm_noisy": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_cm_combine": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_cm_loss": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32,
+                   c_f32, c_f32, c_f32, c_p],
+    "jg_noise_level_embedding": [c_p, c_p, c_p, c_i32, c_i32, c_p],
     "jg_nhwc_to_nchw_f32": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_nchw_f32_to_nhwc": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_adamw_ema": [c_p, c_p, c_p, c_p, c_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p],

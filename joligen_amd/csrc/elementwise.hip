@@ -316,6 +316,108 @@ __global__ __launch_bounds__(256) void ddpm_mse_loss_kernel(const float* __restr
   if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * invN * lambda);
 }
 
+// ---- consistency-model glue (cm_generator.py:367-502, cm_model.py:27-43,353-375) -------------------------
+// noisy = x + sigma[b] * noise; with a mask: noisy * clamp(mask,0,1) + (1 - clamp(mask,0,1)) * x.  Written twice:
+// fp32 NCHW (the c_skip * x term / visuals) and 16-bit NHWC with `cond` (optional, Ccond channels) in front
+// = torch.cat([x_cond, x], 1), zero padded to Cpad: the UNet input.
+template <typename T>
+__global__ void cm_noisy_kernel(const float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ sigma,
+                                const int64_t* __restrict__ mask, const float* __restrict__ cond, float* __restrict__ out_nchw,
+                                T* __restrict__ out_nhwc, int B, int C, int Ccond, int HW, int Cpad) {
+  const long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / HW;
+    const long p = i % HW;
+    const float sg = sigma[b];
+    float m = 1.0f;
+    if (mask) {
+      const int64_t mv = mask[i];
+      m = mv < 0 ? 0.f : (mv > 1 ? 1.f : (float)mv);
+    }
+    T* o = out_nhwc + i * Cpad;
+    for (int c = 0; c < Cpad; ++c) {
+      float v = 0.f;
+      if (c < Ccond) {
+        v = cond[((long)b * Ccond + c) * HW + p];
+      } else if (c < Ccond + C) {
+        const long q = ((long)b * C + (c - Ccond)) * HW + p;
+        const float xv = x[q];
+        float nv = xv + sg * noise[q];
+        if (mask) nv = nv * m + (1.0f - m) * xv;
+        out_nchw[q] = nv;
+        v = nv;
+      }
+      o[c] = from_f32<T>(v);
+    }
+  }
+}
+
+// out[b,c,p] = c_skip[b] * noisy[b,c,p] + c_out[b] * F[b,p,c]     (cm_forward, cm_generator.py:383-385)
+template <typename T>
+__global__ void cm_combine_kernel(const float* __restrict__ noisy, const T* __restrict__ F, const float* __restrict__ cskip,
+                                  const float* __restrict__ cout, float* __restrict__ out, int B, int C, int HW, int Cpad) {
+  const long total = (long)B * C * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % HW;
+    const long r = i / HW;
+    const int c = r % C;
+    const int b = r / C;
+    out[i] = cskip[b] * noisy[i] + cout[b] * to_f32(F[((long)b * HW + p) * Cpad + c]);
+  }
+}
+
+// Consistency loss with its gradient in one pass (compute_cm_loss, cm_model.py:353-375 + pseudo_huber_loss :27-43):
+//   pred = cs_n*noisy_n + co_n*F_n (student),  target = cs_c*noisy_c + co_c*F_c (no-grad teacher),
+//   loss = lambda * mean( w[b] * (sqrt((m*pred - m*target)^2 + c^2) - c) ),  m = the label mask AS IS (not clamped)
+//   dF_n = grad_scale * lambda * w[b]/N * d/sqrt(d^2+c^2) * m * co_n
+template <typename T>
+__global__ __launch_bounds__(256) void cm_loss_kernel(const T* __restrict__ Fn, const T* __restrict__ Fc,
+                                                      const float* __restrict__ noisy_n, const float* __restrict__ noisy_c,
+                                                      const float* __restrict__ cs_n, const float* __restrict__ co_n,
+                                                      const float* __restrict__ cs_c, const float* __restrict__ co_c,
+                                                      const int64_t* __restrict__ mask, const float* __restrict__ w,
+                                                      float* __restrict__ loss, T* __restrict__ dFn, int B, int C, int HW,
+                                                      int Cpad, float chub, float lambda, float grad_scale) {
+  __shared__ float s_part[4];
+  const long total = (long)B * HW;
+  const float invN = 1.0f / ((float)total * (float)C);
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / HW;
+    const long p = i % HW;
+    const float m = mask ? (float)mask[i] : 1.0f;
+    const float wb = w[b];
+    for (int c = 0; c < Cpad; ++c) {
+      float gout = 0.f;
+      if (c < C) {
+        const long q = ((long)b * C + c) * HW + p;
+        const float pred = cs_n[b] * noisy_n[q] + co_n[b] * to_f32(Fn[i * Cpad + c]);
+        const float targ = cs_c[b] * noisy_c[q] + co_c[b] * to_f32(Fc[i * Cpad + c]);
+        const float d = m * pred - m * targ;
+        const float r = sqrtf(d * d + chub * chub);
+        acc += wb * (r - chub);
+        gout = grad_scale * lambda * invN * wb * (d / r) * m * co_n[b];
+      }
+      if (dFn) dFn[i * Cpad + c] = from_f32<T>(gout);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * invN * lambda);
+}
+
+// NoiseLevelEmbedding (cm_generator.py:276-280): h = sigma * W * 2 * pi; [sin(h) | cos(h)]
+__global__ void noise_level_embedding_kernel(const float* __restrict__ sigma, const float* __restrict__ W, float* __restrict__ emb,
+                                             int Bn, int half) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Bn * 2 * half) return;
+  const int b = idx / (2 * half), j = idx % (2 * half);
+  const int k = j < half ? j : j - half;
+  const float h = ((sigma[b] * W[k]) * 2.0f) * 3.14159265358979323846f;
+  emb[idx] = j < half ? sinf(h) : cosf(h);
+}
+
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__ y, int B, int C, int HW, int Cpad) {
   const long total = (long)B * C * HW;
@@ -471,6 +573,46 @@ extern "C" int jg_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int B, in
   const long total = (long)B * H * W * Cpad;
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
                                               x, (T*)y, B, C, H * W, Cpad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_cm_noisy(int dtype, const float* x, const float* noise, const float* sigma, const int64_t* mask,
+                           const float* cond, float* out_nchw, void* out_nhwc, int B, int C, int Ccond, int H, int W, int Cpad,
+                           jg_stream_t s) {
+  if (!x || !noise || !sigma || !out_nchw || !out_nhwc || Cpad < C + Ccond || Cpad % 8 || (Ccond > 0 && !cond)) return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cm_noisy_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, x, noise,
+                                              sigma, mask, cond, out_nchw, (T*)out_nhwc, B, C, Ccond, H * W, Cpad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_cm_combine(int dtype, const float* noisy, const void* F, const float* cskip, const float* cout, float* out,
+                             int B, int C, int H, int W, int Cpad, jg_stream_t s) {
+  if (!noisy || !F || !cskip || !cout || !out || Cpad < C || Cpad % 8) return JG_ERR_BAD_ARG;
+  const long total = (long)B * C * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cm_combine_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, noisy,
+                                              (const T*)F, cskip, cout, out, B, C, H * W, Cpad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_cm_loss(int dtype, const void* Fn, const void* Fc, const float* noisy_n, const float* noisy_c,
+                          const float* cs_n, const float* co_n, const float* cs_c, const float* co_c, const int64_t* mask,
+                          const float* w, float* loss, void* dFn, int B, int C, int H, int W, int Cpad, float c_huber,
+                          float lambda, float grad_scale, jg_stream_t s) {
+  if (!Fn || !Fc || !noisy_n || !noisy_c || !cs_n || !co_n || !cs_c || !co_c || !w || !loss || Cpad < C || Cpad % 8)
+    return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cm_loss_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)Fn, (const T*)Fc, noisy_n, noisy_c, cs_n, co_n, cs_c, co_c, mask, w, loss,
+                                              (T*)dFn, B, C, H * W, Cpad, c_huber, lambda, grad_scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_noise_level_embedding(const float* sigma, const float* W, float* emb, int Bn, int half, jg_stream_t s) {
+  if (!sigma || !W || !emb || Bn < 1 || half < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(noise_level_embedding_kernel, dim3((Bn * 2 * half + 255) / 256), dim3(256), 0, (hipStream_t)s, sigma, W, emb,
+                     Bn, half);
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

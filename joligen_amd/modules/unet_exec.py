@@ -285,10 +285,13 @@ class UNetExecutor:
         out = conv_fwd(hn, head)
         tape.append(dict(kind="head", x=h.t, ab=ab, mr=mr, hn=hn, gn=gn, m=head, in_id=h.pid, add_hs=h.hs_j, cat_j=None))
         self._pool_need[key] = self.pool.off   # exact size from the second forward of a shape on
-        self._key = key
         self.cats = None
         self.pool = None
-        return out
+        # the tape belongs to THIS call (several forwards may be alive before their backwards, e.g. the
+        # student / no-grad teacher pair of the consistency model)
+        state = (self.tape, self.emb, key)
+        self.tape = self.emb = None
+        return out, state
 
     def _in_fields(self, X):
         if isinstance(X.pid, tuple):
@@ -354,11 +357,11 @@ class UNetExecutor:
         return Act(out_t, out_st, T, len(self.tape) - 1)
 
     # ---- backward ----------------------------------------------------------------------------------
-    def backward(self, dout, need_dx=False):
-        tape, self.tape = self.tape, None
+    def backward(self, state, dout, need_dx=False):
+        tape, self.emb, self._key = state
         self.dxin = None
         if tape is None:
-            raise RuntimeError("UNetExecutor.backward without a forward")
+            raise RuntimeError("UNetExecutor.backward: this forward's tape was already consumed")
         self.demb = torch.empty_like(self.emb)
         bkey = ("bwd",) + self._key
         self.bpool = _Pool(self._pool_need.get(bkey, 2 * self._pool_need[self._key] + 65536), self.demb.device)
@@ -473,15 +476,15 @@ class _FusedUNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xin, emb, exe):
         ctx.exe = exe
-        out = exe.forward(xin, emb)
-        if not (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
-            exe.tape = exe.emb = None   # inference: nothing to keep
+        out, state = exe.forward(xin, emb)
+        ctx.state = state if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None   # inference keeps nothing
         return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
-        demb = ctx.exe.backward(dout.contiguous(), ctx.needs_input_grad[0])
+        state, ctx.state = ctx.state, None
+        demb = ctx.exe.backward(state, dout.contiguous(), ctx.needs_input_grad[0])
         dx, ctx.exe.dxin = ctx.exe.dxin, None
         return dx, demb, None
 

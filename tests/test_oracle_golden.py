@@ -96,3 +96,58 @@ def test_palette_three_steps(golden_dir, name):
                 torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
     for k, ref in g["param_sample"].items():
         torch.testing.assert_close(tr.P[k].flatten()[:8], ref, rtol=1e-3, atol=2e-5, msg=k)
+
+
+# ---- consistency model (cm_model): oracle/make_golden_cm.py fixtures --------------------------------------
+CM_CFGS = ["tiny_eff", "tiny_attn"]
+
+
+def cm_cfg_of(c):
+    return O.UNetCfg(in_channel=3, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"],
+                     attn_res=c["attn_res"], channel_mults=c["mults"], efficient=c["efficient"], cond_embed_dim=256)
+
+
+def cm_synth_for(golden_dir, name):
+    g = load(golden_dir, f"cm_step_{name}.pt")
+    ref_sd = {k: torch.empty(g["shapes"][k]) for k in g["keys"]}
+    return O.synth_state_dict(ref_sd, seed=0), g
+
+
+@pytest.mark.parametrize("name", CM_CFGS)
+def test_cm_generator_forward(golden_dir, name):
+    sd, _ = cm_synth_for(golden_dir, name)
+    g = load(golden_dir, f"cm_gen_{name}.pt")
+    cfg = cm_cfg_of(g["cfg"])
+    with torch.no_grad():
+        out = O.cm_generator_forward(sd, g["B"], g["mask"], g["noise"], g["timesteps"], 0, g["total_t"], cfg)
+    assert out[2] == g["num_timesteps"]
+    assert torch.equal(out[3], g["sigmas"])
+    torch.testing.assert_close(out[4], g["loss_weights"], rtol=1e-6, atol=0)
+    torch.testing.assert_close(out[5], g["next_noisy_x"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[6], g["current_noisy_x"], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out[0], g["next_x"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(out[1], g["current_x"], rtol=1e-4, atol=1e-5)
+    noise, ts = O.cm_draw_step_randomness(torch.Generator().manual_seed(55), g["B"], g["sigmas"])
+    assert torch.equal(noise, g["noise"]) and torch.equal(ts, g["timesteps"])
+
+
+@pytest.mark.parametrize("name", CM_CFGS)
+def test_cm_three_steps(golden_dir, name):
+    sd, g = cm_synth_for(golden_dir, name)
+    hp = g["hp"]
+    tr = O.OracleCMTrainer(sd, cm_cfg_of(g["cfg"]), g["total_t"], lr=hp["lr"], beta1=hp["beta1"], beta2=hp["beta2"],
+                           eps=hp["eps"], weight_decay=hp["weight_decay"], ema_beta=hp["ema_beta"] if hp["ema"] else None,
+                           lambda_G=hp["lambda_G"], optim=hp["optim"])
+    for it, s in enumerate(g["steps"]):
+        loss = tr.optimize_parameters(s["B"], s["mask"], s["noise"], s["timesteps"])
+        torch.testing.assert_close(loss, s["loss"], rtol=2e-4, atol=1e-6)
+        if "param_checks" in s:
+            for k, ref in s["param_checks"].items():
+                v = tr.P[k]
+                mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+                torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
+            if hp["ema"]:
+                for k, ref in s["ema_checks"].items():
+                    v = tr.ema[k]
+                    mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+                    torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
