@@ -223,6 +223,10 @@ int jg_cm_loss(int dtype, const void* Fn, const void* Fc, const float* noisy_n, 
                const float* co_n, const float* cs_c, const float* co_c, const int64_t* mask, const float* w, float* loss,
                void* dFn, int B, int C, int H, int W, int Cpad, float c_huber, float lambda, float grad_scale, jg_stream_t s);
 int jg_noise_level_embedding(const float* sigma, const float* W, float* emb, int Bn, int half, jg_stream_t s);
+/* gradient of the embedding with respect to W, ACCUMULATED into dW (the reference trains W: set_requires_grad(net, True),
+ * base_model.py:1196-1217) */
+int jg_noise_level_embedding_bwd(const float* sigma, const float* W, const float* demb, float* dW, int Bn, int half,
+                                 jg_stream_t s);
 
 /* NHWC(T, Cpad) <-> NCHW(fp32, C) layout converters at the module boundary. */
 int jg_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);

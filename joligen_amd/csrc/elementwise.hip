@@ -609,6 +609,29 @@ extern "C" int jg_cm_loss(int dtype, const void* Fn, const void* Fc, const float
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
+// dW[k] += sum_b 2 pi sigma_b (demb[b][k] cos(h) - demb[b][half + k] sin(h)),  h = sigma_b W_k 2 pi
+__global__ void noise_level_embedding_bwd_kernel(const float* __restrict__ sigma, const float* __restrict__ W,
+                                                 const float* __restrict__ demb, float* __restrict__ dW, int Bn, int half) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= half) return;
+  float acc = 0.f;
+  for (int b = 0; b < Bn; ++b) {
+    const float two_pi_s = (sigma[b] * 2.0f) * 3.14159265358979323846f;
+    const float h = ((sigma[b] * W[k]) * 2.0f) * 3.14159265358979323846f;
+    acc += two_pi_s * (demb[(long)b * 2 * half + k] * cosf(h) - demb[(long)b * 2 * half + half + k] * sinf(h));
+  }
+  atomicAdd(dW + k, acc);
+}
+
+extern "C" int jg_noise_level_embedding_bwd(const float* sigma, const float* W, const float* demb, float* dW, int Bn, int half,
+                                            jg_stream_t s) {
+  if (!sigma || !W || !demb || !dW || Bn < 1 || half < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(noise_level_embedding_bwd_kernel, dim3((half + 255) / 256), dim3(256), 0, (hipStream_t)s, sigma, W, demb, dW,
+                     Bn, half);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
 extern "C" int jg_noise_level_embedding(const float* sigma, const float* W, float* emb, int Bn, int half, jg_stream_t s) {
   if (!sigma || !W || !emb || Bn < 1 || half < 1) return JG_ERR_BAD_ARG;
   hipLaunchKernelGGL(noise_level_embedding_kernel, dim3((Bn * 2 * half + 255) / 256), dim3(256), 0, (hipStream_t)s, sigma, W, emb,

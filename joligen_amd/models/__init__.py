@@ -7,4 +7,8 @@ def create_model(opt, rank):
         from .palette_model import PaletteModel
 
         return PaletteModel(opt, rank)
+    if opt.model_type == "cm":
+        from .cm_model import CMModel
+
+        return CMModel(opt, rank)
     raise NotImplementedError(f"model_type {opt.model_type!r} is not implemented in joligen_amd yet")

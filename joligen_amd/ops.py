@@ -583,6 +583,99 @@ def ddpm_mse_loss(noise_hat_nhwc, noise, mask, w=None, lam=1.0, grad_scale=1.0):
     return _MSELossFn.apply(noise_hat_nhwc, noise.contiguous(), m, wv, float(lam), float(grad_scale), noise.shape[1])
 
 
+# ======================================================================================
+# consistency-model glue (cm_generator.py / cm_model.py of the reference)
+# ======================================================================================
+class _NoiseLevelEmbFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sigmas, W, dW):
+        s = sigmas.reshape(-1).contiguous().float()
+        emb = torch.empty((s.shape[0], 2 * W.shape[0]), device=s.device, dtype=torch.float32)
+        check(_lib.lib().jg_noise_level_embedding(s.data_ptr(), W.data_ptr(), emb.data_ptr(), s.shape[0], W.shape[0], _st()),
+              "jg_noise_level_embedding")
+        ctx.save_for_backward(s, W)
+        ctx.dW = dW
+        return emb
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, demb):
+        s, W = ctx.saved_tensors
+        if ctx.dW is not None:
+            demb = demb.contiguous().float()
+            check(_lib.lib().jg_noise_level_embedding_bwd(s.data_ptr(), W.data_ptr(), demb.data_ptr(), ctx.dW.data_ptr(),
+                                                          s.shape[0], W.shape[0], _st()), "jg_noise_level_embedding_bwd")
+        return None, None, None
+
+
+def noise_level_embedding(sigmas, W):
+    """[sin | cos](sigma * W * 2 pi) (NoiseLevelEmbedding.forward, cm_generator.py:276-280); the gradient with respect
+    to W is accumulated into W.grad (arena view) by the backward kernel."""
+    _require_cuda(sigmas, W)
+    return _NoiseLevelEmbFn.apply(sigmas, W, W.grad if W.requires_grad else None)
+
+
+def cm_noisy(x, noise, sigma, mask, cond, act_dtype, cpad=8):
+    """(noisy fp32 NCHW, UNet input 16-bit NHWC [cond | noisy | 0]) -- cm_generator.py:452-460,377-381."""
+    _require_cuda(x, noise, sigma)
+    B, Cc, H, W = x.shape
+    Ccond = 0 if cond is None else cond.shape[1]
+    m = None
+    if mask is not None:
+        m = mask.contiguous()
+        if m.dtype != torch.int64:
+            m = m.long()
+    out = torch.empty_like(x, dtype=torch.float32)
+    xin = torch.empty((B, H, W, cpad), device=x.device, dtype=act_dtype)
+    check(_lib.lib().jg_cm_noisy(_DT[act_dtype], x.contiguous().float().data_ptr(), noise.contiguous().float().data_ptr(),
+                                 sigma.contiguous().float().data_ptr(), _p(m), None if cond is None else cond.contiguous().float().data_ptr(),
+                                 out.data_ptr(), xin.data_ptr(), B, Cc, Ccond, H, W, cpad, _st()), "jg_cm_noisy")
+    return out, xin
+
+
+def cm_combine(noisy, F_nhwc, cskip, cout):
+    """c_skip * noisy + c_out * F as fp32 NCHW (cm_forward, cm_generator.py:383-385); no autograd (outputs / visuals)."""
+    B, Cc, H, W = noisy.shape
+    out = torch.empty_like(noisy)
+    check(_lib.lib().jg_cm_combine(_dt(F_nhwc), noisy.data_ptr(), F_nhwc.data_ptr(), cskip.contiguous().data_ptr(),
+                                   cout.contiguous().data_ptr(), out.data_ptr(), B, Cc, H, W, F_nhwc.shape[-1], _st()), "jg_cm_combine")
+    return out
+
+
+class _CMLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Fn, Fc, noisy_n, noisy_c, cs_n, co_n, cs_c, co_c, mask, w, chub, lam, grad_scale):
+        B, Cc, H, W = noisy_n.shape
+        loss = torch.zeros((), device=Fn.device, dtype=torch.float32)
+        dFn = torch.empty_like(Fn)
+        check(_lib.lib().jg_cm_loss(_dt(Fn), Fn.data_ptr(), Fc.data_ptr(), noisy_n.data_ptr(), noisy_c.data_ptr(), cs_n.data_ptr(),
+                                    co_n.data_ptr(), cs_c.data_ptr(), co_c.data_ptr(), _p(mask), w.data_ptr(), loss.data_ptr(),
+                                    dFn.data_ptr(), B, Cc, H, W, Fn.shape[-1], chub, lam, grad_scale, _st()), "jg_cm_loss")
+        ctx.save_for_backward(dFn)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        (dFn,) = ctx.saved_tensors
+        return (axpby(dFn, 1.0, alpha_dev=gout.contiguous().float()),) + (None,) * 12
+
+
+def cm_loss(F_next, F_cur, noisy_next, noisy_cur, cs_n, co_n, cs_c, co_c, mask, loss_weights, lam=1.0, grad_scale=1.0):
+    """compute_cm_loss (cm_model.py:353-375, no perceptual terms) on the two UNet outputs (NHWC 16-bit); gradient with
+    respect to F_next produced in the same pass."""
+    B, Cc, H, W = noisy_next.shape
+    m = None
+    if mask is not None:
+        m = mask.contiguous()
+        if m.dtype != torch.int64:
+            m = m.long()
+    chub = 0.00054 * math.sqrt(Cc * H * W)
+    f = lambda t: t.reshape(-1).contiguous().float()
+    return _CMLossFn.apply(F_next, F_cur.detach(), noisy_next, noisy_cur, f(cs_n), f(co_n), f(cs_c), f(co_c), m, f(loss_weights),
+                           chub, float(lam), float(grad_scale))
+
+
 class _ToNCHWFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, Cc):

@@ -28,6 +28,7 @@ DEFAULTS = dict(
     alg_diffusion_task="inpainting", alg_diffusion_cond_embed="", alg_diffusion_cond_embed_dim=32,
     alg_diffusion_cond_image_creation="y_t", alg_diffusion_lambda_G=1.0, alg_diffusion_dropout_prob=0.0,
     alg_diffusion_ref_embed_net="clip", alg_diffusion_ddpm_cm_ft=False,
+    alg_cm_num_steps=1000000, alg_cm_perceptual_loss=[""], alg_cm_lambda_perceptual=1.0, alg_ddpm_ft_mode="cm", total_iters=0,
     data_crop_size=256, data_load_size=286, data_preprocess="resize_and_crop", data_online_context_pixels=0,
     data_inverted_mask=False, data_refined_mask=False,
     f_s_semantic_nclasses=2, cls_semantic_nclasses=2,

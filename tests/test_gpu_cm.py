@@ -1,0 +1,130 @@
+"""GPU parity tests of the consistency-model path (cm_model): CMGenerator.forward and 3 x optimize_parameters()
+against fixtures produced by the unmodified reference (oracle/make_golden_cm.py), through the C ABI."""
+import os
+
+import pytest
+import torch
+
+import jg_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CFGS = ["tiny_eff", "tiny_attn"]
+TOL_OUT = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def make_model(c, dtype_name, hp=None):
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    ov = dict(model_type="cm", G_ngf=c["ngf"], G_unet_mha_channel_mults=c["mults"], G_unet_mha_res_blocks=c["res_blocks"],
+              G_unet_mha_attn_res=c["attn_res"], G_unet_mha_vit_efficient=c["efficient"], data_crop_size=c["S"],
+              train_batch_size=c["B"], gpu_ids="0", jg_act_dtype=dtype_name, train_optim="adamw", train_G_ema=True,
+              train_iter_size=1, checkpoints_dir="/tmp/jg_amd_ckpt/", name="cm")
+    if hp:
+        ov.update(train_G_lr=hp["lr"], train_beta1=hp["beta1"], train_beta2=hp["beta2"], train_optim_eps=hp["eps"],
+                  train_optim_weight_decay=hp["weight_decay"], train_G_ema_beta=hp["ema_beta"], train_G_ema=hp["ema"],
+                  alg_diffusion_lambda_G=hp["lambda_G"], train_optim=hp["optim"])
+    opt = opt_from_json({}, ov)
+    model = create_model(opt, 0)
+    model.netG_A.load_state_dict(O.synth_state_dict(model.netG_A.state_dict(), seed=0))
+    model.setup(opt)
+    model.single_gpu()
+    return model
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", CFGS)
+def test_cm_generator_vs_reference_golden(golden_dir, name, dtype_name):
+    g = load(golden_dir, f"cm_gen_{name}.pt")
+    dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
+    model = make_model(g["cfg"], dtype_name)
+    assert model.total_t == g["total_t"]
+    d = torch.device("cuda:0")
+    net = model.netG_A
+    net.current_t = 0
+    with torch.no_grad():
+        out = net(g["B"].to(d), g["total_t"], g["mask"].to(d), None, noise=g["noise"], timesteps=g["timesteps"])
+    assert out[2] == g["num_timesteps"]
+    assert relerr(out[3], g["sigmas"]) < 1e-6            # device pow / arange in fp32
+    assert relerr(out[4], g["loss_weights"]) < 1e-5
+    assert relerr(out[5], g["next_noisy_x"]) < 1e-6 and relerr(out[6], g["current_noisy_x"]) < 1e-6
+    # bit-exact mask semantics: unmasked pixels are exact copies of x
+    keep = (g["mask"] == 0).expand_as(g["B"])
+    assert torch.equal(out[5].cpu()[keep], g["B"][keep])
+    assert relerr(out[0], g["next_x"]) < TOL_OUT[dtype], relerr(out[0], g["next_x"])
+    assert relerr(out[1], g["current_x"]) < TOL_OUT[dtype], relerr(out[1], g["current_x"])
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", CFGS)
+def test_cm_three_steps_vs_reference_golden(golden_dir, name, dtype_name):
+    """3 x optimize_parameters() (2 UNet forwards + 1 backward, AdamW + EMA) with the reference's injected
+    (noise, timesteps): loss per step and per-parameter checksums after steps 1 and 3."""
+    g = load(golden_dir, f"cm_step_{name}.pt")
+    dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
+    model = make_model(g["cfg"], dtype_name, g["hp"])
+    model.netG_A.current_t = 0
+    lr = g["hp"]["lr"]
+    for it, s in enumerate(g["steps"]):
+        model.rng_injection = lambda b, s=s: (s["noise"], s["timesteps"])
+        model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "A_img_paths": ["x"]})
+        model.optimize_parameters()
+        loss = float(model.get_current_losses()["G_tot"])
+        assert abs(loss - float(s["loss"])) < (0.03 if dtype == torch.float16 else 0.08) * abs(float(s["loss"])), (it, loss, float(s["loss"]))
+        if "param_checks" in s:
+            params = dict(model.netG_A.named_parameters())
+            ema = dict(model.netG_A_ema.named_parameters())
+            for k, ref in s["param_checks"].items():
+                v = params[k].detach().float().cpu()
+                travel = 1.05 * (it + 1) * lr * v.numel() ** 0.5     # Adam's first steps move every weight by ~lr
+                assert abs(float(v.norm() - ref[0])) < 2e-3 * float(ref[0]) + travel, (it, k)
+                ve = ema[k].detach().float().cpu()
+                assert abs(float(ve.norm() - s["ema_checks"][k][0])) < 2e-3 * float(s["ema_checks"][k][0]) + travel, (it, k)
+    assert model.netG_A.current_t == 3 * g["cfg"]["B"]
+
+
+def test_cm_first_step_gradients_vs_oracle():
+    """A larger case than the fixtures (64x64, ngf 64: halo kernels, fused statistics, flash attention live) against
+    the CPU oracle: loss and gradient of every parameter group after one consistency step."""
+    c = dict(ngf=64, mults=[1, 2], res_blocks=[1, 1], attn_res=[2], efficient=True, S=64, B=2)
+    model = make_model(c, "fp16")
+    net = model.netG_A
+    sd = {k: v.float().cpu() for k, v in net.state_dict().items()}
+    cfg = O.UNetCfg(in_channel=3, inner_channel=64, out_channel=3, res_blocks=[1, 1], attn_res=[2], channel_mults=[1, 2],
+                    efficient=True, cond_embed_dim=256)
+    g = torch.Generator().manual_seed(9)
+    Bimg = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    mask = torch.zeros(2, 1, 64, 64, dtype=torch.int64)
+    mask[:, :, 10:40, 20:50] = 1
+    A = Bimg * (1 - mask) + torch.randn(Bimg.shape, generator=g) * mask
+    tr = O.OracleCMTrainer(sd, cfg, model.total_t)
+    noise, ts = O.cm_draw_step_randomness(torch.Generator().manual_seed(3), Bimg, tr.sigmas())
+    loss_ref, grads, _ = tr.loss_and_grads(Bimg, mask, noise, ts)
+    # one backward on the device (no optimizer step): drive the group's loss function directly
+    net.current_t = 0
+    model.rng_injection = lambda b: (noise, ts)
+    model.set_input({"A": A, "B": Bimg, "B_label_mask": mask})
+    net.arena.g.zero_()
+    model.compute_cm_loss()
+    model.loss_G_tot.backward()
+    torch.cuda.synchronize()
+    assert abs(float(model.loss_G_tot) - float(loss_ref)) < 2e-2 * abs(float(loss_ref)), (float(model.loss_G_tot), float(loss_ref))
+    scale = model.loss_scale
+    bad = []
+    for k, p in net.named_parameters():
+        if k.endswith(".weight") and p.dim() >= 2 or k == "cm_cond_embed.W":
+            mine = p.grad.detach().float().cpu() / scale
+            ref = grads[k]
+            if float(ref.norm()) > 1e-12 and relerr(mine, ref) > 6e-2:
+                bad.append((k, relerr(mine, ref)))
+    assert not bad, bad[:8]
