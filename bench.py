@@ -65,7 +65,7 @@ def build_model(args, rank, local_rank, world):
     from joligen_amd.models import create_model
     from joligen_amd.options import opt_from_json
 
-    ov = dict(model_type="palette", G_netG="unet_mha", G_ngf=64, G_unet_mha_channel_mults=[1, 2, 4, 8],
+    ov = dict(model_type=args.model, G_netG="unet_mha", G_ngf=64, G_unet_mha_channel_mults=[1, 2, 4, 8],
               G_unet_mha_res_blocks=[2, 2, 2, 2], G_unet_mha_attn_res=[16], G_unet_mha_num_head_channels=32,
               G_unet_mha_vit_efficient=bool(args.efficient), data_crop_size=args.size, data_load_size=args.size,
               train_batch_size=args.batch, train_iter_size=1, train_optim="adamw", train_G_ema=True,
@@ -109,7 +109,7 @@ def cpu_baseline_subprocess(args, timeout_s=240):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
-           "--efficient", str(args.efficient)]
+           "--efficient", str(args.efficient), "--model", args.model]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in out.stdout.splitlines():
@@ -131,13 +131,31 @@ def cpu_baseline(args):
     cores = usable_cores()
     torch.set_num_threads(cores)
     S, Bc = args.size, 1
-    opt = opt_from_json({}, dict(G_unet_mha_vit_efficient=bool(args.efficient), data_crop_size=S))
+    opt = opt_from_json({}, dict(G_unet_mha_vit_efficient=bool(args.efficient), data_crop_size=S, model_type=args.model))
     torch.manual_seed(0)
+    batch = synth_batch(Bc, S, 99, "cpu")
+    gen = torch.Generator().manual_seed(3)
+    if args.model == "cm":
+        from joligen_amd.models.cm_model import define_G_cm
+
+        opt.alg_diffusion_cond_embed_dim = 256
+        sd = {k: v.detach().float() for k, v in define_G_cm(opt).state_dict().items()}
+        tr = O.OracleCMTrainer(sd, O.UNetCfg(in_channel=3, efficient=bool(args.efficient), cond_embed_dim=256), 1000000)
+        times = []
+        for it in range(17):
+            noise, ts = O.cm_draw_step_randomness(gen, batch["B"], tr.sigmas())
+            t0 = time.perf_counter()
+            tr.optimize_parameters(batch["B"], batch["B_label_mask"], noise, ts)
+            times.append(time.perf_counter() - t0)
+            if it and sum(times[1:]) > 15.0:
+                break
+        per_step = sum(times[1:]) / len(times[1:])
+        return {"value": round(Bc / per_step, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                "sample": f"oracle/jg_oracle.py OracleCMTrainer, {len(times) - 1} timed full steps (2 fwd + bwd + AdamW + EMA) "
+                          f"of batch {Bc} at {S}x{S} fp32 after 1 warm-up, {cores} torch threads"}
     sd = {k: v.detach().float() for k, v in define_G(**vars(opt)).state_dict().items()}
     cfg = O.UNetCfg(efficient=bool(args.efficient))
     tr = O.OraclePaletteTrainer(sd, cfg)
-    batch = synth_batch(Bc, S, 99, "cpu")
-    gen = torch.Generator().manual_seed(3)
     times = []
     budget_s, t_start = 15.0, time.perf_counter()   # bounded sample: ~15 s of CPU work after the warm-up call
     for it in range(33):  # first call is the warm-up
@@ -164,6 +182,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--efficient", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--model", default="palette", choices=["palette", "cm"],
+                    help="palette = BASELINE configs[1] (the bench line); cm = the consistency-model step of configs[4] (same UNet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -263,7 +283,8 @@ def main():
                                                 "time_per_step_ms": round(t2 / 2 * 1e3, 3)}
         gf = FWD_GFLOP_PER_IMG.get((args.size, bool(args.efficient)))
         if gf:
-            step_tflop = 3 * gf * args.batch / 1e3
+            # palette: forward + backward (2x) = 3x; cm: student forward + teacher forward + backward = 4x
+            step_tflop = (3 if args.model == "palette" else 4) * gf * args.batch / 1e3
             roofline["step_algorithmic_tflop"] = round(step_tflop, 3)
             roofline["step_frac_of_mfma_peak"] = round(step_tflop / (ms_per_step * 1e-3) / PEAK_BF16_TFLOPS, 4)
 
@@ -273,11 +294,11 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "train images/sec at 256x256 (DDPM UNet step)" if args.size == 256 else f"train images/sec at {args.size}x{args.size} (DDPM UNet step)",
+            "metric": f"train images/sec at {args.size}x{args.size} ({'DDPM' if args.model == 'palette' else 'CM'} UNet step)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"palette_model DDPM, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
+            "config": {"workload": f"{'palette_model DDPM' if args.model == 'palette' else 'cm_model consistency'}, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
                                    f"res_blocks[2,2,2,2] mid-attn 16x32, {args.size}x{args.size}, batch {args.batch}/GPU, "
                                    "inpainting synthetic masks, AdamW+EMA, iter_size 1 "
                                    "(example_ddpm_noglasses2glasses.json + SURVEY Appendix C overrides)",
