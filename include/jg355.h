@@ -207,6 +207,16 @@ int jg_ddpm_prepare(int dtype, const float* y0, const float* ycond, const float*
 int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
                      float* loss, void* dnh, int B, int C, int H, int W, int Cpad, float lambda, float grad_scale,
                      jg_stream_t s);
+/* One DDPM ancestral sampling step after the UNet (DiffusionGenerator.p_sample / p_mean_variance, restoration_ddpm:
+ * models/modules/diffusion_generator.py:187-284, predict_start_from_noise / q_posterior: diffusion_utils.py:122-137):
+ *   y0_hat = clamp(sr*y_t - srm1*noise_hat, -1, 1);  y' = c1*y0_hat + c2*y_t + z*sigma;  y' = y_0*(1-m) + m*y'
+ * coef[b][5] = {sqrt_recip_gammas[t], sqrt_recipm1_gammas[t], posterior_mean_coef1[t], posterior_mean_coef2[t],
+ * exp(0.5*posterior_log_variance_clipped[t])}; z may be NULL (t == 0).  y_t fp32 NCHW is updated in place and the next
+ * UNet input [y_cond | y' | 0] is written as 16-bit NHWC with Cpad_out channels. */
+int jg_ddpm_p_sample(int dtype, float* y_t, const float* y_cond, const void* noise_hat, const float* z, const float* y_0,
+                     const int64_t* mask, const float* coef, void* xin, int B, int C, int H, int W, int Cpad_in, int Cpad_out,
+                     int clip_denoised, jg_stream_t s);
+
 /* Consistency-model (cm_model) glue around the UNet, models/modules/cm_generator.py / models/cm_model.py.
  *   cm_noisy   : noisy = x + sigma[b]*noise, blended with clamp(mask,0,1) (forward :452-460); written as fp32 NCHW
  *                and as the 16-bit NHWC UNet input [cond | noisy | 0-pad] (= torch.cat([x_cond, x], 1) of :377-381)

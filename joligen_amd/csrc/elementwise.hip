@@ -316,6 +316,45 @@ __global__ __launch_bounds__(256) void ddpm_mse_loss_kernel(const float* __restr
   if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * invN * lambda);
 }
 
+// ---- DDPM ancestral sampling step (diffusion_generator.py:187-284, diffusion_utils.py:122-137) -------------
+// One reverse step after the UNet: y0_hat = clamp(sr*y_t - srm1*noise_hat, -1, 1); mean = c1*y0_hat + c2*y_t;
+// y' = mean + z * exp(0.5*logvar); with a mask y' = y_0*(1-m) + m*y', m = clamp(mask,0,1).  Writes y' (fp32 NCHW,
+// in place over y_t) and the next UNet input [y_cond | y' | 0-pad] (16-bit NHWC).  coef[b] = {sr, srm1, c1, c2, sigma}.
+template <typename T>
+__global__ void ddpm_p_sample_kernel(float* __restrict__ y_t, const float* __restrict__ y_cond, const T* __restrict__ nh,
+                                     const float* __restrict__ z, const float* __restrict__ y_0,
+                                     const int64_t* __restrict__ mask, const float* __restrict__ coef, T* __restrict__ xin,
+                                     int B, int C, int HW, int Cpad_in, int Cpad_out, int clip) {
+  const long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / HW;
+    const long p = i % HW;
+    const float sr = coef[b * 5], srm1 = coef[b * 5 + 1], c1 = coef[b * 5 + 2], c2 = coef[b * 5 + 3], sg = coef[b * 5 + 4];
+    float m = 1.0f;
+    if (mask) {
+      const int64_t mv = mask[i];
+      m = mv < 0 ? 0.f : (mv > 1 ? 1.f : (float)mv);
+    }
+    T* o = xin + i * Cpad_out;
+    for (int c = 0; c < Cpad_out; ++c) {
+      float v = 0.f;
+      if (c < C) {
+        v = y_cond[((long)b * C + c) * HW + p];
+      } else if (c < 2 * C) {
+        const long q = ((long)b * C + (c - C)) * HW + p;
+        const float yt = y_t[q];
+        float y0h = sr * yt - srm1 * to_f32(nh[i * Cpad_in + (c - C)]);
+        if (clip) y0h = fminf(fmaxf(y0h, -1.0f), 1.0f);
+        float yn = c1 * y0h + c2 * yt + (z ? z[q] * sg : 0.f);
+        if (mask) yn = y_0[q] * (1.0f - m) + m * yn;
+        y_t[q] = yn;
+        v = yn;
+      }
+      o[c] = from_f32<T>(v);
+    }
+  }
+}
+
 // ---- consistency-model glue (cm_generator.py:367-502, cm_model.py:27-43,353-375) -------------------------
 // noisy = x + sigma[b] * noise; with a mask: noisy * clamp(mask,0,1) + (1 - clamp(mask,0,1)) * x.  Written twice:
 // fp32 NCHW (the c_skip * x term / visuals) and 16-bit NHWC with `cond` (optional, Ccond channels) in front
@@ -636,6 +675,20 @@ extern "C" int jg_noise_level_embedding(const float* sigma, const float* W, floa
   if (!sigma || !W || !emb || Bn < 1 || half < 1) return JG_ERR_BAD_ARG;
   hipLaunchKernelGGL(noise_level_embedding_kernel, dim3((Bn * 2 * half + 255) / 256), dim3(256), 0, (hipStream_t)s, sigma, W, emb,
                      Bn, half);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_ddpm_p_sample(int dtype, float* y_t, const float* y_cond, const void* noise_hat, const float* z,
+                                const float* y_0, const int64_t* mask, const float* coef, void* xin, int B, int C, int H, int W,
+                                int Cpad_in, int Cpad_out, int clip_denoised, jg_stream_t s) {
+  if (!y_t || !y_cond || !noise_hat || !coef || !xin || Cpad_in < C || Cpad_out < 2 * C || (Cpad_in % 8) || (Cpad_out % 8) ||
+      (mask && !y_0))
+    return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ddpm_p_sample_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, y_t,
+                                              y_cond, (const T*)noise_hat, z, y_0, mask, coef, (T*)xin, B, C, H * W, Cpad_in,
+                                              Cpad_out, clip_denoised););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -7,7 +7,7 @@
 state_dict keys are the reference's: `denoise_fn.model.<unet...>`, the 14 schedule buffers
 `denoise_fn.model.{gammas,...}_{train,test}` and `cond_embed.{0,2}.{weight,bias}`.
 
-The sampling / restoration loops (reference :83-455) are not part of the training hot path.
+`restoration` (reference :83-284) is the DDPM sampler of SURVEY.md 8(f); the DDIM sampler (:286-455) is not built.
 """
 from __future__ import annotations
 
@@ -159,6 +159,58 @@ class DiffusionGenerator(nn.Module):
         """reference :457-521 signature; returns (noise, noise_hat, min_snr_loss_weight) NCHW fp32."""
         noise, nh, w, _ = self.forward_nhwc(y_0, y_cond, mask, noise, t, u)
         return noise, ops.to_nchw_f32(nh, y_0.shape[1]), w
+
+    # ---- sampling (reference :83-284) ---------------------------------------------------------
+    @torch.no_grad()
+    def restoration(self, y_cond, y_t=None, y_0=None, mask=None, sample_num=8, cls=None, ref=None, guidance_scale=0.0,
+                    ddim_num_steps=10, ddim_eta=0.5, noises=None, clip_denoised=True):
+        """reference :83-183 (`restoration` -> `restoration_ddpm`): ancestral sampling over the TEST schedule.
+        Per step: one UNet forward on the fused schedule + ONE fused kernel (`jg_ddpm_p_sample`) for
+        predict_start_from_noise, clamp, q_posterior, the noise injection, the mask blend and the next UNet input.
+        `noises`: optional list of the per-step N(0,1) draws in loop order (parity runs); else the device RNG.
+        Returns (y_t, ret_arr) like the reference, NCHW fp32."""
+        if self.sampling_method != "ddpm":
+            raise NotImplementedError("only the DDPM sampler is implemented (alg_palette_sampling_method='ddpm')")
+        if guidance_scale > 0.0 or cls is not None or ref is not None:
+            raise NotImplementedError("classifier-free guidance / class / reference conditioning are outside SURVEY.md 8")
+        if self.arena is None:
+            raise RuntimeError("DiffusionGenerator.jg_finalize(device) has not been called")
+        self.arena.ensure_fresh()
+        model = self.denoise_fn.model
+        T = model.num_timesteps_test
+        assert T > sample_num, "num_timesteps must greater than sample_num"
+        sample_inter = T // sample_num
+        b, Cc, H, W = y_cond.shape
+        dev = y_cond.device
+        y_cond = y_cond.float().contiguous()
+        if y_t is None:
+            y_t = torch.randn((b, model.out_channel, H, W), device=dev, dtype=torch.float32)
+        y_t = y_t.float().clone()
+        ret = [y_t.clone()]
+        m = None
+        if mask is not None:
+            m = mask.contiguous() if mask.dtype == torch.int64 else mask.long().contiguous()
+            y_0 = y_0.float().contiguous()
+        cpad = (2 * Cc + 7) // 8 * 8
+        xin = ops.to_nhwc(torch.cat([y_cond, y_t], dim=1), self.act_dtype, cpad)
+        L = ops._lib.lib()
+        for step, i in enumerate(reversed(range(T))):
+            t = torch.full((b,), i, device=dev, dtype=torch.long)
+            emb = self.compute_gammas(model.gammas_test.gather(-1, t).view(b, 1))
+            nh = self.denoise_fn(xin, emb)
+            coef = torch.stack([model.sqrt_recip_gammas_test.gather(-1, t), model.sqrt_recipm1_gammas_test.gather(-1, t),
+                                model.posterior_mean_coef1_test.gather(-1, t), model.posterior_mean_coef2_test.gather(-1, t),
+                                (0.5 * model.posterior_log_variance_clipped_test.gather(-1, t)).exp()], dim=1).contiguous()
+            z = None
+            if i > 0:
+                z = (noises[step].to(dev).float().contiguous() if noises is not None else torch.randn_like(y_t))
+            xin = torch.empty_like(xin)
+            ops.check(L.jg_ddpm_p_sample(ops._DT[self.act_dtype], y_t.data_ptr(), y_cond.data_ptr(), nh.data_ptr(), ops._p(z),
+                                         ops._p(y_0 if m is not None else None), ops._p(m), coef.data_ptr(), xin.data_ptr(), b, Cc,
+                                         H, W, nh.shape[-1], cpad, int(clip_denoised), ops._st()), "jg_ddpm_p_sample")
+            if i % sample_inter == 0:
+                ret.append(y_t.clone())
+        return y_t, torch.cat(ret, dim=0)
 
     def set_new_sampling_method(self, sampling_method):
         self.sampling_method = sampling_method

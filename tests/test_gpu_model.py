@@ -371,3 +371,32 @@ def test_rccl_exchange_path_single_rank():
     r = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["tiny_eff", "tiny_attn"])
+def test_ddpm_restoration_vs_reference_golden(golden_dir, name, dtype):
+    """DiffusionGenerator.restoration (DDPM sampler, short test schedule) against the reference's own samples with
+    the per-step noise injected: one UNet forward + one fused `jg_ddpm_p_sample` kernel per step."""
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    g = load(golden_dir, f"sampling_{name}.pt")
+    opt = opt_from_json({}, overrides_of(g["cfg"], G_diff_n_timestep_test=g["T"]))
+    net = define_G(**vars(opt))
+    sd = net.state_dict()
+    for k, v in g["sched_test"].items():   # schedule buffers of this implementation == the reference's, bit for bit
+        assert torch.equal(sd["denoise_fn.model." + k], v), k
+    net.load_state_dict(O.synth_state_dict(sd, seed=0))
+    net.jg_finalize(torch.device("cuda:0"), dtype)
+    d = torch.device("cuda:0")
+    y, ret = net.restoration(g["A"].to(d), y_t=g["y_t0"].to(d), y_0=g["B"].to(d), mask=g["mask"].to(d), sample_num=2,
+                             noises=g["noises"])
+    torch.cuda.synchronize()
+    assert ret.shape == g["ret"].shape
+    # unmasked pixels are exact copies of y_0 at every recorded step (mask blend is bit exact)
+    keep = (g["mask"] == 0).expand_as(g["B"])
+    assert torch.equal(y.cpu()[keep], g["B"][keep])
+    e = relerr(y, g["y_out"])
+    assert e < 2 * TOL_OUT[dtype], e
+    assert relerr(ret, g["ret"]) < 2 * TOL_OUT[dtype]

@@ -151,3 +151,25 @@ def test_cm_three_steps(golden_dir, name):
                     v = tr.ema[k]
                     mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
                     torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
+
+
+# ---- DDPM sampling (restoration): oracle/make_golden_sampling.py fixtures ----------------------------------
+@pytest.mark.parametrize("name", ["tiny_eff", "tiny_attn"])
+def test_ddpm_restoration(golden_dir, name):
+    g = load(golden_dir, f"sampling_{name}.pt")
+    ref_sd = {}
+    for k in g["keys"]:
+        leaf = k.split(".")[-1]
+        if O._is_buffer(k):
+            ref_sd[k] = g["sched_test"][leaf] if leaf in g["sched_test"] else torch.zeros(g["shapes"][k])
+        else:
+            ref_sd[k] = torch.empty(g["shapes"][k])
+    sd = O.synth_state_dict(ref_sd, seed=0)
+    # the short test schedule is the reference's (float64 numpy -> fp32, bit exact)
+    mine = O.noise_schedule_buffers("test", g["T"])
+    for k, v in g["sched_test"].items():
+        assert torch.equal(mine[k], v), k
+    with torch.no_grad():
+        y, ret = O.ddpm_restoration(sd, g["A"], g["y_t0"], g["B"], g["mask"], g["noises"], cfg_of(g["cfg"]), sample_num=2)
+    torch.testing.assert_close(y, g["y_out"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ret, g["ret"], rtol=1e-4, atol=1e-5)
