@@ -212,7 +212,9 @@ int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise_hat, const
  *   y0_hat = clamp(sr*y_t - srm1*noise_hat, -1, 1);  y' = c1*y0_hat + c2*y_t + z*sigma;  y' = y_0*(1-m) + m*y'
  * coef[b][5] = {sqrt_recip_gammas[t], sqrt_recipm1_gammas[t], posterior_mean_coef1[t], posterior_mean_coef2[t],
  * exp(0.5*posterior_log_variance_clipped[t])}; z may be NULL (t == 0).  y_t fp32 NCHW is updated in place and the next
- * UNet input [y_cond | y' | 0] is written as 16-bit NHWC with Cpad_out channels. */
+ * UNet input [y_cond | y' | 0] is written as 16-bit NHWC with Cpad_out channels.  clip_denoised bit 0 clamps y0_hat,
+ * bit 1 clamps y' before the mask blend: the reference's DDIM step (ddim_p_mean_variance :383-455) is the same kernel
+ * with coef = {0, -1, coef_eps - sqrt(g_prev (1 - g_t) / g_t), sqrt(g_prev / g_t), 0}, clip 3, z NULL. */
 int jg_ddpm_p_sample(int dtype, float* y_t, const float* y_cond, const void* noise_hat, const float* z, const float* y_0,
                      const int64_t* mask, const float* coef, void* xin, int B, int C, int H, int W, int Cpad_in, int Cpad_out,
                      int clip_denoised, jg_stream_t s);

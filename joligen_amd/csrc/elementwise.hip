@@ -344,8 +344,9 @@ __global__ void ddpm_p_sample_kernel(float* __restrict__ y_t, const float* __res
         const long q = ((long)b * C + (c - C)) * HW + p;
         const float yt = y_t[q];
         float y0h = sr * yt - srm1 * to_f32(nh[i * Cpad_in + (c - C)]);
-        if (clip) y0h = fminf(fmaxf(y0h, -1.0f), 1.0f);
+        if (clip & 1) y0h = fminf(fmaxf(y0h, -1.0f), 1.0f);
         float yn = c1 * y0h + c2 * yt + (z ? z[q] * sg : 0.f);
+        if (clip & 2) yn = fminf(fmaxf(yn, -1.0f), 1.0f);   // DDIM: the reference also clamps the mean (:452-453)
         if (mask) yn = y_0[q] * (1.0f - m) + m * yn;
         y_t[q] = yn;
         v = yn;

@@ -7,7 +7,7 @@
 state_dict keys are the reference's: `denoise_fn.model.<unet...>`, the 14 schedule buffers
 `denoise_fn.model.{gammas,...}_{train,test}` and `cond_embed.{0,2}.{weight,bias}`.
 
-`restoration` (reference :83-284) is the DDPM sampler of SURVEY.md 8(f); the DDIM sampler (:286-455) is not built.
+`restoration` (reference :83-455) = the DDPM and DDIM samplers of SURVEY.md 8(f).
 """
 from __future__ import annotations
 
@@ -169,8 +169,8 @@ class DiffusionGenerator(nn.Module):
         predict_start_from_noise, clamp, q_posterior, the noise injection, the mask blend and the next UNet input.
         `noises`: optional list of the per-step N(0,1) draws in loop order (parity runs); else the device RNG.
         Returns (y_t, ret_arr) like the reference, NCHW fp32."""
-        if self.sampling_method != "ddpm":
-            raise NotImplementedError("only the DDPM sampler is implemented (alg_palette_sampling_method='ddpm')")
+        if self.sampling_method not in ("ddpm", "ddim"):
+            raise NotImplementedError(f"sampling method {self.sampling_method!r}")
         if guidance_scale > 0.0 or cls is not None or ref is not None:
             raise NotImplementedError("classifier-free guidance / class / reference conditioning are outside SURVEY.md 8")
         if self.arena is None:
@@ -194,6 +194,32 @@ class DiffusionGenerator(nn.Module):
         cpad = (2 * Cc + 7) // 8 * 8
         xin = ops.to_nhwc(torch.cat([y_cond, y_t], dim=1), self.act_dtype, cpad)
         L = ops._lib.lib()
+        if self.sampling_method == "ddim":
+            # reference :286-349 + ddim_p_mean_variance :383-455 (deterministic: the noise it draws is not used).
+            # The UNet output is clamped to [-1,1], mean = sqrt(g_prev) (y_t - sqrt(1-g_t) e) / sqrt(g_t) + coef_eps e,
+            # clamped again -- the same fused kernel with other coefficients.
+            tseq = list(np.linspace(0, T - 1, ddim_num_steps).astype(int))
+            for i in range(ddim_num_steps):
+                ti = int(tseq[-1 - i])
+                prev = int(tseq[-2 - i]) if i != ddim_num_steps - 1 else -1
+                t = torch.full((b,), ti, device=dev, dtype=torch.long)
+                emb = self.compute_gammas(model.gammas_test.gather(-1, t).view(b, 1))
+                nh = self.denoise_fn(xin, emb)
+                gamma_t = model.gammas_test.gather(-1, t)
+                gamma_p = model.gammas_prev_test.gather(-1, torch.full((b,), prev + 1, device=dev, dtype=torch.long))
+                sigma = ddim_eta * torch.sqrt((1 - gamma_p) / (1 - gamma_t) * (1 - gamma_t / gamma_p))
+                coef_eps = torch.sqrt(torch.clamp(1 - gamma_p - sigma ** 2, min=0))
+                c_e = coef_eps - torch.sqrt(gamma_p) * torch.sqrt(1.0 - gamma_t) / torch.sqrt(gamma_t)
+                c_y = torch.sqrt(gamma_p) / torch.sqrt(gamma_t)
+                coef = torch.stack([torch.zeros_like(c_e), -torch.ones_like(c_e), c_e, c_y, torch.zeros_like(c_e)], dim=1).contiguous()
+                xin = torch.empty_like(xin)
+                ops.check(L.jg_ddpm_p_sample(ops._DT[self.act_dtype], y_t.data_ptr(), y_cond.data_ptr(), nh.data_ptr(), None,
+                                             ops._p(y_0 if m is not None else None), ops._p(m), coef.data_ptr(), xin.data_ptr(),
+                                             b, Cc, H, W, nh.shape[-1], cpad, 3 if clip_denoised else 0, ops._st()),
+                          "jg_ddpm_p_sample")
+                if i % sample_inter == 0:
+                    ret.append(y_t.clone())
+            return y_t, torch.cat(ret, dim=0)
         for step, i in enumerate(reversed(range(T))):
             t = torch.full((b,), i, device=dev, dtype=torch.long)
             emb = self.compute_gammas(model.gammas_test.gather(-1, t).view(b, 1))

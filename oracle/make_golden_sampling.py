@@ -43,8 +43,12 @@ def main():
         torch.manual_seed(32)   # the reference draws randn_like(y_t) from the default generator once per step with t > 0
         with torch.no_grad():
             y_out, ret = netG.restoration(y_cond, y_t=y_t0.clone(), y_0=y_0, mask=mask, sample_num=2)
+        netG.set_new_sampling_method("ddim")
+        with torch.no_grad():
+            y_ddim, ret_ddim = netG.restoration(y_cond, y_t=y_t0.clone(), y_0=y_0, mask=mask, sample_num=2, ddim_num_steps=4,
+                                                ddim_eta=0.5)
         sched = {k.split(".")[-1]: v.clone() for k, v in netG.state_dict().items() if O._is_buffer(k) and k.endswith("_test")}
-        torch.save(dict(cfg=c, T=T_TEST, A=y_cond, B=y_0, mask=mask, y_t0=y_t0, noises=noises, y_out=y_out, ret=ret,
+        torch.save(dict(cfg=c, T=T_TEST, A=y_cond, B=y_0, mask=mask, y_t0=y_t0, noises=noises, y_out=y_out, ret=ret, y_ddim=y_ddim, ret_ddim=ret_ddim,
                         sched_test=sched, keys=list(ref_sd.keys()), shapes={k: tuple(v.shape) for k, v in ref_sd.items()}),
                    os.path.join(OUT, f"sampling_{name}.pt"))
         print(name, "sampled", float(y_out.abs().mean()), tuple(ret.shape))

@@ -400,3 +400,11 @@ def test_ddpm_restoration_vs_reference_golden(golden_dir, name, dtype):
     e = relerr(y, g["y_out"])
     assert e < 2 * TOL_OUT[dtype], e
     assert relerr(ret, g["ret"]) < 2 * TOL_OUT[dtype]
+    # DDIM sampler: same kernel, other coefficients
+    net.set_new_sampling_method("ddim")
+    y, ret = net.restoration(g["A"].to(d), y_t=g["y_t0"].to(d), y_0=g["B"].to(d), mask=g["mask"].to(d), sample_num=2,
+                             ddim_num_steps=4, ddim_eta=0.5)
+    assert ret.shape == g["ret_ddim"].shape
+    assert torch.equal(y.cpu()[keep], g["B"][keep])
+    assert relerr(y, g["y_ddim"]) < 2 * TOL_OUT[dtype], relerr(y, g["y_ddim"])
+    assert relerr(ret, g["ret_ddim"]) < 2 * TOL_OUT[dtype]

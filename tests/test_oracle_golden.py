@@ -173,3 +173,7 @@ def test_ddpm_restoration(golden_dir, name):
         y, ret = O.ddpm_restoration(sd, g["A"], g["y_t0"], g["B"], g["mask"], g["noises"], cfg_of(g["cfg"]), sample_num=2)
     torch.testing.assert_close(y, g["y_out"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(ret, g["ret"], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        y, ret = O.ddim_restoration(sd, g["A"], g["y_t0"], g["B"], g["mask"], cfg_of(g["cfg"]), sample_num=2, num_steps=4, eta=0.5)
+    torch.testing.assert_close(y, g["y_ddim"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ret, g["ret_ddim"], rtol=1e-4, atol=1e-5)
