@@ -26,7 +26,7 @@ typedef void* jg_stream_t; /* hipStream_t */
 
 enum { JG_F16 = 0, JG_BF16 = 1 };
 enum { JG_OK = 0, JG_ERR_BAD_ARG = -1, JG_ERR_UNSUPPORTED = -2, JG_ERR_LAUNCH = -3 };
-enum { JG_ACT_NONE = 0, JG_ACT_SILU = 1 };
+enum { JG_ACT_NONE = 0, JG_ACT_SILU = 1, JG_ACT_RELU = 2, JG_ACT_LRELU = 3 /* slope 0.2 */, JG_ACT_TANH = 4 /* jg_act_* only */ };
 enum { JG_OUT_ATOMIC_F32 = 0, JG_OUT_STORE_F32 = 1, JG_OUT_STORE_T = 2 };
 
 int jg_version(void);
@@ -207,6 +207,23 @@ int jg_ddpm_prepare(int dtype, const float* y0, const float* ycond, const float*
 int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
                      float* loss, void* dnh, int B, int C, int H, int W, int Cpad, float lambda, float grad_scale,
                      jg_stream_t s);
+/* Glue of the CUT networks (ResnetGenerator models/modules/resnet_architecture/resnet_generator.py:11-347,
+ * NLayerDiscriminator models/modules/discriminators.py:10-118), NHWC 16-bit, C % 8 == 0:
+ *   act_fwd / act_bwd        : nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh where no normalisation precedes them; the backward
+ *                              takes the OUTPUT y (tanh' = 1 - y^2)
+ *   reflect_pad2d (+ _bwd)   : nn.ReflectionPad2d(pad) and its adjoint (gather form, deterministic)
+ *   dilate2d / subsample2d   : zero insertion y[s*i, s*j] = x[i, j] into [Ho, Wo] and its adjoint: a stride-s
+ *                              nn.ConvTranspose2d (and the input gradient of a stride-s nn.Conv2d) is jg_conv2d_nt at
+ *                              stride 1 over the dilated tensor with the flipped / transposed weight copy
+ *   channel_sum              : out[c] += scale * sum_p x[p][c] (bias gradient of the transposed convolution) */
+int jg_act_fwd(int dtype, const void* x, void* y, int64_t n, int act, jg_stream_t s);
+int jg_act_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, int act, jg_stream_t s);
+int jg_reflect_pad2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int pad, jg_stream_t s);
+int jg_reflect_pad2d_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int pad, jg_stream_t s);
+int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s);
+int jg_subsample2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s);
+int jg_channel_sum(int dtype, const void* x, int64_t ldx, float* out, int64_t P, int C, float scale, jg_stream_t s);
+
 /* One DDPM ancestral sampling step after the UNet (DiffusionGenerator.p_sample / p_mean_variance, restoration_ddpm:
  * models/modules/diffusion_generator.py:187-284, predict_start_from_noise / q_posterior: diffusion_utils.py:122-137):
  *   y0_hat = clamp(sr*y_t - srm1*noise_hat, -1, 1);  y' = c1*y0_hat + c2*y_t + z*sigma;  y' = y_0*(1-m) + m*y'

@@ -17,7 +17,7 @@ SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "gemm_tn.hip", "wgra
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 JG_F16, JG_BF16 = 0, 1
-JG_ACT_NONE, JG_ACT_SILU = 0, 1
+JG_ACT_NONE, JG_ACT_SILU, JG_ACT_RELU, JG_ACT_LRELU, JG_ACT_TANH = 0, 1, 2, 3, 4
 JG_OUT_ATOMIC_F32, JG_OUT_STORE_F32, JG_OUT_STORE_T = 0, 1, 2
 
 c_i32, c_i64, c_f32, c_p = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -81,6 +81,13 @@ SIGNATURES = {
     "jg_gamma_embedding": [c_p, c_p, c_i32, c_i32, c_f32, c_p],
     "jg_ddpm_prepare": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_ddpm_mse_loss": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_p],
+    "jg_act_fwd": [c_i32, c_p, c_p, c_i64, c_i32, c_p],
+    "jg_act_bwd": [c_i32, c_p, c_p, c_p, c_i64, c_i32, c_p],
+    "jg_reflect_pad2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_reflect_pad2d_bwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_dilate2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_subsample2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_channel_sum": [c_i32, c_p, c_i64, c_p, c_i64, c_i32, c_f32, c_p],
     "jg_ddpm_p_sample": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_cm_noisy": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_cm_combine": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],

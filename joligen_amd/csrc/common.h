@@ -88,6 +88,31 @@ __device__ __forceinline__ float silu_grad_f(float u) {
   return s * (1.0f + u * (1.0f - s));
 }
 
+// activation fused into the normalisation passes: y = act(u); act_grad_f = d act / d u
+template <int ACT> __device__ __forceinline__ float act_f(float u) {
+  if (ACT == JG_ACT_SILU) return silu_f(u);
+  if (ACT == JG_ACT_RELU) return fmaxf(u, 0.f);
+  if (ACT == JG_ACT_LRELU) return u > 0.f ? u : 0.2f * u;
+  return u;
+}
+template <int ACT> __device__ __forceinline__ float act_grad_f(float u) {
+  if (ACT == JG_ACT_SILU) return silu_grad_f(u);
+  if (ACT == JG_ACT_RELU) return u > 0.f ? 1.f : 0.f;
+  if (ACT == JG_ACT_LRELU) return u > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+__device__ __forceinline__ float act_grad_rt(float u, int act) {
+  return act == JG_ACT_SILU ? silu_grad_f(u) : act == JG_ACT_RELU ? (u > 0.f ? 1.f : 0.f) : act == JG_ACT_LRELU ? (u > 0.f ? 1.f : 0.2f) : 1.f;
+}
+
+#define JG_DISPATCH_ACT(act, ...)                          \
+  do {                                                     \
+    if ((act) == JG_ACT_SILU) { constexpr int ACT = JG_ACT_SILU; __VA_ARGS__ }        \
+    else if ((act) == JG_ACT_RELU) { constexpr int ACT = JG_ACT_RELU; __VA_ARGS__ }   \
+    else if ((act) == JG_ACT_LRELU) { constexpr int ACT = JG_ACT_LRELU; __VA_ARGS__ } \
+    else { constexpr int ACT = JG_ACT_NONE; __VA_ARGS__ }                              \
+  } while (0)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -89,7 +89,7 @@ __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][
 #pragma unroll
           for (int q = 0; q < 8; ++q) {
             float du = v[q];
-            if (p.gact == JG_ACT_SILU) du *= silu_grad_f(ga[q] * xf[q] + gb[q]);
+            du *= act_grad_rt(ga[q] * xf[q] + gb[q], p.gact);
             s1[q] += du;
             s2[q] += du * xf[q];
           }

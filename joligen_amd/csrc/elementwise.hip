@@ -316,6 +316,129 @@ __global__ __launch_bounds__(256) void ddpm_mse_loss_kernel(const float* __restr
   if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * invN * lambda);
 }
 
+// ---- CUT / ResNet-generator glue (resnet_generator.py, discriminators.py) ------------------------------------
+// standalone activations on 16-byte vectors: y = act(x); backward from the OUTPUT y (tanh: 1 - y^2; (leaky) relu: the
+// sign of y is the sign of x)
+template <typename T>
+__global__ void act_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long n8, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(x + i * 8), f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      f[q] = act == JG_ACT_TANH ? tanhf(f[q]) : act == JG_ACT_RELU ? fmaxf(f[q], 0.f) : act == JG_ACT_LRELU ? (f[q] > 0.f ? f[q] : 0.2f * f[q])
+                                : act == JG_ACT_SILU ? silu_f(f[q]) : f[q];
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8<T>(f);
+  }
+}
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, long n8, int act) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    float f[8], g[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(y + i * 8), f);
+    unpack8<T>(*reinterpret_cast<const uint4*>(dy + i * 8), g);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      g[q] *= act == JG_ACT_TANH ? (1.f - f[q] * f[q]) : act == JG_ACT_RELU ? (f[q] > 0.f ? 1.f : 0.f) : act == JG_ACT_LRELU ? (f[q] > 0.f ? 1.f : 0.2f) : 1.f;
+    *reinterpret_cast<uint4*>(dx + i * 8) = pack8<T>(g);
+  }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+
+// nn.ReflectionPad2d(pad), NHWC: y[b, i, j] = x[b, refl(i - pad), refl(j - pad)]
+template <typename T>
+__global__ void reflect_pad_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int pad) {
+  const int Ho = H + 2 * pad, Wo = W + 2 * pad, noct = C / 8;
+  const long total = (long)B * Ho * Wo * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    long t = i / noct;
+    const int ow = t % Wo; t /= Wo;
+    const int oh = t % Ho;
+    const int b = t / Ho;
+    const int ih = reflect_idx(oh - pad, H), iw = reflect_idx(ow - pad, W);
+    *reinterpret_cast<uint4*>(y + i * 8) = *reinterpret_cast<const uint4*>(x + (((long)b * H + ih) * W + iw) * C + co * 8);
+  }
+}
+// its adjoint as a gather: dx[b, i, j] = sum of dy over the (<= 2 x 2) padded positions that mirror onto (i, j)
+template <typename T>
+__global__ void reflect_pad_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int pad) {
+  const int Ho = H + 2 * pad, Wo = W + 2 * pad, noct = C / 8;
+  const long total = (long)B * H * W * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    long t = i / noct;
+    const int iw = t % W; t /= W;
+    const int ih = t % H;
+    const int b = t / H;
+    int hs[3], ws[3], nh = 0, nw = 0;
+    hs[nh++] = ih + pad;
+    if (ih >= 1 && ih <= pad) hs[nh++] = pad - ih;
+    if (ih <= H - 2 && ih >= H - 1 - pad) hs[nh++] = 2 * (H - 1) - ih + pad;
+    ws[nw++] = iw + pad;
+    if (iw >= 1 && iw <= pad) ws[nw++] = pad - iw;
+    if (iw <= W - 2 && iw >= W - 1 - pad) ws[nw++] = 2 * (W - 1) - iw + pad;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < nh; ++a)
+      for (int c = 0; c < nw; ++c) {
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(dy + (((long)b * Ho + hs[a]) * Wo + ws[c]) * C + co * 8), f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += f[q];
+      }
+    *reinterpret_cast<uint4*>(dx + i * 8) = pack8<T>(acc);
+  }
+}
+
+// zero insertion y[b, s*i, s*j] = x[b, i, j] into a [B, Ho, Wo] buffer (0 elsewhere): the stride-s transposed convolution /
+// the input gradient of a stride-s convolution is a stride-1 convolution of this buffer with the flipped weights.
+// `gather` = the adjoint: y[b, i, j] = x[b, s*i, s*j].
+template <typename T>
+__global__ void dilate_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo, int s) {
+  const int noct = C / 8;
+  const long total = (long)B * Ho * Wo * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    long t = i / noct;
+    const int ow = t % Wo; t /= Wo;
+    const int oh = t % Ho;
+    const int b = t / Ho;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (oh % s == 0 && ow % s == 0 && oh / s < H && ow / s < W)
+      v = *reinterpret_cast<const uint4*>(x + (((long)b * H + oh / s) * W + ow / s) * C + co * 8);
+    *reinterpret_cast<uint4*>(y + i * 8) = v;
+  }
+}
+template <typename T>
+__global__ void subsample_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo, int s) {
+  const int noct = C / 8;
+  const long total = (long)B * Ho * Wo * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    long t = i / noct;
+    const int ow = t % Wo; t /= Wo;
+    const int oh = t % Ho;
+    const int b = t / Ho;
+    *reinterpret_cast<uint4*>(y + i * 8) = *reinterpret_cast<const uint4*>(x + (((long)b * H + oh * s) * W + ow * s) * C + co * 8);
+  }
+}
+
+// out[c] += scale * sum over P pixels of x[p][c]  (bias gradient of a transposed convolution)
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ x, long ldx, float* __restrict__ out, long P,
+                                                          int C, float scale) {
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int lane_p = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (long p = blockIdx.x * 4L + lane_p; p < P; p += (long)gridDim.x * 4) acc += to_f32(x[p * ldx + c]);
+  __shared__ float sacc[4][64];
+  sacc[lane_p][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (lane_p == 0 && c < C) atomicAdd(out + c, scale * (sacc[0][threadIdx.x] + sacc[1][threadIdx.x] + sacc[2][threadIdx.x] + sacc[3][threadIdx.x]));
+}
+
 // ---- DDPM ancestral sampling step (diffusion_generator.py:187-284, diffusion_utils.py:122-137) -------------
 // One reverse step after the UNet: y0_hat = clamp(sr*y_t - srm1*noise_hat, -1, 1); mean = c1*y0_hat + c2*y_t;
 // y' = mean + z * exp(0.5*logvar); with a mask y' = y_0*(1-m) + m*y', m = clamp(mask,0,1).  Writes y' (fp32 NCHW,
@@ -690,6 +813,63 @@ extern "C" int jg_ddpm_p_sample(int dtype, float* y_t, const float* y_cond, cons
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ddpm_p_sample_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, y_t,
                                               y_cond, (const T*)noise_hat, z, y_0, mask, coef, (T*)xin, B, C, H * W, Cpad_in,
                                               Cpad_out, clip_denoised););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_act_fwd(int dtype, const void* x, void* y, int64_t n, int act, jg_stream_t s) {
+  if (!x || !y || n < 8 || n % 8) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_fwd_kernel<T>), dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                              (T*)y, (long)(n / 8), act););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_act_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, int act, jg_stream_t s) {
+  if (!y || !dy || !dx || n < 8 || n % 8) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(grid_for(n / 8)), dim3(256), 0, (hipStream_t)s, (const T*)y,
+                                              (const T*)dy, (T*)dx, (long)(n / 8), act););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_reflect_pad2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int pad, jg_stream_t s) {
+  if (!x || !y || C % 8 || pad < 1 || pad >= H || pad >= W) return JG_ERR_BAD_ARG;
+  const long total = (long)B * (H + 2 * pad) * (W + 2 * pad) * (C / 8);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((reflect_pad_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, (T*)y, B, H, W, C, pad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_reflect_pad2d_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int pad, jg_stream_t s) {
+  if (!dy || !dx || C % 8 || pad < 1 || pad >= H || pad >= W) return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W * (C / 8);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((reflect_pad_bwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)dy, (T*)dx, B, H, W, C, pad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s) {
+  if (!x || !y || C % 8 || stride < 1 || Ho < (H - 1) * stride + 1 || Wo < (W - 1) * stride + 1) return JG_ERR_BAD_ARG;
+  const long total = (long)B * Ho * Wo * (C / 8);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dilate_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                              (T*)y, B, H, W, C, Ho, Wo, stride););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_subsample2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s) {
+  if (!x || !y || C % 8 || stride < 1 || H < (Ho - 1) * stride + 1 || W < (Wo - 1) * stride + 1) return JG_ERR_BAD_ARG;
+  const long total = (long)B * Ho * Wo * (C / 8);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((subsample_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, (T*)y, B, H, W, C, Ho, Wo, stride););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_channel_sum(int dtype, const void* x, int64_t ldx, float* out, int64_t P, int C, float scale, jg_stream_t s) {
+  if (!x || !out || P < 1 || C < 1 || ldx < C) return JG_ERR_BAD_ARG;
+  long gx = (P + 1023) / 1024;
+  if (gx > 512) gx = 512;
+  dim3 grid((unsigned)gx, (C + 63) / 64);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, (long)ldx,
+                                              out, (long)P, C, scale););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

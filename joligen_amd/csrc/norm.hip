@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float u = a[q] * f[q] + bb[q];
-      f[q] = ACT == JG_ACT_SILU ? silu_f(u) : u;
+      f[q] = act_f<ACT>(u);
     }
     *reinterpret_cast<uint4*>(y + (row0 + p) * ldy + co * 8) = pack8<T>(f);
   }
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         float du = fg[q];
-        if (ACT == JG_ACT_SILU) du *= silu_grad_f(a[q] * fx[q] + bb[q]);
+        if (ACT != JG_ACT_NONE) du *= act_grad_f<ACT>(a[q] * fx[q] + bb[q]);
         s1[q] += du;
         s2[q] += du * fx[q];
       }
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float du = fg[q];
-      if (ACT == JG_ACT_SILU) du *= silu_grad_f(a[q] * fx[q] + bb[q]);
+      if (ACT != JG_ACT_NONE) du *= act_grad_f<ACT>(a[q] * fx[q] + bb[q]);
       fg[q] = du * P[q] + fx[q] * Q[q] + R[q];
     }
     if (add1) {   // fused gradient accumulation of the other consumers of x (residual / skip / concat paths)
@@ -349,10 +349,8 @@ extern "C" int jg_gn_apply_ld(int dtype, const void* x, int64_t ldx, const float
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   hipStream_t st = (hipStream_t)s;
-  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0, st,
-                                                                       (const T*)x, (long)ldx, ab, (T*)y, (long)ldy, HW, C);
-                    else hipLaunchKernelGGL((gn_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x, (long)ldx,
-                                            ab, (T*)y, (long)ldy, HW, C););
+  JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_apply_kernel<T, ACT>), grid, dim3(256), 0, st, (const T*)x,
+                                                            (long)ldx, ab, (T*)y, (long)ldy, HW, C);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -371,10 +369,8 @@ extern "C" int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const 
   const Map mp = make_map_red(C, mult);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   const size_t shm = 2 * C * sizeof(float);
-  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_SILU>), grid, dim3(256), shm,
-                                                                       st, (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult);
-                    else hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, JG_ACT_NONE>), grid, dim3(256), shm, st, (const T*)x,
-                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult););
+  JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, ACT>), grid, dim3(256), shm, st, (const T*)x,
+                                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -411,13 +407,10 @@ extern "C" int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const v
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   hipStream_t st = (hipStream_t)s;
   static const int rev = [] { const char* e = getenv("JG_GN_REVERSE"); return e ? atoi(e) : 1; }();
-  JG_DISPATCH_DTYPE(dtype, if (act == JG_ACT_SILU) hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_SILU>), grid, dim3(256), 0,
-                                                                       st, (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, pqr,
-                                                                       (T*)dx, (long)lddx, (const T*)add1, (long)ldadd1, scale1,
-                                                                       (const T*)add2, (long)ldadd2, scale2, HW, C, rev);
-                    else hipLaunchKernelGGL((gn_bwd_apply_kernel<T, JG_ACT_NONE>), grid, dim3(256), 0, st, (const T*)x, (long)ldx,
-                                            (const T*)dy, (long)lddy, ab, pqr, (T*)dx, (long)lddx, (const T*)add1,
-                                            (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2, HW, C, rev););
+  JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT>), grid, dim3(256), 0, st, (const T*)x,
+                                                            (long)ldx, (const T*)dy, (long)lddy, ab, pqr, (T*)dx, (long)lddx,
+                                                            (const T*)add1, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2,
+                                                            scale2, HW, C, rev);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

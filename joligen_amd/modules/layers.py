@@ -50,6 +50,26 @@ class JGConv1d(nn.Conv1d, JGConvNd):
         return y.view(B, T, y.shape[-1])
 
 
+class JGConvTranspose2d(nn.ConvTranspose2d, JGConvNd):
+    """nn.ConvTranspose2d parameters (weight [Cin, Cout, k, k]); the arena keeps it as the stride-s CONVOLUTION whose
+    input-gradient it is (O = Cin, I = Cout), so the forward reads the flipped / transposed 16-bit copy (`w16T`) over the
+    zero-dilated input and the backward is that convolution's forward + weight gradient."""
+
+    jg_transposed = True
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, output_padding=0):
+        super().__init__(cin, cout, k, stride=stride, padding=padding, output_padding=output_padding)
+        if cin % 8 or cout % 8:
+            raise NotImplementedError("transposed convolutions need channel counts that are multiples of 8")
+        self.needs_dgrad = True
+        self.jg_padding, self.jg_stride, self.jg_output_padding = padding, stride, output_padding
+
+    def forward(self, x):
+        if self.meta is None:
+            raise RuntimeError("JGConvTranspose2d used before ParamArena finalisation")
+        return ops.conv_transpose2d(x, self.meta, self.jg_output_padding)
+
+
 class GroupNorm(nn.Module):
     """Same attribute layout as the reference wrapper (unet_attn_utils.py:42-48): `.norm` is an
     nn.GroupNorm that only holds (weight, bias); the computation is ops.group_norm."""

@@ -1,0 +1,148 @@
+"""ResNet generator of the CUT / CycleGAN family on the HIP ops: mirror of
+/root/reference/models/modules/resnet_architecture/resnet_generator.py (`ResnetBlock` :11-95, `ResnetGenerator` :98-164,
+`ResnetEncoder` :167-271, `ResnetDecoder` :274-347) for InstanceNorm (affine=False, hence conv bias=True,
+models/modules/utils.py:101-104), reflect padding, no dropout, no spectral norm.
+
+Same `nn.Sequential` indices as the reference, so `state_dict()` keys (`encoder.model.1.weight`,
+`encoder.model.10.conv_block.5.bias`, `decoder.model.3.weight` ...) and the NCE tap ids of
+`get_feats(x, [0, 4, 8, 12, 16])` are the reference's.  Execution: NHWC 16-bit; InstanceNorm + ReLU is one fused
+normalisation pass (GroupNorm kernels with groups == C); reflection padding is a gather kernel in front of a pad-0
+convolution; the stride-2 transposed convolutions run as stride-1 MFMA convolutions over the zero-dilated input.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import JG_ACT_NONE, JG_ACT_RELU, JG_ACT_TANH
+from .layers import JGConv2d, JGConvTranspose2d
+
+
+def _run(seq, x, taps=None, feats=None, upto=None):
+    """Walk a reference-shaped nn.Sequential on the HIP ops.  InstanceNorm2d followed by ReLU is fused into one pass
+    (the ReLU index then returns the same tensor, which is also what an in-place nn.ReLU(True) leaves in the
+    reference's InstanceNorm output)."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.ReflectionPad2d):
+            x = ops.reflect_pad2d(x, m.padding[0])
+        elif isinstance(m, (JGConv2d, JGConvTranspose2d, ResnetBlock)):
+            x = m(x)
+        elif isinstance(m, nn.InstanceNorm2d):
+            # nn.ReLU(True) is IN PLACE in the reference: a feature tapped at the InstanceNorm index is the tensor the
+            # ReLU then overwrites, i.e. the post-ReLU values -- exactly what the fused pass produces
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = ops.group_norm(x, x.shape[-1], None, None, None, JG_ACT_RELU if fuse else JG_ACT_NONE, m.eps)
+            if fuse:
+                if taps and i in taps:
+                    feats.append(x)
+                i += 1      # the ReLU is done
+        elif isinstance(m, nn.ReLU):
+            x = ops.activation(x, JG_ACT_RELU)
+        elif isinstance(m, nn.Tanh):
+            x = ops.activation(x, JG_ACT_TANH)
+        else:
+            raise NotImplementedError(type(m))
+        if taps and i in taps:
+            feats.append(x)
+        i += 1
+    return x
+
+
+class ResnetBlock(nn.Module):
+    """resnet_generator.py:11-95: x + [ReflPad1, Conv3, IN, ReLU, ReflPad1, Conv3, IN](x)."""
+
+    def __init__(self, dim, padding_type="reflect", use_bias=True):
+        super().__init__()
+        if padding_type != "reflect":
+            raise NotImplementedError("G_padding_type=%r (only 'reflect' is built)" % padding_type)
+        self.conv_block = nn.Sequential(
+            nn.ReflectionPad2d(1), JGConv2d(dim, dim, 3, padding=0), nn.InstanceNorm2d(dim), nn.ReLU(True),
+            nn.ReflectionPad2d(1), JGConv2d(dim, dim, 3, padding=0), nn.InstanceNorm2d(dim))
+        for c in (self.conv_block[1], self.conv_block[5]):
+            if not use_bias:
+                c.bias = None
+
+    def forward(self, x):
+        return _AddFn.apply(x, _run(self.conv_block, x))     # out = x + conv_block(x)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpby(a, 1.0, b, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class ResnetEncoder(nn.Module):
+    def __init__(self, input_nc, output_nc, ngf=64, n_blocks=6, padding_type="reflect"):
+        super().__init__()
+        model = [nn.ReflectionPad2d(3), JGConv2d(input_nc, ngf, 7, padding=0, needs_dgrad=True), nn.InstanceNorm2d(ngf), nn.ReLU(True)]
+        for i in range(2):
+            mult = 2 ** i
+            model += [JGConv2d(ngf * mult, ngf * mult * 2, 3, padding=1, stride=2), nn.InstanceNorm2d(ngf * mult * 2), nn.ReLU(True)]
+        for _ in range(n_blocks):
+            model += [ResnetBlock(ngf * 4, padding_type)]
+        self.model = nn.Sequential(*model)
+
+    def compute_feats(self, input, extract_layer_ids=()):
+        feats = []
+        feat = _run(self.model, input, taps=set(extract_layer_ids), feats=feats)
+        return feat, feats
+
+    def forward(self, input):
+        return _run(self.model, input)
+
+
+class ResnetDecoder(nn.Module):
+    def __init__(self, input_nc, output_nc, ngf=64, padding_type="reflect"):
+        super().__init__()
+        model = []
+        for i in range(2):
+            mult = 2 ** (2 - i)
+            model += [JGConvTranspose2d(ngf * mult, ngf * mult // 2, 3, stride=2, padding=1, output_padding=1),
+                      nn.InstanceNorm2d(ngf * mult // 2), nn.ReLU(True)]
+        model += [nn.ReflectionPad2d(3), JGConv2d(ngf, output_nc, 7, padding=0), nn.Tanh()]
+        self.model = nn.Sequential(*model)
+
+    def forward(self, input):
+        return _run(self.model, input)
+
+
+class ResnetGenerator(nn.Module):
+    """resnet_generator.py:98-164.  Inputs / outputs are NHWC 16-bit with the image channels zero-padded to 8."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, n_blocks=9, padding_type="reflect", use_dropout=False, use_spectral=False):
+        super().__init__()
+        if use_dropout or use_spectral:
+            raise NotImplementedError("dropout / spectral norm in the ResNet generator are outside the built path")
+        self.encoder = ResnetEncoder(input_nc, output_nc, ngf, n_blocks, padding_type)
+        self.decoder = ResnetDecoder(input_nc, output_nc, ngf, padding_type)
+        self.arena = None
+
+    def jg_finalize(self, device, act_dtype):
+        from ..arena import ParamArena
+
+        if self.arena is None:
+            self.act_dtype = act_dtype
+            self.arena = ParamArena(self, device, act_dtype, priority=())
+        return self.arena
+
+    def compute_feats(self, input, extract_layer_ids=()):
+        return self.encoder.compute_feats(input, extract_layer_ids)
+
+    def get_feats(self, input, extract_layer_ids=()):
+        if self.arena is not None:
+            self.arena.ensure_fresh()
+        return self.compute_feats(input, extract_layer_ids)[1]
+
+    def forward(self, input):
+        if self.arena is not None:
+            self.arena.ensure_fresh()
+        return self.decoder(self.encoder(input))

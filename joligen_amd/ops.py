@@ -19,7 +19,8 @@ import math
 import torch
 
 from . import _lib
-from ._lib import JG_ACT_NONE, JG_ACT_SILU, JG_OUT_ATOMIC_F32, JG_OUT_STORE_T, ConvArgs, WgradArgs, check
+from ._lib import (JG_ACT_LRELU, JG_ACT_NONE, JG_ACT_RELU, JG_ACT_SILU, JG_ACT_TANH, JG_OUT_ATOMIC_F32, JG_OUT_STORE_T, ConvArgs,
+                   WgradArgs, check)
 
 _DT = {torch.float16: _lib.JG_F16, torch.bfloat16: _lib.JG_BF16}
 
@@ -173,13 +174,26 @@ def conv2d_forward(x, m: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
     return y
 
 
+def dilate2d(x, Ho, Wo, stride):
+    """zero insertion: y[:, s*i, s*j] = x[:, i, j] in a [B, Ho, Wo, C] buffer."""
+    B, H, W, Cc = x.shape
+    y = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_dilate2d(_dt(x), x.contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc, Ho, Wo, stride, _st()), "jg_dilate2d")
+    return y
+
+
 def conv2d_dgrad(dy, m: ConvMeta, x_shape, alpha=1.0):
-    """dx = conv(dy, flipped/transposed weights), stride 1 only (UNet)."""
-    if m.stride != 1:
-        raise NotImplementedError("input-gradient of strided convolutions is not implemented yet")
+    """dx = conv(dy, flipped/transposed weights).  Stride s > 1: the same stride-1 convolution over the zero-dilated
+    dy (length H + 2p - k + 1 per axis) with pad k-1-p."""
     B, H, W, Cin = x_shape
     _, Ho, Wo, Cout = dy.shape
     dx = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
+    if m.stride != 1:
+        Hd, Wd = H + 2 * m.pad - m.R + 1, W + 2 * m.pad - m.S + 1
+        dyd = dilate2d(dy, Hd, Wd, m.stride)
+        conv_nt(dyd, m.w16T, dx, B=B, H=Hd, W=Wd, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,
+                ldx=Cout, ldw=m.R * m.S * Cout, ldy=Cin, alpha=alpha)
+        return dx
     conv_nt(dy, m.w16T, dx, B=B, H=Ho, W=Wo, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,
             ldx=Cout, ldw=m.R * m.S * Cout, ldy=Cin, alpha=alpha)
     return dx
@@ -286,6 +300,116 @@ class _GroupNormFn(torch.autograd.Function):
 def group_norm(x, G, gamma=None, beta=None, film=None, act=JG_ACT_NONE, eps=1e-5):
     """act(GroupNorm_G(x) * gamma + beta [* (1 + scale) + shift]); statistics in fp32."""
     return _GroupNormFn.apply(x, gamma, beta, film, G, act, eps)
+
+
+# ======================================================================================
+# CUT networks: transposed convolution, reflection padding, stand-alone activations
+# ======================================================================================
+def conv_transpose2d_forward(x, m: ConvMeta, output_padding=0):
+    """nn.ConvTranspose2d(Cin_t, Cout_t, k, stride s, padding p, output_padding op).  `m` holds the weight as the
+    stride-s CONV whose input-gradient this is (m.Cout = Cin_t, m.Cin = Cout_t): forward = stride-1 conv of the
+    zero-dilated input with m.w16T (the flipped / transposed copy)."""
+    B, H, W, Cin_t = x.shape
+    assert Cin_t == m.Cout, (Cin_t, m.Cout)
+    Ho = (H - 1) * m.stride - 2 * m.pad + m.R + output_padding
+    Wo = (W - 1) * m.stride - 2 * m.pad + m.S + output_padding
+    Hd, Wd = Ho + 2 * m.pad - m.R + 1, Wo + 2 * m.pad - m.S + 1
+    xd = dilate2d(x, Hd, Wd, m.stride)
+    y = torch.empty((B, Ho, Wo, m.Cin), device=x.device, dtype=x.dtype)
+    conv_nt(xd, m.w16T, y, B=B, H=Hd, W=Wd, Cin=Cin_t, Cout=m.Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=Ho, Wo=Wo,
+            ldx=Cin_t, ldw=m.R * m.S * Cin_t, ldy=m.Cin, bias=m.bias)
+    return y
+
+
+class _ConvTranspose2dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, meta, output_padding):
+        _require_cuda(x)
+        y = conv_transpose2d_forward(x, meta, output_padding)
+        ctx.save_for_backward(x)
+        ctx.meta = meta
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        m = ctx.meta
+        dy = dy.contiguous()
+        B, H, W, Cin_t = x.shape
+        _, Ho, Wo, Cout_t = dy.shape
+        dx = None
+        if ctx.needs_input_grad[0]:      # the forward of the stride-s convolution
+            dx = torch.empty_like(x)
+            conv_nt(dy, m.w16, dx, B=B, H=Ho, W=Wo, Cin=Cout_t, Cout=Cin_t, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=H, Wo=W,
+                    ldx=Cout_t, ldw=m.R * m.S * Cout_t, ldy=Cin_t)
+        if ctx.needs_input_grad[1]:
+            wg = m.weight.grad
+            if wg is None:
+                raise RuntimeError("conv-transpose weight has no arena-backed .grad")
+            ktot = m.R * m.S * Cout_t
+            tiles = ((Cin_t + 127) // 128) * ((ktot + 127) // 128)
+            wgrad_tn(x, dy, wg, B=B, H=Ho, W=Wo, Cin=Cout_t, Cout=Cin_t, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=H, Wo=W,
+                     lddy=Cin_t, ldx=Cout_t, lddw=ktot, splitk=_wgrad_splitk(tiles, B * H * W))
+        if ctx.needs_input_grad[2] and m.bias is not None:
+            check(_lib.lib().jg_channel_sum(_dt(dy), dy.data_ptr(), Cout_t, m.bias.grad.data_ptr(), B * Ho * Wo, Cout_t, 1.0, _st()),
+                  "jg_channel_sum")
+        return dx, None, None, None, None
+
+
+def conv_transpose2d(x, meta: ConvMeta, output_padding=0):
+    return _ConvTranspose2dFn.apply(x, meta.weight, meta.bias, meta, output_padding)
+
+
+class _ReflectPadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pad):
+        _require_cuda(x)
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, H + 2 * pad, W + 2 * pad, Cc), device=x.device, dtype=x.dtype)
+        check(_lib.lib().jg_reflect_pad2d(_dt(x), x.contiguous().data_ptr(), y.data_ptr(), B, H, W, Cc, pad, _st()), "jg_reflect_pad2d")
+        ctx.pad, ctx.shape = pad, x.shape
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        B, H, W, Cc = ctx.shape
+        dx = torch.empty(ctx.shape, device=dy.device, dtype=dy.dtype)
+        check(_lib.lib().jg_reflect_pad2d_bwd(_dt(dy), dy.contiguous().data_ptr(), dx.data_ptr(), B, H, W, Cc, ctx.pad, _st()),
+              "jg_reflect_pad2d_bwd")
+        return dx, None
+
+
+def reflect_pad2d(x, pad):
+    """nn.ReflectionPad2d(pad) on NHWC."""
+    return _ReflectPadFn.apply(x, pad)
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        _require_cuda(x)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        check(_lib.lib().jg_act_fwd(_dt(x), x.data_ptr(), y.data_ptr(), x.numel(), act, _st()), "jg_act_fwd")
+        ctx.save_for_backward(y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(_lib.lib().jg_act_bwd(_dt(y), y.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.numel(), ctx.act, _st()), "jg_act_bwd")
+        return dx, None
+
+
+def activation(x, act):
+    """stand-alone nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh (JG_ACT_*) where no normalisation precedes the activation."""
+    return _ActFn.apply(x, act)
 
 
 # ======================================================================================

@@ -419,3 +419,91 @@ def test_c_abi_rejects_bad_arguments():
     assert L.jg_gn_stats(_lib.JG_BF16, None, None, 1, 1, 8, None) == -1
     assert L.jg_pool2x2(_lib.JG_BF16, 1, 1, 1, 3, 4, 8, 1.0, None) == -1  # odd H
     assert b"bad argument" in L.jg_strerror(-1)
+
+
+# ---- CUT glue ops (resnet_generator.py / discriminators.py of the reference) ----------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_reflect_pad_and_activations(dtype):
+    from joligen_amd import ops
+
+    x = rnd((2, 16, 12, 10), dtype, 71)
+    for pad in (1, 3):
+        xr = x.float().requires_grad_(True)
+        yr = F.pad(xr, (pad,) * 4, mode="reflect")
+        R = rnd(tuple(yr.shape), dtype, 72)
+        yr.backward(R.float())
+        xd = nhwc(x).to(dev()).requires_grad_(True)
+        y = ops.reflect_pad2d(xd, pad)
+        y.backward(nhwc(R).to(dev()))
+        assert torch.equal(nchw(y).cpu().float(), yr.detach())                 # index op: bit exact
+        assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype]                     # sums of <= 4 16-bit values
+    for act, fn in ((ops.JG_ACT_TANH, torch.tanh), (ops.JG_ACT_LRELU, lambda t: F.leaky_relu(t, 0.2)), (ops.JG_ACT_RELU, F.relu)):
+        xr = x.float().requires_grad_(True)
+        yr = fn(xr)
+        R = rnd(tuple(yr.shape), dtype, 73)
+        yr.backward(R.float())
+        xd = nhwc(x).to(dev()).requires_grad_(True)
+        y = ops.activation(xd, act)
+        y.backward(nhwc(R).to(dev()))
+        assert relerr(nchw(y), yr.detach()) < TOL[dtype] and relerr(nchw(xd.grad), xr.grad) < 2 * TOL[dtype], act
+    # InstanceNorm2d(affine=False) + ReLU / LeakyReLU(0.2) as one fused pass
+    for act, fn in ((ops.JG_ACT_RELU, F.relu), (ops.JG_ACT_LRELU, lambda t: F.leaky_relu(t, 0.2))):
+        xr = x.float().requires_grad_(True)
+        yr = fn(F.instance_norm(xr))
+        R = rnd(tuple(yr.shape), dtype, 74)
+        yr.backward(R.float())
+        xd = nhwc(x).to(dev()).requires_grad_(True)
+        y = ops.group_norm(xd, 16, None, None, None, act, 1e-5)
+        y.backward(nhwc(R).to(dev()))
+        assert relerr(nchw(y), yr.detach()) < TOL[dtype] and relerr(nchw(xd.grad), xr.grad) < 2 * TOL[dtype], act
+
+
+STRIDED_CASES = [
+    ("conv3 s2 p1", dict(k=3, stride=2, padding=1, transposed=False)),
+    ("conv4 s2 p1", dict(k=4, stride=2, padding=1, transposed=False)),
+    ("conv7 p0", dict(k=7, stride=1, padding=0, transposed=False)),
+    ("convT3 s2 p1 op1", dict(k=3, stride=2, padding=1, transposed=True)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", STRIDED_CASES, ids=[c[0] for c in STRIDED_CASES])
+def test_strided_and_transposed_conv(case, dtype):
+    """Strided convolutions (forward on the generic kernel, input gradient = stride-1 convolution over the zero-dilated
+    output gradient) and nn.ConvTranspose2d (the same identity the other way round) against torch autograd."""
+    import torch.nn as nn
+
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.modules.layers import JGConv2d, JGConvTranspose2d
+
+    _, c = case
+    Cin, Cout = 16, 32
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = (JGConvTranspose2d(Cin, Cout, c["k"], stride=c["stride"], padding=c["padding"], output_padding=1) if c["transposed"]
+                      else JGConv2d(Cin, Cout, c["k"], padding=c["padding"], stride=c["stride"]))
+
+    m = M()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        m.c.weight.copy_((torch.randn(m.c.weight.shape, generator=g) / math.sqrt(m.c.weight[0].numel())).to(dtype).float())
+        m.c.bias.copy_(torch.randn(m.c.bias.shape, generator=g) * 0.1)
+    w0, b0 = m.c.weight.detach().clone(), m.c.bias.detach().clone()
+    arena = ParamArena(m, dev(), dtype, priority=())
+    arena.refresh()
+    x = rnd((2, Cin, 12, 12), dtype, 81)
+    xr, wr, br = x.float().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = (F.conv_transpose2d(xr, wr, br, stride=c["stride"], padding=c["padding"], output_padding=1) if c["transposed"]
+          else F.conv2d(xr, wr, br, stride=c["stride"], padding=c["padding"]))
+    R = rnd(tuple(yr.shape), dtype, 82)
+    yr.backward(R.float())
+    xd = nhwc(x).to(dev()).requires_grad_(True)
+    y = m.c(xd)
+    y.backward(nhwc(R).to(dev()))
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), yr.detach()) < TOL[dtype]
+    assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype]
+    assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype]
+    assert relerr(m.c.bias.grad, br.grad) < TOL[dtype]

@@ -177,3 +177,35 @@ def test_ddpm_restoration(golden_dir, name):
         y, ret = O.ddim_restoration(sd, g["A"], g["y_t0"], g["B"], g["mask"], cfg_of(g["cfg"]), sample_num=2, num_steps=4, eta=0.5)
     torch.testing.assert_close(y, g["y_ddim"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(ret, g["ret_ddim"], rtol=1e-4, atol=1e-5)
+
+
+# ---- CUT networks (ResnetGenerator, NLayerDiscriminator): oracle/make_golden_cut.py fixtures ------------------
+@pytest.mark.parametrize("name", ["small", "wide"])
+def test_cut_networks(golden_dir, name):
+    g = load(golden_dir, f"cutnet_{name}.pt")
+    c = g["cfg"]
+    G, D = g["G"], g["D"]
+    P = {k: v.clone().requires_grad_(True) for k, v in O.synth_state_dict({k: torch.empty(G["shapes"][k]) for k in G["keys"]}, 0).items()}
+    x = G["x"].clone().requires_grad_(True)
+    out = O.resnet_generator(P, x, c["n_blocks"])
+    torch.testing.assert_close(out, G["out"], rtol=1e-4, atol=1e-5)
+    (out * G["R"]).sum().backward()
+    torch.testing.assert_close(x.grad, G["dx"], rtol=1e-3, atol=1e-4)
+    for k, ref in G["grad_checks"].items():
+        v = P[k].grad
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        torch.testing.assert_close(mine, ref, rtol=1e-3, atol=1e-3 * float(ref[0]) + 1e-5, msg=k)
+    with torch.no_grad():
+        feats = O.resnet_encoder({k: v.detach() for k, v in P.items()}, G["x"], c["n_blocks"], g["nce_layers"])[1]
+    for a, b in zip(feats, G["feats"]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    Pd = {k: v.clone().requires_grad_(True) for k, v in O.synth_state_dict({k: torch.empty(D["shapes"][k]) for k in D["keys"]}, 1).items()}
+    xd = G["x"].clone().requires_grad_(True)
+    pred = O.nlayer_discriminator(Pd, xd)
+    torch.testing.assert_close(pred, D["out"], rtol=1e-4, atol=1e-5)
+    (pred * D["R"]).sum().backward()
+    torch.testing.assert_close(xd.grad, D["dx"], rtol=1e-3, atol=1e-4)
+    for k, ref in D["grad_checks"].items():
+        v = Pd[k].grad
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        torch.testing.assert_close(mine, ref, rtol=1e-3, atol=1e-3 * float(ref[0]) + 1e-5, msg=k)
