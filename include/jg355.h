@@ -224,6 +224,45 @@ int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, i
 int jg_subsample2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s);
 int jg_channel_sum(int dtype, const void* x, int64_t ldx, float* out, int64_t P, int C, float scale, jg_stream_t s);
 
+/* PatchSampleF (models/modules/cut_networks.py:6-73) and GANLoss "lsgan" (models/modules/loss.py:59-85) glue:
+ *   gather_rows / scatter_rows : feat[B,HW,C] -> [B*P, C] fp32 at the shared patch ids (:43-57) and its adjoint (ids unique)
+ *   l2norm_fwd / bwd           : torch.nn.functional.normalize(x, eps=1e-7) over the last dim (:66), fp32
+ *   jg_linear_* with act = JG_ACT_RELU : the Linear-ReLU-Linear MLP (:26-29)
+ *   lsgan_loss                 : loss += scale * mean((pred[..., 0] - target)^2), dpred in the same pass (padding channels 0) */
+int jg_gather_rows(int dtype, const void* src, int64_t ld, const int64_t* ids, float* dst, int B, int64_t HW, int C, int P,
+                   jg_stream_t s);
+int jg_scatter_rows(int dtype, void* dsrc, int64_t ld, const int64_t* ids, const float* ddst, int B, int64_t HW, int C, int P,
+                    jg_stream_t s);
+int jg_l2norm_fwd(const float* x, float* y, float* nrm, int64_t R, int D, float eps, jg_stream_t s);
+int jg_l2norm_bwd(const float* y, const float* nrm, const float* dy, float* dx, int64_t R, int D, float eps, jg_stream_t s);
+int jg_lsgan_loss(int dtype, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
+                  float grad_scale, jg_stream_t s);
+
+/* Strided, batched fp32 GEMM: C[z][m][n] = alpha sum_k actA(A[z][m][k]) actB(B[z][n][k]) + bias[n], then
+ * C *= act'(E[z][m][n]) (E shares C's strides), then C += beta C_old.  Element strides s??, batch strides b?.
+ * Replaces torch.bmm / nn.Linear on the patch features (cut_networks.py:26-29,61; base_NCE.py:55,64). */
+int jg_sgemm(const float* A, const float* B, float* C, const float* bias, const float* E, int M, int N, int K, int64_t sam,
+             int64_t sak, int64_t sbn, int64_t sbk, int64_t scm, int64_t scn, int nbatch, int64_t ba, int64_t bb, int64_t bc,
+             float alpha, float beta, int act_a, int act_b, int act_e, jg_stream_t s);
+
+/* PatchNCE / MoNCE loss (models/modules/NCE/base_NCE.py:17-77, monce.py:16-33, sinkhorn.py:6-58) on the similarity
+ * matrices S[nimg][P][P] = q k^T (k detached):
+ *   nce_sinkhorn_fwd : K = exp(S / eps) with the diagonal at exp(-10 / eps); niter Sinkhorn iterations (u = 1/(K v),
+ *                      v = 1/(K^T u)); writes K and the histories u_hist[nimg][niter][P], v_hist[nimg][niter+1][P]
+ *   nce_ce           : per patch CE([S_ii | S_ij (+ T log(u_i K_ij v_j pm1 + 1e-8)), diagonal -10] / T, target 0) -> loss_rows;
+ *                      if dS: dS_ij = grow_i dloss_i/dl_neg_ij (diagonal 0), gpos_i = grow_i dloss_i/dl_pos_i and, for MoNCE
+ *                      (u != NULL), gW = dL/d(u_i K_ij v_j).  l_pos sees k detached, l_neg does not (base_NCE.py:52-66).
+ *   nce_sinkhorn_bwd : reverse sweep through the iterations; dS += the transport-plan path of the gradient
+ *                      (gW is consumed/overwritten; ds_hist, dr_hist [nimg][niter][P] are scratch) */
+/* y[r][:] += g[r] x[r][:]  (the l_pos path of dq: dq_i += gpos_i k_i) */
+int jg_row_axpy(float* y, const float* g, const float* x, int64_t R, int D, jg_stream_t s);
+int jg_nce_sinkhorn_fwd(const float* S, float* K, float* u_hist, float* v_hist, int nimg, int P, int niter, float eps,
+                        jg_stream_t s);
+int jg_nce_ce(const float* S, const float* u, int64_t ustride, const float* v, int64_t vstride, float* loss_rows, float* dS,
+              float* gW, int nimg, int P, float T, float pm1, const float* grow, float* gpos, float eps, jg_stream_t s);
+int jg_nce_sinkhorn_bwd(const float* K, const float* u_hist, const float* v_hist, float* gW, float* ds_hist, float* dr_hist,
+                        float* dS, int nimg, int P, int niter, jg_stream_t s);
+
 /* One DDPM ancestral sampling step after the UNet (DiffusionGenerator.p_sample / p_mean_variance, restoration_ddpm:
  * models/modules/diffusion_generator.py:187-284, predict_start_from_noise / q_posterior: diffusion_utils.py:122-137):
  *   y0_hat = clamp(sr*y_t - srm1*noise_hat, -1, 1);  y' = c1*y0_hat + c2*y_t + z*sigma;  y' = y_0*(1-m) + m*y'

@@ -168,71 +168,23 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const T* __restrict__ 
 }
 
 // ---- small fp32 linears (embedding path) --------------------------------------------------------
-__device__ __forceinline__ float act_f(float v, int act) { return act == JG_ACT_SILU ? v / (1.0f + expf(-v)) : v; }
+__device__ __forceinline__ float act_f(float v, int act) {
+  return act == JG_ACT_SILU ? v / (1.0f + expf(-v)) : act == JG_ACT_RELU ? fmaxf(v, 0.f) : v;
+}
 __device__ __forceinline__ float act_grad_f(float v, int act) {
+  if (act == JG_ACT_RELU) return v > 0.f ? 1.0f : 0.f;
   if (act != JG_ACT_SILU) return 1.0f;
   const float s = 1.0f / (1.0f + expf(-v));
   return s * (1.0f + v * (1.0f - s));
 }
 
-__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                                  float* __restrict__ y, int Bn, int K, int N, int act) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Bn * N) return;
-  const int b = idx / N, n = idx % N;
-  float acc = bias ? bias[n] : 0.f;
-  for (int k = 0; k < K; ++k) acc += act_f(x[(long)b * K + k], act) * W[(long)n * K + k];
-  y[idx] = acc;
-}
-// dx[b][k] = act'(x[b][k]) * sum_n dy[b][n] W[n][k]: one block per (b, 32-wide k tile); threads stride
-// over n (W rows are read as contiguous 128-byte segments), 32 partial sums per thread, LDS reduce.
-__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                            const float* __restrict__ dy, float* __restrict__ dx, int Bn,
-                                                            int K, int N, int act) {
-  __shared__ float s_red[8][33];
-  const int b = blockIdx.x, k0 = blockIdx.y * 32;
-  const int kt = min(32, K - k0);
-  float acc[32];
-#pragma unroll
-  for (int q = 0; q < 32; ++q) acc[q] = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float g = dy[(long)b * N + n];
-    const float* wr = W + (long)n * K + k0;
-    if (kt == 32) {
-#pragma unroll
-      for (int q = 0; q < 32; ++q) acc[q] += g * wr[q];
-    } else {
-      for (int q = 0; q < kt; ++q) acc[q] += g * wr[q];
-    }
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int q = 0; q < 32; ++q) {
-    const float v = wave_sum(acc[q]);
-    if (lane == 0) s_red[wv][q] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < kt) {
-    const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-    const long o = (long)b * K + k0 + threadIdx.x;
-    dx[o] = v * act_grad_f(x[o], act);
-  }
-}
-__global__ void linear_bwd_dw_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
-                                     float* __restrict__ dbias, int Bn, int K, int N, int act) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * (K + 1)) return;
-  const int n = idx / (K + 1), k = idx % (K + 1);
+// dbias[n] += sum_b dy[b][n]
+__global__ void linear_bwd_dbias_kernel(const float* __restrict__ dy, float* __restrict__ dbias, int Bn, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
   float acc = 0.f;
-  if (k < K) {
-    if (!dW) return;
-    for (int b = 0; b < Bn; ++b) acc += dy[(long)b * N + n] * act_f(x[(long)b * K + k], act);
-    dW[(long)n * K + k] += acc;
-  } else {
-    if (!dbias) return;
-    for (int b = 0; b < Bn; ++b) acc += dy[(long)b * N + n];
-    dbias[n] += acc;
-  }
+  for (int b = 0; b < Bn; ++b) acc += dy[(long)b * N + n];
+  dbias[n] += acc;
 }
 
 __global__ void gamma_embedding_kernel(const float* __restrict__ gammas, float* __restrict__ emb, int Bn, int dim,
@@ -437,6 +389,82 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
   sacc[lane_p][threadIdx.x & 63] = acc;
   __syncthreads();
   if (lane_p == 0 && c < C) atomicAdd(out + c, scale * (sacc[0][threadIdx.x] + sacc[1][threadIdx.x] + sacc[2][threadIdx.x] + sacc[3][threadIdx.x]));
+}
+
+// ---- PatchSampleF / GAN-loss glue (cut_networks.py:6-73, loss.py:59-85) ------------------------------------------
+// dst[b*P + p][c] = src[b, ids[p], c] as fp32 (the SAME patch ids for every image of the batch, cut_networks.py:43-57);
+// scatter = its adjoint (ids come from randperm: unique, so plain stores into a zeroed gradient).
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, long ld, const int64_t* __restrict__ ids, float* __restrict__ dst,
+                                   int B, long HW, int C, int P) {
+  const long total = (long)B * P * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const long r = i / C;
+    const int p = r % P, b = r / P;
+    dst[i] = to_f32(src[((long)b * HW + ids[p]) * ld + c]);
+  }
+}
+template <typename T>
+__global__ void scatter_rows_kernel(T* __restrict__ dsrc, long ld, const int64_t* __restrict__ ids, const float* __restrict__ ddst,
+                                    int B, long HW, int C, int P) {
+  const long total = (long)B * P * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    const long r = i / C;
+    const int p = r % P, b = r / P;
+    dsrc[((long)b * HW + ids[p]) * ld + c] = from_f32<T>(ddst[i]);
+  }
+}
+
+// torch.nn.functional.normalize(x, eps): y = x / max(||x||_2, eps) per row; one wave per row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ nrm,
+                                                         long R, int D, float eps) {
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) { const float v = x[row * D + d]; acc += v * v; }
+  acc = wave_sum(acc);
+  const float n = fmaxf(sqrtf(acc), eps);
+  if (lane == 0) nrm[row] = n;
+  for (int d = lane; d < D; d += 64) y[row * D + d] = x[row * D + d] / n;
+}
+// dx = (dy - y (y . dy)) / n   (rows with ||x|| <= eps: dx = dy / eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ nrm,
+                                                         const float* __restrict__ dy, float* __restrict__ dx, long R, int D,
+                                                         float eps) {
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) acc += y[row * D + d] * dy[row * D + d];
+  acc = wave_sum(acc);
+  const float n = nrm[row];
+  const bool clamped = n <= eps;
+  for (int d = lane; d < D; d += 64) dx[row * D + d] = (dy[row * D + d] - (clamped ? 0.f : y[row * D + d] * acc)) / n;
+}
+
+// GANLoss "lsgan" (loss.py:69-76,80-85): loss += scale * mean((pred - target)^2) over the FIRST channel of a [*, Cpad] logit
+// map; dpred = grad_scale * scale * 2 (pred - target) / N in channel 0, zero in the padding channels
+template <typename T>
+__global__ __launch_bounds__(256) void lsgan_loss_kernel(const T* __restrict__ pred, float target, float* __restrict__ loss,
+                                                         T* __restrict__ dpred, long Npix, int Cpad, float scale, float grad_scale) {
+  __shared__ float s_part[4];
+  float acc = 0.f;
+  const float invN = 1.0f / (float)Npix;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < Npix; i += (long)gridDim.x * blockDim.x) {
+    const float d = to_f32(pred[i * Cpad]) - target;
+    acc += d * d;
+    if (dpred) {
+      dpred[i * Cpad] = from_f32<T>(grad_scale * scale * 2.0f * d * invN);
+      for (int c = 1; c < Cpad; ++c) dpred[i * Cpad + c] = from_f32<T>(0.f);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * invN * scale);
 }
 
 // ---- DDPM ancestral sampling step (diffusion_generator.py:187-284, diffusion_utils.py:122-137) -------------
@@ -679,20 +707,22 @@ extern "C" int jg_softmax_bwd(int dtype, const void* P, const float* dP, void* d
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
+// nn.Linear on the fp32 GEMM of nce.hip: y = act(x) W^T + b; dx = act'(x) .* (dy W); dW += dy^T act(x); db += sum_b dy
 extern "C" int jg_linear_fwd(const float* x, const float* W, const float* bias, float* y, int Bn, int K, int N, int act,
                              jg_stream_t s) {
   if (!x || !W || !y || Bn < 1 || K < 1 || N < 1) return JG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(linear_fwd_kernel, dim3((Bn * N + 255) / 256), dim3(256), 0, (hipStream_t)s, x, W, bias, y, Bn, K, N, act);
-  JG_CHECK_LAUNCH();
-  return JG_OK;
+  return jg_sgemm(x, W, y, bias, nullptr, Bn, N, K, K, 1, K, 1, N, 1, 1, 0, 0, 0, 1.0f, 0.0f, act, JG_ACT_NONE, JG_ACT_NONE, s);
 }
 extern "C" int jg_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* dbias, int Bn,
                              int K, int N, int act, jg_stream_t s) {
   if (!x || !W || !dy || Bn < 1 || K < 1 || N < 1) return JG_ERR_BAD_ARG;
-  hipStream_t st = (hipStream_t)s;
-  if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(Bn, (K + 31) / 32), dim3(256), 0, st, x, W, dy, dx, Bn, K, N, act);
-  if (dW || dbias)
-    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3((N * (K + 1) + 255) / 256), dim3(256), 0, st, x, dy, dW, dbias, Bn, K, N, act);
+  int rc = JG_OK;
+  if (dx) rc = jg_sgemm(dy, W, dx, nullptr, act == JG_ACT_NONE ? nullptr : x, Bn, K, N, N, 1, 1, K, K, 1, 1, 0, 0, 0, 1.0f, 0.0f,
+                        JG_ACT_NONE, JG_ACT_NONE, act, s);
+  if (rc != JG_OK) return rc;
+  if (dW) rc = jg_sgemm(dy, x, dW, nullptr, nullptr, N, K, Bn, 1, N, 1, K, K, 1, 1, 0, 0, 0, 1.0f, 1.0f, JG_ACT_NONE, act, JG_ACT_NONE, s);
+  if (rc != JG_OK) return rc;
+  if (dbias) hipLaunchKernelGGL(linear_bwd_dbias_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, dy, dbias, Bn, N);
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -870,6 +900,43 @@ extern "C" int jg_channel_sum(int dtype, const void* x, int64_t ldx, float* out,
   dim3 grid((unsigned)gx, (C + 63) / 64);
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((channel_sum_kernel<T>), grid, dim3(256), 0, (hipStream_t)s, (const T*)x, (long)ldx,
                                               out, (long)P, C, scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gather_rows(int dtype, const void* src, int64_t ld, const int64_t* ids, float* dst, int B, int64_t HW, int C, int P,
+                              jg_stream_t s) {
+  if (!src || !ids || !dst || B < 1 || P < 1 || C < 1 || ld < C) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(grid_for((long)B * P * C)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)src, (long)ld, ids, dst, B, (long)HW, C, P););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_scatter_rows(int dtype, void* dsrc, int64_t ld, const int64_t* ids, const float* ddst, int B, int64_t HW, int C,
+                               int P, jg_stream_t s) {
+  if (!dsrc || !ids || !ddst || B < 1 || P < 1 || C < 1 || ld < C) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scatter_rows_kernel<T>), dim3(grid_for((long)B * P * C)), dim3(256), 0, (hipStream_t)s,
+                                              (T*)dsrc, (long)ld, ids, ddst, B, (long)HW, C, P););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_l2norm_fwd(const float* x, float* y, float* nrm, int64_t R, int D, float eps, jg_stream_t s) {
+  if (!x || !y || !nrm || R < 1 || D < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)s, x, y, nrm, (long)R, D, eps);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_l2norm_bwd(const float* y, const float* nrm, const float* dy, float* dx, int64_t R, int D, float eps, jg_stream_t s) {
+  if (!y || !nrm || !dy || !dx || R < 1 || D < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)s, y, nrm, dy, dx, (long)R, D, eps);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_lsgan_loss(int dtype, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
+                             float grad_scale, jg_stream_t s) {
+  if (!pred || !loss || Npix < 1 || Cpad < 1) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((lsgan_loss_kernel<T>), dim3(grid_for(Npix, 256, 256)), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)pred, target, loss, (T*)dpred, (long)Npix, Cpad, scale, grad_scale););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -1,0 +1,407 @@
+// Patch-contrastive losses of the CUT path, fp32:
+//   * jg_sgemm            strided/batched fp32 GEMM (PatchSampleF MLP, the q k^T similarity bmm, their adjoints, and
+//                          the small nn.Linear layers of the embedding path) -- LDS-tiled 64x64x16, FMA
+//   * jg_nce_sinkhorn_fwd  MoNCE optimal-transport weights: K = exp(S), 50 Sinkhorn iterations, one workgroup per image
+//   * jg_nce_ce            cross-entropy over [l_pos | l_neg] / T per patch, loss + dS (+ dW for MoNCE) in one pass
+//   * jg_nce_sinkhorn_bwd  reverse sweep through the Sinkhorn iterations (the reference differentiates through them w.r.t. q)
+//   * jg_nce_sinkhorn_gk   dS += K .* (rank-2T update assembled from the forward/backward histories)
+// reference: models/modules/NCE/base_NCE.py:17-77, monce.py:16-33, sinkhorn.py:6-58
+#include "common.h"
+
+namespace {
+
+struct SgemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* E;
+  int M, N, K;
+  long sam, sak, sbn, sbk, scm, scn;
+  long ba, bb, bc;
+  float alpha, beta;
+  int act_a, act_b, act_e;
+};
+
+__device__ __forceinline__ float act_rt(float v, int act) {
+  return act == JG_ACT_SILU ? v / (1.0f + expf(-v)) : act == JG_ACT_RELU ? fmaxf(v, 0.f) : v;
+}
+__device__ __forceinline__ float act_grad_rt2(float v, int act) {
+  if (act == JG_ACT_RELU) return v > 0.f ? 1.0f : 0.f;
+  if (act != JG_ACT_SILU) return 1.0f;
+  const float s = 1.0f / (1.0f + expf(-v));
+  return s * (1.0f + v * (1.0f - s));
+}
+
+// C[z][m][n] = alpha * sum_k actA(A[z][m][k]) actB(B[z][n][k]) + bias[n], then *= act'(E[z][m][n]), then += beta * C.
+// AKC / BKC: the operand is contiguous along k (else along m / n); picks the coalesced load pattern.
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
+  __shared__ float As[16][68];
+  __shared__ float Bs[16][68];
+  const int z = blockIdx.z;
+  const float* A = p.A + z * p.ba;
+  const float* B = p.B + z * p.bb;
+  float* C = p.C + z * p.bc;
+  const float* E = p.E ? p.E + z * p.bc : nullptr;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x;
+  const int tm = t >> 4, tn = t & 15;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      {
+        const int m = AKC ? (t >> 2) : (t & 63);
+        const int kk = AKC ? ((t & 3) * 4 + i) : ((t >> 6) * 4 + i);
+        const bool ok = (m0 + m < p.M) && (k0 + kk < p.K);
+        float v = ok ? A[(long)(m0 + m) * p.sam + (long)(k0 + kk) * p.sak] : 0.f;
+        As[kk][m] = act_rt(v, p.act_a);
+      }
+      {
+        const int n = BKC ? (t >> 2) : (t & 63);
+        const int kk = BKC ? ((t & 3) * 4 + i) : ((t >> 6) * 4 + i);
+        const bool ok = (n0 + n < p.N) && (k0 + kk < p.K);
+        float v = ok ? B[(long)(n0 + n) * p.sbn + (long)(k0 + kk) * p.sbk] : 0.f;
+        Bs[kk][n] = act_rt(v, p.act_b);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[kk][tm * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[kk][tn * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w};
+      const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + tm * 4 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tn * 4 + j;
+      if (n >= p.N) continue;
+      const long o = (long)m * p.scm + (long)n * p.scn;
+      float c = p.alpha * acc[i][j];
+      if (p.bias) c += p.bias[n];
+      if (E) c *= act_grad_rt2(E[o], p.act_e);
+      if (p.beta != 0.f) c += p.beta * C[o];
+      C[o] = c;
+    }
+  }
+}
+
+int sgemm_launch(const SgemmP& p, int nbatch, hipStream_t st) {
+  const dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, nbatch);
+  const bool akc = p.sak == 1, bkc = p.sbk == 1;
+  if (akc && bkc) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, st, p);
+  else if (akc) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, p);
+  else if (bkc) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((sgemm_kernel<false, false>), grid, dim3(256), 0, st, p);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+// ---- Sinkhorn (sinkhorn.py:6-24) -------------------------------------------------------------------------------------
+// one 1024-thread workgroup per image; K [P,P] lives in global memory (L2-resident: 256 KB at P = 256), u / v in LDS.
+constexpr int SK_THREADS = 1024;
+constexpr int SK_MAXP = 1024;
+
+// out[i] = sum_j K[i][j] vec[j]  (wave per row, lanes along j)
+__device__ __forceinline__ void row_matvec(const float* __restrict__ K, const float* vec, float* out, int P, int wave, int lane,
+                                           int nwaves) {
+  for (int i = wave; i < P; i += nwaves) {
+    float acc = 0.f;
+    for (int j = lane; j < P; j += 64) acc += K[(long)i * P + j] * vec[j];
+    acc = wave_sum(acc);
+    if (lane == 0) out[i] = acc;
+  }
+}
+// out[j] = sum_i vec[i] K[i][j]  (threads along j, row groups reduced through LDS); contains its own barriers
+__device__ __forceinline__ void col_matvec(const float* __restrict__ K, const float* vec, float* out, float* part, int P, int t) {
+  const int ppad = (P + 63) & ~63;
+  const int ngroups = SK_THREADS / ppad < 1 ? 1 : SK_THREADS / ppad;
+  const int j = t % ppad, grp = t / ppad;
+  if (grp < ngroups && j < P) {
+    float acc = 0.f;
+    for (int i = grp; i < P; i += ngroups) acc += vec[i] * K[(long)i * P + j];
+    part[grp * ppad + j] = acc;
+  }
+  __syncthreads();
+  if (t < P) {
+    float acc = 0.f;
+    for (int g = 0; g < ngroups; ++g) acc += part[g * ppad + t];
+    out[t] = acc;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(SK_THREADS) void sinkhorn_fwd_kernel(const float* __restrict__ S, float* __restrict__ Kout,
+                                                                   float* __restrict__ u_hist, float* __restrict__ v_hist, int P,
+                                                                   int niter, float eps) {
+  __shared__ float s_u[SK_MAXP], s_v[SK_MAXP], s_tmp[SK_MAXP], s_part[SK_THREADS];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* Sb = S + (long)b * P * P;
+  float* K = Kout + (long)b * P * P;
+  float* uh = u_hist + (long)b * niter * P;
+  float* vh = v_hist + (long)b * (niter + 1) * P;
+  for (long i = t; i < (long)P * P; i += SK_THREADS) {
+    const int r = i / P, c = i % P;
+    K[i] = expf((r == c ? -10.0f : Sb[i]) / eps);
+  }
+  for (int i = t; i < P; i += SK_THREADS) {
+    s_v[i] = 1.0f;
+    vh[i] = 1.0f;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    row_matvec(K, s_v, s_tmp, P, wave, lane, SK_THREADS / 64);
+    __syncthreads();
+    for (int i = t; i < P; i += SK_THREADS) {
+      const float u = 1.0f / s_tmp[i];  // a = out_size / in_size = 1
+      s_u[i] = u;
+      uh[(long)it * P + i] = u;
+    }
+    __syncthreads();
+    col_matvec(K, s_u, s_tmp, s_part, P, t);
+    for (int i = t; i < P; i += SK_THREADS) {
+      const float v = 1.0f / s_tmp[i];
+      s_v[i] = v;
+      vh[(long)(it + 1) * P + i] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// reverse sweep: inputs gW = dL/d(u_i K_ij v_j); outputs the per-iteration adjoints ds_t, dr_t
+__global__ __launch_bounds__(SK_THREADS) void sinkhorn_bwd_kernel(const float* __restrict__ Kin, const float* __restrict__ u_hist,
+                                                                   const float* __restrict__ v_hist, float* __restrict__ gW,
+                                                                   float* __restrict__ ds_hist, float* __restrict__ dr_hist, int P,
+                                                                   int niter) {
+  __shared__ float s_gu[SK_MAXP], s_gv[SK_MAXP], s_x[SK_MAXP], s_tmp[SK_MAXP], s_part[SK_THREADS];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* K = Kin + (long)b * P * P;
+  float* G = gW + (long)b * P * P;
+  const float* uh = u_hist + (long)b * niter * P;
+  const float* vh = v_hist + (long)b * (niter + 1) * P;
+  float* dsh = ds_hist + (long)b * niter * P;
+  float* drh = dr_hist + (long)b * niter * P;
+  // G <- gW .* K in place (both seeds contract against it)
+  for (long i = t; i < (long)P * P; i += SK_THREADS) G[i] *= K[i];
+  for (int i = t; i < P; i += SK_THREADS) {
+    s_x[i] = vh[(long)niter * P + i];
+    s_tmp[i] = uh[(long)(niter - 1) * P + i];
+  }
+  __threadfence_block();
+  __syncthreads();
+  row_matvec(G, s_x, s_gu, P, wave, lane, SK_THREADS / 64);   // gu_i = sum_j gW_ij K_ij v_j
+  __syncthreads();
+  col_matvec(G, s_tmp, s_gv, s_part, P, t);                   // gv_j = sum_i gW_ij u_i K_ij
+  for (int it = niter - 1; it >= 0; --it) {
+    // v_{it+1} = 1 / (K^T u_it):  ds = -gv v^2 ; gu += K ds
+    for (int i = t; i < P; i += SK_THREADS) {
+      const float v = vh[(long)(it + 1) * P + i];
+      const float ds = -s_gv[i] * v * v;
+      s_x[i] = ds;
+      dsh[(long)it * P + i] = ds;
+    }
+    __syncthreads();
+    row_matvec(K, s_x, s_tmp, P, wave, lane, SK_THREADS / 64);
+    __syncthreads();
+    // u_it = 1 / (K v_it):  dr = -gu u^2 ; gv <- K^T dr ; gu <- 0
+    for (int i = t; i < P; i += SK_THREADS) {
+      const float u = uh[(long)it * P + i];
+      const float dr = -(s_gu[i] + s_tmp[i]) * u * u;
+      s_x[i] = dr;
+      drh[(long)it * P + i] = dr;
+      s_gu[i] = 0.f;
+    }
+    __syncthreads();
+    col_matvec(K, s_x, s_gv, s_part, P, t);
+  }
+}
+
+// dS_ij += K_ij * ( G_ij / K_ij * u_T,i v_T,j + sum_t u_t,i ds_t,j + dr_t,i v_t,j )   (j != i), G = gW .* K from the sweep
+// grid (P / 16 row blocks, images); thread j owns a column, 16 rows per block
+__global__ __launch_bounds__(256) void sinkhorn_gk_kernel(const float* __restrict__ Kin, const float* __restrict__ G,
+                                                          const float* __restrict__ u_hist, const float* __restrict__ v_hist,
+                                                          const float* __restrict__ ds_hist, const float* __restrict__ dr_hist,
+                                                          float* __restrict__ dS, int P, int niter) {
+  extern __shared__ float s_rows[];  // [niter][16] u, then [niter][16] dr
+  const int b = blockIdx.y, i0 = blockIdx.x * 16, t = threadIdx.x;
+  const float* uh = u_hist + (long)b * niter * P;
+  const float* vh = v_hist + (long)b * (niter + 1) * P;
+  const float* dsh = ds_hist + (long)b * niter * P;
+  const float* drh = dr_hist + (long)b * niter * P;
+  float* s_u = s_rows;
+  float* s_dr = s_rows + niter * 16;
+  for (int e = t; e < niter * 16; e += 256) {
+    const int it = e / 16, r = e % 16;
+    const bool ok = i0 + r < P;
+    s_u[e] = ok ? uh[(long)it * P + i0 + r] : 0.f;
+    s_dr[e] = ok ? drh[(long)it * P + i0 + r] : 0.f;
+  }
+  __syncthreads();
+  for (int j = t; j < P; j += 256) {
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int it = 0; it < niter; ++it) {
+      const float ds = dsh[(long)it * P + j], v = vh[(long)it * P + j];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += s_u[it * 16 + r] * ds + s_dr[it * 16 + r] * v;
+    }
+    const float vT = vh[(long)niter * P + j];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int i = i0 + r;
+      if (i >= P || i == j) continue;
+      const long o = ((long)b * P + i) * P + j;
+      dS[o] += acc[r] * Kin[o] + G[o] * s_u[(niter - 1) * 16 + r] * vT;
+    }
+  }
+}
+
+// ---- cross-entropy over [l_pos | l_neg] / T (base_NCE.py:43-50,67-77; monce.py:24-31) ---------------------------------
+// wave per patch row.  MONCE: l_neg_ij += T log(u_i exp(S_ij) v_j (num_patches - 1) + 1e-8) before the diagonal fill.
+template <bool MONCE>
+__global__ __launch_bounds__(256) void nce_ce_kernel(const float* __restrict__ S, const float* __restrict__ u, long ustride,
+                                                     const float* __restrict__ v, long vstride, float* __restrict__ loss_rows, float* __restrict__ dS, float* __restrict__ gW,
+                                                     long rows, int P, float T, float pm1, const float* __restrict__ grow, float* __restrict__ gpos,
+                                                     float eps) {
+  const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int i = row % P;
+  const long b = row / P;
+  const float* Sr = S + row * P;
+  const float invT = 1.0f / T;
+  const float pos = Sr[i] * invT;
+  const float ui = MONCE ? u[b * ustride + i] : 0.f;
+  const float* vb = MONCE ? v + b * vstride : nullptr;
+  float mx = pos;
+  for (int j = lane; j < P; j += 64) {
+    float l;
+    if (j == i) l = -10.0f * invT;
+    else {
+      l = Sr[j];
+      if (MONCE) l += T * logf(ui * expf(Sr[j] / eps) * vb[j] * pm1 + 1e-8f);
+      l *= invT;
+    }
+    mx = fmaxf(mx, l);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float se = 0.f;
+  for (int j = lane; j < P; j += 64) {
+    float l;
+    if (j == i) l = -10.0f * invT;
+    else {
+      l = Sr[j];
+      if (MONCE) l += T * logf(ui * expf(Sr[j] / eps) * vb[j] * pm1 + 1e-8f);
+      l *= invT;
+    }
+    se += expf(l - mx);
+  }
+  se = wave_sum(se) + expf(pos - mx);
+  const float lse = mx + logf(se);
+  if (lane == 0) loss_rows[row] = lse - pos;
+  if (!dS) return;
+  const float gscale = grow[row];
+  if (lane == 0) gpos[row] = gscale * (expf(pos - lse) - 1.0f) * invT;
+  for (int j = lane; j < P; j += 64) {
+    float g, gw = 0.f;
+    if (j == i) g = 0.f;
+    else {
+      float l = Sr[j];
+      float f = 0.f;
+      if (MONCE) {
+        f = ui * expf(Sr[j] / eps) * vb[j] * pm1 + 1e-8f;
+        l += T * logf(f);
+      }
+      g = gscale * expf(l * invT - lse) * invT;
+      if (MONCE) gw = g * T * pm1 / f;
+    }
+    dS[row * P + j] = g;
+    if (MONCE) gW[row * P + j] = gw;
+  }
+}
+
+// y[r][:] += g[r] * x[r][:]
+__global__ void row_axpy_kernel(float* __restrict__ y, const float* __restrict__ g, const float* __restrict__ x, long R, int D) {
+  const long total = R * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) y[i] += g[i / D] * x[i];
+}
+
+}  // namespace
+
+extern "C" int jg_row_axpy(float* y, const float* g, const float* x, int64_t R, int D, jg_stream_t s) {
+  if (!y || !g || !x || R < 1 || D < 1) return JG_ERR_BAD_ARG;
+  const long total = (long)R * D;
+  hipLaunchKernelGGL(row_axpy_kernel, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                     y, g, x, (long)R, D);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_sgemm(const float* A, const float* B, float* C, const float* bias, const float* E, int M, int N, int K, int64_t sam,
+                        int64_t sak, int64_t sbn, int64_t sbk, int64_t scm, int64_t scn, int nbatch, int64_t ba, int64_t bb, int64_t bc,
+                        float alpha, float beta, int act_a, int act_b, int act_e, jg_stream_t s) {
+  if (!A || !B || !C || M < 1 || N < 1 || K < 1 || nbatch < 1 || nbatch > 65535) return JG_ERR_BAD_ARG;
+  SgemmP p{A, B, C, bias, E, M, N, K, sam, sak, sbn, sbk, scm, scn, ba, bb, bc, alpha, beta, act_a, act_b, act_e};
+  return sgemm_launch(p, nbatch, (hipStream_t)s);
+}
+
+extern "C" int jg_nce_sinkhorn_fwd(const float* S, float* K, float* u_hist, float* v_hist, int nimg, int P, int niter, float eps,
+                                   jg_stream_t s) {
+  if (!S || !K || !u_hist || !v_hist || nimg < 1 || P < 1 || niter < 1) return JG_ERR_BAD_ARG;
+  if (P > SK_MAXP) return JG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sinkhorn_fwd_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, S, K, u_hist, v_hist, P, niter, eps);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_nce_ce(const float* S, const float* u, int64_t ustride, const float* v, int64_t vstride, float* loss_rows, float* dS, float* gW, int nimg, int P, float T,
+                         float pm1, const float* grow, float* gpos, float eps, jg_stream_t s) {
+  if (!S || !loss_rows || nimg < 1 || P < 1 || T <= 0.f) return JG_ERR_BAD_ARG;
+  const long rows = (long)nimg * P;
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  if (u) {
+    if (!v || (dS && !gW)) return JG_ERR_BAD_ARG;
+  }
+  if (dS && (!grow || !gpos)) return JG_ERR_BAD_ARG;
+  if (u) {
+    hipLaunchKernelGGL((nce_ce_kernel<true>), grid, dim3(256), 0, (hipStream_t)s, S, u, (long)ustride, v, (long)vstride, loss_rows, dS, gW, rows, P, T, pm1, grow, gpos,
+                       eps);
+  } else {
+    hipLaunchKernelGGL((nce_ce_kernel<false>), grid, dim3(256), 0, (hipStream_t)s, S, u, (long)ustride, v, (long)vstride, loss_rows, dS, gW, rows, P, T, pm1, grow, gpos,
+                       eps);
+  }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_nce_sinkhorn_bwd(const float* K, const float* u_hist, const float* v_hist, float* gW, float* ds_hist, float* dr_hist,
+                                   float* dS, int nimg, int P, int niter, jg_stream_t s) {
+  if (!K || !u_hist || !v_hist || !gW || !ds_hist || !dr_hist || !dS || nimg < 1 || P < 1 || niter < 1) return JG_ERR_BAD_ARG;
+  if (P > SK_MAXP || niter * 32 * sizeof(float) > 48 * 1024) return JG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, K, u_hist, v_hist, gW, ds_hist, dr_hist, P,
+                     niter);
+  hipLaunchKernelGGL(sinkhorn_gk_kernel, dim3((P + 15) / 16, nimg), dim3(256), niter * 32 * sizeof(float), (hipStream_t)s, K, gW, u_hist,
+                     v_hist, ds_hist, dr_hist, dS, P, niter);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}

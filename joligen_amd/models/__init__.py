@@ -11,4 +11,8 @@ def create_model(opt, rank):
         from .cm_model import CMModel
 
         return CMModel(opt, rank)
+    if opt.model_type == "cut":
+        from .cut_model import CUTModel
+
+        return CUTModel(opt, rank)
     raise NotImplementedError(f"model_type {opt.model_type!r} is not implemented in joligen_amd yet")

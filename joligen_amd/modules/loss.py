@@ -1,0 +1,50 @@
+"""GAN objectives of the CUT path on the HIP ops: /root/reference/models/modules/loss.py `GANLoss` (:11-85) for
+gan_mode='lsgan' (the train_gan_mode default) and `DiscriminatorGANLoss` (:249-313) without APA / D-diffusion augmentation.
+Predictions are NHWC logit maps whose channel 0 is valid (PatchGAN output padded to 8 channels)."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from .. import ops
+
+
+class GANLoss(nn.Module):
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
+        super().__init__()
+        if gan_mode != "lsgan":
+            raise NotImplementedError(f"gan mode {gan_mode!r}: only 'lsgan' is built (vanilla / wgangp / projected are not)")
+        self.gan_mode = gan_mode
+        self.real_label, self.fake_label = float(target_real_label), float(target_fake_label)
+
+    def __call__(self, prediction, target_is_real, relu=True):
+        """loss.py:59-71: nn.MSELoss()(prediction, label.expand_as(prediction))."""
+        return ops.lsgan_loss(prediction, self.real_label if target_is_real else self.fake_label)
+
+
+class DiscriminatorGANLoss(nn.Module):
+    """loss.py:249-313 (`compute_loss_D` :288-307, `compute_loss_G` :309-313)."""
+
+    def __init__(self, netD, device, train_gan_mode="lsgan", dataaug_D_label_smooth=False, dataaug_APA=False,
+                 dataaug_D_diffusion=False):
+        super().__init__()
+        if dataaug_APA or dataaug_D_diffusion:
+            raise NotImplementedError("APA / D-diffusion augmentation are outside the built path")
+        self.netD, self.device = netD, device
+        self.gan_mode = train_gan_mode
+        self.criterionGAN = GANLoss(train_gan_mode, target_real_label=0.9 if dataaug_D_label_smooth else 1.0)
+        self.adaptive_pseudo_augmentation_p, self.adjust = 0.0, 0
+
+    def compute_loss_D(self, netD, real, fake, fake_2=None):
+        self.real, self.fake = real, fake
+        self.pred_real = netD(self.real)
+        self.loss_D_real = self.criterionGAN(self.pred_real, True)
+        pred_fake = netD(self.fake.detach())
+        loss_D_fake = self.criterionGAN(pred_fake, False)
+        return (self.loss_D_real + loss_D_fake) * 0.5
+
+    def compute_loss_G(self, netD, real, fake):
+        self.real, self.fake = real, fake
+        return self.criterionGAN(netD(self.fake), True, relu=False)
+
+    def update(self, niter):
+        pass

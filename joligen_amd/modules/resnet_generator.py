@@ -48,6 +48,8 @@ def _run(seq, x, taps=None, feats=None, upto=None):
             raise NotImplementedError(type(m))
         if taps and i in taps:
             feats.append(x)
+        if upto is not None and i >= upto:
+            break
         i += 1
     return x
 
@@ -91,10 +93,20 @@ class ResnetEncoder(nn.Module):
             model += [ResnetBlock(ngf * 4, padding_type)]
         self.model = nn.Sequential(*model)
 
-    def compute_feats(self, input, extract_layer_ids=()):
+    def compute_feats(self, input, extract_layer_ids=(), upto=None):
         feats = []
-        feat = _run(self.model, input, taps=set(extract_layer_ids), feats=feats)
+        feat = _run(self.model, input, taps=set(extract_layer_ids), feats=feats, upto=upto)
         return feat, feats
+
+    def feat_channels(self, extract_layer_ids):
+        """real channel count of each tapped activation (the reference reads feat.shape[1])."""
+        c, out = self.model[1].in_channels, {}
+        for i, m in enumerate(self.model):
+            if isinstance(m, JGConv2d):
+                c = m.out_channels
+            if i in extract_layer_ids:
+                out[i] = c
+        return [out[i] for i in extract_layer_ids]
 
     def forward(self, input):
         return _run(self.model, input)
@@ -138,9 +150,13 @@ class ResnetGenerator(nn.Module):
         return self.encoder.compute_feats(input, extract_layer_ids)
 
     def get_feats(self, input, extract_layer_ids=()):
+        """resnet_generator.py:151-153; the encoder stops after the last tapped layer (the rest never reaches the loss)."""
         if self.arena is not None:
             self.arena.ensure_fresh()
-        return self.compute_feats(input, extract_layer_ids)[1]
+        return self.encoder.compute_feats(input, extract_layer_ids, upto=max(extract_layer_ids))[1]
+
+    def feat_channels(self, extract_layer_ids):
+        return self.encoder.feat_channels(list(extract_layer_ids))
 
     def forward(self, input):
         if self.arena is not None:

@@ -660,6 +660,170 @@ def gamma_embedding(gammas, dim, max_period=10000.0):
 
 
 # ======================================================================================
+# CUT patch features and contrastive / adversarial losses (fp32)
+# ======================================================================================
+def sgemm(A, B, C, M, N, K, sa, sb, sc, nbatch=1, bstr=(0, 0, 0), bias=None, E=None, alpha=1.0, beta=0.0,
+          act_a=JG_ACT_NONE, act_b=JG_ACT_NONE, act_e=JG_ACT_NONE):
+    """C[z][m][n] = alpha sum_k actA(A[z][m][k]) actB(B[z][n][k]) (+bias, *act'(E), +beta C); sa=(sam,sak), sb=(sbn,sbk), sc=(scm,scn)."""
+    check(_lib.lib().jg_sgemm(A.data_ptr(), B.data_ptr(), C.data_ptr(), _p(bias), _p(E), M, N, K, sa[0], sa[1], sb[0], sb[1],
+                              sc[0], sc[1], nbatch, bstr[0], bstr[1], bstr[2], alpha, beta, act_a, act_b, act_e, _st()), "jg_sgemm")
+    return C
+
+
+class _GatherPatchesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, ids, C):
+        _require_cuda(feat, ids)
+        B, H, W, ld = feat.shape
+        P = ids.numel()
+        out = torch.empty((B * P, C), device=feat.device, dtype=torch.float32)
+        check(_lib.lib().jg_gather_rows(_dt(feat), feat.data_ptr(), ld, ids.data_ptr(), out.data_ptr(), B, H * W, C, P, _st()),
+              "jg_gather_rows")
+        ctx.save_for_backward(ids)
+        ctx.shape, ctx.dtype, ctx.C = feat.shape, feat.dtype, C
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        (ids,) = ctx.saved_tensors
+        B, H, W, ld = ctx.shape
+        dfeat = torch.zeros(ctx.shape, device=dout.device, dtype=ctx.dtype)
+        dout = dout.contiguous()
+        check(_lib.lib().jg_scatter_rows(_DT[ctx.dtype], dfeat.data_ptr(), ld, ids.data_ptr(), dout.data_ptr(), B, H * W, ctx.C,
+                                         ids.numel(), _st()), "jg_scatter_rows")
+        return dfeat, None, None
+
+
+def gather_patches(feat, ids, C):
+    """feat [B,H,W,ld] 16-bit NHWC -> [B*P, C] fp32 rows at the flattened positions `ids` (shared by the batch):
+    `feat.permute(0,2,3,1).flatten(1,2)[:, patch_id, :].flatten(0,1)` of cut_networks.py:45-57."""
+    return _GatherPatchesFn.apply(feat, ids.contiguous().long(), C)
+
+
+class _L2NormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        x = x.contiguous()
+        R, D = x.shape
+        y = torch.empty_like(x)
+        nrm = torch.empty(R, device=x.device, dtype=torch.float32)
+        check(_lib.lib().jg_l2norm_fwd(x.data_ptr(), y.data_ptr(), nrm.data_ptr(), R, D, eps, _st()), "jg_l2norm_fwd")
+        ctx.save_for_backward(y, nrm)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        y, nrm = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(y)
+        check(_lib.lib().jg_l2norm_bwd(y.data_ptr(), nrm.data_ptr(), dy.data_ptr(), dx.data_ptr(), y.shape[0], y.shape[1], ctx.eps,
+                                       _st()), "jg_l2norm_bwd")
+        return dx, None
+
+
+def l2_normalize(x, eps=1e-7):
+    """torch.nn.functional.normalize(x, eps=eps) for fp32 [R, D] (cut_networks.py:66)."""
+    return _L2NormFn.apply(x, eps)
+
+
+SINKHORN_ITERS = 50  # monce.py:24
+
+
+class _PatchNCEFn(torch.autograd.Function):
+    """Per-patch PatchNCE / MoNCE loss.  q, k: [nimg*P, D] fp32, L2-normalised.  k is detached in the positive logit and in the
+    optimal-transport weights but NOT in the negative logits (base_NCE.py:52-66, monce.py:21-22), reproduced here."""
+
+    @staticmethod
+    def forward(ctx, q, k, nimg, T, pm1, monce):
+        _require_cuda(q, k)
+        q, k = q.contiguous(), k.contiguous()
+        R, D = q.shape
+        P = R // nimg
+        L = _lib.lib()
+        S = torch.empty((nimg, P, P), device=q.device, dtype=torch.float32)
+        sgemm(q, k, S, P, P, D, (D, 1), (D, 1), (P, 1), nimg, (P * D, P * D, P * P))
+        loss = torch.empty(R, device=q.device, dtype=torch.float32)
+        K = uh = vh = None
+        if monce:
+            K = torch.empty_like(S)
+            uh = torch.empty((nimg, SINKHORN_ITERS, P), device=q.device, dtype=torch.float32)
+            vh = torch.empty((nimg, SINKHORN_ITERS + 1, P), device=q.device, dtype=torch.float32)
+            check(L.jg_nce_sinkhorn_fwd(S.data_ptr(), K.data_ptr(), uh.data_ptr(), vh.data_ptr(), nimg, P, SINKHORN_ITERS, 1.0, _st()),
+                  "jg_nce_sinkhorn_fwd")
+        u = uh[:, -1] if monce else None
+        v = vh[:, -1] if monce else None
+        check(L.jg_nce_ce(S.data_ptr(), _p(u), SINKHORN_ITERS * P, _p(v), (SINKHORN_ITERS + 1) * P, loss.data_ptr(), None, None,
+                          nimg, P, T, pm1, None, None, 1.0, _st()), "jg_nce_ce")
+        ctx.save_for_backward(q, k, S, K, uh, vh)
+        ctx.cfg = (nimg, P, D, T, pm1, monce)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dloss):
+        q, k, S, K, uh, vh = ctx.saved_tensors
+        nimg, P, D, T, pm1, monce = ctx.cfg
+        L = _lib.lib()
+        dloss = dloss.contiguous().float()
+        dS = torch.empty_like(S)
+        gW = torch.empty_like(S) if monce else None
+        gpos = torch.empty(nimg * P, device=q.device, dtype=torch.float32)
+        scratch = torch.empty_like(q)
+        u = uh[:, -1] if monce else None
+        v = vh[:, -1] if monce else None
+        check(L.jg_nce_ce(S.data_ptr(), _p(u), SINKHORN_ITERS * P, _p(v), (SINKHORN_ITERS + 1) * P, scratch.data_ptr(), dS.data_ptr(),
+                          _p(gW), nimg, P, T, pm1, dloss.data_ptr(), gpos.data_ptr(), 1.0, _st()), "jg_nce_ce")
+        dk = None
+        if ctx.needs_input_grad[1]:
+            # dk_j = sum_i dS_ij q_i over the negatives only (diagonal of dS is zero, the positive pair is detached)
+            dk = torch.empty_like(k)
+            sgemm(dS, q, dk, P, D, P, (1, P), (1, D), (D, 1), nimg, (P * P, P * D, P * D))
+        if monce:
+            dsh = torch.empty_like(uh)
+            drh = torch.empty_like(uh)
+            check(L.jg_nce_sinkhorn_bwd(K.data_ptr(), uh.data_ptr(), vh.data_ptr(), gW.data_ptr(), dsh.data_ptr(), drh.data_ptr(),
+                                        dS.data_ptr(), nimg, P, SINKHORN_ITERS, _st()), "jg_nce_sinkhorn_bwd")
+        dq = torch.empty_like(q)
+        sgemm(dS, k, dq, P, D, P, (P, 1), (1, D), (D, 1), nimg, (P * P, P * D, P * D))
+        check(L.jg_row_axpy(dq.data_ptr(), gpos.data_ptr(), k.data_ptr(), nimg * P, D, _st()), "jg_row_axpy")
+        return dq, dk, None, None, None, None
+
+
+def patch_nce_loss(q, k, nimg, T, num_patches, monce=False):
+    """BaseNCELoss.forward / MoNCELoss (base_NCE.py:17-50, monce.py:16-33): per-patch loss [nimg*P]."""
+    return _PatchNCEFn.apply(q, k, nimg, float(T), float(num_patches - 1), bool(monce))
+
+
+class _LSGANLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, scale):
+        _require_cuda(pred)
+        pred = pred.contiguous()
+        cpad = pred.shape[-1]
+        npix = pred.numel() // cpad
+        loss = torch.zeros((), device=pred.device, dtype=torch.float32)
+        dpred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().jg_lsgan_loss(_dt(pred), pred.data_ptr(), target, loss.data_ptr(), _p(dpred), npix, cpad, scale, 1.0, _st()),
+              "jg_lsgan_loss")
+        ctx.dpred = dpred
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        dpred, ctx.dpred = ctx.dpred, None
+        return axpby(dpred, 1.0, None, 0.0, alpha_dev=g.reshape(1).float(), out=dpred), None, None
+
+
+def lsgan_loss(pred, target, scale=1.0):
+    """GANLoss('lsgan') (loss.py:69-71): scale * mean((pred[..., 0] - target)^2) on an NHWC logit map whose channel 0 is valid."""
+    return _LSGANLossFn.apply(pred, float(target), float(scale))
+
+
+# ======================================================================================
 # DDPM glue + layout converters
 # ======================================================================================
 def ddpm_prepare(y0, ycond, noise, mask, gammas, act_dtype, cpad=8):

@@ -1,0 +1,304 @@
+"""GPU parity tests of the CUT loss path: fp32 GEMM, PatchSampleF, PatchNCE / MoNCE (50 Sinkhorn
+iterations and their reverse sweep), LSGAN loss, image pool, and N x CUTModel.optimize_parameters() against fixtures recorded
+from the unmodified reference (oracle/make_golden_cutstep.py) and against the CPU oracle on identical inputs."""
+import os
+import random
+
+import pytest
+import torch
+
+import jg_oracle as O
+from test_oracle_golden import ReplayRandom, cut_ids
+
+pytestmark = pytest.mark.gpu
+D0 = "cuda:0"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+@pytest.mark.parametrize("M,N,K,nb", [(64, 64, 16, 1), (256, 256, 256, 4), (37, 130, 75, 2), (2048, 256, 3, 1), (5, 7, 300, 3)])
+def test_sgemm_layouts(M, N, K, nb):
+    """all four operand-contiguity variants, ragged edges, bias / activation / gradient epilogue / accumulate"""
+    from joligen_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(nb, M, K, generator=g)
+    Bm = torch.randn(nb, N, K, generator=g)
+    ref = torch.einsum("zmk,znk->zmn", A.double(), Bm.double()).float()
+    for a_t in (False, True):
+        for b_t in (False, True):
+            Ad = (A.transpose(1, 2).contiguous() if a_t else A).to(D0)      # a_t: stored [K][M] (contiguous along m)
+            Bd = (Bm.transpose(1, 2).contiguous() if b_t else Bm).to(D0)
+            C = torch.empty(nb, M, N, device=D0)
+            ops.sgemm(Ad, Bd, C, M, N, K, (1, M) if a_t else (K, 1), (1, N) if b_t else (K, 1), (N, 1), nb, (M * K, N * K, M * N))
+            assert relerr(C, ref) < 1e-5, (a_t, b_t, relerr(C, ref))
+    bias = torch.randn(N, generator=g)
+    E = torch.randn(nb, M, N, generator=g)
+    C0 = torch.randn(nb, M, N, generator=g)
+    C = C0.clone().to(D0)
+    ops.sgemm(A.to(D0), Bm.to(D0), C, M, N, K, (K, 1), (K, 1), (N, 1), nb, (M * K, N * K, M * N), bias=bias.to(D0), E=E.to(D0), alpha=0.5,
+              beta=2.0, act_a=ops.JG_ACT_RELU, act_e=ops.JG_ACT_RELU)
+    ref2 = (0.5 * torch.einsum("zmk,znk->zmn", A.relu().double(), Bm.double()).float() + bias) * (E > 0) + 2.0 * C0
+    assert relerr(C, ref2) < 1e-5
+
+
+def test_linear_relu_on_input():
+    from joligen_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(300, 48, generator=g)
+    W = torch.randn(70, 48, generator=g) * 0.2
+    b = torch.randn(70, generator=g)
+    xr, Wr, br = (t.clone().requires_grad_(True) for t in (x, W, b))
+    yr = torch.nn.functional.linear(xr.relu(), Wr, br)
+    R = torch.randn(yr.shape, generator=g)
+    (yr * R).sum().backward()
+    xd = x.to(D0).requires_grad_(True)
+    Wd = torch.nn.Parameter(W.to(D0))
+    bd = torch.nn.Parameter(b.to(D0))
+    Wd.grad, bd.grad = torch.zeros_like(Wd), torch.zeros_like(bd)
+    y = ops.linear(xd, Wd, bd, ops.JG_ACT_RELU)
+    y.backward(R.to(D0))
+    assert relerr(y, yr) < 1e-5 and relerr(xd.grad, xr.grad) < 1e-5
+    assert relerr(Wd.grad, Wr.grad) < 1e-5 and relerr(bd.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("monce", [False, True])
+@pytest.mark.parametrize("nimg,P,D", [(2, 64, 256), (3, 256, 256), (1, 100, 64), (2, 16, 32)])
+def test_patch_nce_vs_oracle(nimg, P, D, monce):
+    """same fp32 inputs on both sides: values and both gradients (q, and k through the negatives)"""
+    from joligen_amd import ops
+    g = torch.Generator().manual_seed(nimg * 1000 + P)
+    k = torch.nn.functional.normalize(torch.randn(nimg * P, D, generator=g))
+    q = torch.nn.functional.normalize(k + 0.5 * torch.randn(nimg * P, D, generator=g))
+    w = torch.rand(nimg * P, generator=g)
+    qr, kr = q.clone().requires_grad_(True), k.clone().requires_grad_(True)
+    lr = O.patch_nce_loss(qr, kr, nimg, 0.07, 256, monce)
+    (lr * w).sum().backward()
+    qd, kd = q.to(D0).requires_grad_(True), k.to(D0).requires_grad_(True)
+    l = ops.patch_nce_loss(qd, kd, nimg, 0.07, 256, monce)
+    (l * w.to(D0)).sum().backward()
+    torch.cuda.synchronize()
+    assert relerr(l, lr) < 2e-5, relerr(l, lr)
+    assert relerr(qd.grad, qr.grad) < 2e-4, relerr(qd.grad, qr.grad)
+    assert relerr(kd.grad, kr.grad) < 2e-4, relerr(kd.grad, kr.grad)
+
+
+def test_sinkhorn_path_matters():
+    """the reverse sweep through the 50 iterations is not a no-op: dropping it changes dq measurably (guards against a silently
+    skipped transport-plan gradient)"""
+    g = torch.Generator().manual_seed(5)
+    k = torch.nn.functional.normalize(torch.randn(64, 32, generator=g))
+    q = torch.nn.functional.normalize(k + 0.5 * torch.randn(64, 32, generator=g))
+    qr = q.clone().requires_grad_(True)
+    O.patch_nce_loss(qr, k, 1, 0.07, 256, True).mean().backward()
+    q2 = q.clone().requires_grad_(True)
+    q3, k3 = q2.view(1, 64, 32), k.view(1, 64, 32)
+    f = O.ot_weights(q3.detach(), k3).permute(0, 2, 1) * 255 + 1e-8
+    l_neg = (torch.bmm(q3, k3.transpose(1, 2)) + torch.log(f) * 0.07).masked_fill(torch.eye(64, dtype=torch.bool)[None], -10.0).view(-1, 64)
+    out = torch.cat(((q2 * k).sum(1, keepdim=True), l_neg), 1) / 0.07
+    torch.nn.functional.cross_entropy(out, torch.zeros(64, dtype=torch.long)).backward()
+    assert relerr(q2.grad, qr.grad) > 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_patch_sample_and_nce_vs_reference_golden(golden_dir, name, dtype):
+    from joligen_amd import ops
+    from joligen_amd.modules.NCE.patchnce import MoNCELoss, PatchNCELoss
+    from joligen_amd.modules.cut_networks import PatchSampleF
+    from types import SimpleNamespace
+
+    g = load(golden_dir, f"cutloss_{name}.pt")
+    B, P = g["B"], g["P"]
+    chans = [f.shape[1] for f in g["feats_k"]]
+    netF = PatchSampleF(use_mlp=True, nc=256)
+    netF.data_dependent_initialize(None, chans)
+    assert list(netF.state_dict().keys()) == g["keysF"]
+    netF.load_state_dict(O.synth_state_dict(netF.state_dict(), seed=3))
+    netF.jg_finalize(torch.device(D0), dtype)
+    # the features are rounded to the activation dtype on BOTH sides (the oracle then runs in fp32 on the rounded values)
+    fk16 = [f.to(dtype) for f in g["feats_k"]]
+    fq16 = [f.to(dtype) for f in g["feats_q"]]
+    ids = [i.to(D0) for i in g["ids"]]
+    opt = SimpleNamespace(alg_cut_nce_includes_all_negatives_from_minibatch=False, alg_cut_nce_T=0.07, alg_cut_num_patches=P)
+    sdF = {k: v.detach().float().cpu() for k, v in netF.state_dict().items()}
+    for lname, cls in (("monce", MoNCELoss), ("patchnce", PatchNCELoss)):
+        netF.arena.zero_grad()
+        fk = [ops.to_nhwc(f.float().to(D0), dtype).requires_grad_(True) for f in fk16]
+        fq = [ops.to_nhwc(f.float().to(D0), dtype).requires_grad_(True) for f in fq16]
+        k_pool, rid = netF(fk, P, ids, chans)
+        q_pool, _ = netF(fq, P, rid, chans)
+        crit = cls(opt)
+        per = [crit(feat_q=q, feat_k=k, current_batch=B) for q, k in zip(q_pool, k_pool)]
+        total = sum(p.mean() for p in per) / len(per)
+        LS = 4096.0        # static loss scale: the 16-bit feature gradients (~1e-5 unscaled) would be fp16 subnormals
+        (total * LS).backward()
+        torch.cuda.synchronize()
+        # oracle on the same rounded features
+        Fp = {k: v.clone().requires_grad_(True) for k, v in sdF.items()}
+        fko = [f.float().requires_grad_(True) for f in fk16]
+        fqo = [f.float().requires_grad_(True) for f in fq16]
+        ko = O.patch_sample_f(Fp, fko, P, g["ids"])
+        qo = O.patch_sample_f(Fp, fqo, P, g["ids"])
+        for a, b in zip(k_pool + q_pool, ko + qo):
+            assert relerr(a, b) < 1e-5, relerr(a, b)
+        pero = [O.patch_nce_loss(q, k, B, 0.07, P, lname == "monce") for q, k in zip(qo, ko)]
+        for a, b in zip(per, pero):
+            assert relerr(a, b) < 1e-4, relerr(a, b)
+        (sum(p.mean() for p in pero) / len(pero) * LS).backward()
+        tol_g = 2e-3 if dtype == torch.float16 else 1.5e-2          # feature gradients are stored in 16 bits
+        for f, fo, c in zip(fq + fk, fqo + fko, chans + chans):
+            mine = f.grad.permute(0, 3, 1, 2)[:, :c].float()
+            assert relerr(mine, fo.grad) < tol_g, (lname, tuple(fo.shape), relerr(mine, fo.grad))
+        for kname, p in netF.named_parameters():
+            assert relerr(p.grad, Fp[kname].grad) < 2e-4, (lname, kname, relerr(p.grad, Fp[kname].grad))
+        # and against the reference's own numbers (unrounded features): 16-bit input rounding only
+        tol_in = 3e-3 if dtype == torch.float16 else 2.5e-2
+        for a, b in zip(per, g[lname]["per"]):
+            assert relerr(a, b) < tol_in, (lname, relerr(a, b))
+        assert abs(float(total) - float(g[lname]["total"])) < tol_in * abs(float(g[lname]["total"]))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_lsgan_vs_reference_golden(golden_dir, dtype):
+    from joligen_amd import ops
+    ls = load(golden_dir, "cutloss_a.pt")["lsgan"]
+    pred16 = ls["pred"].to(dtype)
+    for target, lk, gk in ((1.0, "real", "dreal"), (0.0, "fake", "dfake")):
+        p = ops.to_nhwc(pred16.float().to(D0), dtype, 8).requires_grad_(True)
+        loss = ops.lsgan_loss(p, target)
+        (loss * 3.0).backward()
+        pr = pred16.float().requires_grad_(True)
+        lo = O.lsgan(pr, target)
+        (lo * 3.0).backward()
+        assert abs(float(loss) - float(lo)) < 1e-5 * abs(float(lo)) + 1e-7
+        mine = p.grad.permute(0, 3, 1, 2).float().cpu()
+        assert relerr(mine[:, :1], pr.grad) < (2e-3 if dtype == torch.float16 else 1e-2)
+        assert float(mine[:, 1:].abs().max()) == 0.0
+        assert abs(float(loss) - float(ls[lk])) < 2e-2 * abs(float(ls[lk]))
+
+
+def test_image_pool_replays_reference_draws():
+    from joligen_amd.util.image_pool import ImagePool
+    rr = random.Random(4)
+    ref_rng, my_rng = random.Random(7), random.Random(7)
+    ref_pool, my_pool = O.OracleImagePool(3, ref_rng), ImagePool(3, my_rng)
+    for it in range(12):
+        x = torch.full((2, 4, 4, 8), float(it)) + torch.arange(2).view(2, 1, 1, 1) * 0.5
+        a = ref_pool.query(x)
+        b = my_pool.query(x.to(D0))
+        assert torch.equal(a, b.cpu())
+
+
+def build_cut_model(g, dtype):
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    c, hp = g["cfg"], g["hp"]
+    cfg = {"model_type": "cut", "G": {"netG": "resnet", "ngf": c["ngf"], "nblocks": c["n_blocks"]}, "D": {"netDs": ["basic"], "ndf": c["ndf"]},
+           "alg": {"cut": {"nce_layers": c["nce_layers"], "num_patches": c["num_patches"], "nce_loss": c["nce_loss"]}},
+           "data": {"crop_size": c["S"], "load_size": c["S"]},
+           "train": {"batch_size": c["B"], "pool_size": c["pool"], "G_ema": True, "G_ema_beta": hp["ema_beta"], "G_lr": hp["lr_G"], "D_lr": hp["lr_D"]}}
+    opt = opt_from_json(cfg, overrides={"jg_act_dtype": "fp16" if dtype == torch.float16 else "bf16", "gpu_ids": "0"})
+    return create_model(opt, 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["monce", "patchnce"])
+def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
+    g = load(golden_dir, f"cutstep_{name}.pt")
+    c = g["cfg"]
+    model = build_cut_model(g, dtype)
+    s0 = g["steps"][0]
+    model.data_dependent_initialize({"A": s0["A"], "B": s0["B"]})
+    assert list(model.netG_A.state_dict().keys()) == g["keysG"]
+    assert list(model.netD_B_basic.state_dict().keys()) == g["keysD"]
+    assert list(model.netF.state_dict().keys()) == g["keysF"]
+    model.netG_A.load_state_dict(O.synth_state_dict(model.netG_A.state_dict(), seed=0))
+    model.netD_B_basic.load_state_dict(O.synth_state_dict(model.netD_B_basic.state_dict(), seed=1))
+    model.netF.load_state_dict(O.synth_state_dict(model.netF.state_dict(), seed=3))
+    rng = ReplayRandom([d for s in g["steps"] for d in s["pool_draws"]])
+    model.set_pool_rng(rng)
+    nl = len(c["nce_layers"].split(","))
+    tol = 6e-3 if dtype == torch.float16 else 4e-2
+    for it, s in enumerate(g["steps"]):
+        ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
+        model.patch_ids_injection = lambda call, shapes, a=ids_ab, b=ids_idt: [i.to(D0) for i in (a if call == 0 else b)]
+        model.set_input({"A": s["A"], "B": s["B"]})
+        model.optimize_parameters()
+        torch.cuda.synchronize()
+        losses = {k: float(v) for k, v in model.get_current_losses().items()}
+        for k, ref in s["losses"].items():
+            assert abs(losses[k] - ref) <= tol * abs(ref) * (1 + it) + 1e-4, (it, k, losses[k], ref)
+        fb = model.fake_B.permute(0, 3, 1, 2)[:, :3].float()
+        assert relerr(fb, s["fake_B"]) < tol * (1 + it), (it, relerr(fb, s["fake_B"]))
+    assert rng.i == len(rng.log)
+    # parameters after the last step: Adam's first steps move every weight by ~lr regardless of the gradient scale, so the
+    # norm / projection checksums stay tight unless an update is missing or mis-signed
+    # Conv biases in front of an InstanceNorm have an analytically ZERO gradient: what Adam normalises there is rounding noise
+    # (in the reference too), so those move by up to lr per step in an arbitrary direction -> bounded by lr * steps * sqrt(n).
+    last, n_it = g["steps"][-1], len(g["steps"])
+    for net, key, lr in ((model.netG_A, "G_checks", g["hp"]["lr_G"]), (model.netF, "F_checks", g["hp"]["lr_G"]),
+                         (model.netD_B_basic, "D_checks", g["hp"]["lr_D"])):
+        P = dict(net.named_parameters())
+        for k, ref in last[key].items():
+            v = P[k].detach().float().cpu()
+            slack = lr * n_it * v.numel() ** 0.5 if (k.endswith(".bias") and key != "F_checks") else 0.0
+            assert abs(float(v.norm()) - float(ref[0])) < 2e-3 * float(ref[0]) + 1e-5 + slack, (key, k, float(v.norm()), float(ref[0]))
+    ema = dict(model.netG_A_ema.named_parameters())
+    for k, ref in last["ema_checks"].items():
+        v = ema[k].detach().float().cpu()
+        slack = g["hp"]["lr_G"] * n_it * v.numel() ** 0.5 if k.endswith(".bias") else 0.0
+        assert abs(float(v.norm()) - float(ref[0])) < 2e-3 * float(ref[0]) + 1e-5 + slack, ("ema", k)
+
+
+@pytest.mark.parametrize("name", ["monce"])
+def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
+    """first G-group backward on identical (fp16-representable) weights and inputs: per-parameter gradient checksums of G and F
+    against the CPU oracle's autograd (includes the k-side path through the negatives and the Sinkhorn reverse sweep)"""
+    from test_oracle_golden import cut_trainer_for
+    dtype = torch.float16
+    g = load(golden_dir, f"cutstep_{name}.pt")
+    c = g["cfg"]
+    model = build_cut_model(g, dtype)
+    s = g["steps"][0]
+    model.data_dependent_initialize({"A": s["A"], "B": s["B"]})
+    sdG = {k: v.half().float() for k, v in O.synth_state_dict(model.netG_A.state_dict(), seed=0).items()}
+    sdD = {k: v.half().float() for k, v in O.synth_state_dict(model.netD_B_basic.state_dict(), seed=1).items()}
+    sdF = O.synth_state_dict(model.netF.state_dict(), seed=3)
+    model.netG_A.load_state_dict(sdG)
+    model.netD_B_basic.load_state_dict(sdD)
+    model.netF.load_state_dict(sdF)
+    nl = len(c["nce_layers"].split(","))
+    ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
+    model.patch_ids_injection = lambda call, shapes: [i.to(D0) for i in (ids_ab if call == 0 else ids_idt)]
+    A, Bi = s["A"].half().float(), s["B"].half().float()
+    model.set_input({"A": A, "B": Bi})
+    for net in ("G_A", "F", "D_B_basic"):
+        model.set_requires_grad(getattr(model, "net" + net), net != "D_B_basic")
+    model.forward()
+    model.compute_G_loss()
+    model.loss_G_tot.backward()
+    torch.cuda.synchronize()
+    tr, _ = cut_trainer_for(g)
+    tr.G, tr.D = {k: v.clone() for k, v in sdG.items()}, {k: v.clone() for k, v in sdD.items()}
+    tr.pool.rng = tr.real_pools[0].rng = tr.real_pools[1].rng = random.Random(0)
+    tr.step(A, Bi, ids_ab, ids_idt)
+    ls = model.loss_scale
+    bad = []
+    for net, key in ((model.netG_A, "G"), (model.netF, "F")):
+        for k, p in net.named_parameters():
+            ref = tr.last_grads[key][k]
+            mine = p.grad.detach().float().cpu() / ls
+            # conv biases in front of an InstanceNorm have an analytically zero gradient: absolute floor from the weight's
+            floor = 2e-3 * float(tr.last_grads[key][k[:-4] + "weight"].norm()) if k.endswith(".bias") else 0.0
+            err = float((mine.double() - ref.double()).norm())
+            if err > 0.08 * float(ref.norm()) + floor:
+                bad.append((key, k, err, float(ref.norm()), floor))
+    assert not bad, bad[:8]

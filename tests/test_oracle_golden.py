@@ -209,3 +209,108 @@ def test_cut_networks(golden_dir, name):
         v = Pd[k].grad
         mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
         torch.testing.assert_close(mine, ref, rtol=1e-3, atol=1e-3 * float(ref[0]) + 1e-5, msg=k)
+
+
+# ---- CUT losses and training step: oracle/make_golden_cutstep.py fixtures (unmodified reference modules / CUTModel) --------
+class ReplayRandom:
+    """replays the recorded python-`random` draws of the reference's image pools, checking the call kinds"""
+
+    def __init__(self, log):
+        self.log, self.i = list(log), 0
+
+    def _next(self, kind):
+        k, v = self.log[self.i]
+        assert k == kind, (self.i, k, kind)
+        self.i += 1
+        return v
+
+    def uniform(self, a, b):
+        return self._next("uniform")
+
+    def randint(self, a, b):
+        return self._next("randint")
+
+
+def _chk(named, refs, rtol, msg=""):
+    for k, ref in refs.items():
+        v = named[k].detach()
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        torch.testing.assert_close(mine, ref, rtol=rtol, atol=rtol * float(ref[0]) + 1e-6, msg=f"{msg}{k} {mine.tolist()} {ref.tolist()}")
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+def test_cut_losses(golden_dir, name):
+    g = load(golden_dir, f"cutloss_{name}.pt")
+    B, P = g["B"], g["P"]
+    sdF = O.synth_state_dict({k: torch.empty(g["shapesF"][k]) for k in g["keysF"]}, 3)
+    for lname, monce in (("monce", True), ("patchnce", False)):
+        r = g[lname]
+        Fp = {k: v.clone().requires_grad_(True) for k, v in sdF.items()}
+        fk = [f.clone().requires_grad_(True) for f in g["feats_k"]]
+        fq = [f.clone().requires_grad_(True) for f in g["feats_q"]]
+        k_pool = O.patch_sample_f(Fp, fk, P, g["ids"])
+        q_pool = O.patch_sample_f(Fp, fq, P, g["ids"])
+        for a, b in zip(k_pool + q_pool, g["k_pool"] + g["q_pool"]):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+        per = [O.patch_nce_loss(q, k, B, 0.07, P, monce) for q, k in zip(q_pool, k_pool)]
+        for a, b in zip(per, r["per"]):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+        gq, gk = torch.autograd.grad(per[0].mean(), [q_pool[0], k_pool[0]], retain_graph=True)
+        torch.testing.assert_close(gq, r["dq0"], rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(gk, r["dk0"], rtol=1e-3, atol=1e-6)
+        total = sum(p.mean() for p in per) / len(per)
+        total.backward()
+        for a, b in zip([f.grad for f in fq] + [f.grad for f in fk], r["dfeats_q"] + r["dfeats_k"]):
+            torch.testing.assert_close(a, b, rtol=1e-3, atol=1e-7)
+        _chk({k: v.grad for k, v in Fp.items()}, r["gradF"], 1e-3, lname + " ")
+    ls = g["lsgan"]
+    pred = ls["pred"].clone().requires_grad_(True)
+    l1 = O.lsgan(pred, 1.0)
+    torch.testing.assert_close(l1, ls["real"])
+    torch.testing.assert_close(torch.autograd.grad(l1, pred)[0], ls["dreal"])
+    l0 = O.lsgan(pred, 0.0)
+    torch.testing.assert_close(l0, ls["fake"])
+    torch.testing.assert_close(torch.autograd.grad(l0, pred)[0], ls["dfake"])
+
+
+def cut_trainer_for(g):
+    c, hp = g["cfg"], g["hp"]
+    sdG = O.synth_state_dict({k: torch.empty(g["shapesG"][k]) for k in g["keysG"]}, 0)
+    sdD = O.synth_state_dict({k: torch.empty(g["shapesD"][k]) for k in g["keysD"]}, 1)
+    sdF = O.synth_state_dict({k: torch.empty(g["shapesF"][k]) for k in g["keysF"]}, 3)
+    draws = [d for s in g["steps"] for d in s["pool_draws"]]
+    rng = ReplayRandom(draws)
+    tr = O.OracleCUTTrainer(sdG, sdF, sdD, c["n_blocks"], [int(i) for i in c["nce_layers"].split(",")], num_patches=c["num_patches"],
+                            T=hp["T"], monce=c["nce_loss"] == "monce", lambda_NCE=hp["lambda_NCE"], lambda_GAN=hp["lambda_GAN"],
+                            lr_G=hp["lr_G"], lr_D=hp["lr_D"], beta1=hp["beta1"], beta2=hp["beta2"], eps=hp["eps"], pool_size=c["pool"],
+                            pool_rng=rng, ema_beta=hp["ema_beta"])
+    return tr, rng
+
+
+def cut_ids(step, nlayers, num_patches):
+    """the reference draws one randperm per tapped layer on the k pass of each calculate_feats call (cut_networks.py:50-54)"""
+    perms = step["perms"]
+    assert len(perms) == 2 * nlayers
+    ids = [p[: min(num_patches, p.numel())] for p in perms]
+    return ids[:nlayers], ids[nlayers:]
+
+
+@pytest.mark.parametrize("name", ["monce", "patchnce"])
+def test_cut_steps(golden_dir, name):
+    g = load(golden_dir, f"cutstep_{name}.pt")
+    c = g["cfg"]
+    tr, rng = cut_trainer_for(g)
+    nl = len(c["nce_layers"].split(","))
+    for it, s in enumerate(g["steps"]):
+        ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
+        losses = tr.step(s["A"], s["B"], ids_ab, ids_idt)
+        ref = s["losses"]
+        for mine_k, ref_k in (("G_tot", "G_tot"), ("G_GAN", "G_GAN_D_B_basic"), ("G_NCE", "G_NCE"), ("G_NCE_Y", "G_NCE_Y"), ("D_tot", "D_tot")):
+            assert abs(losses[mine_k] - ref[ref_k]) <= 2e-4 * abs(ref[ref_k]) + 1e-5, (it, mine_k, losses[mine_k], ref[ref_k])
+        torch.testing.assert_close(tr.fake_B, s["fake_B"], rtol=1e-3, atol=1e-4)
+        if "G_checks" in s:
+            _chk(tr.G, s["G_checks"], 2e-4, f"G it{it} ")
+            _chk(tr.Fp, s["F_checks"], 2e-4, f"F it{it} ")
+            _chk(tr.D, s["D_checks"], 2e-4, f"D it{it} ")
+            _chk(tr.ema, s["ema_checks"], 2e-4, f"ema it{it} ")
+    assert rng.i == len(rng.log)
