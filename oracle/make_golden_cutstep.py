@@ -25,6 +25,8 @@ from make_golden import checks  # noqa: E402
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 STEP_CFGS = {
     "monce": dict(ngf=16, n_blocks=2, ndf=16, S=32, B=2, nce_layers="0,4,8,10,11", num_patches=64, nce_loss="monce", pool=2, iters=4),
+    # BASELINE.json configs[0]: cut_model, resnet_9blocks G + basic D, 128x128, batch 1 (example_gan_horse2zebra.json shape)
+    "config0": dict(ngf=64, n_blocks=9, ndf=64, S=128, B=1, nce_layers="0,4,8,12,16", num_patches=256, nce_loss="monce", pool=50, iters=2),
     "patchnce": dict(ngf=16, n_blocks=3, ndf=16, S=32, B=1, nce_layers="0,4,8,12", num_patches=32, nce_loss="patchnce", pool=1, iters=3),
 }
 
@@ -47,6 +49,7 @@ class RecordingRandom:
 
 
 def loss_fixtures():
+    torch.manual_seed(0)
     from models.modules.NCE.monce import MoNCELoss
     from models.modules.NCE.patchnce import PatchNCELoss
     from models.modules.cut_networks import PatchSampleF
@@ -131,6 +134,8 @@ def step_fixtures():
 
     real_randperm = torch.randperm
     for name, c in STEP_CFGS.items():
+        if ONLY and name not in ONLY:
+            continue
         opt = build_opt(c)
         torch.manual_seed(0)
         model = create_model(opt, 0)
@@ -163,7 +168,7 @@ def step_fixtures():
                 torch.manual_seed(100 + it)
                 model.optimize_parameters()
                 losses = {k: float(v) for k, v in model.get_current_losses().items()}
-                rec = dict(A=data["A"], B=data["B"], perms=[p.clone() for p in perms], pool_draws=list(rr.log[n_log:]), losses=losses,
+                rec = dict(A=data["A"], B=data["B"], perms=[p[: c["num_patches"]].clone() for p in perms], pool_draws=list(rr.log[n_log:]), losses=losses,
                            fake_B=model.fake_B.detach().clone())
                 if it in (0, c["iters"] - 1):
                     rec["G_checks"] = checks(dict(model.netG_A.named_parameters()))
@@ -183,9 +188,12 @@ def step_fixtures():
                    os.path.join(OUT, f"cutstep_{name}.pt"))
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # e.g. `config0` regenerates only that step fixture
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     os.chdir("/tmp")
-    loss_fixtures()
+    if not ONLY:
+        loss_fixtures()
     step_fixtures()
     print("bytes:", {f: os.path.getsize(os.path.join(OUT, f)) for f in sorted(os.listdir(OUT)) if f.startswith("cut")})

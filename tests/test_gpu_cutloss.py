@@ -210,7 +210,7 @@ def build_cut_model(g, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name", ["monce", "patchnce"])
+@pytest.mark.parametrize("name", ["monce", "patchnce", "config0"])
 def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
     g = load(golden_dir, f"cutstep_{name}.pt")
     c = g["cfg"]
@@ -236,8 +236,13 @@ def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
         losses = {k: float(v) for k, v in model.get_current_losses().items()}
         for k, ref in s["losses"].items():
             assert abs(losses[k] - ref) <= tol * abs(ref) * (1 + it) + 1e-4, (it, k, losses[k], ref)
+        # it = 0 is a pure forward pass.  Later iterations see weights that went through Adam's sign-like first steps: with 16-bit
+        # activations the gradient DIRECTION of this ReLU / InstanceNorm stack is only good to ~10 % (fp16) / ~30 % (bf16) at
+        # random weights (tools/dbg_cut_grads.py; an fp32 oracle whose forward is merely rounded to fp16 moves by the same 10 %),
+        # which one optimizer step turns into a 2 - 3 % / 5 - 8 % change of the generator output.
         fb = model.fake_B.permute(0, 3, 1, 2)[:, :3].float()
-        assert relerr(fb, s["fake_B"]) < tol * (1 + it), (it, relerr(fb, s["fake_B"]))
+        tol_fb = tol if it == 0 else (4e-2 if dtype == torch.float16 else 1.2e-1)
+        assert relerr(fb, s["fake_B"]) < tol_fb, (it, relerr(fb, s["fake_B"]))
     assert rng.i == len(rng.log)
     # parameters after the last step: Adam's first steps move every weight by ~lr regardless of the gradient scale, so the
     # norm / projection checksums stay tight unless an update is missing or mis-signed

@@ -295,7 +295,7 @@ def cut_ids(step, nlayers, num_patches):
     return ids[:nlayers], ids[nlayers:]
 
 
-@pytest.mark.parametrize("name", ["monce", "patchnce"])
+@pytest.mark.parametrize("name", ["monce", "patchnce", "config0"])
 def test_cut_steps(golden_dir, name):
     g = load(golden_dir, f"cutstep_{name}.pt")
     c = g["cfg"]
@@ -314,3 +314,29 @@ def test_cut_steps(golden_dir, name):
             _chk(tr.D, s["D_checks"], 2e-4, f"D it{it} ")
             _chk(tr.ema, s["ema_checks"], 2e-4, f"ema it{it} ")
     assert rng.i == len(rng.log)
+
+
+def test_torch_cpu_instance_norm_channels_last_backward():
+    """Documents why oracle._inorm / ref_shim wrap instance_norm: with a channels-last grad_output the stock CPU backward disagrees
+    with central finite differences (float64), the wrapped one agrees.  If a future torch fixes the bug both agree -- still green."""
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 16, 6, 6, dtype=torch.float64, generator=g)
+    G = torch.randn(1, 6, 6, 16, dtype=torch.float64, generator=g).permute(0, 3, 1, 2)       # channels-last strides
+    orig = getattr(F.instance_norm, "_jg_orig", F.instance_norm)
+    xs = x.clone().requires_grad_(True)
+    (stock,) = torch.autograd.grad(orig(xs, eps=1e-5), xs, G)
+    xo = x.clone().requires_grad_(True)
+    (mine,) = torch.autograd.grad(O._inorm(xo), xo, G)
+    eps, fd = 1e-6, []
+    idx = [(0, 3, 2, 5), (0, 10, 0, 0), (0, 15, 5, 5), (0, 7, 4, 1)]
+    for i in idx:
+        xp, xm = x.clone(), x.clone()
+        xp[i] += eps
+        xm[i] -= eps
+        fd.append(float(((orig(xp, eps=1e-5) - orig(xm, eps=1e-5)) * G).sum() / (2 * eps)))
+    for i, f in zip(idx, fd):
+        assert abs(float(mine[i]) - f) < 1e-6 * max(1.0, abs(f)), (i, float(mine[i]), f)
+    stock_err = max(abs(float(stock[i]) - f) for i, f in zip(idx, fd))
+    print("stock CPU instance_norm backward, channels-last grad: max abs error vs finite differences =", stock_err)
