@@ -178,13 +178,18 @@ __device__ __forceinline__ float act_grad_f(float v, int act) {
   return s * (1.0f + v * (1.0f - s));
 }
 
-// dbias[n] += sum_b dy[b][n]
-__global__ void linear_bwd_dbias_kernel(const float* __restrict__ dy, float* __restrict__ dbias, int Bn, int N) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// dbias[n] += sum_b dy[b][n]: 64 columns x 4 row groups per block, 256 rows per block, one atomic per column per block
+__global__ __launch_bounds__(256) void linear_bwd_dbias_kernel(const float* __restrict__ dy, float* __restrict__ dbias, int Bn, int N) {
+  __shared__ float s_red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * 256, r1 = min(Bn, r0 + 256);
   float acc = 0.f;
-  for (int b = 0; b < Bn; ++b) acc += dy[(long)b * N + n];
-  dbias[n] += acc;
+  if (n < N)
+    for (int b = r0 + ty; b < r1; b += 4) acc += dy[(long)b * N + n];
+  s_red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && n < N) atomicAdd(&dbias[n], s_red[0][tx] + s_red[1][tx] + s_red[2][tx] + s_red[3][tx]);
 }
 
 __global__ void gamma_embedding_kernel(const float* __restrict__ gammas, float* __restrict__ emb, int Bn, int dim,
@@ -722,7 +727,8 @@ extern "C" int jg_linear_bwd(const float* x, const float* W, const float* dy, fl
   if (rc != JG_OK) return rc;
   if (dW) rc = jg_sgemm(dy, x, dW, nullptr, nullptr, N, K, Bn, 1, N, 1, K, K, 1, 1, 0, 0, 0, 1.0f, 1.0f, JG_ACT_NONE, act, JG_ACT_NONE, s);
   if (rc != JG_OK) return rc;
-  if (dbias) hipLaunchKernelGGL(linear_bwd_dbias_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, dy, dbias, Bn, N);
+  if (dbias)
+    hipLaunchKernelGGL(linear_bwd_dbias_kernel, dim3((N + 63) / 64, (Bn + 255) / 256), dim3(256), 0, (hipStream_t)s, dy, dbias, Bn, N);
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -6,6 +6,8 @@
 //   * jg_nce_sinkhorn_bwd  reverse sweep through the Sinkhorn iterations (the reference differentiates through them w.r.t. q)
 //   * jg_nce_sinkhorn_gk   dS += K .* (rank-2T update assembled from the forward/backward histories)
 // reference: models/modules/NCE/base_NCE.py:17-77, monce.py:16-33, sinkhorn.py:6-58
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -21,6 +23,7 @@ struct SgemmP {
   long ba, bb, bc;
   float alpha, beta;
   int act_a, act_b, act_e;
+  int ksplit;   // > 1: blockIdx.z is a K slice (single batch), the epilogue is atomicAdd(alpha * acc) onto C
 };
 
 __device__ __forceinline__ float act_rt(float v, int act) {
@@ -39,7 +42,10 @@ template <bool AKC, bool BKC>
 __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
   __shared__ float As[16][68];
   __shared__ float Bs[16][68];
-  const int z = blockIdx.z;
+  const int z = p.ksplit > 1 ? 0 : blockIdx.z;
+  const int kchunk = p.ksplit > 1 ? ((p.K + p.ksplit - 1) / p.ksplit + 15) / 16 * 16 : p.K;
+  const int kbeg = p.ksplit > 1 ? blockIdx.z * kchunk : 0;
+  const int kend = min(p.K, kbeg + kchunk);
   const float* A = p.A + z * p.ba;
   const float* B = p.B + z * p.bb;
   float* C = p.C + z * p.bc;
@@ -53,20 +59,20 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
 
-  for (int k0 = 0; k0 < p.K; k0 += 16) {
+  for (int k0 = kbeg; k0 < kend; k0 += 16) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       {
         const int m = AKC ? (t >> 2) : (t & 63);
         const int kk = AKC ? ((t & 3) * 4 + i) : ((t >> 6) * 4 + i);
-        const bool ok = (m0 + m < p.M) && (k0 + kk < p.K);
+        const bool ok = (m0 + m < p.M) && (k0 + kk < kend);
         float v = ok ? A[(long)(m0 + m) * p.sam + (long)(k0 + kk) * p.sak] : 0.f;
         As[kk][m] = act_rt(v, p.act_a);
       }
       {
         const int n = BKC ? (t >> 2) : (t & 63);
         const int kk = BKC ? ((t & 3) * 4 + i) : ((t >> 6) * 4 + i);
-        const bool ok = (n0 + n < p.N) && (k0 + kk < p.K);
+        const bool ok = (n0 + n < p.N) && (k0 + kk < kend);
         float v = ok ? B[(long)(n0 + n) * p.sbn + (long)(k0 + kk) * p.sbk] : 0.f;
         Bs[kk][n] = act_rt(v, p.act_b);
       }
@@ -95,6 +101,10 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
       if (n >= p.N) continue;
       const long o = (long)m * p.scm + (long)n * p.scn;
       float c = p.alpha * acc[i][j];
+      if (p.ksplit > 1) {
+        atomicAdd(&C[o], c);
+        continue;
+      }
       if (p.bias) c += p.bias[n];
       if (E) c *= act_grad_rt2(E[o], p.act_e);
       if (p.beta != 0.f) c += p.beta * C[o];
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
 }
 
 int sgemm_launch(const SgemmP& p, int nbatch, hipStream_t st) {
-  const dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, nbatch);
+  const dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.ksplit > 1 ? p.ksplit : nbatch);
   const bool akc = p.sak == 1, bkc = p.sbk == 1;
   if (akc && bkc) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, st, p);
   else if (akc) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, p);
@@ -231,6 +241,205 @@ __global__ __launch_bounds__(SK_THREADS) void sinkhorn_bwd_kernel(const float* _
     }
     __syncthreads();
     col_matvec(K, s_x, s_gv, s_part, P, t);
+  }
+}
+
+// ---- register-resident Sinkhorn for P <= 256 -------------------------------------------------------------------------------
+// 1024 threads as a 32 x 32 grid of 8 x 8 tiles of K (64 VGPRs per lane): both matvecs of an iteration run out of registers.
+// Lane (ti, tj) = (t >> 5, t & 31); a wave holds 2 tile rows x 32 tile columns.
+//   row matvec  y_i = sum_j K_ij x_j : 8 partial sums per lane, reduced over the 32 tj lanes by a halving exchange (9 shuffles)
+//   col matvec  z_j = sum_i x_i K_ij : 8 partial sums per lane, halved over the 2 ti of the wave, then 16 waves through LDS
+constexpr int SKR = 256;
+
+struct SkTile {
+  float k[8][8];
+};
+
+// after the call, lanes with (lane & 3) == 0 hold the row sum of tile row  a = ((lane >> 2) & 7)  (bits 4,3,2 of the lane)
+__device__ __forceinline__ float sk_row_reduce(const float* p, int lane) {
+  float k4[4], k2[2];
+  const bool h16 = lane & 16, h8 = lane & 8, h4 = lane & 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float recv = __shfl_xor(h16 ? p[k] : p[k + 4], 16);
+    k4[k] = (h16 ? p[k + 4] : p[k]) + recv;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const float recv = __shfl_xor(h8 ? k4[k] : k4[k + 2], 8);
+    k2[k] = (h8 ? k4[k + 2] : k4[k]) + recv;
+  }
+  float r = (h4 ? k2[1] : k2[0]) + __shfl_xor(h4 ? k2[0] : k2[1], 4);
+  r += __shfl_xor(r, 2);
+  r += __shfl_xor(r, 1);
+  return r;
+}
+__device__ __forceinline__ int sk_row_of(int t, int lane) { return 8 * (t >> 5) + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1); }
+
+__device__ __forceinline__ void sk_row_partials(const SkTile& K, const float* __restrict__ vec, int tj, float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(vec + 8 * tj);
+  const float4 b = *reinterpret_cast<const float4*>(vec + 8 * tj + 4);
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc += K.k[r][c] * x[c];
+    p[r] = acc;
+  }
+}
+// halve the 8 column partials over the wave's two tile rows and park them in part[wave][256]
+__device__ __forceinline__ void sk_col_store(const float* q, int tj, int lane, float* part_w) {
+  const bool h32 = lane & 32;
+  float4 o;
+  float k4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float recv = __shfl_xor(h32 ? q[k] : q[k + 4], 32);
+    k4[k] = (h32 ? q[k + 4] : q[k]) + recv;
+  }
+  o.x = k4[0]; o.y = k4[1]; o.z = k4[2]; o.w = k4[3];
+  *reinterpret_cast<float4*>(part_w + 8 * tj + (h32 ? 4 : 0)) = o;
+}
+// partial column sums of this wave -> part[wave][256]
+__device__ __forceinline__ void sk_col_partials(const SkTile& K, const float* __restrict__ vec, int ti, int tj, int lane, float* part_w) {
+  const float4 a = *reinterpret_cast<const float4*>(vec + 8 * ti);
+  const float4 b = *reinterpret_cast<const float4*>(vec + 8 * ti + 4);
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  float q[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc += x[r] * K.k[r][c];
+    q[c] = acc;
+  }
+  sk_col_store(q, tj, lane, part_w);
+}
+
+__global__ __launch_bounds__(1024) void sinkhorn_fwd_reg_kernel(const float* __restrict__ S, float* __restrict__ Kout,
+                                                                 float* __restrict__ u_hist, float* __restrict__ v_hist, int P, int niter,
+                                                                 float eps) {
+  __shared__ __attribute__((aligned(16))) float s_u[SKR], s_v[SKR], s_part[16][SKR];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, ti = t >> 5, tj = t & 31;
+  const float* Sb = S + (long)b * P * P;
+  float* Kb = Kout + (long)b * P * P;
+  float* uh = u_hist + (long)b * niter * P;
+  float* vh = v_hist + (long)b * (niter + 1) * P;
+  SkTile K;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = 8 * ti + r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int col = 8 * tj + c;
+      const bool ok = row < P && col < P;
+      const float v = ok ? expf((row == col ? -10.0f : Sb[(long)row * P + col]) / eps) : 0.f;
+      K.k[r][c] = v;
+      if (ok) Kb[(long)row * P + col] = v;
+    }
+  }
+  if (t < SKR) {
+    s_v[t] = t < P ? 1.0f : 0.f;
+    if (t < P) vh[t] = 1.0f;
+  }
+  __syncthreads();
+  const int myrow = sk_row_of(t, lane);
+  for (int it = 0; it < niter; ++it) {
+    float p[8];
+    sk_row_partials(K, s_v, tj, p);
+    const float y = sk_row_reduce(p, lane);
+    if ((lane & 3) == 0) {
+      const float u = myrow < P ? 1.0f / y : 0.f;
+      s_u[myrow] = u;
+      if (myrow < P) uh[(long)it * P + myrow] = u;
+    }
+    __syncthreads();
+    sk_col_partials(K, s_u, ti, tj, lane, s_part[wave]);
+    __syncthreads();
+    if (t < SKR) {
+      float z = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) z += s_part[w][t];
+      const float v = t < P ? 1.0f / z : 0.f;
+      s_v[t] = v;
+      if (t < P) vh[(long)(it + 1) * P + t] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// seeds of the reverse sweep (any P): G = gW .* K in place, gu_i = sum_j G_ij v_T,j -> dr_hist[niter-1], gv_j = sum_i G_ij u_T,i ->
+// ds_hist[niter-1] (the sweep kernel reads them there before it overwrites those slots with dr / ds of the last iteration)
+__global__ __launch_bounds__(SK_THREADS) void sinkhorn_seed_kernel(const float* __restrict__ Kin, const float* __restrict__ u_hist,
+                                                                    const float* __restrict__ v_hist, float* __restrict__ gW,
+                                                                    float* __restrict__ ds_hist, float* __restrict__ dr_hist, int P,
+                                                                    int niter) {
+  __shared__ float s_u[SK_MAXP], s_v[SK_MAXP], s_part[SK_THREADS];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* K = Kin + (long)b * P * P;
+  float* G = gW + (long)b * P * P;
+  for (long i = t; i < (long)P * P; i += SK_THREADS) G[i] *= K[i];
+  for (int i = t; i < P; i += SK_THREADS) {
+    s_v[i] = v_hist[((long)b * (niter + 1) + niter) * P + i];
+    s_u[i] = u_hist[((long)b * niter + niter - 1) * P + i];
+  }
+  __threadfence_block();
+  __syncthreads();
+  row_matvec(G, s_v, dr_hist + ((long)b * niter + niter - 1) * P, P, wave, lane, SK_THREADS / 64);
+  col_matvec(G, s_u, ds_hist + ((long)b * niter + niter - 1) * P, s_part, P, t);
+}
+
+__global__ __launch_bounds__(1024) void sinkhorn_bwd_reg_kernel(const float* __restrict__ Kin, const float* __restrict__ u_hist,
+                                                                 const float* __restrict__ v_hist, float* __restrict__ ds_hist,
+                                                                 float* __restrict__ dr_hist, int P, int niter) {
+  __shared__ __attribute__((aligned(16))) float s_x[SKR], s_y[SKR], s_part[16][SKR];
+  const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, ti = t >> 5, tj = t & 31;
+  const float* Kb = Kin + (long)b * P * P;
+  const float* uh = u_hist + (long)b * niter * P;
+  const float* vh = v_hist + (long)b * (niter + 1) * P;
+  float* dsh = ds_hist + (long)b * niter * P;
+  float* drh = dr_hist + (long)b * niter * P;
+  SkTile K;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int row = 8 * ti + r;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int col = 8 * tj + c;
+      K.k[r][c] = (row < P && col < P) ? Kb[row * P + col] : 0.f;
+    }
+  }
+  const int myrow = sk_row_of(t, lane);
+  for (int it = niter - 1; it >= 0; --it) {
+    // gv (for v_{it+1}): the seed on the first pass, else the column sums of the previous pass; ds = -gv v^2
+    if (t < SKR) {
+      float z = 0.f;
+      if (it == niter - 1) z = t < P ? dsh[(long)it * P + t] : 0.f;
+      else {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) z += s_part[w][t];
+      }
+      const float v = t < P ? vh[(long)(it + 1) * P + t] : 0.f;
+      const float ds = -z * v * v;
+      s_x[t] = ds;
+      if (t < P) dsh[(long)it * P + t] = ds;
+    }
+    __syncthreads();
+    float p[8];
+    sk_row_partials(K, s_x, tj, p);
+    const float y = sk_row_reduce(p, lane);
+    if ((lane & 3) == 0) {
+      const bool ok = myrow < P;
+      const float u = ok ? uh[(long)it * P + myrow] : 0.f;
+      const float seed = (it == niter - 1 && ok) ? drh[(long)it * P + myrow] : 0.f;
+      const float dr = -(seed + y) * u * u;
+      s_y[myrow] = dr;
+      if (ok) drh[(long)it * P + myrow] = dr;
+    }
+    __syncthreads();
+    sk_col_partials(K, s_y, ti, tj, lane, s_part[wave]);
+    __syncthreads();
   }
 }
 
@@ -361,7 +570,15 @@ extern "C" int jg_sgemm(const float* A, const float* B, float* C, const float* b
                         int64_t sak, int64_t sbn, int64_t sbk, int64_t scm, int64_t scn, int nbatch, int64_t ba, int64_t bb, int64_t bc,
                         float alpha, float beta, int act_a, int act_b, int act_e, jg_stream_t s) {
   if (!A || !B || !C || M < 1 || N < 1 || K < 1 || nbatch < 1 || nbatch > 65535) return JG_ERR_BAD_ARG;
-  SgemmP p{A, B, C, bias, E, M, N, K, sam, sak, sbn, sbk, scm, scn, ba, bb, bc, alpha, beta, act_a, act_b, act_e};
+  SgemmP p{A, B, C, bias, E, M, N, K, sam, sak, sbn, sbk, scm, scn, ba, bb, bc, alpha, beta, act_a, act_b, act_e, 1};
+  // accumulating GEMMs with a long reduction and a small output (the nn.Linear weight gradient: 16 tiles, K = rows of the batch)
+  // are split along K so that the launch fills the chip; partial tiles land with atomics
+  const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
+  if (nbatch == 1 && beta == 1.0f && !bias && !E && tiles < 128 && K >= 256) {
+    int ks = 256 / tiles;
+    while (ks > 1 && K / ks < 64) ks >>= 1;
+    p.ksplit = ks;
+  }
   return sgemm_launch(p, nbatch, (hipStream_t)s);
 }
 
@@ -369,7 +586,10 @@ extern "C" int jg_nce_sinkhorn_fwd(const float* S, float* K, float* u_hist, floa
                                    jg_stream_t s) {
   if (!S || !K || !u_hist || !v_hist || nimg < 1 || P < 1 || niter < 1) return JG_ERR_BAD_ARG;
   if (P > SK_MAXP) return JG_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sinkhorn_fwd_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, S, K, u_hist, v_hist, P, niter, eps);
+  if (P <= SKR && !getenv("JG_SINKHORN_GENERIC"))
+    hipLaunchKernelGGL(sinkhorn_fwd_reg_kernel, dim3(nimg), dim3(1024), 0, (hipStream_t)s, S, K, u_hist, v_hist, P, niter, eps);
+  else
+    hipLaunchKernelGGL(sinkhorn_fwd_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, S, K, u_hist, v_hist, P, niter, eps);
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -398,8 +618,12 @@ extern "C" int jg_nce_sinkhorn_bwd(const float* K, const float* u_hist, const fl
                                    float* dS, int nimg, int P, int niter, jg_stream_t s) {
   if (!K || !u_hist || !v_hist || !gW || !ds_hist || !dr_hist || !dS || nimg < 1 || P < 1 || niter < 1) return JG_ERR_BAD_ARG;
   if (P > SK_MAXP || niter * 32 * sizeof(float) > 48 * 1024) return JG_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, K, u_hist, v_hist, gW, ds_hist, dr_hist, P,
-                     niter);
+  if (P <= SKR && !getenv("JG_SINKHORN_GENERIC")) {
+    hipLaunchKernelGGL(sinkhorn_seed_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, K, u_hist, v_hist, gW, ds_hist, dr_hist, P, niter);
+    hipLaunchKernelGGL(sinkhorn_bwd_reg_kernel, dim3(nimg), dim3(1024), 0, (hipStream_t)s, K, u_hist, v_hist, ds_hist, dr_hist, P, niter);
+  } else
+    hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, K, u_hist, v_hist, gW, ds_hist, dr_hist, P,
+                       niter);
   hipLaunchKernelGGL(sinkhorn_gk_kernel, dim3((P + 15) / 16, nimg), dim3(256), niter * 32 * sizeof(float), (hipStream_t)s, K, gW, u_hist,
                      v_hist, ds_hist, dr_hist, dS, P, niter);
   JG_CHECK_LAUNCH();

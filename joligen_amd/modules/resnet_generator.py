@@ -69,9 +69,6 @@ class ResnetBlock(nn.Module):
                 c.bias = None
 
     def forward(self, x):
-        import os
-        if os.environ.get("JG_ADD_TORCH"):
-            return x + _run(self.conv_block, x)
         return _AddFn.apply(x, _run(self.conv_block, x))     # out = x + conv_block(x)
 
 
@@ -82,9 +79,6 @@ class _AddFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        import os
-        if os.environ.get("JG_ADD_CLONE"):
-            return g.clone(), g.clone()
         return g, g
 
 
