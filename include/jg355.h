@@ -71,6 +71,10 @@ typedef struct {
    * (x, dy) is folded into this epilogue (one extra 16-byte read of x per output row). */
   int32_t stats_mode;
   const void* gn_x; int64_t gn_ldx; const float* gn_ab; int32_t gn_act;
+  /* pad_mode 1: out-of-image taps read the MIRRORED interior pixel instead of zero -- nn.ReflectionPad2d(1) followed by a
+   * pad-0 3x3 convolution (resnet_generator.py:52-60) as ONE launch (pad = 1, Ho = H, Wo = W).  Halo-resident kernel only:
+   * 3x3, stride 1, Cin % 64 == 0, Cout % 64 == 0, H % 16 == 0, W % 16 == 0, else JG_ERR_UNSUPPORTED. */
+  int32_t pad_mode;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 
@@ -92,6 +96,7 @@ typedef struct {
   float alpha;
   int32_t out_mode;
   float dbias_scale; /* dbias[co] += dbias_scale * sum_p dy[p][co]; 0 means 1 (a skip-path conv fed with skipw*dy) */
+  int32_t pad_mode;  /* 1: x is read with mirrored borders (see jg_conv_args.pad_mode); same shape limits */
 } jg_wgrad_args;
 int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream);
 

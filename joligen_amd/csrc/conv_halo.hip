@@ -98,7 +98,11 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     const int pos = rd * NT + tid;
     const int hp = pos >> 3, cpos = pos & 7;
     const int hy = hp / HW_, hx = hp - hy * HW_;
-    const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+    int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+    if (p.reflect) {
+      ih = JG_REFLECT1(ih, p.H);
+      iw = JG_REFLECT1(iw, p.W);
+    }
     const bool ok = pos < HALO_CH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
     const int kc = cpos ^ ((hx >> 1) & 7);   // swizzle by the COLUMN inside the halo row: the same for every row
     aoff[rd] = ok ? (int)((((long)b * p.H + ih) * p.W + iw) * p.ldx) + kc * 8 : -1;

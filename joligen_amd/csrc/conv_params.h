@@ -1,5 +1,7 @@
 // Kernel-side parameter block shared by the convolution kernels (gemm_nt.hip, conv_halo.hip).
 #pragma once
+// mirror index of nn.ReflectionPad2d for a 1-pixel border: -1 -> 1, n -> n - 2
+#define JG_REFLECT1(i, n) ((i) < 0 ? -(i) : ((i) >= (n) ? 2 * ((n) - 1) - (i) : (i)))
 #include "common.h"
 
 struct ConvP {
@@ -21,6 +23,7 @@ struct ConvP {
   int stats_mode;
   int dbg;        // ablation switches of the dev tools (JG_HALO_DBG): 1 = no epilogue, 2 = no MFMA/LDS reads, 4 = no halo DMA
   const char* gx; long gldx; const float* gab; int gact;
+  int reflect;    // 1: out-of-image halo pixels mirror the interior (nn.ReflectionPad2d(1) in front of a pad-0 3x3 conv)
 };
 
 // Per-wave reduction of the epilogue's (sum, sum^2) partials over the 16 pixel lanes of an MFMA tile

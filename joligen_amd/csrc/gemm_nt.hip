@@ -399,6 +399,7 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
     JG_CHECK_LAUNCH();
     return JG_OK;
   }
+  if (p.reflect) return JG_ERR_UNSUPPORTED;   // mirrored borders exist only in the halo-resident kernel
   if (variant >= 2) {
     if (p.N <= 64) {
       if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);
@@ -447,6 +448,8 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.alpha = a->alpha; p.res_scale = a->res_scale; p.out_f32 = a->out_f32;
   p.B = a->B; p.stats = a->stats; p.ldstats = a->ldstats > 0 ? a->ldstats : a->Cout;
   p.nslots = a->stats_slots > 0 ? a->stats_slots : 1;
+  p.reflect = a->pad_mode == 1;
+  if (a->pad_mode != 0 && a->pad_mode != 1) return JG_ERR_BAD_ARG;
   p.dbg = 0; p.stats_mode = a->stats_mode; p.gx = (const char*)a->gn_x; p.gldx = a->gn_ldx; p.gab = a->gn_ab; p.gact = a->gn_act;
   if (p.stats && p.stats_mode == 1 && (!p.gx || !p.gab || p.gldx < a->Cout || (a->Cout & 7))) return JG_ERR_BAD_ARG;
   if (p.stats) {

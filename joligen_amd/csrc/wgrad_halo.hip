@@ -19,6 +19,7 @@
 // of the pixel COLUMN (so that vertical tap shifts are plain address offsets) that is injective on
 // every such set: conflict-free for every tap.  LDS-DMA writes lane-linearly, so the swizzle is
 // applied to the SOURCE chunk index (cdna_hip_programming.md 5.4 rule 21).
+#include "conv_params.h"
 #include "wgrad_params.h"
 #include <cstdlib>
 
@@ -142,9 +143,13 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
           const int hp = pos >> 3, cpos = pos & 7;
           const int hy = hp / HW_, hx = hp - hy * HW_;
           const int chunk = (((cpos >> 1) ^ f4(hx)) << 1) | (cpos & 1);
-          const int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+          int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
+          if (p.reflect) {
+            ih = JG_REFLECT1(ih, p.H);
+            iw = JG_REFLECT1(iw, p.W);
+          }
           const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-          glds16(ok ? xb + ((hy - 1) * p.W + (hx - 1)) * (int)p.ldx + chunk * 8 : zp, l0 + rd * NT * 16);
+          glds16(ok ? xb + ((ih - oh0) * p.W + (iw - ow0)) * (int)p.ldx + chunk * 8 : zp, l0 + rd * NT * 16);
         }
       }
     
@@ -165,7 +170,9 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
         if (a_yx[rd] >= 0) {
           const int ih = oh0 - 1 + (a_yx[rd] >> 8), iw = ow0 - 1 + (a_yx[rd] & 255);
           const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-          glds16(ok ? xb + a_rel[rd] : zp, l0 + rd * NT * 16);
+          int rel = a_rel[rd];
+          if (p.reflect && !ok) rel += ((JG_REFLECT1(ih, p.H) - ih) * p.W + (JG_REFLECT1(iw, p.W) - iw)) * (int)p.ldx;
+          glds16((ok || p.reflect) ? xb + rel : zp, l0 + rd * NT * 16);
         }
       }
     

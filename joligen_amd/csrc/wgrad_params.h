@@ -14,6 +14,7 @@ struct WgP {
   int out_mode;
   int B;
   float dbias_scale;
+  int reflect;   // 1: the x halo mirrors the interior at the image border (ReflectionPad2d(1) + pad-0 3x3 conv)
 };
 
 // wgrad_halo.hip: returns true when the shape was handled by the halo-resident 3x3 kernel.

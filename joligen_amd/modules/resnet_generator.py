@@ -11,12 +11,17 @@ convolution; the stride-2 transposed convolutions run as stride-1 MFMA convoluti
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from .. import ops
 from ..ops import JG_ACT_NONE, JG_ACT_RELU, JG_ACT_TANH
 from .layers import JGConv2d, JGConvTranspose2d
+
+
+FUSE_REFLECT = os.environ.get("JG_FUSE_REFLECT", "1") != "0"
 
 
 def _run(seq, x, taps=None, feats=None, upto=None):
@@ -28,7 +33,13 @@ def _run(seq, x, taps=None, feats=None, upto=None):
     while i < len(mods):
         m = mods[i]
         if isinstance(m, nn.ReflectionPad2d):
-            x = ops.reflect_pad2d(x, m.padding[0])
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if (FUSE_REFLECT and m.padding[0] == 1 and isinstance(nxt, JGConv2d) and not (taps and i in taps)
+                    and ops.reflect_conv_ok(x, nxt.meta)):
+                x = ops.reflect_conv2d(x, nxt.meta)       # pad + conv in one launch (mirrored halo)
+                i += 1
+            else:
+                x = ops.reflect_pad2d(x, m.padding[0])
         elif isinstance(m, (JGConv2d, JGConvTranspose2d, ResnetBlock)):
             x = m(x)
         elif isinstance(m, nn.InstanceNorm2d):

@@ -75,7 +75,7 @@ def _wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode):
 
 def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
             ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
-            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None):
+            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0):
     """jg_conv2d_nt with element offsets into the operand tensors."""
     a = ConvArgs()
     es = 2
@@ -93,6 +93,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     a.srb, a.srh = sr
     a.alpha, a.res_scale, a.out_f32 = alpha, res_scale, int(out_f32)
     a.stats, a.ldstats, a.stats_slots = _p(stats), ldstats, stats_slots
+    a.pad_mode = pad_mode
     if gn_reduce is not None:   # (norm input x, pixel stride, ab coefficients, act): GroupNorm-backward reductions in the epilogue
         gx, gldx, gab, gact = gn_reduce
         a.stats_mode, a.gn_x, a.gn_ldx, a.gn_ab, a.gn_act = 1, gx.data_ptr(), gldx, gab.data_ptr(), gact
@@ -108,7 +109,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
              Cout_out=0, splitk=1, nbatch=1, nh=1, sdy=(0, 0), sx=(0, 0), sdw=(0, 0), alpha=1.0,
-             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0, dbias_scale=0.0):
+             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0, dbias_scale=0.0, pad_mode=0):
     a = WgradArgs()
     a.dy = dy.data_ptr() + dy_off * 2
     a.x = x.data_ptr() + x_off * 2
@@ -122,6 +123,7 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.sxb, a.sxh = sx
     a.sdwb, a.sdwh = sdw
     a.alpha, a.out_mode, a.dbias_scale = alpha, out_mode, dbias_scale
+    a.pad_mode = pad_mode
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -241,6 +243,59 @@ class _Conv2dFn(torch.autograd.Function):
 def conv2d(x, meta: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
     """y = alpha*conv(x) + bias + res_scale*res   (nn.Conv2d / Conv1d(k=1) of the reference)."""
     return _Conv2dFn.apply(x, meta.weight, meta.bias, res, meta, res_scale, alpha)
+
+
+def reflect_conv_ok(x, m: ConvMeta):
+    """shape limits of pad_mode = 1 (halo-resident kernels): ReflectionPad2d(1) + 3x3 / stride 1 / pad 0 convolution"""
+    B, H, W, Cin = x.shape
+    return (m.R == 3 and m.S == 3 and m.stride == 1 and m.pad == 0 and Cin % 64 == 0 and m.Cout % 64 == 0 and H % 16 == 0
+            and W % 16 == 0 and H >= 16 and W >= 16 and B * H * W * max(Cin, m.Cout) < (1 << 31))
+
+
+class _ReflectConv2dFn(torch.autograd.Function):
+    """nn.ReflectionPad2d(1) -> nn.Conv2d(3x3, padding 0) as one launch: the halo-resident kernel mirrors the border pixels while
+    it loads its halo, so the padded tensor is never written.  Backward: the weight gradient reads x with the same mirrored halo;
+    the input gradient is the full convolution over the (H+2, W+2) padded domain folded back by the reflection's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, meta):
+        _require_cuda(x)
+        x = x.contiguous()
+        B, H, W, Cin = x.shape
+        m = meta
+        y = torch.empty((B, H, W, m.Cout), device=x.device, dtype=x.dtype)
+        conv_nt(x, m.w16, y, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=9 * Cin,
+                ldy=m.Cout, bias=m.bias_pad if m.bias_pad is not None else m.bias, pad_mode=1)
+        ctx.save_for_backward(x)
+        ctx.meta = m
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        m = ctx.meta
+        dy = dy.contiguous()
+        B, H, W, Cin = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = conv2d_dgrad(dy, m, (B, H + 2, W + 2, Cin))
+            dx = torch.empty_like(x)
+            check(_lib.lib().jg_reflect_pad2d_bwd(_dt(dy), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cin, 1, _st()), "jg_reflect_pad2d_bwd")
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            wg = m.weight.grad
+            if wg is None:
+                raise RuntimeError("conv weight has no arena-backed .grad (module not finalised by ParamArena)")
+            dbias = m.bias.grad if (ctx.needs_input_grad[2] and m.bias is not None) else None
+            wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, lddy=m.Cout, ldx=Cin,
+                     lddw=9 * m.Cin_real, dbias=dbias, Cin_out=m.Cin_real, Cout_out=m.Cout_real,
+                     splitk=_wgrad_splitk(((m.Cout + 127) // 128) * ((9 * Cin + 127) // 128), B * H * W), pad_mode=1)
+        return dx, None, None, None
+
+
+def reflect_conv2d(x, meta: ConvMeta):
+    """conv(reflection_pad(x, 1)) for a 3x3 / pad-0 ConvMeta (see reflect_conv_ok)."""
+    return _ReflectConv2dFn.apply(x, meta.weight, meta.bias, meta)
 
 
 # ======================================================================================

@@ -507,3 +507,51 @@ def test_strided_and_transposed_conv(case, dtype):
     assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype]
     assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype]
     assert relerr(m.c.bias.grad, br.grad) < TOL[dtype]
+
+
+REFLECT_CASES = [
+    (2, 16, 16, 64, 64),      # one tile per image: every halo pixel of the border is mirrored
+    (1, 64, 64, 256, 256),    # the ResnetBlock shape of the CUT generator at 256x256
+    (3, 32, 48, 128, 64),     # rectangular, 64-wide output tile
+    (2, 16, 32, 64, 256),     # 256-wide output tile
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", REFLECT_CASES)
+def test_reflect_conv_fused(case, dtype):
+    """ReflectionPad2d(1) + 3x3 conv as one launch (pad_mode = 1): forward, input gradient, weight / bias gradient against the
+    fp32 torch reference, and the fallback outside the halo kernel's shape limits is refused loudly by the C ABI."""
+    from joligen_amd import ops
+
+    B, H, W, Cin, Cout = case
+    m, arena, w_ref, b_ref = _make_conv_module(Cin, Cout, 3, 0, dtype)
+    x = rnd((B, Cin, H, W), dtype, 21)
+    gy = rnd((B, Cout, H, W), dtype, 22)
+    xr = x.float().requires_grad_(True)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b_ref.clone().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr, br)
+    yr.backward(gy.float())
+    xd = nhwc(x).to(dev()).requires_grad_(True)
+    assert ops.reflect_conv_ok(xd, m.c.meta)
+    y = ops.reflect_conv2d(xd, m.c.meta)
+    assert relerr(nchw(y), yr.detach()) < TOL[dtype], relerr(nchw(y), yr.detach())
+    # the unfused pair gives the same values up to the accumulation order
+    y2 = m.c(ops.reflect_pad2d(xd.detach(), 1))
+    assert relerr(y.float(), y2.float()) < (2e-3 if dtype == torch.float16 else 1.6e-2)
+    y.backward(nhwc(gy).to(dev()))
+    torch.cuda.synchronize()
+    assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype], ("dx", relerr(nchw(xd.grad), xr.grad))
+    assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype], ("dw", relerr(m.c.weight.grad, wr.grad))
+    assert relerr(m.c.bias.grad, br.grad) < TOL[dtype], ("db", relerr(m.c.bias.grad, br.grad))
+
+
+def test_reflect_conv_unsupported_shape_is_refused():
+    from joligen_amd import ops
+
+    m, arena, _, _ = _make_conv_module(64, 64, 3, 0, torch.bfloat16)
+    x = torch.zeros(1, 12, 12, 64, device=dev(), dtype=torch.bfloat16)     # 12 is not a multiple of 16
+    assert not ops.reflect_conv_ok(x, m.c.meta)
+    with pytest.raises(RuntimeError, match="jg_conv2d_nt"):
+        ops.reflect_conv2d(x, m.c.meta)
