@@ -212,6 +212,15 @@ int jg_ddpm_prepare(int dtype, const float* y0, const float* ycond, const float*
 int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
                      float* loss, void* dnh, int B, int C, int H, int W, int Cpad, float lambda, float grad_scale,
                      jg_stream_t s);
+/* alg_palette_loss in {L1, multiscale_L1, multiscale_MSE} (palette_model.py:231-256,597-618; MultiScaleDiffusionLoss
+ * models/modules/loss.py:397-467) on d = w m (noise - noise_hat): level l (factor f = 2^l, l < nlevels) is the loss of the
+ * bilinear down-sampling of d to S / f -- for integer factors the mean of the central 2x2 pixels of each f x f cell --
+ * weighted 32 / (2 S / f); multiscale = 0: a single full-resolution level with weight 1 (plain nn.L1Loss / nn.MSELoss).
+ * losses[nlevels] (zeroed by the caller) receive lambda * the per-level terms (their sum is loss_G_tot); dnh (may be NULL) =
+ * grad_scale * d(sum)/d noise_hat.  ws: caller-provided fp32 workspace of sum_{l>=1} B C (H >> l)(W >> l) elements. */
+int jg_ddpm_multiscale_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
+                            float* losses, void* dnh, float* ws, int B, int C, int H, int W, int Cpad, int nlevels, int l1,
+                            int multiscale, float lambda, float grad_scale, jg_stream_t s);
 /* Glue of the CUT networks (ResnetGenerator models/modules/resnet_architecture/resnet_generator.py:11-347,
  * NLayerDiscriminator models/modules/discriminators.py:10-118), NHWC 16-bit, C % 8 == 0:
  *   act_fwd / act_bwd        : nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh where no normalisation precedes them; the backward

@@ -88,6 +88,8 @@ SIGNATURES = {
     "jg_dilate2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_subsample2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_channel_sum": [c_i32, c_p, c_i64, c_p, c_i64, c_i32, c_f32, c_p],
+    "jg_ddpm_multiscale_loss": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32,
+                                c_f32, c_p],
     "jg_gather_rows": [c_i32, c_p, c_i64, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p],
     "jg_scatter_rows": [c_i32, c_p, c_i64, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p],
     "jg_l2norm_fwd": [c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],

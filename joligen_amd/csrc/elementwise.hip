@@ -273,6 +273,107 @@ __global__ __launch_bounds__(256) void ddpm_mse_loss_kernel(const float* __restr
   if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * invN * lambda);
 }
 
+// ---- L1 / multiscale diffusion losses (models/modules/loss.py:397-467, palette_model.py:231-256,597-618) ---------------------
+// d = w m (noise - noise_hat).  F.interpolate(size = S / f, mode="bilinear", align_corners=False) with an integer factor f >= 2
+// samples at (i + 0.5) f - 0.5: the mean of the CENTRAL 2x2 pixels of every f x f cell (rows f i + f/2 - 1, f i + f/2).
+// Level l has factor f = 1 << l.  Pass 1 writes the down-sampled d of the levels l >= 1 into `ws` and their loss sums;
+// pass 2 handles level 0 and scatters every level's derivative back to the full-resolution gradient.
+__device__ __forceinline__ float ms_g(float x, int l1) { return l1 ? fabsf(x) : x * x; }
+__device__ __forceinline__ float ms_dg(float x, int l1) { return l1 ? (x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f)) : 2.0f * x; }
+__device__ __forceinline__ float ms_wm(const int64_t* mask, const float* w, int b, long pix) {
+  float wm = w ? w[b] : 1.0f;
+  if (mask) {
+    const int64_t mv = mask[pix];
+    wm *= mv < 0 ? 0.f : (mv > 1 ? 1.f : (float)mv);
+  }
+  return wm;
+}
+__device__ __forceinline__ long ms_level_offset(int l, int B, int C, int H, int W) {   // elements of levels 1 .. l-1
+  long off = 0;
+  for (int k = 1; k < l; ++k) off += (long)B * C * (H >> k) * (W >> k);
+  return off;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ms_loss_down_kernel(const float* __restrict__ noise, const T* __restrict__ nh,
+                                                           const int64_t* __restrict__ mask, const float* __restrict__ w,
+                                                           float* __restrict__ ws, float* __restrict__ losses, int B, int C, int H, int W,
+                                                           int Cpad, int nlevels, int l1, float lambda) {
+  __shared__ float s_part[4];
+  const int l = blockIdx.y + 1;
+  const int f = 1 << l, Hl = H >> l, Wl = W >> l;
+  const long total = (long)B * C * Hl * Wl;
+  float* out = ws + ms_level_offset(l, B, C, H, W);
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int J = i % Wl;
+    long r = i / Wl;
+    const int I = r % Hl;
+    r /= Hl;
+    const int c = r % C, b = r / C;
+    const int y0 = f * I + f / 2 - 1, x0 = f * J + f / 2 - 1;
+    float v = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const long pix = ((long)b * H + y0 + dy) * W + x0 + dx;
+        const float wm = ms_wm(mask, w, b, pix);
+        v += wm * noise[((long)b * C + c) * H * W + (long)(y0 + dy) * W + x0 + dx] - wm * to_f32(nh[pix * Cpad + c]);
+      }
+    v *= 0.25f;
+    out[i] = v;
+    acc += ms_g(v, l1);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  // weight of the level: min_res / (2 res) with min_res = 32, res = W / f   (loss.py:440-447,463-465)
+  if (threadIdx.x == 0) atomicAdd(losses + l, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)total * (16.0f * f / (float)W) * lambda);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ms_loss_grad_kernel(const float* __restrict__ noise, const T* __restrict__ nh,
+                                                           const int64_t* __restrict__ mask, const float* __restrict__ w,
+                                                           const float* __restrict__ ws, float* __restrict__ losses, T* __restrict__ dnh,
+                                                           int B, int C, int H, int W, int Cpad, int nlevels, int l1, int multiscale,
+                                                           float lambda, float grad_scale) {
+  __shared__ float s_part[4];
+  const long HW = (long)H * W, total = (long)B * HW;
+  const float c0 = (multiscale ? 16.0f / (float)W : 1.0f) * lambda / ((float)total * (float)C);
+  float acc = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int b = i / HW;
+    const long p = i % HW;
+    const int y = p / W, x = p % W;
+    const float wm = ms_wm(mask, w, b, i);
+    for (int c = 0; c < Cpad; ++c) {
+      float gout = 0.f;
+      if (c < C) {
+        const float d = wm * noise[((long)b * C + c) * HW + p] - wm * to_f32(nh[i * Cpad + c]);
+        acc += ms_g(d, l1);
+        float g = c0 * ms_dg(d, l1);
+        long off = 0;
+        for (int l = 1; l < nlevels; ++l) {
+          const int f = 1 << l, Hl = H >> l, Wl = W >> l;
+          const int ry = y & (f - 1), rx = x & (f - 1);
+          if ((ry == f / 2 - 1 || ry == f / 2) && (rx == f / 2 - 1 || rx == f / 2)) {
+            const float v = ws[off + (((long)b * C + c) * Hl + (y >> l)) * Wl + (x >> l)];
+            g += 0.25f * ms_dg(v, l1) * (16.0f * f / (float)W) * lambda / ((float)B * C * Hl * Wl);
+          }
+          off += (long)B * C * Hl * Wl;
+        }
+        gout = -wm * g * grad_scale;
+      }
+      if (dnh) dnh[i * Cpad + c] = from_f32<T>(gout);
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(losses, (s_part[0] + s_part[1] + s_part[2] + s_part[3]) * c0);
+}
+
 // ---- CUT / ResNet-generator glue (resnet_generator.py, discriminators.py) ------------------------------------
 // standalone activations on 16-byte vectors: y = act(x); backward from the OUTPUT y (tanh: 1 - y^2; (leaky) relu: the
 // sign of y is the sign of x)
@@ -943,6 +1044,26 @@ extern "C" int jg_lsgan_loss(int dtype, const void* pred, float target, float* l
   if (!pred || !loss || Npix < 1 || Cpad < 1) return JG_ERR_BAD_ARG;
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((lsgan_loss_kernel<T>), dim3(grid_for(Npix, 256, 256)), dim3(256), 0, (hipStream_t)s,
                                               (const T*)pred, target, loss, (T*)dpred, (long)Npix, Cpad, scale, grad_scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_ddpm_multiscale_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,
+                                       float* losses, void* dnh, float* ws, int B, int C, int H, int W, int Cpad, int nlevels, int l1,
+                                       int multiscale, float lambda, float grad_scale, jg_stream_t s) {
+  if (!noise || !noise_hat || !losses || Cpad < C || Cpad % 8 || nlevels < 1 || nlevels > 8) return JG_ERR_BAD_ARG;
+  if (nlevels > 1 && (!ws || !multiscale || (H & ((1 << (nlevels - 1)) - 1)) || (W & ((1 << (nlevels - 1)) - 1)) || H != W))
+    return JG_ERR_BAD_ARG;
+  const long total = (long)B * H * W;
+  hipStream_t st = (hipStream_t)s;
+  if (nlevels > 1) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ms_loss_down_kernel<T>), dim3(grid_for((long)B * C * (H / 2) * (W / 2), 256, 512), nlevels - 1),
+                                                dim3(256), 0, st, noise, (const T*)noise_hat, mask, w, ws, losses, B, C, H, W, Cpad, nlevels,
+                                                l1, lambda););
+  }
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ms_loss_grad_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, noise,
+                                              (const T*)noise_hat, mask, w, ws, losses, (T*)dnh, B, C, H, W, Cpad, nlevels, l1, multiscale,
+                                              lambda, grad_scale););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

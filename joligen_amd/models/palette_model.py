@@ -55,8 +55,8 @@ class PaletteModel(BaseModel):
             raise NotImplementedError(f"alg_diffusion_task={self.task!r} is outside the SURVEY.md 8 hot path")
         if opt.alg_diffusion_cond_image_creation != "y_t":
             raise NotImplementedError("only alg_diffusion_cond_image_creation='y_t' is implemented")
-        if opt.alg_palette_loss != "MSE":
-            raise NotImplementedError("only alg_palette_loss='MSE' has a fused loss kernel yet")
+        if opt.alg_palette_loss not in ("MSE", "L1", "multiscale_MSE", "multiscale_L1"):
+            raise NotImplementedError(f"alg_palette_loss={opt.alg_palette_loss!r}")
         if opt.alg_diffusion_dropout_prob > 0:
             raise NotImplementedError("alg_diffusion_dropout_prob > 0 (classifier-free guidance) is not implemented")
         if opt.G_nblocks == 9 and "resnet" not in opt.G_netG:
@@ -69,6 +69,11 @@ class PaletteModel(BaseModel):
                                                    weight_decay=opt.train_optim_weight_decay, eps=opt.train_optim_eps)
             self.optimizers.append(self.optimizer_G)
         self.loss_names_G = ["G_tot"]
+        if "multiscale" in opt.alg_palette_loss:      # palette_model.py:231-241
+            import math
+
+            S = opt.data_crop_size
+            self.loss_names_G += ["G_%d" % (2 ** k) for k in range(5, math.floor(math.log2(S)) + 1)] + ["G_%d" % S]
         self.loss_names = list(self.loss_names_G)
         self.group_G = NetworkGroup(networks_to_optimize=["G_A"], forward_functions=[],
                                     backward_functions=["compute_palette_loss"], loss_names_list=["loss_names_G"],
@@ -106,6 +111,9 @@ class PaletteModel(BaseModel):
         net = self._net("G_A")
         noise, noise_hat, min_snr_w, _ = net.forward_nhwc(y_0, y_cond, mask, noise, t, u)
         w = min_snr_w if self.opt.alg_palette_minsnr else None
-        loss = ops.ddpm_mse_loss(noise_hat, noise.float(), mask, w, lam=self.opt.alg_diffusion_lambda_G,
-                                 grad_scale=self.loss_scale)
+        loss, levels = ops.ddpm_loss(noise_hat, noise.float(), mask, w, lam=self.opt.alg_diffusion_lambda_G,
+                                     grad_scale=self.loss_scale, lossname=self.opt.alg_palette_loss)
+        lam = self.opt.alg_diffusion_lambda_G
+        for res, val in levels.items():          # palette_model.py:610-616: the per-resolution terms are logged before lambda_G
+            setattr(self, "loss_G_" + res, val / lam if lam not in (0, 1) else val)
         self.loss_G_tot = loss

@@ -926,6 +926,53 @@ def ddpm_mse_loss(noise_hat_nhwc, noise, mask, w=None, lam=1.0, grad_scale=1.0):
     return _MSELossFn.apply(noise_hat_nhwc, noise.contiguous(), m, wv, float(lam), float(grad_scale), noise.shape[1])
 
 
+class _MultiScaleLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, nh, noise, mask, w, lam, grad_scale, Cc, nlevels, l1, multiscale):
+        B, H, W, cpad = nh.shape
+        losses = torch.zeros(nlevels, device=nh.device, dtype=torch.float32)
+        dnh = torch.empty_like(nh)
+        nws = sum(B * Cc * (H >> l) * (W >> l) for l in range(1, nlevels))
+        ws = torch.empty(max(nws, 1), device=nh.device, dtype=torch.float32)
+        check(_lib.lib().jg_ddpm_multiscale_loss(_dt(nh), noise.data_ptr(), nh.data_ptr(), _p(mask), _p(w), losses.data_ptr(),
+                                                 dnh.data_ptr(), ws.data_ptr(), B, Cc, H, W, cpad, nlevels, int(l1), int(multiscale), lam,
+                                                 grad_scale, _st()), "jg_ddpm_multiscale_loss")
+        ctx.save_for_backward(dnh)
+        ctx.mark_non_differentiable(losses)
+        return losses.sum(), losses
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout, _g_levels):
+        (dnh,) = ctx.saved_tensors
+        return (axpby(dnh, 1.0, alpha_dev=gout.contiguous().float().reshape(1)),) + (None,) * 9
+
+
+def ddpm_loss(noise_hat_nhwc, noise, mask, w=None, lam=1.0, grad_scale=1.0, lossname="MSE", min_res=32):
+    """alg_palette_loss in {MSE, L1, multiscale_MSE, multiscale_L1} (palette_model.py:231-256,597-618): returns
+    (lambda * total, {resolution: lambda * term}) -- the per-resolution terms only for the multiscale variants."""
+    if lossname == "MSE":
+        return ddpm_mse_loss(noise_hat_nhwc, noise, mask, w, lam, grad_scale), {}
+    m = None
+    if mask is not None:
+        m = mask.contiguous()
+        if m.dtype != torch.int64:
+            m = m.long()
+    wv = None if w is None else w.reshape(-1).contiguous().float()
+    S = noise_hat_nhwc.shape[1]
+    multiscale = lossname.startswith("multiscale")
+    if min_res != 32:
+        raise NotImplementedError("MultiScaleDiffusionLoss.min_res is 32 in the reference")
+    nlevels = 1
+    if multiscale:
+        import math
+
+        nlevels = max(1, math.floor(math.log2(S)) - 5 + 1)        # resolutions 32 .. S (loss.py:406-409, palette_model.py:232-241)
+    tot, levels = _MultiScaleLossFn.apply(noise_hat_nhwc, noise.contiguous(), m, wv, float(lam), float(grad_scale), noise.shape[1],
+                                          nlevels, lossname.endswith("L1"), multiscale)
+    return tot, ({str(S >> l): levels[l] for l in range(nlevels)} if multiscale else {})
+
+
 # ======================================================================================
 # consistency-model glue (cm_generator.py / cm_model.py of the reference)
 # ======================================================================================

@@ -217,6 +217,45 @@ def test_first_step_gradients_vs_oracle_medium(golden_dir, dtype_name):
     assert med < 1.5e-2, med
 
 
+@pytest.mark.parametrize("lossname", ["L1", "multiscale_L1", "multiscale_MSE"])
+def test_palette_loss_variants_first_step_vs_oracle(golden_dir, lossname):
+    """alg_palette_loss != MSE through the model API (64x64 so that two resolutions exist): total loss, the logged per-resolution
+    terms and the parameter gradients of the first step against the CPU oracle."""
+    c = dict(ngf=32, mults=[1, 2], res_blocks=[1, 1], attn_res=[16], efficient=True, S=64, B=2)
+    model = make_model(c, "fp16", golden_dir, train_G_ema=False, alg_palette_loss=lossname, alg_diffusion_lambda_G=2.0)
+    net = model.netG_A
+    g = torch.Generator().manual_seed(6)
+    Bimg = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    mask = torch.zeros(2, 1, 64, 64, dtype=torch.int64)
+    mask[:, :, 8:44, 16:56] = 1
+    A = Bimg * (1 - mask) + torch.randn(2, 3, 64, 64, generator=g) * mask
+    t, u, noise = O.draw_step_randomness(torch.Generator().manual_seed(10), Bimg, 2000)
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    tr = O.OraclePaletteTrainer(sd, cfg_of(c), ema_beta=None, lambda_G=2.0, lossname=lossname)
+    loss_ref, grads_ref, nh_ref = tr.loss_and_grads(Bimg, A, mask, noise, t, u)
+    model.rng_injection = lambda b: (t, u, noise)
+    model.set_input({"A": A, "B": Bimg, "B_label_mask": mask})
+    model.compute_palette_loss()
+    model.loss_G_tot.backward()
+    torch.cuda.synchronize()
+    assert abs(float(model.loss_G_tot) - float(loss_ref)) < 5e-3 * float(loss_ref), (float(model.loss_G_tot), float(loss_ref))
+    if lossname.startswith("multiscale"):
+        _, lev = O.palette_loss_variants(noise, nh_ref, mask, lossname)
+        assert model.loss_names_G == ["G_tot", "G_32", "G_64", "G_64"]
+        for k, v in lev.items():
+            assert abs(float(getattr(model, "loss_G_" + k)) - float(v)) < 5e-3 * float(v), k
+    ref_norms = {k: float(v.norm()) for k, v in grads_ref.items()}
+    errs = []
+    for k, p in net.named_parameters():
+        gr = grads_ref[k]
+        mine = (p.grad / model.loss_scale).detach().float().cpu()
+        errs.append((float((mine - gr).norm() / (gr.norm() + noise_floor(k, ref_norms, torch.float16) + 1e-12)), k))
+    errs.sort(reverse=True)
+    # L1's sign() gradient flips wherever the 16-bit prediction error crosses zero: looser than the MSE bound
+    assert errs[0][0] < (0.2 if lossname.endswith("L1") else 6e-2), errs[:6]
+    assert sorted(e for e, _ in errs)[len(errs) // 2] < (6e-2 if lossname.endswith("L1") else 1.5e-2)
+
+
 def test_checkpoint_roundtrip_reference_layout(golden_dir, tmp_path):
     """save_networks writes `<suffix>_net_G_A.pth` with the reference's keys, plain contiguous
     fp32 tensors in the reference's logical (OIHW) layout, loadable by both sides."""

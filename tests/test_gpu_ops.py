@@ -555,3 +555,42 @@ def test_reflect_conv_unsupported_shape_is_refused():
     assert not ops.reflect_conv_ok(x, m.c.meta)
     with pytest.raises(RuntimeError, match="jg_conv2d_nt"):
         ops.reflect_conv2d(x, m.c.meta)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("lossname", ["L1", "multiscale_L1", "multiscale_MSE"])
+def test_ddpm_loss_variants_vs_reference_golden(golden_dir, lossname, dtype):
+    """alg_palette_loss in {L1, multiscale_L1, multiscale_MSE}: value, per-resolution terms and gradient against the fixtures recorded
+    from the reference's nn.L1Loss / MultiScaleDiffusionLoss and against the oracle on the 16-bit-rounded prediction."""
+    import os
+
+    import jg_oracle as O
+    from joligen_amd import ops
+
+    G = torch.load(os.path.join(golden_dir, "palette_loss.pt"), weights_only=False)
+    d = dev()
+    for S in (128, 64, 32):
+        inp = O.palette_loss_inputs(S, G[("inputs", S)]["B"])
+        nh16 = inp["noise_hat"].to(dtype)
+        for use_mask in (True, False):
+            for use_w in (False, True):
+                r = G[(S, lossname, use_mask, use_w)]
+                nhd = nhwc(nh16).to(d)
+                nhd = torch.cat([nhd, torch.zeros(*nhd.shape[:3], 5, dtype=dtype, device=d)], -1).contiguous().requires_grad_(True)
+                mask = inp["mask"].to(d) if use_mask else None
+                w = inp["w"].to(d) if use_w else None
+                loss, levels = ops.ddpm_loss(nhd, inp["noise"].to(d), mask, w, lam=1.0, grad_scale=256.0, lossname=lossname)
+                loss.backward()
+                torch.cuda.synchronize()
+                nhr = nh16.float().requires_grad_(True)
+                lo, lev_o = O.palette_loss_variants(inp["noise"], nhr, inp["mask"] if use_mask else None, lossname, inp["w"] if use_w else 1.0)
+                lo.backward()
+                assert abs(float(loss) - float(lo)) < 2e-5 * abs(float(lo)) + 1e-8, (S, use_mask, use_w, float(loss), float(lo))
+                assert sorted(levels) == sorted(lev_o) == sorted(r["levels"])
+                for k in lev_o:
+                    assert abs(float(levels[k]) - float(lev_o[k])) < 2e-5 * abs(float(lev_o[k])) + 1e-9, (S, k)
+                gd = nhd.grad[..., :3].permute(0, 3, 1, 2).float().cpu() / 256.0
+                assert relerr(gd, nhr.grad) < TOL[dtype], (S, use_mask, use_w, relerr(gd, nhr.grad))
+                assert float(nhd.grad[..., 3:].float().abs().max()) == 0.0
+                # against the reference's numbers (unrounded prediction): only the 16-bit rounding of noise_hat in between
+                assert abs(float(loss) - float(r["loss"])) < (2e-3 if dtype == torch.float16 else 1e-2) * abs(float(r["loss"]))

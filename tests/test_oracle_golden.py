@@ -340,3 +340,25 @@ def test_torch_cpu_instance_norm_channels_last_backward():
         assert abs(float(mine[i]) - f) < 1e-6 * max(1.0, abs(f)), (i, float(mine[i]), f)
     stock_err = max(abs(float(stock[i]) - f) for i, f in zip(idx, fd))
     print("stock CPU instance_norm backward, channels-last grad: max abs error vs finite differences =", stock_err)
+
+
+def test_palette_loss_variants(golden_dir):
+    """L1 / multiscale_L1 / multiscale_MSE (reference nn.L1Loss and MultiScaleDiffusionLoss called as palette_model.py:597-618 does)"""
+    g = load(golden_dir, "palette_loss.pt")
+    for key, r in g.items():
+        if key[0] == "inputs":
+            continue
+        S, lossname, use_mask, use_w = key
+        inp = O.palette_loss_inputs(S, g[("inputs", S)]["B"])
+        assert abs(float(inp["noise_hat"].double().sum()) - g[("inputs", S)]["check"]) < 1e-6
+        nh = inp["noise_hat"].clone().requires_grad_(True)
+        loss, levels = O.palette_loss_variants(inp["noise"], nh, inp["mask"] if use_mask else None, lossname, inp["w"] if use_w else 1.0)
+        torch.testing.assert_close(loss, r["loss"], rtol=1e-5, atol=1e-7)
+        assert sorted(levels) == sorted(r["levels"])
+        for k, v in r["levels"].items():
+            torch.testing.assert_close(levels[k], v, rtol=1e-5, atol=1e-8)
+        (gr,) = torch.autograd.grad(loss, nh)
+        chk = torch.stack([gr.norm(), (gr * O.projection_vector("palette_loss_grad", gr.shape)).sum()])
+        torch.testing.assert_close(chk, r["grad_check"], rtol=1e-4, atol=1e-7)
+        if "grad" in r:
+            torch.testing.assert_close(gr, r["grad"], rtol=1e-5, atol=1e-9)
