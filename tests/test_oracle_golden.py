@@ -362,3 +362,29 @@ def test_palette_loss_variants(golden_dir):
         torch.testing.assert_close(chk, r["grad_check"], rtol=1e-4, atol=1e-7)
         if "grad" in r:
             torch.testing.assert_close(gr, r["grad"], rtol=1e-5, atol=1e-9)
+
+
+# ---- SegFormer attention generator (a19): oracle/make_golden_segformer.py fixtures (unmodified reference, train mode) ----------
+@pytest.mark.parametrize("name", ["s64", "s128"])
+def test_segformer_generator(golden_dir, name):
+    g = load(golden_dir, f"segformer_{name}.pt")
+    sd = O.synth_state_dict({k: torch.empty(g["shapes"][k]) for k in g["keys"]}, 4)
+    P = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = g["x"].clone().requires_grad_(True)
+    bn = {}
+    out, _ = O.segformer_generator_attn(P, x, rand=iter(g["rands"][: g["n_fwd"]]), bn_state=bn)
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+    for k, v in bn.items():                       # one training forward updated the BatchNorm running statistics
+        torch.testing.assert_close(v, g["bn_after"][k], rtol=1e-4, atol=1e-6)
+    assert int(g["bn_after"]["final_conv.model.1.num_batches_tracked"]) == 1
+    (out * g["R"]).sum().backward()
+    torch.testing.assert_close(x.grad, g["dx"], rtol=2e-3, atol=1e-5)
+    _chk({k: v.grad for k, v in P.items()}, g["grad_checks"], 2e-3, "segformer ")
+    with torch.no_grad():
+        feats = O.segformer_backbone(sd, g["x"], rand=iter(g["rands"][g["n_fwd"]:]))
+        for a, b in zip(feats, g["feats"]):
+            torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+        sd_eval = dict(sd)
+        sd_eval.update({k: v for k, v in g["bn_after"].items()})
+        out_eval, _ = O.segformer_generator_attn(sd_eval, g["x"], rand=None)
+        torch.testing.assert_close(out_eval, g["out_eval"], rtol=1e-4, atol=1e-5)
