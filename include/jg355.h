@@ -277,6 +277,49 @@ int jg_nce_ce(const float* S, const float* u, int64_t ustride, const float* v, i
 int jg_nce_sinkhorn_bwd(const float* K, const float* u_hist, const float* v_hist, float* gW, float* ds_hist, float* dr_hist,
                         float* dS, int nimg, int P, int niter, jg_stream_t s);
 
+/* ---- SegFormer attention generator (G_netG = segformer_attn_conv; models/modules/segformer/, attn_network.py) -------------------
+ * Token sequences [B, N, C] are the NHWC maps [B, H, W, C]; C % 8 == 0.
+ *   layernorm_fwd/bwd : nn.LayerNorm(C, eps) of backbone.py:382,402,503,601 (mr[R][2] = mean, rstd saved for the backward;
+ *                       dgamma / dbeta accumulate)
+ *   dwconv3x3_fwd/bwd : MixFFN's depth-wise positional conv + the nn.GELU() behind it (backbone.py:59-77); `pre` keeps the
+ *                       pre-activation; bwd writes du = dy gelu'(pre), dx, and accumulates dw[C][9], dbias
+ *   attn_smallkv_*    : the softmax(q k^T / sqrt(d)) v core of nn.MultiheadAttention as used by EfficientMultiheadAttention
+ *                       (backbone.py:293-313): head dim 32, T_kv <= 256 spatially-reduced keys / values resident in LDS;
+ *                       q / o rows of stride ldq / ldo, k and v rows of stride ldkv (views into a packed projection);
+ *                       bwd needs fp32 scratch dkf / dvf [B][Tkv][heads*32] and writes 16-bit dk / dv of that shape
+ *   bilinear_fwd/bwd  : F.interpolate(mode="bilinear", align_corners=False) of SegformerHead.forward (segformer_head.py:166-174),
+ *                       written into a channel slice (row stride ldy) of the concat buffer; bwd for up-sampling
+ *   bn_coef/bn_bwd_coef: nn.BatchNorm2d of the ResnetDecoder tail (default norm_layer, segformer_generator.py:135-140) on top of
+ *                       the per-(image, channel) sums of jg_gn_stats / jg_gn_bwd_reduce: they fill the ab / pqr coefficient
+ *                       tables that jg_gn_apply / jg_gn_bwd_apply consume; training also updates the running statistics
+ *   attn_compose_*    : BaseGenerator_attn.forward (attn_network.py:14-46): softmax over the `na` attention logits of every f x f
+ *                       cell, out = sum_{i < ni} img[nc i .. nc i + nc) a_i + xin sum_{i >= ni} a_i
+ *   jg_scale          : y = x * s (+ res): DropPath (s[B], backbone.py:700-712) / Dropout2d (s[B][C], decode_head.py:181-186) */
+int jg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mr, int64_t R, int C, float eps,
+                     jg_stream_t s);
+int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, void* dx, float* dgamma, float* dbeta,
+                     int64_t R, int C, jg_stream_t s);
+int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C, int gelu,
+                     jg_stream_t s);
+int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw, float* dbias,
+                     int B, int H, int W, int C, int gelu, jg_stream_t s);
+int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tkv, int heads,
+                        int64_t ldq, int64_t ldkv, int64_t ldo, float scale, jg_stream_t s);
+int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                        float* dkf, float* dvf, void* dk, void* dv, int B, int Tq, int Tkv, int heads, int64_t ldq, int64_t ldkv, int64_t ldo,
+                        float scale, jg_stream_t s);
+int jg_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, jg_stream_t s);
+int jg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, jg_stream_t s);
+int jg_bn_coef(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* ab, float* mr, int B,
+               int HW, int C, float eps, float momentum, int training, jg_stream_t s);
+int jg_bn_bwd_coef(const float* red, const float* gamma, const float* mr, float* pqr, float* dgamma, float* dbeta, int B, int HW, int C,
+                   int training, jg_stream_t s);
+int jg_attn_compose_fwd(int dtype, const void* img, const void* logits, const void* xin, void* out, int B, int S, int f, int na, int ni, int nc,
+                        int ldimg, int ldl, int ldx, int ldo, jg_stream_t s);
+int jg_attn_compose_bwd(int dtype, const void* img, const void* logits, const void* xin, const void* dout, void* dimg, void* dlogits, void* dxin,
+                        int B, int S, int f, int na, int ni, int nc, int ldimg, int ldl, int ldx, int ldo, jg_stream_t s);
+int jg_scale(int dtype, const void* x, const float* scale, const void* res, void* y, int B, int64_t HW, int C, int per_channel, jg_stream_t s);
+
 /* One DDPM ancestral sampling step after the UNet (DiffusionGenerator.p_sample / p_mean_variance, restoration_ddpm:
  * models/modules/diffusion_generator.py:187-284, predict_start_from_noise / q_posterior: diffusion_utils.py:122-137):
  *   y0_hat = clamp(sr*y_t - srm1*noise_hat, -1, 1);  y' = c1*y0_hat + c2*y_t + z*sigma;  y' = y_0*(1-m) + m*y'

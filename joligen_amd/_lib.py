@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libjg355.so")
-SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "gemm_tn.hip", "wgrad_halo.hip", "nce.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
+SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "gemm_tn.hip", "wgrad_halo.hip", "nce.hip", "segformer.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 JG_F16, JG_BF16 = 0, 1
@@ -101,6 +101,20 @@ SIGNATURES = {
     "jg_nce_sinkhorn_fwd": [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_nce_ce": [c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i32, c_i32, c_f32, c_f32, c_p, c_p, c_f32, c_p],
     "jg_nce_sinkhorn_bwd": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p],
+    "jg_layernorm_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
+    "jg_layernorm_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p],
+    "jg_dwconv3x3_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_dwconv3x3_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_attn_smallkv_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f32, c_p],
+    "jg_attn_smallkv_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64,
+                            c_f32, c_p],
+    "jg_bilinear_fwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_p],
+    "jg_bilinear_bwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_p],
+    "jg_bn_coef": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p],
+    "jg_bn_bwd_coef": [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_attn_compose_fwd": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_attn_compose_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_scale": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p],
     "jg_ddpm_p_sample": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_cm_noisy": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_cm_combine": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],

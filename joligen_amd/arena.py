@@ -83,13 +83,14 @@ class ParamArena:
         n16 = n16t = 0
         desc = []
         for name, conv in convs:
-            cout, cin = conv.weight.shape[0], conv.weight.shape[1]
-            rs = conv.weight.numel() // (cout * cin)
+            wt = getattr(conv, conv.jg_wname)
+            cout, cin = wt.shape[0], wt.shape[1]
+            rs = wt.numel() // (cout * cin)
             R = S = int(round(rs ** 0.5))
             assert R * S == rs
             coutp, cinp = _pad8(cout), _pad8(cin)
             size = coutp * rs * cinp
-            off, _ = self.slices[name + ".weight"]
+            off, _ = self.slices[(name + "." if name else "") + conv.jg_wname]
             dst, dstT = n16, (n16t if conv.needs_dgrad else -1)
             desc.append([off, dst, dstT, cout, rs, cin, coutp, cinp])
             n16 += size
@@ -107,11 +108,11 @@ class ParamArena:
             m.R, m.S, m.pad, m.stride = R, S, conv.jg_padding, conv.jg_stride
             m.w16 = self.w16[dst:dst + coutp * rs * cinp].view(coutp, R, S, cinp)
             m.w16T = self.w16T[dstT:dstT + coutp * rs * cinp].view(cinp, R, S, coutp) if dstT >= 0 else None
-            m.weight, m.bias = conv.weight, conv.bias
+            m.weight, m.bias = getattr(conv, conv.jg_wname), getattr(conv, conv.jg_bname)
             m.bias_pad = None
-            if conv.bias is not None and coutp != cout:
+            if m.bias is not None and coutp != cout:
                 m.bias_pad = torch.zeros(coutp, **f32)
-                self._bias_pads.append((m.bias_pad, conv.bias, cout))
+                self._bias_pads.append((m.bias_pad, m.bias, cout))
             conv.meta = m
         self.dirty = True
         module._jg_arena = self

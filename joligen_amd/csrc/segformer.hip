@@ -1,0 +1,806 @@
+// Kernels of the SegFormer attention generator (models/modules/segformer/*.py, attn_network.py), NHWC 16-bit
+// activations (a token sequence [B, N, C] IS the NHWC map [B, H, W, C]), fp32 parameters and statistics:
+//   layernorm fwd/bwd        nn.LayerNorm(C, eps 1e-6) over the channel row of every token          HBM-bound, one pass each
+//   dwconv3x3(+GELU) fwd/bwd the positional depth-wise conv of MixFFN with the following nn.GELU()    HBM-bound
+//   attn_smallkv fwd/bwd     nn.MultiheadAttention core with the spatially-reduced key/value set (T_kv <= 256, head dim 32)
+//   bilinear fwd/bwd         F.interpolate(mode="bilinear", align_corners=False) written straight into the concat buffer
+//   bn_coef / bn_bwd_coef    nn.BatchNorm2d on top of the (b, c) sums of the GroupNorm kernels (ResnetDecoder tail)
+//   attn_compose fwd/bwd     10-way softmax attention x (9 generated images | input) blend of BaseGenerator_attn
+//   scale_rows / scale_bc    DropPath (per sample) and Dropout2d (per sample and channel) as multiplications by given factors
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+  long g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+}
+
+// ---- LayerNorm over C (multiple of 8, <= 512): LPR lanes per row, 64 / LPR rows per wave ---------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mr,
+                                                            long R, int C, int lpr, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % lpr, rsub = lane / lpr, rpw = 64 / lpr;
+  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwaves = gridDim.x * 4L;
+  const bool act = sub * 8 < C;
+  float g[8], bt[8];
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      g[j] = gamma[sub * 8 + j];
+      bt[j] = beta[sub * 8 + j];
+    }
+  }
+  for (long r0 = wave * rpw; r0 < R; r0 += nwaves * rpw) {
+    const long row = r0 + rsub;
+    const bool ok = act && row < R;
+    float f[8];
+    float s = 0.f, ss = 0.f;
+    if (ok) {
+      unpack8<T>(*reinterpret_cast<const uint4*>(x + row * C + sub * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += f[j];
+    }
+    for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = f[j] - mean;
+        ss += d * d;
+      }
+    }
+    for (int o = 1; o < lpr; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss / (float)C + eps);
+    if (ok) {
+      float o8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = (f[j] - mean) * rstd * g[j] + bt[j];
+      *reinterpret_cast<uint4*>(y + row * C + sub * 8) = pack8<T>(o8);
+      if (sub == 0 && mr) {
+        mr[row * 2] = mean;
+        mr[row * 2 + 1] = rstd;
+      }
+    }
+  }
+}
+
+// dx = rstd (g - mean(g) - xh mean(g xh)),  g = dy gamma,  xh = (x - mean) rstd;  dgamma += sum dy xh;  dbeta += sum dy
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mr, T* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, long R, int C, int lpr) {
+  __shared__ float s_red[2][512];
+  const int lane = threadIdx.x & 63;
+  const int sub = lane % lpr, rsub = lane / lpr, rpw = 64 / lpr;
+  const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwaves = gridDim.x * 4L;
+  const bool act = sub * 8 < C;
+  float g[8], ag[8], ab[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    g[j] = act ? gamma[sub * 8 + j] : 0.f;
+    ag[j] = ab[j] = 0.f;
+  }
+  for (long r0 = wave * rpw; r0 < R; r0 += nwaves * rpw) {
+    const long row = r0 + rsub;
+    const bool ok = act && row < R;
+    float xh[8], gy[8], d8[8];
+    float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 0.f;
+    if (ok) {
+      float f[8];
+      unpack8<T>(*reinterpret_cast<const uint4*>(x + row * C + sub * 8), f);
+      unpack8<T>(*reinterpret_cast<const uint4*>(dy + row * C + sub * 8), d8);
+      mean = mr[row * 2];
+      rstd = mr[row * 2 + 1];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        xh[j] = (f[j] - mean) * rstd;
+        gy[j] = d8[j] * g[j];
+        s1 += gy[j];
+        s2 += gy[j] * xh[j];
+        ag[j] += d8[j] * xh[j];
+        ab[j] += d8[j];
+      }
+    }
+    for (int o = 1; o < lpr; o <<= 1) {
+      s1 += __shfl_xor(s1, o);
+      s2 += __shfl_xor(s2, o);
+    }
+    if (ok && dx) {
+      const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+      float o8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = rstd * (gy[j] - m1 - xh[j] * m2);
+      *reinterpret_cast<uint4*>(dx + row * C + sub * 8) = pack8<T>(o8);
+    }
+  }
+  if (!dgamma) return;
+  // per-channel partials of the block: lanes with the same `sub` (over rows-in-wave and the 4 waves) add up in LDS
+  for (int i = threadIdx.x; i < 1024; i += 256) (&s_red[0][0])[i] = 0.f;
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      atomicAdd(&s_red[0][sub * 8 + j], ag[j]);
+      atomicAdd(&s_red[1][sub * 8 + j], ab[j]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, s_red[0][c]);
+    atomicAdd(dbeta + c, s_red[1][c]);
+  }
+}
+
+// ---- depth-wise 3x3 (pad 1) + bias (+ GELU): thread per (pixel, 8 channels) ---------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            T* __restrict__ pre, T* __restrict__ y, int B, int H, int W, int C, int gelu) {
+  const int c8n = C >> 3;
+  const long total = (long)B * H * W * c8n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = i % c8n;
+    const long p = i / c8n;
+    const int px = p % W, py = (p / W) % H;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c8 * 8 + j] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int iy = py + r - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ix = px + s - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(x + (p + (long)(r - 1) * W + (s - 1)) * C + c8 * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j] * w[(c8 * 8 + j) * 9 + r * 3 + s];
+      }
+    }
+    if (pre) *reinterpret_cast<uint4*>(pre + p * C + c8 * 8) = pack8<T>(acc);
+    if (gelu) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = gelu_f(acc[j]);
+    }
+    *reinterpret_cast<uint4*>(y + p * C + c8 * 8) = pack8<T>(acc);
+  }
+}
+
+// du = dy gelu'(pre) (written to `du`), dbias += sum du, dw[c][tap] += sum_p du[p][c] x[p + tap][c]; each thread keeps ONE channel
+// chunk and strides over pixels, block partials through LDS, one atomic per (channel, tap) per block
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restrict__ x, const T* __restrict__ pre, const T* __restrict__ dy,
+                                                              T* __restrict__ du, float* __restrict__ dw, float* __restrict__ dbias, int B,
+                                                              int H, int W, int C, int gelu) {
+  extern __shared__ float s_acc[];   // [c8n * 8][10]
+  const int c8n = C >> 3;
+  const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;          // pixel lanes per block (c8n <= 256)
+  const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
+  const bool act = pl < tpb;
+  float aw[8][9], ab[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ab[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) aw[j][t] = 0.f;
+  }
+  const long npix = (long)B * H * W;
+  if (act) {
+    for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb) {
+      const int px = p % W, py = (p / W) % H;
+      float d[8];
+      unpack8<T>(*reinterpret_cast<const uint4*>(dy + p * C + c8 * 8), d);
+      if (gelu) {
+        float q[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(pre + p * C + c8 * 8), q);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] *= gelu_grad_f(q[j]);
+      }
+      if (du) *reinterpret_cast<uint4*>(du + p * C + c8 * 8) = pack8<T>(d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ab[j] += d[j];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int iy = py + r - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const int ix = px + s - 1;
+          if ((unsigned)ix >= (unsigned)W) continue;
+          float f[8];
+          unpack8<T>(*reinterpret_cast<const uint4*>(x + (p + (long)(r - 1) * W + (s - 1)) * C + c8 * 8), f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) aw[j][r * 3 + s] += d[j] * f[j];
+        }
+      }
+    }
+  }
+  for (int i = threadIdx.x; i < C * 10; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  if (act) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(&s_acc[(c8 * 8 + j) * 10 + t], aw[j][t]);
+      atomicAdd(&s_acc[(c8 * 8 + j) * 10 + 9], ab[j]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * 10; i += 256) {
+    const int c = i / 10, t = i % 10;
+    if (t < 9) {
+      if (dw) atomicAdd(dw + c * 9 + t, s_acc[i]);
+    } else if (dbias) atomicAdd(dbias + c, s_acc[i]);
+  }
+}
+
+// dx[p][c] = sum_taps du[p - tap][c] w[c][tap]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3x3_bwd_x_kernel(const T* __restrict__ du, const float* __restrict__ w, T* __restrict__ dx, int B,
+                                                              int H, int W, int C) {
+  const int c8n = C >> 3;
+  const long total = (long)B * H * W * c8n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = i % c8n;
+    const long p = i / c8n;
+    const int px = p % W, py = (p / W) % H;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int oy = py - (r - 1);
+      if ((unsigned)oy >= (unsigned)H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int ox = px - (s - 1);
+        if ((unsigned)ox >= (unsigned)W) continue;
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(du + (p - (long)(r - 1) * W - (s - 1)) * C + c8 * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j] * w[(c8 * 8 + j) * 9 + r * 3 + s];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + p * C + c8 * 8) = pack8<T>(acc);
+  }
+}
+
+// ---- attention with a small key/value set (head dim 32): block = (64 queries, head, image), K/V of the head in LDS ----------
+constexpr int AKV_MAX = 256;
+template <typename T, int KVMAX>
+__global__ __launch_bounds__(64) void attn_smallkv_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                              T* __restrict__ o, float* __restrict__ lse, int Tq, int Tkv, int heads, long ldq,
+                                                              long ldkv, long ldo, float scale) {
+  __shared__ float s_k[KVMAX][33], s_v[KVMAX][33];
+  const int h = blockIdx.y, b = blockIdx.z, t = threadIdx.x;
+  for (int i = t; i < Tkv * 4; i += 64) {
+    const int j = i >> 2, c = (i & 3) * 8;
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(k + ((long)b * Tkv + j) * ldkv + h * 32 + c), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_k[j][c + e] = f[e];
+    unpack8<T>(*reinterpret_cast<const uint4*>(v + ((long)b * Tkv + j) * ldkv + h * 32 + c), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_v[j][c + e] = f[e];
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * 64 + t;
+  if (qi >= Tq) return;
+  float qv[32];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) unpack8<T>(*reinterpret_cast<const uint4*>(q + ((long)b * Tq + qi) * ldq + h * 32 + c * 8), qv + c * 8);
+  float m = -3.0e38f;
+  for (int j = 0; j < Tkv; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s += qv[c] * s_k[j][c];
+    m = fmaxf(m, s * scale);
+  }
+  float l = 0.f, acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+  for (int j = 0; j < Tkv; ++j) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) s += qv[c] * s_k[j][c];
+    const float p = expf(s * scale - m);
+    l += p;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) acc[c] += p * s_v[j][c];
+  }
+  const float inv = 1.0f / l;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] *= inv;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(o + ((long)b * Tq + qi) * ldo + h * 32 + c * 8) = pack8<T>(acc + c * 8);
+  if (lse) lse[((long)b * heads + h) * Tq + qi] = m + logf(l);
+}
+
+// dq per query thread; dk / dv summed over the 64 queries of the block in LDS, then fp32 atomics into dkf / dvf [B][Tkv][heads*32]
+template <typename T, int KVMAX>
+__global__ __launch_bounds__(64) void attn_smallkv_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                              const T* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                              T* __restrict__ dq, float* __restrict__ dkf, float* __restrict__ dvf, int Tq, int Tkv,
+                                                              int heads, long ldq, long ldkv, long ldo, float scale) {
+  __shared__ float s_k[AKV_MAX][33], s_v[AKV_MAX][33];
+  __shared__ float s_dk[64][33], s_dv[64][33];     // one 64-key slab of the gradients at a time
+  const int h = blockIdx.y, b = blockIdx.z, t = threadIdx.x;
+  for (int i = t; i < Tkv * 4; i += 64) {
+    const int j = i >> 2, c = (i & 3) * 8;
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(k + ((long)b * Tkv + j) * ldkv + h * 32 + c), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_k[j][c + e] = f[e];
+    unpack8<T>(*reinterpret_cast<const uint4*>(v + ((long)b * Tkv + j) * ldkv + h * 32 + c), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_v[j][c + e] = f[e];
+  }
+  const int qi = blockIdx.x * 64 + t;
+  const bool ok = qi < Tq;
+  float qv[32], dov[32], dqv[32];
+  float D = 0.f, L = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) qv[c] = dov[c] = dqv[c] = 0.f;
+  if (ok) {
+    float ov[32];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unpack8<T>(*reinterpret_cast<const uint4*>(q + ((long)b * Tq + qi) * ldq + h * 32 + c * 8), qv + c * 8);
+      unpack8<T>(*reinterpret_cast<const uint4*>(dout + ((long)b * Tq + qi) * ldo + h * 32 + c * 8), dov + c * 8);
+      unpack8<T>(*reinterpret_cast<const uint4*>(o + ((long)b * Tq + qi) * ldo + h * 32 + c * 8), ov + c * 8);
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) D += dov[c] * ov[c];
+    L = lse[((long)b * heads + h) * Tq + qi];
+  }
+  const int H32 = heads * 32;
+  for (int j0 = 0; j0 < Tkv; j0 += 64) {
+    __syncthreads();
+    for (int i = t; i < 64 * 33; i += 64) {
+      (&s_dk[0][0])[i] = 0.f;
+      (&s_dv[0][0])[i] = 0.f;
+    }
+    __syncthreads();
+    if (ok) {
+      const int jn = min(64, Tkv - j0);
+      for (int jj = 0; jj < jn; ++jj) {
+        const int j = j0 + ((jj + t) % jn);          // stagger the key order across threads: fewer LDS atomic collisions
+        float s = 0.f, dp = 0.f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          s += qv[c] * s_k[j][c];
+          dp += dov[c] * s_v[j][c];
+        }
+        const float p = expf(s * scale - L);
+        const float ds = p * (dp - D) * scale;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+          dqv[c] += ds * s_k[j][c];
+          atomicAdd(&s_dk[j - j0][c], ds * qv[c]);
+          atomicAdd(&s_dv[j - j0][c], p * dov[c]);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = t; i < 64 * 32; i += 64) {
+      const int j = i >> 5, c = i & 31;
+      if (j0 + j < Tkv) {
+        atomicAdd(dkf + ((long)b * Tkv + j0 + j) * H32 + h * 32 + c, s_dk[j][c]);
+        atomicAdd(dvf + ((long)b * Tkv + j0 + j) * H32 + h * 32 + c, s_dv[j][c]);
+      }
+    }
+  }
+  if (ok) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(dq + ((long)b * Tq + qi) * ldq + h * 32 + c * 8) = pack8<T>(dqv + c * 8);
+  }
+}
+
+// ---- bilinear resize, align_corners = False (aten upsample_bilinear2d): src = (dst + 0.5) * in / out - 0.5, clamped at 0 ------------
+__device__ __forceinline__ void bil_coord(int o, int in, int out, int& i0, int& i1, float& w1) {
+  float s = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+  s = s < 0.f ? 0.f : s;
+  i0 = (int)s;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = s - (float)i0;
+}
+template <typename T>
+__global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo, long ldy) {
+  const int c8n = C >> 3;
+  const long total = (long)B * Ho * Wo * c8n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = i % c8n;
+    long p = i / c8n;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho, b = p / Ho;
+    int y0, y1, x0, x1;
+    float wy, wx;
+    bil_coord(oy, H, Ho, y0, y1, wy);
+    bil_coord(ox, W, Wo, x0, x1, wx);
+    float a[8], bq[8], c[8], d[8], o8[8];
+    const T* xb = x + (long)b * H * W * C + c8 * 8;
+    unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y0 * W + x0) * C), a);
+    unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y0 * W + x1) * C), bq);
+    unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y1 * W + x0) * C), c);
+    unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y1 * W + x1) * C), d);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o8[j] = (1.f - wy) * ((1.f - wx) * a[j] + wx * bq[j]) + wy * ((1.f - wx) * c[j] + wx * d[j]);
+    *reinterpret_cast<uint4*>(y + (((long)b * Ho + oy) * Wo + ox) * ldy + c8 * 8) = pack8<T>(o8);
+  }
+}
+// adjoint as a gather: an input pixel collects from the output pixels whose two source rows / columns include it
+template <typename T>
+__global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, long lddy) {
+  const int c8n = C >> 3;
+  const long total = (long)B * H * W * c8n;
+  const int fy = (Ho + H - 1) / H, fx = (Wo + W - 1) / W;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = i % c8n;
+    long p = i / c8n;
+    const int ix = p % W;
+    p /= W;
+    const int iy = p % H, b = p / H;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    const int oy_lo = max(0, (iy - 1) * fy), oy_hi = min(Ho - 1, (iy + 2) * fy);
+    const int ox_lo = max(0, (ix - 1) * fx), ox_hi = min(Wo - 1, (ix + 2) * fx);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1;
+      float wy;
+      bil_coord(oy, H, Ho, y0, y1, wy);
+      const float ky = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+      if (ky == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1;
+        float wx;
+        bil_coord(ox, W, Wo, x0, x1, wx);
+        const float kx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+        if (kx == 0.f) continue;
+        float f[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(dy + (((long)b * Ho + oy) * Wo + ox) * lddy + c8 * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += ky * kx * f[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(dx + (((long)b * H + iy) * W + ix) * C + c8 * 8) = pack8<T>(acc);
+  }
+}
+
+// ---- BatchNorm2d coefficients from the per-(image, channel) sums of jg_gn_stats -----------------------------------------------
+__global__ void bn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ ab, float* __restrict__ mr,
+                               int B, int HW, int C, float eps, float momentum, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    float s = 0.f, ss = 0.f;
+    for (int b = 0; b < B; ++b) {
+      s += sums[((long)b * C + c) * 2];
+      ss += sums[((long)b * C + c) * 2 + 1];
+    }
+    const float n = (float)B * (float)HW;
+    mean = s / n;
+    var = fmaxf(ss / n - mean * mean, 0.f);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * n / (n - 1.f);
+    }
+  } else {
+    mean = running_mean[c];
+    var = running_var[c];
+  }
+  const float rstd = rsqrtf(var + eps);
+  const float a = gamma[c] * rstd, bb = beta[c] - mean * a;
+  for (int b = 0; b < B; ++b) {
+    ab[((long)b * C + c) * 2] = a;
+    ab[((long)b * C + c) * 2 + 1] = bb;
+  }
+  mr[c * 2] = mean;
+  mr[c * 2 + 1] = rstd;
+}
+// red[b][c] = (sum du, sum du x) -> dx = du P + x Q + R with batch statistics; dgamma += sum du xh; dbeta += sum du
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ red, const float* __restrict__ gamma, const float* __restrict__ mr,
+                                   float* __restrict__ pqr, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int HW, int C,
+                                   int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int b = 0; b < B; ++b) {
+    s1 += red[((long)b * C + c) * 2];
+    s2 += red[((long)b * C + c) * 2 + 1];
+  }
+  const float mean = mr[c * 2], rstd = mr[c * 2 + 1], g = gamma[c];
+  const float sxh = (s2 - mean * s1) * rstd;          // sum du xh
+  if (dgamma) atomicAdd(dgamma + c, sxh);
+  if (dbeta) atomicAdd(dbeta + c, s1);
+  float P = g * rstd, Q = 0.f, R = 0.f;
+  if (training) {
+    const float n = (float)B * (float)HW;
+    // dx = g rstd (du - s1/n - xh sxh/n),  xh = (x - mean) rstd
+    Q = -g * rstd * rstd * sxh / n;
+    R = -g * rstd * s1 / n - Q * mean;
+  }
+  for (int b = 0; b < B; ++b) {
+    pqr[((long)b * C + c) * 3] = P;
+    pqr[((long)b * C + c) * 3 + 1] = Q;
+    pqr[((long)b * C + c) * 3 + 2] = R;
+  }
+}
+
+// ---- attention composition (attn_network.py:14-46, segformer_generator.py:141-164) ------------------------------------------------
+// thread per attention cell (f x f full-resolution pixels): a = softmax(logits[0 .. na)), out[c] = sum_{i < ni} img[nc i + c] a_i +
+// sum_{i >= ni} xin[c] a_i
+constexpr int ACOMP_MAX = 16;
+template <typename T>
+__global__ void attn_compose_fwd_kernel(const T* __restrict__ img, const T* __restrict__ logits, const T* __restrict__ xin, T* __restrict__ out,
+                                        int B, int S, int f, int na, int ni, int nc, int ldimg, int ldl, int ldx, int ldo) {
+  const int Sa = S / f;
+  const long total = (long)B * Sa * Sa;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ax = i % Sa, ay = (i / Sa) % Sa, b = i / ((long)Sa * Sa);
+    float a[ACOMP_MAX];
+    float m = -3.0e38f, l = 0.f;
+    for (int k = 0; k < na; ++k) {
+      a[k] = to_f32(logits[i * ldl + k]);
+      m = fmaxf(m, a[k]);
+    }
+    for (int k = 0; k < na; ++k) {
+      a[k] = expf(a[k] - m);
+      l += a[k];
+    }
+    float ain = 0.f;
+    for (int k = 0; k < na; ++k) {
+      a[k] /= l;
+      if (k >= ni) ain += a[k];
+    }
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) {
+        const long p = ((long)b * S + ay * f + dy) * S + ax * f + dx;
+        for (int c = 0; c < ldo; ++c) {
+          float v = 0.f;
+          if (c < nc) {
+            v = to_f32(xin[p * ldx + c]) * ain;
+            for (int k = 0; k < ni; ++k) v += to_f32(img[p * ldimg + nc * k + c]) * a[k];
+          }
+          out[p * ldo + c] = from_f32<T>(v);
+        }
+      }
+  }
+}
+template <typename T>
+__global__ void attn_compose_bwd_kernel(const T* __restrict__ img, const T* __restrict__ logits, const T* __restrict__ xin, const T* __restrict__ dout,
+                                        T* __restrict__ dimg, T* __restrict__ dlogits, T* __restrict__ dxin, int B, int S, int f, int na, int ni,
+                                        int nc, int ldimg, int ldl, int ldx, int ldo) {
+  const int Sa = S / f;
+  const long total = (long)B * Sa * Sa;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ax = i % Sa, ay = (i / Sa) % Sa, b = i / ((long)Sa * Sa);
+    float a[ACOMP_MAX], da[ACOMP_MAX];
+    float m = -3.0e38f, l = 0.f;
+    for (int k = 0; k < na; ++k) {
+      a[k] = to_f32(logits[i * ldl + k]);
+      m = fmaxf(m, a[k]);
+      da[k] = 0.f;
+    }
+    for (int k = 0; k < na; ++k) {
+      a[k] = expf(a[k] - m);
+      l += a[k];
+    }
+    float ain = 0.f;
+    for (int k = 0; k < na; ++k) {
+      a[k] /= l;
+      if (k >= ni) ain += a[k];
+    }
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) {
+        const long p = ((long)b * S + ay * f + dy) * S + ax * f + dx;
+        float dain = 0.f;
+        for (int c = 0; c < nc; ++c) {
+          const float g = to_f32(dout[p * ldo + c]);
+          for (int k = 0; k < ni; ++k) {
+            da[k] += g * to_f32(img[p * ldimg + nc * k + c]);
+            dimg[p * ldimg + nc * k + c] = from_f32<T>(g * a[k]);
+          }
+          dain += g * to_f32(xin[p * ldx + c]);
+          if (dxin) dxin[p * ldx + c] = from_f32<T>(g * ain);
+        }
+        for (int k = ni; k < na; ++k) da[k] += dain;
+        for (int c = nc * ni; c < ldimg; ++c) dimg[p * ldimg + c] = from_f32<T>(0.f);
+        if (dxin)
+          for (int c = nc; c < ldx; ++c) dxin[p * ldx + c] = from_f32<T>(0.f);
+      }
+    float dot = 0.f;
+    for (int k = 0; k < na; ++k) dot += a[k] * da[k];
+    for (int k = 0; k < ldl; ++k) dlogits[i * ldl + k] = from_f32<T>(k < na ? a[k] * (da[k] - dot) : 0.f);
+  }
+}
+
+// y[b][p][c] = x * s[b] (DropPath) or x * s[b][c] (Dropout2d), optionally + res (the identity branch)
+template <typename T>
+__global__ void scale_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ res, T* __restrict__ y, int B, long HW,
+                             int C, int per_channel) {
+  const int c8n = C >> 3;
+  const long total = (long)B * HW * c8n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = i % c8n;
+    const long p = i / c8n;
+    const int b = p / HW;
+    float f[8], r[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(x + p * C + c8 * 8), f);
+    if (res) unpack8<T>(*reinterpret_cast<const uint4*>(res + p * C + c8 * 8), r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float sc = per_channel ? s[(long)b * C + c8 * 8 + j] : s[b];
+      f[j] = f[j] * sc + (res ? r[j] : 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + p * C + c8 * 8) = pack8<T>(f);
+  }
+}
+
+// fp32 [n] -> T [n] (the dk / dv accumulators)
+template <typename T>
+__global__ void f32_to_t_kernel(const float* __restrict__ x, T* __restrict__ y, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = from_f32<T>(x[i]);
+}
+
+int lanes_per_row(int C) {
+  int chunks = C / 8, l = 1;
+  while (l < chunks) l <<= 1;
+  return l;
+}
+
+}  // namespace
+
+extern "C" int jg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mr, int64_t R, int C, float eps,
+                                jg_stream_t s) {
+  if (!x || !gamma || !beta || !y || R < 1 || C < 8 || C % 8 || C > 512) return JG_ERR_BAD_ARG;
+  const int lpr = lanes_per_row(C);
+  const long waves = (R + 64 / lpr - 1) / (64 / lpr);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(grid_for(waves, 4, 8192)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                              gamma, beta, (T*)y, mr, (long)R, C, lpr, eps););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, void* dx, float* dgamma,
+                                float* dbeta, int64_t R, int C, jg_stream_t s) {
+  if (!x || !dy || !gamma || !mr || R < 1 || C < 8 || C % 8 || C > 512 || (!dgamma != !dbeta)) return JG_ERR_BAD_ARG;
+  const int lpr = lanes_per_row(C);
+  const long waves = (R + 64 / lpr - 1) / (64 / lpr);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                              (const T*)dy, gamma, mr, (T*)dx, dgamma, dbeta, (long)R, C, lpr););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C,
+                                int gelu, jg_stream_t s) {
+  if (!x || !w || !y || B < 1 || H < 1 || W < 1 || C < 8 || C % 8) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T>), dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, w, bias, (T*)pre, (T*)y, B, H, W, C, gelu););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
+                                float* dbias, int B, int H, int W, int C, int gelu, jg_stream_t s) {
+  if (!x || !dy || !w || !du || B < 1 || C < 8 || C % 8 || (gelu && !pre)) return JG_ERR_BAD_ARG;
+  if (C > 1536) return JG_ERR_UNSUPPORTED;   // C * 10 floats of LDS partials
+  hipStream_t st = (hipStream_t)s;
+  const int c8n = C / 8;
+  const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;
+  const long npix = (long)B * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_w_kernel<T>), dim3(grid_for(npix, tpb * 8, 1024)), dim3(256), C * 10 * sizeof(float), st,
+                                              (const T*)x, (const T*)pre, (const T*)dy, (T*)du, dw, dbias, B, H, W, C, gelu););
+  if (dx) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_x_kernel<T>), dim3(grid_for(npix * c8n)), dim3(256), 0, st, (const T*)du, w, (T*)dx, B,
+                                                H, W, C););
+  }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tkv, int heads,
+                                   int64_t ldq, int64_t ldkv, int64_t ldo, float scale, jg_stream_t s) {
+  if (!q || !k || !v || !o || B < 1 || Tq < 1 || Tkv < 1 || heads < 1 || ldq % 8 || ldkv % 8 || ldo % 8) return JG_ERR_BAD_ARG;
+  if (Tkv > AKV_MAX || B > 65535 || heads > 65535) return JG_ERR_UNSUPPORTED;
+  const dim3 grid((Tq + 63) / 64, heads, B);
+  if (Tkv <= 64) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_fwd_kernel<T, 64>), grid, dim3(64), 0, (hipStream_t)s, (const T*)q, (const T*)k,
+                                                (const T*)v, (T*)o, lse, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo, scale););
+  } else {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_fwd_kernel<T, AKV_MAX>), grid, dim3(64), 0, (hipStream_t)s, (const T*)q, (const T*)k,
+                                                (const T*)v, (T*)o, lse, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo, scale););
+  }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                   void* dq, float* dkf, float* dvf, void* dk, void* dv, int B, int Tq, int Tkv, int heads, int64_t ldq,
+                                   int64_t ldkv, int64_t ldo, float scale, jg_stream_t s) {
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !dkf || !dvf || !dk || !dv) return JG_ERR_BAD_ARG;
+  if (Tkv > AKV_MAX || B > 65535 || heads > 65535) return JG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)s;
+  const long nkv = (long)B * Tkv * heads * 32;
+  if (hipMemsetAsync(dkf, 0, nkv * sizeof(float), st) != hipSuccess || hipMemsetAsync(dvf, 0, nkv * sizeof(float), st) != hipSuccess)
+    return JG_ERR_LAUNCH;
+  const dim3 grid((Tq + 63) / 64, heads, B);
+  if (Tkv <= 64) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_bwd_kernel<T, 64>), grid, dim3(64), 0, st, (const T*)q, (const T*)k, (const T*)v,
+                                                (const T*)o, (const T*)dout, lse, (T*)dq, dkf, dvf, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo,
+                                                scale););
+  } else {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_bwd_kernel<T, AKV_MAX>), grid, dim3(64), 0, st, (const T*)q, (const T*)k, (const T*)v,
+                                                (const T*)o, (const T*)dout, lse, (T*)dq, dkf, dvf, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo,
+                                                scale););
+  }
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((f32_to_t_kernel<T>), dim3(grid_for(nkv)), dim3(256), 0, st, dkf, (T*)dk, nkv);
+                    hipLaunchKernelGGL((f32_to_t_kernel<T>), dim3(grid_for(nkv)), dim3(256), 0, st, dvf, (T*)dv, nkv););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, jg_stream_t s) {
+  if (!x || !y || C < 8 || C % 8 || ldy < C || ldy % 8 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(grid_for((long)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)x, (T*)y, B, H, W, C, Ho, Wo, (long)ldy););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, jg_stream_t s) {
+  if (!dy || !dx || C < 8 || C % 8 || lddy < C || lddy % 8 || Ho < H || Wo < W) return JG_ERR_BAD_ARG;   // up-sampling only
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s,
+                                              (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, (long)lddy););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_bn_coef(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* ab, float* mr,
+                          int B, int HW, int C, float eps, float momentum, int training, jg_stream_t s) {
+  if (!gamma || !beta || !ab || !mr || B < 1 || HW < 1 || C < 1 || (training && !sums) || (!training && (!running_mean || !running_var)))
+    return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, sums, gamma, beta, running_mean, running_var, ab, mr, B, HW, C, eps,
+                     momentum, training);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_bn_bwd_coef(const float* red, const float* gamma, const float* mr, float* pqr, float* dgamma, float* dbeta, int B, int HW, int C,
+                              int training, jg_stream_t s) {
+  if (!red || !gamma || !mr || !pqr || B < 1 || HW < 1 || C < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, red, gamma, mr, pqr, dgamma, dbeta, B, HW, C, training);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_attn_compose_fwd(int dtype, const void* img, const void* logits, const void* xin, void* out, int B, int S, int f, int na, int ni,
+                                   int nc, int ldimg, int ldl, int ldx, int ldo, jg_stream_t s) {
+  if (!img || !logits || !xin || !out || B < 1 || S < 1 || f < 1 || S % f || na < 1 || na > ACOMP_MAX || ni < 0 || ni > na || nc < 1) return JG_ERR_BAD_ARG;
+  if (ldimg < nc * ni || ldl < na || ldx < nc || ldo < nc) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_compose_fwd_kernel<T>), dim3(grid_for((long)B * (S / f) * (S / f), 64)), dim3(64), 0, (hipStream_t)s,
+                                              (const T*)img, (const T*)logits, (const T*)xin, (T*)out, B, S, f, na, ni, nc, ldimg, ldl, ldx, ldo););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_attn_compose_bwd(int dtype, const void* img, const void* logits, const void* xin, const void* dout, void* dimg, void* dlogits,
+                                   void* dxin, int B, int S, int f, int na, int ni, int nc, int ldimg, int ldl, int ldx, int ldo, jg_stream_t s) {
+  if (!img || !logits || !xin || !dout || !dimg || !dlogits || B < 1 || S < 1 || f < 1 || S % f || na < 1 || na > ACOMP_MAX || ni < 0 || ni > na)
+    return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_compose_bwd_kernel<T>), dim3(grid_for((long)B * (S / f) * (S / f), 64)), dim3(64), 0, (hipStream_t)s,
+                                              (const T*)img, (const T*)logits, (const T*)xin, (const T*)dout, (T*)dimg, (T*)dlogits, (T*)dxin, B, S, f,
+                                              na, ni, nc, ldimg, ldl, ldx, ldo););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_scale(int dtype, const void* x, const float* scale, const void* res, void* y, int B, int64_t HW, int C, int per_channel,
+                        jg_stream_t s) {
+  if (!x || !scale || !y || B < 1 || HW < 1 || C < 8 || C % 8) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scale_kernel<T>), dim3(grid_for((long)B * HW * (C / 8))), dim3(256), 0, (hipStream_t)s, (const T*)x, scale,
+                                              (const T*)res, (T*)y, B, (long)HW, C, per_channel););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}

@@ -14,6 +14,8 @@ class JGConvNd:
     meta = None
     jg_padding = 0
     jg_stride = 1
+    jg_wname = "weight"     # attribute names of the parameters (nn.MultiheadAttention calls them in_proj_weight / in_proj_bias)
+    jg_bname = "bias"
 
 
 class JGConv2d(nn.Conv2d, JGConvNd):
@@ -57,8 +59,8 @@ class JGConvTranspose2d(nn.ConvTranspose2d, JGConvNd):
 
     jg_transposed = True
 
-    def __init__(self, cin, cout, k, stride=1, padding=0, output_padding=0):
-        super().__init__(cin, cout, k, stride=stride, padding=padding, output_padding=output_padding)
+    def __init__(self, cin, cout, k, stride=1, padding=0, output_padding=0, bias=True):
+        super().__init__(cin, cout, k, stride=stride, padding=padding, output_padding=output_padding, bias=bias)
         if cin % 8 or cout % 8:
             raise NotImplementedError("transposed convolutions need channel counts that are multiples of 8")
         self.needs_dgrad = True
@@ -68,6 +70,25 @@ class JGConvTranspose2d(nn.ConvTranspose2d, JGConvNd):
         if self.meta is None:
             raise RuntimeError("JGConvTranspose2d used before ParamArena finalisation")
         return ops.conv_transpose2d(x, self.meta, self.jg_output_padding)
+
+
+class JGLinear(nn.Linear, JGConvNd):
+    """nn.Linear parameters (2-D weight [out, in]) applied to 16-bit token sequences [B, N, in] as a 1x1 convolution on the MFMA
+    implicit-GEMM kernel (the arena keeps the 16-bit working copies like for a conv)."""
+
+    def __init__(self, cin, cout, bias=True, needs_dgrad=True):
+        super().__init__(cin, cout, bias=bias)
+        self.needs_dgrad = needs_dgrad
+        self.jg_padding, self.jg_stride = 0, 1
+
+    def forward(self, x, res=None, res_scale=1.0):
+        if self.meta is None:
+            raise RuntimeError("JGLinear used before ParamArena finalisation")
+        shp = x.shape
+        x4 = x.reshape(shp[0], 1, -1, shp[-1])
+        r4 = None if res is None else res.reshape(shp[0], 1, -1, res.shape[-1])
+        y = ops.conv2d(x4, self.meta, r4, res_scale)
+        return y.view(*shp[:-1], y.shape[-1])
 
 
 class GroupNorm(nn.Module):

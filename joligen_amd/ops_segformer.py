@@ -1,0 +1,354 @@
+"""torch.autograd wrappers of the SegFormer-generator kernels (csrc/segformer.hip): LayerNorm, depth-wise 3x3 + GELU, small-KV
+attention, bilinear resize + concat, BatchNorm2d (on the GroupNorm kernels), attention composition, DropPath / Dropout2d scaling.
+Activations are NHWC 16-bit ([B, N, C] token sequences are the same memory as [B, H, W, C] maps); parameters are fp32 arena views
+whose `.grad` the backward kernels accumulate into."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _DT, _dt, _p, _require_cuda, _st, copy_channels
+
+JG_ACT_NONE, JG_ACT_RELU = 0, 2
+
+
+# ---- LayerNorm ---------------------------------------------------------------------------------------------------------------
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_cuda(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        R = x.numel() // C
+        y = torch.empty_like(x)
+        mr = torch.empty((R, 2), device=x.device, dtype=torch.float32)
+        check(_lib.lib().jg_layernorm_fwd(_dt(x), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mr.data_ptr(), R, C, eps, _st()),
+              "jg_layernorm_fwd")
+        ctx.save_for_backward(x, mr, weight)
+        ctx.gw, ctx.gb = weight.grad, bias.grad
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, mr, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        R = x.numel() // C
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        want_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if want_p and (ctx.gw is None or ctx.gb is None):
+            raise RuntimeError("LayerNorm parameters have no arena-backed .grad")
+        check(_lib.lib().jg_layernorm_bwd(_dt(x), x.data_ptr(), dy.data_ptr(), weight.data_ptr(), mr.data_ptr(), _p(dx),
+                                          _p(ctx.gw) if want_p else None, _p(ctx.gb) if want_p else None, R, C, _st()), "jg_layernorm_bwd")
+        return dx, None, None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-6):
+    """nn.LayerNorm(C, eps) over the last dimension."""
+    return _LayerNormFn.apply(x, weight, bias, float(eps))
+
+
+# ---- depth-wise 3x3 + GELU ---------------------------------------------------------------------------------------------------------
+class _DWConvGeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gelu):
+        _require_cuda(x)
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty_like(x)
+        pre = torch.empty_like(x) if gelu else None
+        check(_lib.lib().jg_dwconv3x3_fwd(_dt(x), x.data_ptr(), weight.data_ptr(), _p(bias), _p(pre), y.data_ptr(), B, H, W, C, int(gelu), _st()),
+              "jg_dwconv3x3_fwd")
+        ctx.save_for_backward(x, pre, weight)
+        ctx.gelu, ctx.gw, ctx.gb = gelu, weight.grad, None if bias is None else bias.grad
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, pre, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, H, W, C = x.shape
+        du = torch.empty_like(x)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        want_w = ctx.needs_input_grad[1]
+        if want_w and ctx.gw is None:
+            raise RuntimeError("depth-wise conv weight has no arena-backed .grad")
+        check(_lib.lib().jg_dwconv3x3_bwd(_dt(x), x.data_ptr(), _p(pre), dy.data_ptr(), weight.data_ptr(), du.data_ptr(), _p(dx),
+                                          _p(ctx.gw) if want_w else None, _p(ctx.gb) if (want_w and ctx.gb is not None) else None, B, H, W, C,
+                                          int(ctx.gelu), _st()), "jg_dwconv3x3_bwd")
+        return dx, None, None, None
+
+
+def dwconv3x3(x, weight, bias, gelu=True):
+    """nn.Conv2d(C, C, 3, padding=1, groups=C) (+ nn.GELU()) on an NHWC map; weight is the arena view of [C, 1, 3, 3]."""
+    return _DWConvGeluFn.apply(x, weight, bias, bool(gelu))
+
+
+# ---- attention with a spatially reduced key / value set ---------------------------------------------------------------------------------
+class _AttnSmallKVFn(torch.autograd.Function):
+    """q: [B, Tq, C]; kv: [B, Tkv, 2C] packed (k | v) -- the output of ONE projection with the stacked (W_k; W_v) rows."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads):
+        _require_cuda(q, kv)
+        q, kv = q.contiguous(), kv.contiguous()
+        B, Tq, C = q.shape
+        Tkv = kv.shape[1]
+        assert kv.shape[2] == 2 * C and C == heads * 32, (tuple(kv.shape), C, heads)
+        o = torch.empty_like(q)
+        lse = torch.empty((B, heads, Tq), device=q.device, dtype=torch.float32)
+        es = q.element_size()
+        check(_lib.lib().jg_attn_smallkv_fwd(_dt(q), q.data_ptr(), kv.data_ptr(), kv.data_ptr() + C * es, o.data_ptr(), lse.data_ptr(), B, Tq, Tkv,
+                                             heads, C, 2 * C, C, 1.0 / math.sqrt(32.0), _st()), "jg_attn_smallkv_fwd")
+        ctx.save_for_backward(q, kv, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, do):
+        q, kv, o, lse = ctx.saved_tensors
+        do = do.contiguous()
+        B, Tq, C = q.shape
+        Tkv = kv.shape[1]
+        dq = torch.empty_like(q)
+        dkf = torch.empty((B, Tkv, C), device=q.device, dtype=torch.float32)
+        dvf = torch.empty_like(dkf)
+        dk = torch.empty((B, Tkv, C), device=q.device, dtype=q.dtype)
+        dv = torch.empty_like(dk)
+        es = q.element_size()
+        check(_lib.lib().jg_attn_smallkv_bwd(_dt(q), q.data_ptr(), kv.data_ptr(), kv.data_ptr() + C * es, o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                             dq.data_ptr(), dkf.data_ptr(), dvf.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, Tq, Tkv, ctx.heads, C,
+                                             2 * C, C, 1.0 / math.sqrt(32.0), _st()), "jg_attn_smallkv_bwd")
+        return dq, torch.cat((dk, dv), dim=2), None
+
+
+def attention_smallkv(q, kv, heads):
+    return _AttnSmallKVFn.apply(q, kv, heads)
+
+
+# ---- bilinear resize of several maps into one channel-concatenated buffer -------------------------------------------------------------
+class _ResizeConcatFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Ho, Wo, *xs):
+        _require_cuda(*xs)
+        xs = [x.contiguous() for x in xs]
+        B = xs[0].shape[0]
+        Ct = sum(x.shape[-1] for x in xs)
+        y = torch.empty((B, Ho, Wo, Ct), device=xs[0].device, dtype=xs[0].dtype)
+        es, off = y.element_size(), 0
+        for x in xs:
+            _, H, W, C = x.shape
+            if (H, W) == (Ho, Wo):
+                copy_channels(x, 0, y, off, C)
+            else:
+                check(_lib.lib().jg_bilinear_fwd(_dt(x), x.data_ptr(), y.data_ptr() + off * es, B, H, W, C, Ho, Wo, Ct, _st()), "jg_bilinear_fwd")
+            off += C
+        ctx.shapes = [tuple(x.shape) for x in xs]
+        ctx.Ho, ctx.Wo = Ho, Wo
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        Ct = dy.shape[-1]
+        es, off, outs = dy.element_size(), 0, []
+        for i, (B, H, W, C) in enumerate(ctx.shapes):
+            dx = None
+            if ctx.needs_input_grad[2 + i]:
+                dx = torch.empty((B, H, W, C), device=dy.device, dtype=dy.dtype)
+                if (H, W) == (ctx.Ho, ctx.Wo):
+                    copy_channels(dy, off, dx, 0, C)
+                else:
+                    check(_lib.lib().jg_bilinear_bwd(_dt(dy), dy.data_ptr() + off * es, dx.data_ptr(), B, H, W, C, ctx.Ho, ctx.Wo, Ct, _st()),
+                          "jg_bilinear_bwd")
+            outs.append(dx)
+            off += C
+        return (None, None) + tuple(outs)
+
+
+def resize_concat(xs, Ho, Wo):
+    """torch.cat([F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False) for x in xs], dim=1) on NHWC maps."""
+    return _ResizeConcatFn.apply(Ho, Wo, *xs)
+
+
+# ---- BatchNorm2d (+ ReLU) on the GroupNorm kernels ---------------------------------------------------------------------------------------
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
+        _require_cuda(x)
+        L = _lib.lib()
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        dev, st, dt = x.device, _st(), _dt(x)
+        ab = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        mr = torch.empty((C, 2), device=dev, dtype=torch.float32)
+        sums = None
+        if training:
+            sums = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+            check(L.jg_gn_stats(dt, x.data_ptr(), sums.data_ptr(), B, HW, C, st), "jg_gn_stats")
+        check(L.jg_bn_coef(_p(sums), weight.data_ptr(), bias.data_ptr(), _p(running_mean), _p(running_var), ab.data_ptr(), mr.data_ptr(), B, HW, C,
+                           eps, momentum, int(training), st), "jg_bn_coef")
+        y = torch.empty_like(x)
+        check(L.jg_gn_apply(dt, x.data_ptr(), ab.data_ptr(), y.data_ptr(), B, HW, C, act, st), "jg_gn_apply")
+        ctx.save_for_backward(x, ab, mr, weight)
+        ctx.cfg = (training, act, weight.grad, bias.grad)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, ab, mr, weight = ctx.saved_tensors
+        training, act, gw, gb = ctx.cfg
+        L = _lib.lib()
+        dy = dy.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        dev, st, dt = x.device, _st(), _dt(x)
+        red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        pqr = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
+        want_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if want_p and (gw is None or gb is None):
+            raise RuntimeError("BatchNorm parameters have no arena-backed .grad")
+        check(L.jg_gn_bwd_reduce(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), red.data_ptr(), B, HW, C, act, st), "jg_gn_bwd_reduce")
+        check(L.jg_bn_bwd_coef(red.data_ptr(), weight.data_ptr(), mr.data_ptr(), pqr.data_ptr(), _p(gw) if want_p else None, _p(gb) if want_p else None,
+                               B, HW, C, int(training), st), "jg_bn_bwd_coef")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(L.jg_gn_bwd_apply(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), pqr.data_ptr(), dx.data_ptr(), B, HW, C, act, st), "jg_gn_bwd_apply")
+        return (dx,) + (None,) * 8
+
+
+def batch_norm(x, bn, act=JG_ACT_NONE):
+    """nn.BatchNorm2d `bn` (affine, running statistics) followed by an optional fused activation; train mode uses the batch statistics
+    and updates the running ones in place (momentum 0.1, unbiased variance), like the reference."""
+    training = bn.training
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, float(bn.momentum), float(bn.eps), act)
+
+
+# ---- attention-mask composition ---------------------------------------------------------------------------------------------------------------
+class _AttnComposeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, logits, xin, na, ni, nc):
+        _require_cuda(img, logits, xin)
+        img, logits, xin = img.contiguous(), logits.contiguous(), xin.contiguous()
+        B, S = img.shape[0], img.shape[1]
+        f = S // logits.shape[1]
+        out = torch.empty_like(xin)
+        check(_lib.lib().jg_attn_compose_fwd(_dt(img), img.data_ptr(), logits.data_ptr(), xin.data_ptr(), out.data_ptr(), B, S, f, na, ni, nc,
+                                             img.shape[-1], logits.shape[-1], xin.shape[-1], out.shape[-1], _st()), "jg_attn_compose_fwd")
+        ctx.save_for_backward(img, logits, xin)
+        ctx.cfg = (f, na, ni, nc)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        img, logits, xin = ctx.saved_tensors
+        f, na, ni, nc = ctx.cfg
+        dout = dout.contiguous()
+        B, S = img.shape[0], img.shape[1]
+        dimg, dlog = torch.empty_like(img), torch.empty_like(logits)
+        dxin = torch.empty_like(xin) if ctx.needs_input_grad[2] else None
+        check(_lib.lib().jg_attn_compose_bwd(_dt(img), img.data_ptr(), logits.data_ptr(), xin.data_ptr(), dout.data_ptr(), dimg.data_ptr(),
+                                             dlog.data_ptr(), _p(dxin), B, S, f, na, ni, nc, img.shape[-1], logits.shape[-1], xin.shape[-1],
+                                             dout.shape[-1], _st()), "jg_attn_compose_bwd")
+        return dimg, dlog, dxin, None, None, None
+
+
+def attention_compose(img, logits, xin, na, ni, nc):
+    """BaseGenerator_attn.forward (attn_network.py:14-46): softmax over the `na` logits of each cell (nearest-upsampled), blend of the
+    `ni` generated images (channels [nc i, nc i + nc) of img) and the input."""
+    return _AttnComposeFn.apply(img, logits, xin, na, ni, nc)
+
+
+# ---- DropPath / Dropout2d as given factors ----------------------------------------------------------------------------------------------------
+class _ScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s, res, per_channel):
+        _require_cuda(x)
+        x = x.contiguous()
+        B, C = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C)
+        y = torch.empty_like(x)
+        r = None if res is None else res.contiguous()
+        check(_lib.lib().jg_scale(_dt(x), x.data_ptr(), s.data_ptr(), _p(r), y.data_ptr(), B, HW, C, int(per_channel), _st()), "jg_scale")
+        ctx.save_for_backward(s)
+        ctx.per_channel, ctx.has_res = per_channel, res is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (s,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, C = dy.shape[0], dy.shape[-1]
+        HW = dy.numel() // (B * C)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            check(_lib.lib().jg_scale(_dt(dy), dy.data_ptr(), s.data_ptr(), None, dx.data_ptr(), B, HW, C, int(ctx.per_channel), _st()), "jg_scale")
+        return dx, None, (dy if ctx.has_res and ctx.needs_input_grad[2] else None), None
+
+
+def scale_add(x, s, res=None, per_channel=False):
+    """x * s (+ res) with s of shape [B] (DropPath: floor(keep + U) / keep) or [B, C] (Dropout2d: (U >= p) / (1 - p))."""
+    return _ScaleFn.apply(x, s.contiguous().float(), res, per_channel)
+
+
+# ---- linear on a row slice of a stacked projection (nn.MultiheadAttention's packed in_proj) -----------------------------------------------
+class _SlicedLinearFn(torch.autograd.Function):
+    """y = x W[row0 : row0 + n]^T + b[row0 : row0 + n] for a ConvMeta that holds the stacked [rows, Cin] projection."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, meta, row0, n):
+        from .ops import conv_nt
+
+        _require_cuda(x)
+        x = x.contiguous()
+        B, N, Cin = x.shape
+        m = meta
+        y = torch.empty((B, N, n), device=x.device, dtype=x.dtype)
+        conv_nt(x, m.w16, y, B=B, H=1, W=N, Cin=Cin, Cout=n, R=1, S=1, pad=0, stride=1, Ho=1, Wo=N, ldx=Cin, ldw=Cin, ldy=n,
+                bias=None if m.bias is None else m.bias[row0:row0 + n], w_off=row0 * Cin)
+        ctx.save_for_backward(x)
+        ctx.cfg = (m, row0, n)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        from .ops import _wgrad_splitk, conv_nt, wgrad_tn
+
+        (x,) = ctx.saved_tensors
+        m, row0, n = ctx.cfg
+        dy = dy.contiguous()
+        B, N, Cin = x.shape
+        rows = m.Cout
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv_nt(dy, m.w16T, dx, B=B, H=1, W=N, Cin=n, Cout=Cin, R=1, S=1, pad=0, stride=1, Ho=1, Wo=N, ldx=n, ldw=rows, ldy=Cin, w_off=row0)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            wg = m.weight.grad
+            if wg is None:
+                raise RuntimeError("projection weight has no arena-backed .grad")
+            dbias = m.bias.grad[row0:row0 + n] if (m.bias is not None and ctx.needs_input_grad[2]) else None
+            tiles = ((n + 127) // 128) * ((Cin + 127) // 128)
+            wgrad_tn(dy, x, wg, B=B, H=1, W=N, Cin=Cin, Cout=n, R=1, S=1, pad=0, stride=1, Ho=1, Wo=N, lddy=n, ldx=Cin, lddw=Cin, dbias=dbias,
+                     Cin_out=Cin, Cout_out=n, splitk=_wgrad_splitk(tiles, B * N), dw_off=row0 * Cin)
+        return dx, None, None, None, None, None
+
+
+def sliced_linear(x, meta, row0, n):
+    return _SlicedLinearFn.apply(x, meta.weight, meta.bias, meta, row0, n)
