@@ -55,8 +55,10 @@ class CUTModel(BaseModel):
             # the 1/T = 14x of the contrastive logits makes these gradients ~2 orders larger than the diffusion path's:
             # 65536 overflows fp16 activation gradients, 1024 keeps both ends of the range
             self.loss_scale = 1024.0
-        if opt.G_netG != "resnet" and not opt.G_netG.startswith("resnet"):
-            raise NotImplementedError(f"G_netG={opt.G_netG!r}: the CUT path is built for the resnet generator")
+        if opt.G_netG not in ("resnet", "resnet_9blocks", "resnet_6blocks", "segformer_attn_conv"):
+            raise NotImplementedError(f"G_netG={opt.G_netG!r}: the CUT path is built for the resnet and segformer_attn_conv generators")
+        if "segformer" in opt.G_netG:           # cut_model.py:205-210: enforced by the reference
+            opt.alg_cut_nce_layers, opt.alg_cut_nce_T = "0,1,2,3", 0.2
         if list(opt.D_netDs) != ["basic"]:
             raise NotImplementedError(f"D_netDs={opt.D_netDs!r}: only the 'basic' PatchGAN is built (projected_d needs pretrained "
                                       "timm backbones, unavailable offline)")
@@ -71,8 +73,16 @@ class CUTModel(BaseModel):
         if opt.alg_cut_lambda_SRC > 0 or [s for s in opt.alg_cut_supervised_loss if s] or opt.dataaug_D_noise > 0:
             raise NotImplementedError("SRC / supervised / noisy-D terms are outside the built path")
         self.nce_layers = [int(i) for i in str(opt.alg_cut_nce_layers).split(",")]
-        self.netG_A = ResnetGenerator(opt.model_input_nc, opt.model_output_nc, opt.G_ngf, n_blocks=opt.G_nblocks,
-                                      padding_type=opt.G_padding_type)
+        if "segformer" in opt.G_netG:            # gan_networks.py:177-187
+            from ..modules.segformer import SegformerGenerator_attn
+
+            self.netG_A = SegformerGenerator_attn(getattr(opt, "jg_dir", ""), getattr(opt, "G_config_segformer", ""), opt.model_input_nc,
+                                                  img_size=opt.data_crop_size, nb_mask_attn=getattr(opt, "G_attn_nb_mask_attn", 10),
+                                                  nb_mask_input=getattr(opt, "G_attn_nb_mask_input", 1), final_conv=True,
+                                                  padding_type=opt.G_padding_type)
+        else:
+            self.netG_A = ResnetGenerator(opt.model_input_nc, opt.model_output_nc, opt.G_ngf, n_blocks=opt.G_nblocks,
+                                          padding_type=opt.G_padding_type)
         self.model_names = ["G_A"]
         if opt.isTrain:
             self.netF = PatchSampleF(use_mlp=True, init_type=opt.model_init_type, init_gain=opt.model_init_gain, nc=opt.alg_cut_netF_nc)

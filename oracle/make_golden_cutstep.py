@@ -27,6 +27,9 @@ STEP_CFGS = {
     "monce": dict(ngf=16, n_blocks=2, ndf=16, S=32, B=2, nce_layers="0,4,8,10,11", num_patches=64, nce_loss="monce", pool=2, iters=4),
     # BASELINE.json configs[0]: cut_model, resnet_9blocks G + basic D, 128x128, batch 1 (example_gan_horse2zebra.json shape)
     "config0": dict(ngf=64, n_blocks=9, ndf=64, S=128, B=1, nce_layers="0,4,8,12,16", num_patches=256, nce_loss="monce", pool=50, iters=2),
+    # BASELINE.json configs[2] shape with the buildable discriminator: SegFormer-attn G (MiT-b0 + ResnetDecoder tail) + basic D + MoNCE
+    "segformer": dict(netG="segformer_attn_conv", ngf=64, n_blocks=9, ndf=16, S=64, B=2, nce_layers="0,1,2,3", num_patches=64, nce_loss="monce",
+                      pool=2, iters=3),
     "patchnce": dict(ngf=16, n_blocks=3, ndf=16, S=32, B=1, nce_layers="0,4,8,12", num_patches=32, nce_loss="patchnce", pool=1, iters=3),
 }
 
@@ -108,7 +111,7 @@ def build_opt(c):
     cfg["train"]["semantic_mask"] = False
     cfg["train"]["mask"]["out_mask"] = False
     cfg["gpu_ids"] = "-1"
-    cfg["G"].update(netG="resnet", ngf=c["ngf"], nblocks=c["n_blocks"])
+    cfg["G"].update(netG=c.get("netG", "resnet"), ngf=c["ngf"], nblocks=c["n_blocks"])
     cfg["D"].update(netDs=["basic"], ndf=c["ndf"])
     cfg["alg"]["cut"].update(nce_layers=c["nce_layers"], num_patches=c["num_patches"], nce_loss=c["nce_loss"])
     cfg["output"]["display"]["type"] = ["none"]
@@ -150,6 +153,10 @@ def step_fixtures():
             return p
 
         torch.randperm = rec_randperm
+        from make_golden_segformer import Recorder        # DropPath / Dropout2d uniforms of the SegFormer generator (none for resnet)
+        import torch.nn.functional as F
+        urec = Recorder(31)
+        torch.rand, F.dropout2d = urec.rand, urec.dropout2d
         try:
             data0 = batch(c["B"], c["S"], 500)
             model.data_dependent_initialize(data0)
@@ -164,12 +171,12 @@ def step_fixtures():
                 data = batch(c["B"], c["S"], 500 + it)
                 model.set_input(data)
                 perms.clear()
-                n_log = len(rr.log)
+                n_log, n_u = len(rr.log), len(urec.log)
                 torch.manual_seed(100 + it)
                 model.optimize_parameters()
                 losses = {k: float(v) for k, v in model.get_current_losses().items()}
                 rec = dict(A=data["A"], B=data["B"], perms=[p[: c["num_patches"]].clone() for p in perms], pool_draws=list(rr.log[n_log:]), losses=losses,
-                           fake_B=model.fake_B.detach().clone())
+                           fake_B=model.fake_B.detach().clone(), uniforms=[u.clone() for u in urec.log[n_u:]])
                 if it in (0, c["iters"] - 1):
                     rec["G_checks"] = checks(dict(model.netG_A.named_parameters()))
                     rec["F_checks"] = checks(dict(model.netF.named_parameters()))
@@ -178,6 +185,7 @@ def step_fixtures():
                 steps.append(rec)
                 print(name, it, {k: round(v, 5) for k, v in losses.items()}, "perms", [len(p) for p in perms], "draws", len(rec["pool_draws"]))
         finally:
+            torch.rand, F.dropout2d = urec.real_rand, urec.real_d2
             torch.randperm = real_randperm
             ref_pool.random = random
         hp = dict(lr_G=opt.train_G_lr, lr_D=opt.train_D_lr, beta1=opt.train_beta1, beta2=opt.train_beta2, eps=opt.train_optim_eps,
