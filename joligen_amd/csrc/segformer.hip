@@ -139,33 +139,47 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   }
 }
 
-// ---- depth-wise 3x3 (pad 1) + bias (+ GELU): thread per (pixel, 8 channels) ---------------------------------------------------
+// ---- depth-wise 3x3 (pad 1) + bias (+ GELU): a thread owns ONE 8-channel chunk (its 72 weights stay in registers) and strides
+// over pixels; a block covers all chunks of 256 / (C/8) pixels at a time, so a wave reads contiguous channel rows
+template <typename T, bool FLIP>
+__device__ __forceinline__ void dw_apply(const T* __restrict__ x, const float (&wr)[8][9], const float* bs, long p, int px, int py, int H, int W,
+                                         int C, int c8, float* acc) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = bs ? bs[j] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const int dy = FLIP ? 1 - r : r - 1;
+    if ((unsigned)(py + dy) >= (unsigned)H) continue;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int dx = FLIP ? 1 - s : s - 1;
+      if ((unsigned)(px + dx) >= (unsigned)W) continue;
+      float f[8];
+      unpack8<T>(*reinterpret_cast<const uint4*>(x + (p + (long)dy * W + dx) * C + c8 * 8), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j] * wr[j][r * 3 + s];
+    }
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                             T* __restrict__ pre, T* __restrict__ y, int B, int H, int W, int C, int gelu) {
   const int c8n = C >> 3;
-  const long total = (long)B * H * W * c8n;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c8 = i % c8n;
-    const long p = i / c8n;
+  const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;
+  const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
+  if (pl >= tpb) return;
+  float wr[8][9], bs[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bs[j] = bias ? bias[c8 * 8 + j] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[j][t] = w[(c8 * 8 + j) * 9 + t];
+  }
+  const long npix = (long)B * H * W;
+  for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb) {
     const int px = p % W, py = (p / W) % H;
     float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c8 * 8 + j] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int iy = py + r - 1;
-      if ((unsigned)iy >= (unsigned)H) continue;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int ix = px + s - 1;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        float f[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(x + (p + (long)(r - 1) * W + (s - 1)) * C + c8 * 8), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += f[j] * w[(c8 * 8 + j) * 9 + r * 3 + s];
-      }
-    }
+    dw_apply<T, false>(x, wr, bs, p, px, py, H, W, C, c8, acc);
     if (pre) *reinterpret_cast<uint4*>(pre + p * C + c8 * 8) = pack8<T>(acc);
     if (gelu) {
 #pragma unroll
@@ -243,33 +257,24 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restric
   }
 }
 
-// dx[p][c] = sum_taps du[p - tap][c] w[c][tap]
+// dx[p][c] = sum_taps du[p - tap][c] w[c][tap]   (same thread layout as the forward)
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_x_kernel(const T* __restrict__ du, const float* __restrict__ w, T* __restrict__ dx, int B,
                                                               int H, int W, int C) {
   const int c8n = C >> 3;
-  const long total = (long)B * H * W * c8n;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int c8 = i % c8n;
-    const long p = i / c8n;
+  const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;
+  const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
+  if (pl >= tpb) return;
+  float wr[8][9];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[j][t] = w[(c8 * 8 + j) * 9 + t];
+  const long npix = (long)B * H * W;
+  for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb) {
     const int px = p % W, py = (p / W) % H;
     float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const int oy = py - (r - 1);
-      if ((unsigned)oy >= (unsigned)H) continue;
-#pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const int ox = px - (s - 1);
-        if ((unsigned)ox >= (unsigned)W) continue;
-        float f[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(du + (p - (long)(r - 1) * W - (s - 1)) * C + c8 * 8), f);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += f[j] * w[(c8 * 8 + j) * 9 + r * 3 + s];
-      }
-    }
+    dw_apply<T, true>(du, wr, nullptr, p, px, py, H, W, C, c8, acc);
     *reinterpret_cast<uint4*>(dx + p * C + c8 * 8) = pack8<T>(acc);
   }
 }
@@ -325,14 +330,17 @@ __global__ __launch_bounds__(64) void attn_smallkv_fwd_kernel(const T* __restric
   if (lse) lse[((long)b * heads + h) * Tq + qi] = m + logf(l);
 }
 
-// dq per query thread; dk / dv summed over the 64 queries of the block in LDS, then fp32 atomics into dkf / dvf [B][Tkv][heads*32]
+// dq per query thread.  dk / dv: each 64-key slab first parks p and ds of the block's 64 queries in LDS ([key][query]), then the
+// threads switch roles -- thread = key -- and contract them against the block's q / dO rows (no LDS atomics); one fp32 global
+// atomic per (key, channel) and block into dkf / dvf [B][Tkv][heads*32]
 template <typename T, int KVMAX>
 __global__ __launch_bounds__(64) void attn_smallkv_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                               const T* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ lse,
                                                               T* __restrict__ dq, float* __restrict__ dkf, float* __restrict__ dvf, int Tq, int Tkv,
                                                               int heads, long ldq, long ldkv, long ldo, float scale) {
-  __shared__ float s_k[AKV_MAX][33], s_v[AKV_MAX][33];
-  __shared__ float s_dk[64][33], s_dv[64][33];     // one 64-key slab of the gradients at a time
+  __shared__ float s_k[KVMAX][33], s_v[KVMAX][33];
+  __shared__ float s_q[64][33], s_do[64][33];
+  __shared__ float s_p[64][65], s_ds[64][65];
   const int h = blockIdx.y, b = blockIdx.z, t = threadIdx.x;
   for (int i = t; i < Tkv * 4; i += 64) {
     const int j = i >> 2, c = (i & 3) * 8;
@@ -362,40 +370,49 @@ __global__ __launch_bounds__(64) void attn_smallkv_bwd_kernel(const T* __restric
     for (int c = 0; c < 32; ++c) D += dov[c] * ov[c];
     L = lse[((long)b * heads + h) * Tq + qi];
   }
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    s_q[t][c] = qv[c];
+    s_do[t][c] = dov[c];
+  }
   const int H32 = heads * 32;
   for (int j0 = 0; j0 < Tkv; j0 += 64) {
-    __syncthreads();
-    for (int i = t; i < 64 * 33; i += 64) {
-      (&s_dk[0][0])[i] = 0.f;
-      (&s_dv[0][0])[i] = 0.f;
+    const int jn = min(64, Tkv - j0);
+    __syncthreads();                        // K / V / q / dO visible; previous slab's role-switched reads done
+    for (int jj = 0; jj < jn; ++jj) {
+      const int j = j0 + jj;
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        s += qv[c] * s_k[j][c];
+        dp += dov[c] * s_v[j][c];
+      }
+      const float p = ok ? expf(s * scale - L) : 0.f;
+      const float ds = p * (dp - D) * scale;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) dqv[c] += ds * s_k[j][c];
+      s_p[jj][t] = p;
+      s_ds[jj][t] = ds;
     }
     __syncthreads();
-    if (ok) {
-      const int jn = min(64, Tkv - j0);
-      for (int jj = 0; jj < jn; ++jj) {
-        const int j = j0 + ((jj + t) % jn);          // stagger the key order across threads: fewer LDS atomic collisions
-        float s = 0.f, dp = 0.f;
+    if (t < jn) {                           // thread = key j0 + t
+      float dk[32], dv[32];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) dk[c] = dv[c] = 0.f;
+      for (int u = 0; u < 64; ++u) {
+        const float pv = s_p[t][u], dsv = s_ds[t][u];
 #pragma unroll
         for (int c = 0; c < 32; ++c) {
-          s += qv[c] * s_k[j][c];
-          dp += dov[c] * s_v[j][c];
-        }
-        const float p = expf(s * scale - L);
-        const float ds = p * (dp - D) * scale;
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          dqv[c] += ds * s_k[j][c];
-          atomicAdd(&s_dk[j - j0][c], ds * qv[c]);
-          atomicAdd(&s_dv[j - j0][c], p * dov[c]);
+          dk[c] += dsv * s_q[u][c];
+          dv[c] += pv * s_do[u][c];
         }
       }
-    }
-    __syncthreads();
-    for (int i = t; i < 64 * 32; i += 64) {
-      const int j = i >> 5, c = i & 31;
-      if (j0 + j < Tkv) {
-        atomicAdd(dkf + ((long)b * Tkv + j0 + j) * H32 + h * 32 + c, s_dk[j][c]);
-        atomicAdd(dvf + ((long)b * Tkv + j0 + j) * H32 + h * 32 + c, s_dv[j][c]);
+      float* dkp = dkf + ((long)b * Tkv + j0 + t) * H32 + h * 32;
+      float* dvp = dvf + ((long)b * Tkv + j0 + t) * H32 + h * 32;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) {
+        atomicAdd(dkp + c, dk[c]);
+        atomicAdd(dvp + c, dv[c]);
       }
     }
   }
@@ -686,7 +703,9 @@ extern "C" int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const 
 extern "C" int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C,
                                 int gelu, jg_stream_t s) {
   if (!x || !w || !y || B < 1 || H < 1 || W < 1 || C < 8 || C % 8) return JG_ERR_BAD_ARG;
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T>), dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s,
+  if (C > 2048) return JG_ERR_UNSUPPORTED;
+  const int tpb_f = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T>), dim3(grid_for((long)B * H * W, tpb_f * 4, 4096)), dim3(256), 0, (hipStream_t)s,
                                               (const T*)x, w, bias, (T*)pre, (T*)y, B, H, W, C, gelu););
   JG_CHECK_LAUNCH();
   return JG_OK;
@@ -702,8 +721,8 @@ extern "C" int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_w_kernel<T>), dim3(grid_for(npix, tpb * 8, 1024)), dim3(256), C * 10 * sizeof(float), st,
                                               (const T*)x, (const T*)pre, (const T*)dy, (T*)du, dw, dbias, B, H, W, C, gelu););
   if (dx) {
-    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_x_kernel<T>), dim3(grid_for(npix * c8n)), dim3(256), 0, st, (const T*)du, w, (T*)dx, B,
-                                                H, W, C););
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_x_kernel<T>), dim3(grid_for(npix, tpb * 4, 4096)), dim3(256), 0, st, (const T*)du, w,
+                                                (T*)dx, B, H, W, C););
   }
   JG_CHECK_LAUNCH();
   return JG_OK;

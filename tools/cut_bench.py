@@ -22,9 +22,10 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--nce", default="monce")
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--netG", default="resnet", help="resnet | segformer_attn_conv (BASELINE configs[2] generator)")
 args = ap.parse_args()
 
-cfg = {"model_type": "cut", "G": {"netG": "resnet", "ngf": 64, "nblocks": 9}, "D": {"netDs": ["basic"], "ndf": 64},
+cfg = {"model_type": "cut", "G": {"netG": args.netG, "ngf": 64, "nblocks": 9}, "D": {"netDs": ["basic"], "ndf": 64},
        "alg": {"cut": {"nce_loss": args.nce}}, "data": {"crop_size": args.size, "load_size": args.size},
        "train": {"batch_size": args.batch, "G_ema": False}}
 opt = opt_from_json(cfg, overrides={"jg_act_dtype": args.dtype, "gpu_ids": "0"})
@@ -50,5 +51,5 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.steps
 losses = {k: round(float(v), 4) for k, v in model.get_current_losses().items()}
-print(json.dumps({"workload": f"cut_model resnet_9blocks + basic D + mlp_sample F, {args.nce}, {args.size}x{args.size}, batch {args.batch}",
+print(json.dumps({"workload": f"cut_model {args.netG} G + basic D + mlp_sample F, {args.nce}, {args.size}x{args.size}, batch {args.batch}",
                   "ms_per_step": round(dt * 1e3, 3), "images_per_sec": round(args.batch / dt, 2), "dtype": args.dtype, "losses": losses}))
