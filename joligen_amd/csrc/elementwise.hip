@@ -178,6 +178,41 @@ __device__ __forceinline__ float act_grad_f(float v, int act) {
   return s * (1.0f + v * (1.0f - s));
 }
 
+// (few rows, very long reduction: the stacked embedding projection of the UNet, Bn = batch, N = sum of 2C over all ResBlocks)
+// dx[b][k] = act'(x[b][k]) * sum_n dy[b][n] W[n][k]: one block per (b, 32-wide k tile); threads stride
+// over n (W rows are read as contiguous 128-byte segments), 32 partial sums per thread, LDS reduce.
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ dy, float* __restrict__ dx, int Bn,
+                                                            int K, int N, int act) {
+  __shared__ float s_red[8][33];
+  const int b = blockIdx.x, k0 = blockIdx.y * 32;
+  const int kt = min(32, K - k0);
+  float acc[32];
+#pragma unroll
+  for (int q = 0; q < 32; ++q) acc[q] = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float g = dy[(long)b * N + n];
+    const float* wr = W + (long)n * K + k0;
+    if (kt == 32) {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) acc[q] += g * wr[q];
+    } else {
+      for (int q = 0; q < kt; ++q) acc[q] += g * wr[q];
+    }
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 32; ++q) {
+    const float v = wave_sum(acc[q]);
+    if (lane == 0) s_red[wv][q] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kt) {
+    const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    const long o = (long)b * K + k0 + threadIdx.x;
+    dx[o] = v * act_grad_f(x[o], act);
+  }
+}
 // dbias[n] += sum_b dy[b][n]: 64 columns x 4 row groups per block, 256 rows per block, one atomic per column per block
 __global__ __launch_bounds__(256) void linear_bwd_dbias_kernel(const float* __restrict__ dy, float* __restrict__ dbias, int Bn, int N) {
   __shared__ float s_red[4][64];
@@ -823,8 +858,10 @@ extern "C" int jg_linear_bwd(const float* x, const float* W, const float* dy, fl
                              int K, int N, int act, jg_stream_t s) {
   if (!x || !W || !dy || Bn < 1 || K < 1 || N < 1) return JG_ERR_BAD_ARG;
   int rc = JG_OK;
-  if (dx) rc = jg_sgemm(dy, W, dx, nullptr, act == JG_ACT_NONE ? nullptr : x, Bn, K, N, N, 1, 1, K, K, 1, 1, 0, 0, 0, 1.0f, 0.0f,
-                        JG_ACT_NONE, JG_ACT_NONE, act, s);
+  if (dx && Bn <= 64 && N >= 2048)     // 4 output tiles and a reduction of thousands: one block per (row, 32 columns) instead
+    hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(Bn, (K + 31) / 32), dim3(256), 0, (hipStream_t)s, x, W, dy, dx, Bn, K, N, act);
+  else if (dx) rc = jg_sgemm(dy, W, dx, nullptr, act == JG_ACT_NONE ? nullptr : x, Bn, K, N, N, 1, 1, K, K, 1, 1, 0, 0, 0, 1.0f, 0.0f,
+                             JG_ACT_NONE, JG_ACT_NONE, act, s);
   if (rc != JG_OK) return rc;
   if (dW) rc = jg_sgemm(dy, x, dW, nullptr, nullptr, N, K, Bn, 1, N, 1, K, K, 1, 1, 0, 0, 0, 1.0f, 1.0f, JG_ACT_NONE, act, JG_ACT_NONE, s);
   if (rc != JG_OK) return rc;

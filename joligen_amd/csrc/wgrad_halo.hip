@@ -44,7 +44,7 @@ __device__ __forceinline__ int f4(int c) { return ((c >> 1) & 1) | (((c >> 3) & 
 // 3-bit swizzle of a 256-byte pixel row (8 blocks of 32 B)
 __device__ __forceinline__ int f8(int c) { return (c & 3) | (((c >> 3) & 1) << 2); }
 
-template <typename T, int TH, int CPW, int WMR>
+template <typename T, int TH, int CPW, int WMR, bool REFLECT>
 __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p, int ntiles, int per, int npairs, int ncot) {
   constexpr int NT = WMR * 256;                // WMR wave rows (output-channel groups) x 4 wave columns (16-channel ci tiles)
   constexpr int BCO = WMR * CPW * 16;          // output channels per block
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
           const int hy = hp / HW_, hx = hp - hy * HW_;
           const int chunk = (((cpos >> 1) ^ f4(hx)) << 1) | (cpos & 1);
           int ih = oh0 - 1 + hy, iw = ow0 - 1 + hx;
-          if (p.reflect) {
+          if constexpr (REFLECT) {
             ih = JG_REFLECT1(ih, p.H);
             iw = JG_REFLECT1(iw, p.W);
           }
@@ -171,8 +171,10 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
           const int ih = oh0 - 1 + (a_yx[rd] >> 8), iw = ow0 - 1 + (a_yx[rd] & 255);
           const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
           int rel = a_rel[rd];
-          if (p.reflect && !ok) rel += ((JG_REFLECT1(ih, p.H) - ih) * p.W + (JG_REFLECT1(iw, p.W) - iw)) * (int)p.ldx;
-          glds16((ok || p.reflect) ? xb + rel : zp, l0 + rd * NT * 16);
+          if constexpr (REFLECT) {
+            if (!ok) rel += ((JG_REFLECT1(ih, p.H) - ih) * p.W + (JG_REFLECT1(iw, p.W) - iw)) * (int)p.ldx;
+          }
+          glds16((ok || REFLECT) ? xb + rel : zp, l0 + rd * NT * 16);
         }
       }
     
@@ -295,14 +297,14 @@ static void pick_split(int npairs, int ntiles, int ovh, int slots, int* per_out,
   *per_out = bper; *splitk_out = bsk;
 }
 
-template <typename T, int TH, int CPW, int WMR>
+template <typename T, int TH, int CPW, int WMR, bool REFLECT = false>
 void launch_wg(const WgP& p, hipStream_t st) {
   constexpr int BCO = WMR * CPW * 16;
   const int ncot = p.Cout / BCO, npairs = ncot * (p.Cin / 64);
   const int ntiles = p.B * (p.H / TH) * (p.W >> 4);
   int per, splitk;
   pick_split(npairs, ntiles, TH == 16 ? 6 : 10, WMR == 1 ? 512 : 256, &per, &splitk);
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot);
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, REFLECT>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot);
 }
 
 template <typename T>
@@ -313,7 +315,10 @@ void dispatch_wg(const WgP& p, hipStream_t st) {
   // volume: it pays once a block has >= 64 (16-row) tiles to walk
   const long per1 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.Cout / 64) * (p.Cin / 64) / 256;
   const bool big = cfg == 2 || (cfg == 0 && per1 >= 64);
-  if (cfg == 3) launch_wg<T, 8, 4, 1>(p, st);   // 4 waves, 64 co x 8-row tiles, 2 workgroups / CU
+  // mirrored borders (pad_mode 1) are compiled only into the 16x16 / 64-co configuration: the extra address arithmetic would push
+  // the register-tight 8-row configurations into spilling
+  if (p.reflect) launch_wg<T, 16, 2, 2, true>(p, st);
+  else if (cfg == 3) launch_wg<T, 8, 4, 1>(p, st);   // 4 waves, 64 co x 8-row tiles, 2 workgroups / CU
   else if (big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2>(p, st);
   else launch_wg<T, 16, 2, 2>(p, st);
 }
