@@ -191,3 +191,29 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "jg_oracle" not in src and "ref_shim" not in src and "/root/reference" not in src.replace(
                     "/root/reference/models", "").replace("/root/reference/", "REF/"), os.path.join(dirpath, f)
+
+
+def test_hot_kernels_do_not_spill(tmp_path):
+    """The halo-resident convolution / weight-gradient kernels sit at the VGPR limit of their occupancy target: any scratch spill
+    costs 2-3x (a reflect-padding edit once pushed the 8-row weight-gradient configuration into 95 spilled registers).  Compile
+    the two translation units with -save-temps and require zero spills and zero private segment for every kernel in them."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    csrc = os.path.join(ROOT, "joligen_amd", "csrc")
+    for src in ("conv_halo.hip", "wgrad_halo.hip"):
+        out = tmp_path / src.replace(".hip", "")
+        out.mkdir()
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", os.path.join(csrc, src), "-o",
+                            str(out / "o.o"), "-save-temps=obj"], capture_output=True, text=True, cwd=str(out))
+        assert r.returncode == 0, r.stderr[-2000:]
+        asm = [f for f in os.listdir(out) if f.endswith("gfx950.s")]
+        assert asm, os.listdir(out)
+        text = open(out / asm[0]).read()
+        names = re.findall(r"\.name:\s+(\S+)", text)
+        spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
+        priv = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)]
+        assert names and len(spills) >= len([n for n in names if "halo_kernel" in n])
+        assert max(spills) == 0 and max(priv) == 0, list(zip(names, spills, priv))
