@@ -400,6 +400,10 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
     return JG_OK;
   }
   if (p.reflect) return JG_ERR_UNSUPPORTED;   // mirrored borders exist only in the halo-resident kernel
+  if (variant >= 6 && jg_conv1x1_try(sizeof(T) == 2 && std::is_same<T, f16_t>::value ? JG_F16 : JG_BF16, p, nbatch, st)) {
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   if (variant >= 2) {
     if (p.N <= 64) {
       if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);

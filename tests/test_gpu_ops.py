@@ -594,3 +594,32 @@ def test_ddpm_loss_variants_vs_reference_golden(golden_dir, lossname, dtype):
                 assert float(nhd.grad[..., 3:].float().abs().max()) == 0.0
                 # against the reference's numbers (unrounded prediction): only the 16-bit rounding of noise_hat in between
                 assert abs(float(loss) - float(r["loss"])) < (2e-3 if dtype == torch.float16 else 1e-2) * abs(float(r["loss"]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cin,Cout,with_res", [(64, 128, True), (64, 192, False), (128, 64, True), (192, 64, False), (128, 256, True), (256, 64, True)])
+def test_conv1x1_streaming_kernel(Cin, Cout, with_res, dtype, monkeypatch):
+    """the LDS-free streaming 1x1 kernel (M >= 65536 pixels) against the fp32 reference and against the generic kernel
+    (JG_CONV1X1=0 is read once per process, so the generic result comes from a sub-threshold call on a slice)"""
+    from joligen_amd import ops
+
+    B, H, W = 4, 128, 128          # 65536 pixels: the streaming path
+    x = rnd((B, H, W, Cin), dtype, 71)
+    w = (rnd((Cout, 1, 1, Cin), dtype, 72).float() / math.sqrt(Cin)).to(dtype)
+    bias = rnd((Cout,), torch.float32, 73) * 0.1
+    res = rnd((B, H, W, Cout), dtype, 74) if with_res else None
+    xd, wd, bd = x.to(dev()), w.to(dev()), bias.to(dev())
+    rd = res.to(dev()) if with_res else None
+    y = torch.empty((B, H, W, Cout), device=dev(), dtype=dtype)
+    geo = dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=Cin, ldy=Cout)
+    ops.conv_nt(xd, wd, y, bias=bd, res=rd, ldres=Cout, alpha=0.5, res_scale=0.7, **geo)
+    torch.cuda.synchronize()
+    ref = 0.5 * torch.einsum("bhwc,oc->bhwo", x.float(), w.float().view(Cout, Cin)) + bias
+    if with_res:
+        ref = ref + 0.7 * res.float()
+    assert relerr(y.float(), ref) < TOL[dtype], relerr(y.float(), ref)
+    # the generic kernel on the first image only (16384 pixels: below the streaming threshold) agrees to the last rounding
+    y1 = torch.empty((1, H, W, Cout), device=dev(), dtype=dtype)
+    g1 = dict(geo, B=1)
+    ops.conv_nt(xd[:1].contiguous(), wd, y1, bias=bd, res=None if rd is None else rd[:1].contiguous(), ldres=Cout, alpha=0.5, res_scale=0.7, **g1)
+    assert relerr(y[:1].float(), y1.float()) < (1e-3 if dtype == torch.float16 else 8e-3)
