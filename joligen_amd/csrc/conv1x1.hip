@@ -92,6 +92,138 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int nti
   }
 }
 
+// ---- the same streaming scheme for the 3x3 stem (and the input gradient of the 3x3 head): Cin = 8 (one 16-byte chunk per tap) ----
+// K = 9 taps x 8 channels = 72 -> 3 MFMA k-steps of 4 taps (the last three tap slots are zero); the B operand of lane (pixel a, group g)
+// for k-step ks is the 16-byte pixel at tap ks*4 + g, read straight from global memory (zero outside the image).  The generic
+// im2col kernel spends 375 us on 32 x 256^2 x (8 -> 64); the layer moves 33 MB in and 268 MB out.
+template <typename T, int PAIRS>
+__global__ __launch_bounds__(256, 2) void conv3x3_c8_stream_kernel(ConvP p, int ntiles) {
+  constexpr int KS = 3;
+  const int lane = threadIdx.x & 63;
+  const int a = lane & 15, g = lane >> 4;
+  const int n0 = blockIdx.y * (PAIRS * 32);
+  const T* __restrict__ x = (const T*)p.x;
+  const T* __restrict__ w = (const T*)p.w;
+  const T* __restrict__ res = (const T*)p.res;
+  T* __restrict__ y = (T*)p.y;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  uint4 wf[PAIRS][2][KS];
+#pragma unroll
+  for (int pr = 0; pr < PAIRS; ++pr)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int n = n0 + pr * 32 + (a >> 2) * 8 + hf * 4 + (a & 3);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int tap = ks * 4 + g;
+        wf[pr][hf][ks] = tap < 9 ? *reinterpret_cast<const uint4*>(w + (long)n * p.ldw + tap * 8) : zero4;
+      }
+    }
+  float bs[PAIRS][8];
+#pragma unroll
+  for (int pr = 0; pr < PAIRS; ++pr)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bs[pr][j] = p.bias ? p.bias[n0 + pr * 32 + g * 8 + j] : 0.f;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+  auto load_tile = [&](int t, uint4* xf) {
+    const long pix = (long)t * 16 + a;
+    const int px = pix % p.W, py = (pix / p.W) % p.H;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int tap = ks * 4 + g;
+      const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+      const bool ok = tap < 9 && (unsigned)(py + dy) < (unsigned)p.H && (unsigned)(px + dx) < (unsigned)p.W;
+      xf[ks] = ok ? *reinterpret_cast<const uint4*>(x + (pix + (long)dy * p.W + dx) * 8) : zero4;
+    }
+  };
+  // a wave owns a CONTIGUOUS run of tiles, so the fused GroupNorm statistics (sum, sum of squares per image and channel, from the
+  // fp32 values) stay in registers until the image changes: one shuffle reduction + atomic pair per channel and image per wave
+  const int per = (ntiles + nwaves - 1) / nwaves;
+  const int t0 = wave * per, t1 = min(ntiles, t0 + per);
+  const int tiles_per_img = (p.H * p.W) >> 4;
+  float s1[PAIRS][8], s2[PAIRS][8];
+#pragma unroll
+  for (int pr = 0; pr < PAIRS; ++pr)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[pr][j] = s2[pr][j] = 0.f;
+  int cur_b = t0 < t1 ? t0 / tiles_per_img : 0;
+  auto flush = [&](int b) {
+    float* base = p.stats + ((long)(b * p.nslots + wave % p.nslots) * p.ldstats) * 2;
+#pragma unroll
+    for (int pr = 0; pr < PAIRS; ++pr)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float u = s1[pr][j], v = s2[pr][j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          u += __shfl_xor(u, o);
+          v += __shfl_xor(v, o);
+        }
+        if (a == 0) {
+          atomicAdd(base + (n0 + pr * 32 + g * 8 + j) * 2, u);
+          atomicAdd(base + (n0 + pr * 32 + g * 8 + j) * 2 + 1, v);
+        }
+        s1[pr][j] = s2[pr][j] = 0.f;
+      }
+  };
+  constexpr int PF = 2;
+  uint4 ring[PF][KS];
+#pragma unroll
+  for (int s = 0; s < PF; ++s)
+    if (t0 + s < t1) load_tile(t0 + s, ring[s]);
+  for (int base = t0; base < t1; base += PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int t = base + s;
+      if (t < t1) {
+        const long prow = ((long)t * 16 + a);
+        if (p.stats) {
+          const int b = t / tiles_per_img;
+          if (b != cur_b) {
+            flush(cur_b);
+            cur_b = b;
+          }
+        }
+        f32x4 acc[PAIRS][2];
+#pragma unroll
+        for (int pr = 0; pr < PAIRS; ++pr) {
+          acc[pr][0] = acc[pr][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            acc[pr][0] = Mfma<T>::run(wf[pr][0][ks], ring[s][ks], acc[pr][0]);
+            acc[pr][1] = Mfma<T>::run(wf[pr][1][ks], ring[s][ks], acc[pr][1]);
+          }
+        }
+        if (t + PF < t1) load_tile(t + PF, ring[s]);
+#pragma unroll
+        for (int pr = 0; pr < PAIRS; ++pr) {
+          float o[8] = {acc[pr][0][0], acc[pr][0][1], acc[pr][0][2], acc[pr][0][3], acc[pr][1][0], acc[pr][1][1], acc[pr][1][2], acc[pr][1][3]};
+          float r8[8];
+          if (res) unpack8<T>(*reinterpret_cast<const uint4*>(res + prow * p.ldres + n0 + pr * 32 + g * 8), r8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            o[j] = p.alpha * o[j] + bs[pr][j] + (res ? p.res_scale * r8[j] : 0.f);
+            s1[pr][j] += o[j];
+            s2[pr][j] += o[j] * o[j];
+          }
+          *reinterpret_cast<uint4*>(y + prow * p.ldy + n0 + pr * 32 + g * 8) = pack8<T>(o);
+        }
+      }
+    }
+  }
+  if (p.stats && t0 < t1) flush(cur_b);
+}
+
+template <typename T>
+void launch_c8(const ConvP& p, hipStream_t st) {
+  const int ntiles = p.M / 16;
+  const int ngroups = p.N / 64;
+  int bx = (ntiles + 3) / 4;
+  const int cap = 256 * 8 / ngroups > 64 ? 256 * 8 / ngroups : 64;
+  if (bx > cap) bx = cap;
+  hipLaunchKernelGGL((conv3x3_c8_stream_kernel<T, 2>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
+}
+
 template <typename T, int PAIRS, int KS>
 void launch_1x1(const ConvP& p, hipStream_t st) {
   const int ntiles = p.M / 16;
@@ -121,6 +253,15 @@ bool dispatch_1x1(const ConvP& p, hipStream_t st) {
 bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   static const int off = [] { const char* e = getenv("JG_CONV1X1"); return e && atoi(e) == 0; }();
   if (off) return false;
+  if (nbatch == 1 && p.nh == 1 && p.R == 3 && p.S == 3 && p.pad == 1 && p.stride == 1 && !p.out_f32 && !(p.stats && p.stats_mode) && !p.reflect &&
+      p.Cin == 8 && ((p.H * p.W) & 15) == 0 &&
+      p.ldx == 8 && p.ldw == 72 && p.N % 64 == 0 && !(p.M & 15) && p.H == p.Ho && p.W == p.Wo && p.ldy % 8 == 0 && (!p.res || p.ldres % 8 == 0) &&
+      (long)p.M >= 65536) {
+    if (dtype == JG_F16) launch_c8<f16_t>(p, st);
+    else if (dtype == JG_BF16) launch_c8<bf16_t>(p, st);
+    else return false;
+    return true;
+  }
   if (nbatch != 1 || p.nh != 1 || p.R != 1 || p.S != 1 || p.pad != 0 || p.stride != 1 || p.out_f32 || p.stats || p.reflect) return false;
   if (p.Cin % 32 || p.Cin > 256 || p.N % 64 || (p.M & 15)) return false;
   if (p.ldx % 8 || p.ldy % 8 || p.ldw % 8 || (p.res && p.ldres % 8)) return false;

@@ -68,6 +68,9 @@ def _conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, M=0):
     if (nbatch == 1 and R == 1 and S == 1 and pad == 0 and stride == 1 and Cin % 32 == 0 and Cin <= 256 and Cout % 64 == 0 and M >= 65536
             and M % 16 == 0 and os.environ.get("JG_CONV1X1", "1") != "0"):
         return "conv1x1_stream_kernel"
+    if (nbatch == 1 and R == 3 and S == 3 and pad == 1 and stride == 1 and Cin == 8 and Cout % 64 == 0 and M >= 65536 and M % 16 == 0
+            and os.environ.get("JG_CONV1X1", "1") != "0"):
+        return "conv3x3_c8_stream_kernel"
     return "conv_nt_glds_kernel<256,64,64,4,1>" if Cout <= 64 else "conv_nt_glds_kernel<128,128,64,2,2>"
 
 
@@ -107,7 +110,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append((_conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, B * Ho * Wo if stats is None else 0), ev0, ev1,
+        KERNEL_TIMING.append((_conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, B * Ho * Wo if (stats is None or (R == 3 and Cin == 8 and gn_reduce is None)) else 0), ev0, ev1,
                               2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
 
 

@@ -623,3 +623,35 @@ def test_conv1x1_streaming_kernel(Cin, Cout, with_res, dtype, monkeypatch):
     g1 = dict(geo, B=1)
     ops.conv_nt(xd[:1].contiguous(), wd, y1, bias=bd, res=None if rd is None else rd[:1].contiguous(), ldres=Cout, alpha=0.5, res_scale=0.7, **g1)
     assert relerr(y[:1].float(), y1.float()) < (1e-3 if dtype == torch.float16 else 8e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Cout,with_res", [(64, False), (128, True)])
+def test_conv3x3_c8_streaming_kernel(Cout, with_res, dtype):
+    """the streaming 3x3 kernel of the 8-channel stem (and of the head's input gradient): borders, bias, residual, alpha"""
+    from joligen_amd import ops
+
+    B, H, W, Cin = 4, 128, 128, 8
+    x = rnd((B, H, W, Cin), dtype, 81)
+    w = (rnd((Cout, 3, 3, Cin), dtype, 82).float() / math.sqrt(9 * Cin)).to(dtype)
+    bias = rnd((Cout,), torch.float32, 83) * 0.1
+    res = rnd((B, H, W, Cout), dtype, 84) if with_res else None
+    y = torch.empty((B, H, W, Cout), device=dev(), dtype=dtype)
+    ops.conv_nt(x.to(dev()), w.to(dev()), y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=9 * Cin, ldy=Cout,
+                bias=bias.to(dev()), res=None if res is None else res.to(dev()), ldres=Cout, alpha=0.5, res_scale=0.7)
+    torch.cuda.synchronize()
+    ref = 0.5 * F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1) + bias
+    if with_res:
+        ref = ref + 0.7 * res.float()
+    assert relerr(y.float(), ref) < TOL[dtype], relerr(y.float(), ref)
+    # fused GroupNorm statistics of the output (per image and channel, replicated over `stats_slots` rows that the consumer sums)
+    nslots = 16
+    stats = torch.zeros((B, nslots, Cout, 2), device=dev(), dtype=torch.float32)
+    y2 = torch.empty_like(y)
+    ops.conv_nt(x.to(dev()), w.to(dev()), y2, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=9 * Cin, ldy=Cout,
+                bias=bias.to(dev()), res=None if res is None else res.to(dev()), ldres=Cout, alpha=0.5, res_scale=0.7, stats=stats, ldstats=Cout,
+                stats_slots=nslots)
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y)
+    st = stats.sum(1).cpu()
+    assert relerr(st[..., 0], ref.sum((1, 2))) < 1e-3 and relerr(st[..., 1], (ref * ref).sum((1, 2))) < 1e-3
