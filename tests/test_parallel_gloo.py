@@ -99,3 +99,48 @@ def test_flat_allreduce_matches_single_process_mean(tmp_path):
     for nch in (1, 3, 4, 7):
         b = chunk_bounds(n, nch)
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+
+
+def _worker_multi(rank, world, port, sizes, out):
+    """the CUT step has three arenas (G, F, D): two are stepped back to back after one backward, the third later in the iteration;
+    tiny arenas (F's MLPs, a few hundred floats in small configs) are a single ragged chunk"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from joligen_amd import parallel
+
+    arenas = [FakeArena(n, seed=10 * i + rank) for i, n in enumerate(sizes)]
+    for a in arenas:
+        parallel.broadcast_params(a, 0)
+    hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False, ema_beta=None, zero_grad=True)
+    for it in range(2):
+        g = torch.Generator().manual_seed(50 + it)
+        grads = [torch.randn(world, n, generator=g) for n in sizes]
+        for i in (0, 1):                       # group G: generator and feature network
+            arenas[i].g += grads[i][rank]
+            arenas[i].step += 1
+            parallel.allreduce_and_step(arenas[i], hp, grad_scale=1.0, n_chunks=4)
+        arenas[2].g += grads[2][rank]          # group D
+        arenas[2].step += 1
+        parallel.allreduce_and_step(arenas[2], hp, grad_scale=1.0, n_chunks=4)
+    torch.save([a.p for a in arenas], out % rank)
+    dist.destroy_process_group()
+
+
+def test_three_arenas_of_the_cut_step(tmp_path):
+    world, sizes = 2, (70000, 300, 5000)
+    out = str(tmp_path / "m%d.pt")
+    mp.spawn(_worker_multi, args=(world, _free_port(), sizes, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    refs = [FakeArena(n, seed=10 * i) for i, n in enumerate(sizes)]
+    hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False)
+    for it in range(2):
+        g = torch.Generator().manual_seed(50 + it)
+        grads = [torch.randn(world, n, generator=g) for n in sizes]
+        for i in range(3):
+            refs[i].g += grads[i].mean(0)
+            refs[i].step += 1
+            refs[i].adamw_step(**hp)
+    for a, b, ref in zip(r0, r1, refs):
+        assert torch.equal(a, b)
+        torch.testing.assert_close(a, ref.p, rtol=1e-5, atol=1e-6)
