@@ -72,9 +72,20 @@ def build_model(args, rank, local_rank, world):
               train_G_ema_beta=0.999, train_G_lr=2e-4, alg_diffusion_task="inpainting", alg_palette_loss="MSE",
               gpu_ids=",".join(str(i) for i in range(world)), jg_act_dtype=args.dtype, name="bench",
               checkpoints_dir="/tmp/jg_bench_ckpt/")
+    if args.model == "cut":
+        # cut_model: resnet_9blocks / SegFormer-attn G + basic PatchGAN D + mlp_sample F, MoNCE, nce_idt, lsgan (example_gan_*.json shape)
+        ov = dict(model_type="cut", G_netG=args.netG, G_ngf=64, G_nblocks=9, D_netDs=["basic"], D_ndf=64, data_crop_size=args.size,
+                  data_load_size=args.size, train_batch_size=args.batch, train_iter_size=1, train_optim="adam", train_G_ema=True,
+                  train_G_ema_beta=0.999, gpu_ids=",".join(str(i) for i in range(world)), jg_act_dtype=args.dtype, name="bench",
+                  checkpoints_dir="/tmp/jg_bench_ckpt/")
     opt = opt_from_json({}, ov)
     torch.manual_seed(0)  # reference-style default init (+ zero_module); identical on every rank
     model = create_model(opt, local_rank if world > 1 else 0)
+    if args.model == "cut":          # train.py:197-199: the feature network is shaped by a first batch
+        g0 = torch.Generator().manual_seed(1)
+        dev0 = torch.device("cuda", local_rank)
+        model.data_dependent_initialize({"A": (torch.rand(args.batch, 3, args.size, args.size, generator=g0) * 2 - 1).to(dev0),
+                                         "B": (torch.rand(args.batch, 3, args.size, args.size, generator=g0) * 2 - 1).to(dev0)})
     model.setup(opt)
     if world > 1:
         model.parallelize(local_rank)
@@ -109,7 +120,7 @@ def cpu_baseline_subprocess(args, timeout_s=240):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
-           "--efficient", str(args.efficient), "--model", args.model]
+           "--efficient", str(args.efficient), "--model", args.model, "--netG", args.netG]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in out.stdout.splitlines():
@@ -135,6 +146,46 @@ def cpu_baseline(args):
     torch.manual_seed(0)
     batch = synth_batch(Bc, S, 99, "cpu")
     gen = torch.Generator().manual_seed(3)
+    if args.model == "cut":
+        import random
+
+        from joligen_amd.modules.discriminators import NLayerDiscriminator
+        from joligen_amd.modules.cut_networks import PatchSampleF
+        seg = "segformer" in args.netG
+        if seg:
+            from joligen_amd.modules.segformer import SegformerGenerator_attn
+            netG = SegformerGenerator_attn(None, None, 3, S, 10, 1)
+            layers, T = [0, 1, 2, 3], 0.2
+        else:
+            from joligen_amd.modules.resnet_generator import ResnetGenerator
+            netG = ResnetGenerator(3, 3, 64, n_blocks=9)
+            layers, T = [0, 4, 8, 12, 16], 0.07
+        netF = PatchSampleF(use_mlp=True)
+        netF.data_dependent_initialize(None, netG.feat_channels(layers))
+        sdG = {k: v.detach() for k, v in netG.state_dict().items()}
+        sdF = {k: v.detach().float() for k, v in netF.state_dict().items()}
+        sdD = {k: v.detach().float() for k, v in NLayerDiscriminator(3, 64).state_dict().items()}
+        tr = O.OracleCUTTrainer(sdG, sdF, sdD, 9, layers, num_patches=256, T=T, monce=True, pool_size=50, pool_rng=random.Random(0),
+                                ema_beta=0.999, gen="segformer" if seg else "resnet")
+        A, Bm = batch["A"], batch["B"]
+        with torch.no_grad():
+            hw = [f.shape[2] * f.shape[3] for f in (O.segformer_backbone(sdG, A) if seg else O.resnet_encoder(sdG, A, 9, layers)[1])]
+        times = []
+        for it in range(9):
+            ids = [[torch.randperm(n, generator=gen)[:min(256, n)] for n in hw] for _ in range(2)]
+            uni = None
+            if seg:   # 14 DropPath draws + 2 Dropout2d draws [., 256] for the generator forward, then 4 x 14 DropPath draws
+                uni = [torch.rand(2 * Bc, generator=gen) for _ in range(14)] + [torch.rand(2 * Bc, 256, generator=gen) for _ in range(2)] \
+                    + [torch.rand(Bc, generator=gen) for _ in range(56)]      # the generator runs on cat(A, B); the 4 encoder passes on B images
+            t0 = time.perf_counter()
+            tr.step(A, Bm, ids[0], ids[1], uniforms=uni)
+            times.append(time.perf_counter() - t0)
+            if it and sum(times[1:]) > 15.0:
+                break
+        per_step = sum(times[1:]) / len(times[1:])
+        return {"value": round(Bc / per_step, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+                "sample": f"oracle/jg_oracle.py OracleCUTTrainer ({args.netG} G + basic D + F, MoNCE), {len(times) - 1} timed full iterations "
+                          f"(G/F group + D group, 3 Adam steps, EMA) of batch {Bc} at {S}x{S} fp32 after 1 warm-up, {cores} torch threads"}
     if args.model == "cm":
         from joligen_amd.models.cm_model import define_G_cm
 
@@ -182,7 +233,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--efficient", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--model", default="palette", choices=["palette", "cm"],
+    ap.add_argument("--netG", default="resnet", help="--model cut only: resnet (BASELINE configs[0] generator, 9 blocks) | segformer_attn_conv (configs[2])")
+    ap.add_argument("--model", default="palette", choices=["palette", "cm", "cut"],
                     help="palette = BASELINE configs[1] (the bench line); cm = the consistency-model step of configs[4] (same UNet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -207,6 +259,8 @@ def main():
 
     model, opt = build_model(args, rank, local_rank, world)
     batch = synth_batch(args.batch, args.size, 1234 + rank, device)
+    if args.model == "cut":
+        batch = {"A": batch["A"], "B": batch["B"]}
 
     def step():
         model.set_input(batch)
@@ -266,6 +320,8 @@ def main():
         # profiles/r01_pmc_hbm_traffic.md) of this same command, committed as profiles/r01_pmc.json
         traffic = None
         try:
+            if args.model != "palette":
+                raise KeyError("the committed PMC passes were taken on the palette_model command")
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
             traffic = round(pmc[dom.split("<")[0]]["bytes_per_launch"], 1)
         except Exception:
@@ -282,7 +338,7 @@ def main():
                                                 "launches_per_step": n2 // 2, "avg_launch_us": round(t2 / n2 * 1e6, 2),
                                                 "time_per_step_ms": round(t2 / 2 * 1e3, 3)}
         gf = FWD_GFLOP_PER_IMG.get((args.size, bool(args.efficient)))
-        if gf:
+        if gf and args.model != "cut":
             # palette: forward + backward (2x) = 3x; cm: student forward + teacher forward + backward = 4x
             step_tflop = (3 if args.model == "palette" else 4) * gf * args.batch / 1e3
             roofline["step_algorithmic_tflop"] = round(step_tflop, 3)
@@ -294,11 +350,13 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": f"train images/sec at {args.size}x{args.size} ({'DDPM' if args.model == 'palette' else 'CM'} UNet step)",
+            "metric": f"train images/sec at {args.size}x{args.size} ({'DDPM UNet' if args.model == 'palette' else 'CM UNet' if args.model == 'cm' else 'CUT'} step)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'palette_model DDPM' if args.model == 'palette' else 'cm_model consistency'}, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
+            "config": {"workload": (f"cut_model, {args.netG} G (ngf 64, 9 blocks) + basic PatchGAN D + mlp_sample F, MoNCE, nce_idt, lsgan, "
+                                    f"{args.size}x{args.size}, batch {args.batch}/GPU, Adam x3 + EMA, iter_size 1") if args.model == "cut" else
+                                   f"{'palette_model DDPM' if args.model == 'palette' else 'cm_model consistency'}, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
                                    f"res_blocks[2,2,2,2] mid-attn 16x32, {args.size}x{args.size}, batch {args.batch}/GPU, "
                                    "inpainting synthetic masks, AdamW+EMA, iter_size 1 "
                                    "(example_ddpm_noglasses2glasses.json + SURVEY Appendix C overrides)",
