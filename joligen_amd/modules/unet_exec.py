@@ -53,6 +53,7 @@ NSLOT = 16
 # GroupNorm-backward reductions inside the producing dgrad convolution (jg_conv_args.stats_mode 1).  Measured on
 # MI355X (profiles/r01_notes.md): the separate reduction pass disappears (-5.4 ms/step) but the un-overlapped epilogue
 # reads of x cost the convolutions +4.8 ms and the slot-summing bwd_coef +1.8 ms: OFF by default.
+NORM_BEFORE_UP = os.environ.get("JG_NORM_BEFORE_UP", "1") != "0"
 FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 
 
@@ -315,7 +316,9 @@ class UNetExecutor:
             Ho, Wo = (H * 2, W * 2) if rb.up else (H // 2, W // 2)
             if rb.up and rb.efficient:     # conv before the upsample (reference :239-242)
                 a1 = h1
-                c1 = up2(conv_fwd(h1, c1m, stats=st1), 1.0)
+                c1 = conv_fwd(h1, c1m, stats=st1)
+                if not NORM_BEFORE_UP:
+                    c1 = up2(c1, 1.0)
                 hw1 = H * W                # statistics of the source: same mean / variance
             else:
                 a1 = up2(h1, 1.0) if rb.up else pool2(h1, 0.25)
@@ -329,13 +332,19 @@ class UNetExecutor:
         film = self.emb[:, off:off + n]
         ab2, mr2 = gn_coef(st1, hw1, gn2.weight, gn2.bias, film, gn2.num_groups, gn2.eps)
         h2 = gn_apply(c1, ab2, JG_ACT_SILU)
+        low2 = rb.updown and rb.up and rb.efficient and NORM_BEFORE_UP
+        if low2:
+            # GroupNorm + FiLM + SiLU are point-wise given the statistics, and a nearest-neighbour upsample leaves the statistics
+            # unchanged: normalise the LOW-resolution conv output and upsample the activated tensor (a quarter of the pass; the
+            # backward pools the gradient first and runs the GroupNorm backward at low resolution as well -- same mathematics)
+            h2 = up2(h2, 1.0)
         skipw = 1.0 / math.sqrt(2) if rb.efficient else 1.0
         identity = isinstance(rb.skip_connection, nn.Identity)
         sk = xs if identity else conv_fwd(xs, rb.skip_connection.meta)
         out_t, out_st = dest(B, Ho, Wo, Cout)
         conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st)
         rec = dict(kind="res", rb=rb, x=x, ab1=ab1, mr1=mr1, a1=a1, c1=c1, ab2=ab2, mr2=mr2, h2=h2, film=film,
-                   xs=None if identity else xs, skipw=skipw, identity=identity)
+                   xs=None if identity else xs, skipw=skipw, identity=identity, low2=low2)
         rec.update(self._in_fields(X))
         self.tape.append(rec)
         return Act(out_t, out_st, Ho * Wo, len(self.tape) - 1)
@@ -410,14 +419,17 @@ class UNetExecutor:
         gn2, c2m = rb.out_layers[0].norm, rb.out_layers[3].meta
         skipw = rec["skipw"]
         # conv2
-        dh2, red2 = conv_dgrad(dO, c2m, rec["h2"].shape, gn=(rec["c1"], rec["ab2"], JG_ACT_SILU), pool=self.bpool)
+        if rec.get("low2"):
+            dh2, red2 = pool2(conv_dgrad(dO, c2m, rec["h2"].shape), 1.0), None      # adjoint of the upsample behind GroupNorm 2
+        else:
+            dh2, red2 = conv_dgrad(dO, c2m, rec["h2"].shape, gn=(rec["c1"], rec["ab2"], JG_ACT_SILU), pool=self.bpool)
         conv_wgrad(dO, rec["h2"], c2m)
         # GroupNorm 2 (+FiLM +SiLU)
         off, n = rb.emb_slice
         dc1 = gn_bwd(rec["c1"], dh2, rec["ab2"], rec["mr2"], gn2.weight, gn2.bias, rec["film"], gn2.num_groups, JG_ACT_SILU,
                      dfilm=self.demb[:, off:off + n], red=red2)
         del dh2
-        if rb.up and rb.efficient:
+        if rb.up and rb.efficient and not rec.get("low2"):
             dc1 = pool2(dc1, 1.0)          # backward of the nearest upsample that follows conv1
         # conv1
         direct = (not rb.updown) or (rb.up and rb.efficient)   # da1 IS the output-gradient of GroupNorm 1
