@@ -217,3 +217,43 @@ def test_hot_kernels_do_not_spill(tmp_path):
         priv = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)]
         assert names and len(spills) >= len([n for n in names if "halo_kernel" in n])
         assert max(spills) == 0 and max(priv) == 0, list(zip(names, spills, priv))
+
+
+def test_image_pool_matches_reference_semantics():
+    """util/image_pool.py:19-56 behaviour of joligen_amd.util.image_pool.ImagePool (host logic, CPU tensors): fill phase, 50 % swap
+    with a random stored image, draw order uniform -> randint, detached returns; against the oracle restatement with the same RNG."""
+    import random
+
+    import torch
+
+    import jg_oracle as O
+    from joligen_amd.util.image_pool import ImagePool
+
+    for size in (0, 1, 3):
+        ref, mine = O.OracleImagePool(size, random.Random(7)), ImagePool(size, random.Random(7))
+        for it in range(15):
+            x = (torch.full((2, 4, 4, 8), float(it)) + torch.arange(2).view(2, 1, 1, 1) * 0.5).requires_grad_(size > 0)
+            a, b = ref.query(x), mine.query(x)
+            assert torch.equal(a, b)
+            assert size == 0 or not b.requires_grad
+        assert len(mine) == min(size, 30) if size else True
+
+
+def test_cut_options_and_forced_segformer_settings():
+    """CUT defaults of cut_model.py (:39-137) and the settings the reference enforces for a SegFormer generator (:205-210); the model
+    class itself refuses to build without a GPU (no CPU fallback in the product path)."""
+    import pytest
+    import torch
+
+    from joligen_amd.models.cut_model import CUT_DEFAULTS
+    from joligen_amd.options import opt_from_json
+
+    assert CUT_DEFAULTS["alg_cut_nce_T"] == 0.07 and CUT_DEFAULTS["alg_cut_num_patches"] == 256
+    assert CUT_DEFAULTS["alg_cut_nce_layers"] == "0,4,8,12,16" and CUT_DEFAULTS["alg_cut_nce_loss"] == "monce"
+    opt = opt_from_json({"model_type": "cut", "G": {"netG": "segformer_attn_conv"}, "alg": {"cut": {"nce_T": 0.07}}}, {"gpu_ids": "0"})
+    assert opt.alg_cut_nce_T == 0.07 and opt.G_netG == "segformer_attn_conv"
+    if not torch.cuda.is_available():
+        from joligen_amd.models import create_model
+
+        with pytest.raises(RuntimeError, match="MI355X"):
+            create_model(opt, 0)
