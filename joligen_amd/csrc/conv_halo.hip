@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
 
   if (p.dbg & 1) return;
   // ---- epilogue: LDS-transposed, full-line stores (conv_epilogue.h) ---------------------------------------
-  static_assert(TN == 4, "the shared epilogue works on 64-channel wave tiles");
+  static_assert(TN % 4 == 0, "the shared epilogue works on 64-channel wave tiles");
   static_assert(sizeof(sm) >= NWAVES * 16384 + BN * 8, "epilogue scratch");
   char* smc = reinterpret_cast<char*>(&sm[0]);          // every wave is past its last LDS read (K-loop barrier)
   float* sred = reinterpret_cast<float*>(smc + NWAVES * 16384);
@@ -241,17 +241,20 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     __syncthreads();
   }
   const long mrow0 = ((long)b * p.H + oh0 + wm * TM) * p.W + ow0;
-  jg_epilogue_lds<T, TM, true>(
-      p, acc, smc + wave * 16384, lane, n0 + wn * WN, b,
-      [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
-      [&](int nch, const float* s1, const float* s2) {
-        // wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          atomicAdd(&sred[(nch - n0 + q) * 2], s1[q]);
-          atomicAdd(&sred[(nch - n0 + q) * 2 + 1], s2[q]);
-        }
-      });
+  for (int h = 0; h < TN / 4; ++h) {     // 64 output channels of the wave tile at a time
+    jg_epilogue_lds<T, TM, true>(
+        p, reinterpret_cast<f32x4(&)[4][TM]>(acc[4 * h]), smc + wave * 16384, lane, n0 + wn * WN + 64 * h, b,
+        [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
+        [&](int nch, const float* s1, const float* s2) {
+          // wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            atomicAdd(&sred[(nch - n0 + q) * 2], s1[q]);
+            atomicAdd(&sred[(nch - n0 + q) * 2 + 1], s2[q]);
+          }
+        });
+  }
   if (p.stats) {
     __syncthreads();
     float* dst = p.stats + (((long)b * p.nslots + sp % p.nslots) * p.ldstats + n0) * 2;
@@ -272,6 +275,8 @@ void dispatch_halo(const ConvP& p, hipStream_t st) {
   // 256-wide tiles run one 8-wave workgroup per CU: worth it only when the grid fills whole rounds of 256
   const long b256 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.N / 256);
   const bool fill256 = p.N % 256 == 0 && (double)b256 / (double)(((b256 + 255) / 256) * 256) >= 0.85;
+  // (tried: <256, 256, 2, 2, 1, 2, 1> = 4 waves x (128 px x 128 ch) with the 256 accumulator registers in AGPRs -- halves the LDS
+  //  fragment traffic per MFMA, but one wave per SIMD cannot hide the halo reloads: 1000-1170 vs 1260-1430 TFLOP/s, not kept)
   if (fill256 && cfg == 0) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
   else if (p.N % 128 == 0 && cfg == 2) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
   else if (p.N % 128 == 0) launch_halo<T, 128, 256, 2, 2, 1, 2, 2>(p, st);   // 4 waves x (128 px x 64 ch), 2 workgroups / CU
