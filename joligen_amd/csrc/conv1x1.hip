@@ -224,6 +224,10 @@ void launch_c8(const ConvP& p, hipStream_t st) {
   hipLaunchKernelGGL((conv3x3_c8_stream_kernel<T, 2>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
 }
 
+// (tried: the same LDS-free scheme for the 3x3 / 64 -> 64 layers at full resolution, weights of 32 output channels in registers and the
+//  nine shifted pixel reads served by L1 / L2: 714 us against 208 us for the halo-resident kernel -- the 9x operand re-read through the
+//  cache hierarchy costs far more than the halo kernel's unoverlapped phases; not kept)
+
 template <typename T, int PAIRS, int KS>
 void launch_1x1(const ConvP& p, hipStream_t st) {
   const int ntiles = p.M / 16;
