@@ -1,6 +1,7 @@
 """GPU parity tests of the CUT loss path: fp32 GEMM, PatchSampleF, PatchNCE / MoNCE (50 Sinkhorn
 iterations and their reverse sweep), LSGAN loss, image pool, and N x CUTModel.optimize_parameters() against fixtures recorded
 from the unmodified reference (oracle/make_golden_cutstep.py) and against the CPU oracle on identical inputs."""
+import math
 import os
 import random
 
@@ -366,3 +367,44 @@ def test_cut_checkpoints_reference_layout(golden_dir, tmp_path):
     torch.cuda.synchronize()
     # same weights -> same output up to the summation order of the atomically accumulated InstanceNorm statistics
     assert relerr(m1.fake_B.float(), m2.fake_B.float()) < 5e-3
+
+
+@pytest.mark.parametrize("netG", ["resnet", "segformer_attn_conv"])
+def test_cut_full_size_properties(netG):
+    """BASELINE shapes (256x256, resnet_9blocks / SegFormer-attn G, ndf 64, 256 patches; batch 2 to bound the test time), properties
+    that need no CPU oracle: finite losses, the NCE loss of an untrained network sits near log(257) per layer, every Adam step moves
+    a parameter tensor by at most lr per element (and by about lr for most of them), and the EMA copy trails the weights."""
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    cfg = {"model_type": "cut", "G": {"netG": netG, "ngf": 64, "nblocks": 9}, "D": {"netDs": ["basic"], "ndf": 64},
+           "data": {"crop_size": 256, "load_size": 256}, "train": {"batch_size": 2, "G_ema": True}}
+    model = create_model(opt_from_json(cfg, overrides={"jg_act_dtype": "bf16", "gpu_ids": "0"}), 0)
+    g = torch.Generator().manual_seed(2)
+    data = {"A": torch.rand(2, 3, 256, 256, generator=g) * 2 - 1, "B": torch.rand(2, 3, 256, 256, generator=g) * 2 - 1}
+    torch.manual_seed(0)
+    model.data_dependent_initialize(data)
+    before = {n: {k: p.detach().clone() for k, p in getattr(model, "net" + n).named_parameters()} for n in ("G_A", "F", "D_B_basic")}
+    n_steps = 2
+    for _ in range(n_steps):
+        model.set_input(data)
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    losses = {k: float(v) for k, v in model.get_current_losses().items()}
+    assert all(math.isfinite(v) for v in losses.values()), losses
+    import math as _m
+    assert 0.5 * _m.log(257) < losses["G_NCE"] < 2.5 * _m.log(257), losses       # ~ log(1 + 256 negatives) at random features
+    lrs = {"G_A": model.opt.train_G_lr, "F": model.opt.train_G_lr, "D_B_basic": model.opt.train_D_lr}
+    for n, params in before.items():
+        moved = 0
+        for k, p0 in params.items():
+            p1 = dict(getattr(model, "net" + n).named_parameters())[k].detach()
+            d = (p1 - p0).abs()
+            assert torch.isfinite(p1).all(), (n, k)
+            assert float(d.max()) <= 1.02 * n_steps * lrs[n], (n, k, float(d.max()))
+            moved += int(float(d.mean()) > 0.2 * n_steps * lrs[n])
+        assert moved >= 0.6 * len(params), (n, moved, len(params))
+    ema = dict(model.netG_A_ema.named_parameters())
+    k0 = next(iter(before["G_A"]))
+    cur = dict(model.netG_A.named_parameters())[k0].detach()
+    assert float((ema[k0] - cur).abs().max()) > 0 and float((ema[k0] - cur).abs().max()) <= 1.02 * n_steps * lrs["G_A"]
