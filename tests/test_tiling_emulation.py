@@ -468,3 +468,29 @@ def test_tr_reads_and_staging_writes_bank_conflict_free():
                 pos = row * 16 + ((((cidx >> 1) ^ swz_tr(row)) << 1) | (cidx & 1))
                 slots.append(pos % 8)
             assert len(set(slots)) == 8
+
+
+def test_subpixel_identity_of_conv_after_nearest_upsample():
+    """Groundwork for the next kernel: conv3x3(pad 1) of a nearest-x2-upsampled map equals four 2x2-tap convolutions
+    of the LOW-resolution map (one per output phase) with summed weights -- 16 instead of 36 tap-MACs per low-resolution pixel.
+        phase 0 along an axis: taps {-1: w0, 0: w1 + w2};   phase 1: taps {0: w0 + w1, +1: w2}"""
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(0)
+    L = torch.randn(2, 5, 6, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(L, scale_factor=2, mode="nearest"), w, padding=1)
+    comb = {0: ((-1, [0]), (0, [1, 2])), 1: ((0, [0, 1]), (1, [2]))}       # phase -> ((offset, summed original taps), ...)
+    Lp = F.pad(L, (1, 1, 1, 1))
+    out = torch.zeros_like(ref)
+    H, W = L.shape[2:]
+    for py in (0, 1):
+        for px in (0, 1):
+            acc = 0
+            for oy, ry in comb[py]:
+                for ox, rx in comb[px]:
+                    wk = w[:, :, ry][:, :, :, rx].sum((2, 3))                 # [Cout, Cin] combined weight of this tap
+                    acc = acc + torch.einsum("oc,bchw->bohw", wk, Lp[:, :, 1 + oy:1 + oy + H, 1 + ox:1 + ox + W])
+            out[:, :, py::2, px::2] = acc
+    torch.testing.assert_close(out, ref, rtol=1e-12, atol=1e-12)
