@@ -149,6 +149,21 @@ int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const void* dy, in
                        const float* pqr, void* dx, int64_t lddx, const void* add1, int64_t ldadd1, float scale1,
                        const void* add2, int64_t ldadd2, float scale2, int B, int HW, int C, int act, jg_stream_t s);
 
+/* y[B, H/2, W/2, C] = scale * sum_{2x2} act(a * x + b): GroupNorm apply + activation + 2x2 pool in one pass (ResBlock-down `h` path,
+ * unet_generator_attn.py:239-246 with Downsample = AvgPool2d at :163-176). */
+int jg_gn_apply_pool(int dtype, const void* x, int64_t ldx, const float* ab, void* y, int64_t ldy, int B, int H, int W, int C, int act,
+                     float scale, jg_stream_t s);
+
+/* GroupNorm backward of a layer whose output went through nn.AvgPool2d(2,2) (the ResBlock-down path `pool(act(norm(x)))`,
+ * unet_generator_attn.py:239-246): dy_low / add1_low are gradients at the POOLED resolution [B, H/2, W/2, C]; the pool's adjoint
+ * (nearest upsample * dy_scale, .25 for the average) is applied while reading, so the full-resolution gradient is never written.
+ * add2 (optional) is a full-resolution addend as in jg_gn_bwd_apply_ld. */
+int jg_gn_bwd_reduce_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
+                        float* red, int B, int H, int W, int C, int act, jg_stream_t s);
+int jg_gn_bwd_apply_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
+                       const float* pqr, void* dx, int64_t lddx, const void* add1_low, int64_t ldadd1, float scale1, const void* add2,
+                       int64_t ldadd2, float scale2, int B, int H, int W, int C, int act, jg_stream_t s);
+
 /* 2x2 sum-pool * scale and nearest x2 upsample * scale, NHWC.  Forward/backward of
  * nn.AvgPool2d(2,2) (pool scale .25 / upsample scale .25) and of
  * F.interpolate(scale_factor=2, mode="nearest") (upsample scale 1 / pool scale 1)

@@ -150,10 +150,53 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   }
 }
 
+// y[B, H/2, W/2, C] = scale * sum over the 2x2 window of act(a * x + b): the ResBlock-down path's pool(act(norm(x))) without the
+// full-resolution intermediate.  HWo = (H/2)*(W/2), Wo = W/2
 template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_apply_pool_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ ab,
+                                                            T* __restrict__ y, long ldy, int HWo, int Wo, int C, float scale) {
+  const Map mp = make_map(C);
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if (tid >= mp.active) return;
+  const int co = tid % mp.noct, pl = tid / mp.noct;
+  float a[8], bb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    a[q] = ab[((long)b * C + co * 8 + q) * 2];
+    bb[q] = ab[((long)b * C + co * 8 + q) * 2 + 1];
+  }
+  const int pbeg = blockIdx.x * mp.chunk;
+  const int pend = min(HWo, pbeg + mp.chunk);
+  const long W = 2L * Wo;
+  for (int p = pbeg + pl; p < pend; p += mp.pl) {
+    const int ho = p / Wo, wo = p - ho * Wo;
+    const T* src = x + ((long)b * HWo * 4 + 2L * ho * W + 2 * wo) * ldx + co * 8;
+    uint4 v[4];
+    v[0] = *reinterpret_cast<const uint4*>(src);
+    v[1] = *reinterpret_cast<const uint4*>(src + ldx);
+    v[2] = *reinterpret_cast<const uint4*>(src + W * ldx);
+    v[3] = *reinterpret_cast<const uint4*>(src + (W + 1) * ldx);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float f[8];
+      unpack8<T>(v[i], f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += act_f<ACT>(a[q] * f[q] + bb[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] *= scale;
+    *reinterpret_cast<uint4*>(y + ((long)b * HWo + p) * ldy + co * 8) = pack8<T>(acc);
+  }
+}
+
+// UP: dy is the gradient of a 2x2 average pool's OUTPUT ([B, H/2, W/2, C], W = full-resolution width): the pool's adjoint
+// (nearest upsample * dysc) is applied while reading, the full-resolution gradient is never materialised
+template <typename T, int ACT, bool UP = false>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                             long lddy, const float* __restrict__ ab,
-                                                            float* __restrict__ red, int HW, int C, int mult) {
+                                                            float* __restrict__ red, int HW, int C, int mult, int W = 0,
+                                                            float dysc = 1.f) {
   extern __shared__ float s_acc[];  // [C][2]
   const Map mp = make_map_red(C, mult);
   const int tid = threadIdx.x, b = blockIdx.y;
@@ -174,13 +217,14 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
 #pragma unroll 4
     for (int p = pbeg + pl; p < pend; p += mp.pl) {
       const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
-      const uint4 vg = *reinterpret_cast<const uint4*>(dy + (row0 + p) * lddy + co * 8);
+      const long pg = UP ? ((long)b * (HW >> 2) + (long)((p / W) >> 1) * (W >> 1) + ((p % W) >> 1)) : row0 + p;
+      const uint4 vg = *reinterpret_cast<const uint4*>(dy + pg * lddy + co * 8);
       float fx[8], fg[8];
       unpack8<T>(vx, fx);
       unpack8<T>(vg, fg);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        float du = fg[q];
+        float du = UP ? fg[q] * dysc : fg[q];
         if (ACT != JG_ACT_NONE) du *= act_grad_f<ACT>(a[q] * fx[q] + bb[q]);
         s1[q] += du;
         s2[q] += du * fx[q];
@@ -253,13 +297,14 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ red, int nslots, co
   }
 }
 
-template <typename T, int ACT>
+// UP: dy AND add1 are low-resolution ([B, H/2, W/2, C]) and read through the nearest-upsample index map (see gn_bwd_reduce_kernel)
+template <typename T, int ACT, bool UP = false>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                            long lddy, const float* __restrict__ ab,
                                                            const float* __restrict__ pqr, T* __restrict__ dx, long lddx,
                                                            const T* __restrict__ add1, long ldadd1, float sc1,
                                                            const T* __restrict__ add2, long ldadd2, float sc2, int HW,
-                                                           int C, int rev) {
+                                                           int C, int rev, int W = 0, float dysc = 1.f) {
   const Map mp = make_map(C);
   // reversed traversal: the pass runs right behind gn_bwd_reduce over the same (x, dy); walking from the END
   // re-reads what the reduction touched last and is still resident in the 256 MB Infinity Cache
@@ -281,19 +326,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   const long row0 = (long)b * HW;
   for (int p = pbeg + pl; p < pend; p += mp.pl) {
     const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
-    const uint4 vg = *reinterpret_cast<const uint4*>(dy + (row0 + p) * lddy + co * 8);
+    const long pg = UP ? ((long)b * (HW >> 2) + (long)((p / W) >> 1) * (W >> 1) + ((p % W) >> 1)) : row0 + p;
+    const uint4 vg = *reinterpret_cast<const uint4*>(dy + pg * lddy + co * 8);
     float fx[8], fg[8];
     unpack8<T>(vx, fx);
     unpack8<T>(vg, fg);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float du = fg[q];
+      float du = UP ? fg[q] * dysc : fg[q];
       if (ACT != JG_ACT_NONE) du *= act_grad_f<ACT>(a[q] * fx[q] + bb[q]);
       fg[q] = du * P[q] + fx[q] * Q[q] + R[q];
     }
     if (add1) {   // fused gradient accumulation of the other consumers of x (residual / skip / concat paths)
       float fa[8];
-      unpack8<T>(*reinterpret_cast<const uint4*>(add1 + (row0 + p) * ldadd1 + co * 8), fa);
+      unpack8<T>(*reinterpret_cast<const uint4*>(add1 + pg * ldadd1 + co * 8), fa);
 #pragma unroll
       for (int q = 0; q < 8; ++q) fg[q] += sc1 * fa[q];
     }
@@ -355,6 +401,18 @@ extern "C" int jg_gn_apply_ld(int dtype, const void* x, int64_t ldx, const float
   return JG_OK;
 }
 
+extern "C" int jg_gn_apply_pool(int dtype, const void* x, int64_t ldx, const float* ab, void* y, int64_t ldy, int B, int H, int W, int C,
+                                int act, float scale, jg_stream_t s) {
+  if (!x || !ab || !y || bad_shape(B, H * W, C) || (H & 1) || (W & 1) || ldx < C || ldy < C || (ldx % 8) || (ldy % 8)) return JG_ERR_BAD_ARG;
+  const int HWo = (H / 2) * (W / 2);
+  const Map mp = make_map(C);
+  dim3 grid((HWo + mp.chunk - 1) / mp.chunk, B);
+  JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_apply_pool_kernel<T, ACT>), grid, dim3(256), 0, (hipStream_t)s,
+                                                            (const T*)x, (long)ldx, ab, (T*)y, (long)ldy, HWo, W / 2, C, scale);););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
 extern "C" int jg_gn_apply(int dtype, const void* x, const float* ab, void* y, int B, int HW, int C, int act,
                            jg_stream_t s) {
   return jg_gn_apply_ld(dtype, x, C, ab, y, C, B, HW, C, act, s);
@@ -371,6 +429,40 @@ extern "C" int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const 
   const size_t shm = 2 * C * sizeof(float);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, ACT>), grid, dim3(256), shm, st, (const T*)x,
                                                             (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult);););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_reduce_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
+                                   float* red, int B, int H, int W, int C, int act, jg_stream_t s) {
+  const int HW = H * W;
+  if (!x || !dy_low || !ab || !red || bad_shape(B, HW, C) || (H & 1) || (W & 1) || ldx < C || lddy < C || (ldx % 8) || (lddy % 8)) return JG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  if (hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
+  const int mult = red_mult(B, HW, C);
+  const Map mp = make_map_red(C, mult);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  const size_t shm = 2 * C * sizeof(float);
+  JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, ACT, true>), grid, dim3(256), shm, st, (const T*)x,
+                                                            (long)ldx, (const T*)dy_low, (long)lddy, ab, red, HW, C, mult, W, dy_scale);););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_apply_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
+                                  const float* pqr, void* dx, int64_t lddx, const void* add1_low, int64_t ldadd1, float scale1,
+                                  const void* add2, int64_t ldadd2, float scale2, int B, int H, int W, int C, int act, jg_stream_t s) {
+  const int HW = H * W;
+  if (!x || !dy_low || !ab || !pqr || !dx || bad_shape(B, HW, C) || (H & 1) || (W & 1)) return JG_ERR_BAD_ARG;
+  if (ldx < C || lddy < C || lddx < C || (ldx % 8) || (lddy % 8) || (lddx % 8)) return JG_ERR_BAD_ARG;
+  if ((add1_low && (ldadd1 < C || ldadd1 % 8)) || (add2 && (ldadd2 < C || ldadd2 % 8))) return JG_ERR_BAD_ARG;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  static const int rev = [] { const char* e = getenv("JG_GN_REVERSE"); return e ? atoi(e) : 1; }();
+  JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, true>), grid, dim3(256), 0, (hipStream_t)s,
+                                                            (const T*)x, (long)ldx, (const T*)dy_low, (long)lddy, ab, pqr, (T*)dx, (long)lddx,
+                                                            (const T*)add1_low, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2,
+                                                            HW, C, rev, W, dy_scale);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

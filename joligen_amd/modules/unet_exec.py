@@ -54,6 +54,9 @@ NSLOT = 16
 # MI355X (profiles/r01_notes.md): the separate reduction pass disappears (-5.4 ms/step) but the un-overlapped epilogue
 # reads of x cost the convolutions +4.8 ms and the slot-summing bwd_coef +1.8 ms: OFF by default.
 NORM_BEFORE_UP = os.environ.get("JG_NORM_BEFORE_UP", "1") != "0"
+# ResBlock-down: pool(act(norm(x))) in one kernel, and the GroupNorm backward reads the pooled-resolution gradients through the
+# upsample index map (jg_gn_apply_pool / jg_gn_bwd_*_up) instead of materialising full-resolution copies
+FUSE_DOWN_POOL = os.environ.get("JG_FUSE_DOWN_POOL", "1") != "0"
 FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 
 
@@ -147,9 +150,11 @@ def gn_apply(x, ab, act):
     return y
 
 
-def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=(), red=None):
+def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=(), red=None, pooled=None):
     """dx = GroupNorm-backward(x, dy) + sum_i scale_i * add_i  (at most two addends, fused).
-    `red`: reductions already accumulated by the convolution that produced dy ([B, NSLOT, C, 2])."""
+    `red`: reductions already accumulated by the convolution that produced dy ([B, NSLOT, C, 2]).
+    `pooled`: (dy_scale, low_add): dy (and the optional addend `low_add` = (tensor, scale)) live at the 2x2-POOLED resolution; the
+    kernels read them through the nearest-upsample map (adjoint of the average pool) instead of materialising the upsampled copy."""
     L = _lib.lib()
     B, H, W, C = x.shape
     HW = H * W
@@ -159,8 +164,12 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
     if red is None:
         nslots = 1
         red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
-        check(L.jg_gn_bwd_reduce_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), red.data_ptr(), B, HW, C,
-                                    act, _st()), "jg_gn_bwd_reduce_ld")
+        if pooled is not None:
+            check(L.jg_gn_bwd_reduce_up(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), pooled[0], ab.data_ptr(), red.data_ptr(),
+                                        B, H, W, C, act, _st()), "jg_gn_bwd_reduce_up")
+        else:
+            check(L.jg_gn_bwd_reduce_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), red.data_ptr(), B, HW, C,
+                                        act, _st()), "jg_gn_bwd_reduce_ld")
     dgamma = gamma.grad if gamma is not None else None
     dbeta = beta.grad if beta is not None else None
     if gamma is not None and dgamma is None:
@@ -172,6 +181,15 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
     if out is None:
         out = torch.empty((B, H, W, C), device=dev, dtype=x.dtype)
     adds = list(adds)
+    if pooled is not None:
+        if len(adds) > 1:
+            raise RuntimeError("at most one full-resolution addend next to the pooled one")
+        a1, s1 = pooled[1] if pooled[1] is not None else (None, 0.0)
+        a2, s2 = adds[0] if adds else (None, 0.0)
+        check(L.jg_gn_bwd_apply_up(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), pooled[0], ab.data_ptr(), pqr.data_ptr(),
+                                   out.data_ptr(), _ld(out), _p(a1), _ld(a1) if a1 is not None else 0, s1, _p(a2),
+                                   _ld(a2) if a2 is not None else 0, s2, B, H, W, C, act, _st()), "jg_gn_bwd_apply_up")
+        return out
     if len(adds) > 2:
         raise RuntimeError("at most two fused gradient addends")
     a1, s1 = adds[0] if len(adds) > 0 else (None, 0.0)
@@ -180,6 +198,14 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
                                _ld(out), _p(a1), _ld(a1) if a1 is not None else 0, s1, _p(a2),
                                _ld(a2) if a2 is not None else 0, s2, B, HW, C, act, _st()), "jg_gn_bwd_apply_ld")
     return out
+
+
+def gn_apply_pool(x, ab, act, scale):
+    B, H, W, C = x.shape
+    y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_gn_apply_pool(_dt(x), x.data_ptr(), _ld(x), ab.data_ptr(), y.data_ptr(), C, B, H, W, C, act, scale, _st()),
+          "jg_gn_apply_pool")
+    return y
 
 
 def pool2(x, scale):
@@ -309,7 +335,8 @@ class UNetExecutor:
         gn1, c1m = rb.in_layers[0].norm, rb.in_layers[2].meta
         gn2, c2m = rb.out_layers[0].norm, rb.out_layers[3].meta
         ab1, mr1 = gn_coef(X.st, X.hw, gn1.weight, gn1.bias, None, gn1.num_groups, gn1.eps)
-        h1 = gn_apply(x, ab1, JG_ACT_SILU)
+        fuse_down = rb.updown and rb.down and FUSE_DOWN_POOL
+        h1 = None if fuse_down else gn_apply(x, ab1, JG_ACT_SILU)
         st1 = self.pool.take(B, Cout)
         Ho, Wo = H, W
         if rb.updown:
@@ -321,7 +348,10 @@ class UNetExecutor:
                     c1 = up2(c1, 1.0)
                 hw1 = H * W                # statistics of the source: same mean / variance
             else:
-                a1 = up2(h1, 1.0) if rb.up else pool2(h1, 0.25)
+                if fuse_down:
+                    a1 = gn_apply_pool(x, ab1, JG_ACT_SILU, 0.25)     # pool(act(norm(x))) in one pass
+                else:
+                    a1 = up2(h1, 1.0) if rb.up else pool2(h1, 0.25)
                 c1 = conv_fwd(a1, c1m, stats=st1)
                 hw1 = Ho * Wo
             xs = up2(x, 1.0) if rb.up else pool2(x, 0.25)
@@ -439,7 +469,11 @@ class UNetExecutor:
             da1, red1 = conv_dgrad(dc1, c1m, rec["a1"].shape), None
         conv_wgrad(dc1, rec["a1"], c1m)
         del dc1
-        if rb.down:
+        pooled = None
+        if rb.down and FUSE_DOWN_POOL:
+            dh1 = da1                      # stays at the pooled resolution; gn_bwd applies the pool's adjoint while reading
+            pooled = (0.25, (dO, skipw * 0.25) if rec["identity"] else None)
+        elif rb.down:
             dh1 = up2(da1, 0.25)
         elif rb.up and not rb.efficient:
             dh1 = pool2(da1, 1.0)
@@ -451,11 +485,12 @@ class UNetExecutor:
             if not rb.updown:
                 adds.append((dO, skipw))
             elif rb.down:
-                adds.append((up2(dO, skipw * 0.25), 1.0))
+                if pooled is None:
+                    adds.append((up2(dO, skipw * 0.25), 1.0))
             else:
                 adds.append((pool2(dO, skipw), 1.0))
             return gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
-                          red=red1)
+                          red=red1, pooled=pooled)
         if rb.updown:
             raise NotImplementedError("resampling ResBlock with a 1x1 skip convolution")
         skm = rb.skip_connection.meta

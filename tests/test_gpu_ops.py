@@ -655,3 +655,45 @@ def test_conv3x3_c8_streaming_kernel(Cout, with_res, dtype):
     assert torch.equal(y2, y)
     st = stats.sum(1).cpu()
     assert relerr(st[..., 0], ref.sum((1, 2))) < 1e-3 and relerr(st[..., 1], (ref * ref).sum((1, 2))) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,G,H,W", [(64, 32, 16, 32), (128, 32, 8, 8), (192, 32, 32, 16)])
+def test_group_norm_pool_fusion(C, G, H, W, dtype):
+    """jg_gn_apply_pool and jg_gn_bwd_{reduce,apply}_up (the ResBlock-down path pool(act(norm(x))), reference
+    unet_generator_attn.py:239-246) against torch fp32: y = avg_pool2d(silu(group_norm(x))) and its input gradient plus
+    one pooled-resolution and one full-resolution addend."""
+    from joligen_amd._lib import JG_ACT_SILU
+    from joligen_amd.modules import unet_exec as ue
+
+    d = dev()
+    B = 2
+    x = rnd((B, H, W, C), dtype, 91).to(d)
+    gamma = (1 + 0.1 * rnd((C,), torch.float32, 92)).to(d).requires_grad_(True)
+    beta = (0.1 * rnd((C,), torch.float32, 93)).to(d).requires_grad_(True)
+    gamma.grad, beta.grad = torch.zeros_like(gamma), torch.zeros_like(beta)
+    gy = rnd((B, H // 2, W // 2, C), dtype, 94).to(d)
+    add_low = rnd((B, H // 2, W // 2, C), dtype, 95).to(d)
+    add_full = rnd((B, H, W, C), dtype, 96).to(d)
+    st = torch.zeros((B, 1, C, 2), device=d, dtype=torch.float32)
+    from joligen_amd import _lib
+    _lib.check(_lib.lib().jg_gn_stats_ld(ue._dt(x), x.data_ptr(), C, st.data_ptr(), C, B, H * W, C, ue._st()), "stats")
+    ab, mr = ue.gn_coef(st, H * W, gamma, beta, None, G, 1e-5)
+    y = ue.gn_apply_pool(x, ab, JG_ACT_SILU, 0.25)
+    dx = ue.gn_bwd(x, gy, ab, mr, gamma, beta, None, G, JG_ACT_SILU, adds=[(add_full, 0.5)], pooled=(0.25, (add_low, 0.125)))
+    torch.cuda.synchronize()
+    # torch fp32 reference
+    xr = x.float().permute(0, 3, 1, 2).detach().requires_grad_(True)
+    gr, br = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    yr = F.avg_pool2d(F.silu(F.group_norm(xr, G, gr, br, 1e-5)), 2)
+    yr.backward(gy.float().permute(0, 3, 1, 2))
+    dxr = xr.grad + 0.5 * add_full.float().permute(0, 3, 1, 2) + \
+        0.125 * F.interpolate(add_low.float().permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+    assert relerr(y.float().permute(0, 3, 1, 2), yr) < TOL[dtype]
+    assert relerr(dx.float().permute(0, 3, 1, 2), dxr) < 2 * TOL[dtype]
+    assert relerr(gamma.grad, gr.grad) < 2 * TOL[dtype]
+    assert relerr(beta.grad, br.grad) < 2 * TOL[dtype]
+    # and bit-compatible routing: the unfused composition of the same kernels agrees to rounding
+    y2 = ue.pool2(ue.gn_apply(x, ab, JG_ACT_SILU), 0.25)
+    assert relerr(y.float(), y2.float()) < TOL[dtype]
