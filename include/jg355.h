@@ -75,6 +75,9 @@ typedef struct {
    * pad-0 3x3 convolution (resnet_generator.py:52-60) as ONE launch (pad = 1, Ho = H, Wo = W).  Halo-resident kernel only:
    * 3x3, stride 1, Cin % 64 == 0, Cout % 64 == 0, H % 16 == 0, W % 16 == 0, else JG_ERR_UNSUPPORTED. */
   int32_t pad_mode;
+  /* res_mode 1: res is [B, Ho/2, Wo/2, Cout] and is read through the nearest-upsample map, i.e. y += res_scale * Upsample(res)
+   * without the upsampled copy (ResBlock-up skip path `self.x_upd(x)`, unet_generator_attn.py:236-246).  Ho, Wo even, nbatch 1. */
+  int32_t res_mode;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 

@@ -78,7 +78,8 @@ __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][
         for (int q = 0; q < 8; ++q) v[q] += bias[q];
         if (res) {
           float rf[8];
-          unpack8<T>(*reinterpret_cast<const uint4*>(res + m * p.ldres + nbase + c8 * 8), rf);
+          const long mr = p.res_up ? jg_res_up_row(p, m) : m;
+          unpack8<T>(*reinterpret_cast<const uint4*>(res + mr * p.ldres + nbase + c8 * 8), rf);
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += p.res_scale * rf[q];
         }

@@ -23,8 +23,18 @@ struct ConvP {
   int stats_mode;
   int dbg;        // ablation switches of the dev tools (JG_HALO_DBG): 1 = no epilogue, 2 = no MFMA/LDS reads, 4 = no halo DMA
   const char* gx; long gldx; const float* gab; int gact;
+  int res_up;     // 1: res is [B, Ho/2, Wo/2, N] and is read through the nearest-upsample index map (UNet up-block skip path)
   int reflect;    // 1: out-of-image halo pixels mirror the interior (nn.ReflectionPad2d(1) in front of a pad-0 3x3 conv)
 };
+
+// output pixel row m = (b * Ho + oh) * Wo + ow  ->  row of the half-resolution residual
+__device__ __forceinline__ long jg_res_up_row(const ConvP& p, long m) {
+  const int ow = (int)(m % p.Wo);
+  const long t = m / p.Wo;
+  const int oh = (int)(t % p.Ho);
+  const long b = t / p.Ho;
+  return (b * (p.Ho >> 1) + (oh >> 1)) * (p.Wo >> 1) + (ow >> 1);
+}
 
 // Per-wave reduction of the epilogue's (sum, sum^2) partials over the 16 pixel lanes of an MFMA tile
 // column group, then one atomic pair per channel from lane (l & 15) == 0.

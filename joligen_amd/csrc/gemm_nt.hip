@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void conv_nt_kernel(ConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[j][i][q] + bv[q];
       if (resb) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(resb + (long)m * p.ldres + n);
+        const long mr = p.res_up ? jg_res_up_row(p, m) : (long)m;
+        const uint2 rv = *reinterpret_cast<const uint2*>(resb + mr * p.ldres + n);
         float rf[4];
         unpack4<T>(rv, rf);
 #pragma unroll
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[j][i][q] + bv[q];
       if (resb) {
-        const uint2 rv = *reinterpret_cast<const uint2*>(resb + (long)m * p.ldres + n);
+        const long mr = p.res_up ? jg_res_up_row(p, m) : (long)m;
+        const uint2 rv = *reinterpret_cast<const uint2*>(resb + mr * p.ldres + n);
         float rf[4];
         unpack4<T>(rv, rf);
 #pragma unroll
@@ -455,6 +457,9 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.nslots = a->stats_slots > 0 ? a->stats_slots : 1;
   p.reflect = a->pad_mode == 1;
   if (a->pad_mode != 0 && a->pad_mode != 1) return JG_ERR_BAD_ARG;
+  p.res_up = a->res_mode == 1;
+  if (a->res_mode != 0 && a->res_mode != 1) return JG_ERR_BAD_ARG;
+  if (p.res_up && (!a->res || a->nbatch != 1 || (a->Ho & 1) || (a->Wo & 1))) return JG_ERR_BAD_ARG;
   p.dbg = 0; p.stats_mode = a->stats_mode; p.gx = (const char*)a->gn_x; p.gldx = a->gn_ldx; p.gab = a->gn_ab; p.gact = a->gn_act;
   if (p.stats && p.stats_mode == 1 && (!p.gx || !p.gab || p.gldx < a->Cout || (a->Cout & 7))) return JG_ERR_BAD_ARG;
   if (p.stats) {

@@ -57,6 +57,7 @@ NORM_BEFORE_UP = os.environ.get("JG_NORM_BEFORE_UP", "1") != "0"
 # ResBlock-down: pool(act(norm(x))) in one kernel, and the GroupNorm backward reads the pooled-resolution gradients through the
 # upsample index map (jg_gn_apply_pool / jg_gn_bwd_*_up) instead of materialising full-resolution copies
 FUSE_DOWN_POOL = os.environ.get("JG_FUSE_DOWN_POOL", "1") != "0"
+RES_UP_ON_READ = os.environ.get("JG_RES_UP_ON_READ", "1") != "0"
 FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 
 
@@ -79,7 +80,7 @@ class _Pool:
 # ---------------------------------------------------------------------------------------------------
 # raw launches (no autograd): every tensor may be a channel slice of a wider buffer
 # ---------------------------------------------------------------------------------------------------
-def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None):
+def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res_up=False):
     B, H, W, Cin = x.shape
     Ho, Wo = m.out_hw(H, W)
     if out is None:
@@ -88,7 +89,8 @@ def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None):
     conv_nt(x, m.w16, out, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
             ldx=_ld(x), ldw=m.R * m.S * Cin, ldy=_ld(out), bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
             ldres=_ld(res) if res is not None else 0, alpha=alpha, res_scale=res_scale,
-            stats=stats if fuse else None, ldstats=stats.stride(1) // 2 if fuse else 0, stats_slots=NSLOT)
+            stats=stats if fuse else None, ldstats=stats.stride(1) // 2 if fuse else 0, stats_slots=NSLOT,
+            res_mode=1 if res_up else 0)
     if stats is not None and not fuse:   # shapes the fused epilogue does not cover: separate statistics pass
         check(_lib.lib().jg_gn_stats_ld(_dt(out), out.data_ptr(), _ld(out), stats.data_ptr(), stats.stride(0) // 2, B, Ho * Wo,  # replica 0
                                         m.Cout, _st()), "jg_gn_stats_ld")
@@ -354,8 +356,12 @@ class UNetExecutor:
                     a1 = up2(h1, 1.0) if rb.up else pool2(h1, 0.25)
                 c1 = conv_fwd(a1, c1m, stats=st1)
                 hw1 = Ho * Wo
-            xs = up2(x, 1.0) if rb.up else pool2(x, 0.25)
+            identity = isinstance(rb.skip_connection, nn.Identity)
+            # identity skip of an up-block: the convolution epilogue reads x through the upsample map (res_mode 1)
+            res_up = rb.up and identity and RES_UP_ON_READ
+            xs = x if res_up else (up2(x, 1.0) if rb.up else pool2(x, 0.25))
         else:
+            res_up = False
             a1, xs, hw1 = h1, x, H * W
             c1 = conv_fwd(h1, c1m, stats=st1)
         off, n = rb.emb_slice
@@ -372,7 +378,7 @@ class UNetExecutor:
         identity = isinstance(rb.skip_connection, nn.Identity)
         sk = xs if identity else conv_fwd(xs, rb.skip_connection.meta)
         out_t, out_st = dest(B, Ho, Wo, Cout)
-        conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st)
+        conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st, res_up=res_up)
         rec = dict(kind="res", rb=rb, x=x, ab1=ab1, mr1=mr1, a1=a1, c1=c1, ab2=ab2, mr2=mr2, h2=h2, film=film,
                    xs=None if identity else xs, skipw=skipw, identity=identity, low2=low2)
         rec.update(self._in_fields(X))

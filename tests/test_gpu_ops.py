@@ -697,3 +697,31 @@ def test_group_norm_pool_fusion(C, G, H, W, dtype):
     # and bit-compatible routing: the unfused composition of the same kernels agrees to rounding
     y2 = ue.pool2(ue.gn_apply(x, ab, JG_ACT_SILU), 0.25)
     assert relerr(y.float(), y2.float()) < TOL[dtype]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, 3, 1), (1, 16, 48, 128, 128, 3, 1), (2, 16, 16, 192, 256, 3, 1),   # halo kernel tiles
+                                  (2, 12, 20, 32, 48, 3, 1), (2, 16, 16, 64, 128, 1, 0)])                                 # generic kernel
+def test_conv_half_resolution_residual(case, dtype):
+    """jg_conv_args.res_mode = 1: y = conv(x) + res_scale * Upsample_nearest(res) with res at half resolution (the ResBlock-up
+    skip path, reference unet_generator_attn.py:236-246), bit-identical to passing the materialised upsampled residual."""
+    from joligen_amd import ops
+
+    B, H, W, Cin, Cout, k, pad = case
+    d = dev()
+    x = nhwc(rnd((B, Cin, H, W), dtype, 71)).to(d)
+    w = rnd((Cout, Cin, k, k), dtype, 72, 1.0 / math.sqrt(Cin * k * k)).permute(0, 2, 3, 1).contiguous().to(d)
+    bias = rnd((Cout,), torch.float32, 73).to(d)
+    res_low = nhwc(rnd((B, Cout, H // 2, W // 2), dtype, 74)).to(d)
+    res_full = res_low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+    ys = []
+    for res, mode in ((res_low, 1), (res_full, 0)):
+        y = torch.empty((B, H, W, Cout), device=d, dtype=dtype)
+        ops.conv_nt(x, w, y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=k, S=k, pad=pad, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=k * k * Cin,
+                    ldy=Cout, bias=bias, res=res, ldres=Cout, alpha=1.0, res_scale=0.7, res_mode=mode)
+        ys.append(y)
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1])
+    ref = F.conv2d(nchw(x).float(), w.permute(0, 3, 1, 2).float(), bias, 1, pad) + 0.7 * nchw(res_full).float()
+    assert relerr(nchw(ys[0]), ref) < TOL[dtype]
