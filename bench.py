@@ -87,7 +87,7 @@ def build_model(args, rank, local_rank, world):
         model.data_dependent_initialize({"A": (torch.rand(args.batch, 3, args.size, args.size, generator=g0) * 2 - 1).to(dev0),
                                          "B": (torch.rand(args.batch, 3, args.size, args.size, generator=g0) * 2 - 1).to(dev0)})
     model.setup(opt)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         model.parallelize(local_rank)
     else:
         model.single_gpu()
@@ -238,6 +238,7 @@ def main():
                     help="palette = BASELINE configs[1] (the bench line); cm = the consistency-model step of configs[4] (same UNet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true", help="dev: run the multi-GPU gradient exchange path on one GPU (1-rank RCCL group)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dump-kernel-timing", default="", help="write the per-shape conv kernel timing table here")
     args = ap.parse_args()
@@ -253,9 +254,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
+    if args.force_exchange:     # dev: run the data-parallel exchange path (1-rank RCCL group) on a single GPU
+        from joligen_amd import parallel
+        parallel.FORCE_EXCHANGE = True
 
     model, opt = build_model(args, rank, local_rank, world)
     batch = synth_batch(args.batch, args.size, 1234 + rank, device)
@@ -364,8 +369,17 @@ def main():
                        "efficient": bool(args.efficient), "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+    # RCCL prints its banner through C stdio (block-buffered when stdout is a pipe, i.e. written at exit): every rank flushes it
+    # now, so that rank 0's JSON line is the LAST line of the job's stdout
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)
+    if dist.is_initialized():
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -78,6 +78,10 @@ ACT_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.
 
 
 class BaseModel:
+    # True: the model's step runs exactly one backward per network and optimizer step, so the data-parallel gradient exchange
+    # may start from inside the backward (parallel.EarlyExchange)
+    overlap_exchange = False
+
     def __init__(self, opt, rank):
         self.rank = rank
         self.opt = opt
@@ -130,6 +134,8 @@ class BaseModel:
             arena = net.jg_finalize(self.device, self.act_dtype)
             self.set_requires_grad(net, True)
             parallel.broadcast_params(arena, 0)
+            if self.overlap_exchange and os.environ.get("JG_OVERLAP_EXCHANGE", "1") != "0":
+                arena.early_exchange = parallel.EarlyExchange(arena, list(net.named_parameters()))
             setattr(self, "net" + name, parallel.FlatDataParallel(net))
 
     def eval(self):

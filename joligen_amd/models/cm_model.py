@@ -38,6 +38,8 @@ def define_G_cm(opt):
 
 
 class CMModel(BaseModel):
+    overlap_exchange = True   # one backward per optimizer step: the gradient all-reduce starts inside the backward
+
     def __init__(self, opt, rank):
         super().__init__(opt, rank)
         self.task = opt.alg_diffusion_task

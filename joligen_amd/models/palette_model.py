@@ -48,6 +48,8 @@ def define_G(model_type, model_input_nc, model_output_nc, G_netG, data_crop_size
 
 
 class PaletteModel(BaseModel):
+    overlap_exchange = True   # one backward per optimizer step: the gradient all-reduce starts inside the backward
+
     def __init__(self, opt, rank):
         super().__init__(opt, rank)
         self.task = opt.alg_diffusion_task

@@ -23,7 +23,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, parallel
 from .._lib import JG_ACT_NONE, JG_ACT_SILU, check
 from ..ops import _dt, _p, _st, attn_core_bwd, attn_core_fwd, conv_nt, wgrad_tn
 
@@ -419,6 +419,7 @@ class UNetExecutor:
                 conv_wgrad(dO, rec["xin"], rec["m"])
                 if need_dx:
                     self.dxin = conv_dgrad(dO, rec["m"], rec["xin"].shape)
+                parallel.grads_final(_own_params(rec))
                 continue
             adds = []
             if rec.get("add_hs") is not None:
@@ -429,6 +430,7 @@ class UNetExecutor:
                 dX = self.res_bwd(rec, dO, adds)
             else:
                 dX = self.attn_bwd(rec, dO, adds)
+            parallel.grads_final(_own_params(rec))     # data parallel: chunks of the gradient arena start their all-reduce here
             if rec["cat_j"] is not None:
                 ca = rec["Ca"]
                 dacts[rec["cat_a_id"]] = dX[..., :ca]
@@ -521,6 +523,30 @@ class UNetExecutor:
         conv_wgrad(dqkv.view(B, 1, T, 3 * C), xn4, blk.qkv.meta)
         adds = list(adds) + [(dO, 1.0)]
         return gn_bwd(x, dxn.view(B, H, W, C), rec["ab"], rec["mr"], None, None, None, C, JG_ACT_NONE, adds=adds, red=red)
+
+
+def _own_params(rec):
+    """parameters whose gradient is complete once this record's backward has been launched (the embedding projections of the
+    ResBlocks are NOT: their gradient comes from the stacked linear behind the node)"""
+    kind = rec["kind"]
+    if kind == "stem":
+        objs = [rec["m"]]
+    elif kind == "head":
+        objs = [rec["gn"], rec["m"]]
+    elif kind == "res":
+        rb = rec["rb"]
+        objs = [rb.in_layers[0].norm, rb.in_layers[2].meta, rb.out_layers[0].norm, rb.out_layers[3].meta]
+        if not rec["identity"]:
+            objs.append(rb.skip_connection.meta)
+    else:
+        objs = [rec["blk"].qkv.meta, rec["blk"].proj_out.meta]
+    out = []
+    for o in objs:
+        for nm in ("weight", "bias"):
+            prm = getattr(o, nm, None)
+            if prm is not None:
+                out.append(prm)
+    return out
 
 
 class _FusedUNetFn(torch.autograd.Function):

@@ -1,7 +1,10 @@
 """Pure data parallelism over the 8 GPUs of one node: one process per GPU
 (torch.distributed, backend "nccl" == RCCL over xGMI), full replica per rank, and ONE exchange
 per optimizer step: an all-reduce(SUM) of the flat gradient arena, issued in a few large chunks
-so that the fused AdamW of chunk i runs while chunk i+1 is still on the wire.  Replaces the
+so that the fused AdamW of chunk i runs while chunk i+1 is still on the wire.  Networks whose step
+runs exactly ONE backward (palette / cm) additionally start the reduction of a chunk from INSIDE the
+backward, as soon as every parameter of the chunk has its final gradient (`EarlyExchange`): the wire
+time hides behind the remaining input-gradient / weight-gradient kernels.  Replaces the
 reference's per-network DistributedDataParallel wrappers (models/base_model.py:725-737) and its
 `no_sync()` accumulation contexts (:1313-1315)."""
 from __future__ import annotations
@@ -50,13 +53,94 @@ def chunk_bounds(n, n_chunks, align=1024):
     return [(lo, min(n, lo + per)) for lo in range(0, n, per)]
 
 
+# id(parameter) -> EarlyExchange that owns it (filled by EarlyExchange.__init__)
+_EARLY = {}
+
+
+class EarlyExchange:
+    """Backward-overlapped reduction of one gradient arena (DDP's bucket-ready hook, on the flat arena).
+
+    The arena is cut into `n_chunks` aligned chunks.  The backward schedule reports parameters whose gradient is
+    final (`grads_final`); the moment the last parameter overlapping a chunk is reported, the chunk's
+    all-reduce(SUM) is enqueued (async: the RCCL stream waits for the kernels already launched on the compute
+    stream, the backward keeps launching).  `drain()` -- called by the optimizer step -- enqueues what is left
+    (parameters outside the fused backward, padding-only chunks) and returns every chunk with its work handle in
+    launch order.  Every rank runs the same schedule, so the collectives are issued in the same order everywhere.
+
+    Contract: between two optimizer steps each parameter is reported at most once and its gradient is not touched
+    afterwards, i.e. ONE backward per step over this arena (accumulation micro-steps run under `no_sync()` and
+    report nothing).  Models opt in (`BaseModel.overlap_exchange`)."""
+
+    def __init__(self, arena, named_params, n_chunks=8):
+        self.arena = arena
+        self.bounds = chunk_bounds(arena.numel, n_chunks)
+        per = self.bounds[0][1] - self.bounds[0][0]
+        self.owner = {}
+        self.total = [0] * len(self.bounds)
+        self.last_early = 0
+        for name, prm in named_params:
+            off, n = arena.slices[name]
+            cs = tuple(range(off // per, min((off + max(n, 1) - 1) // per, len(self.bounds) - 1) + 1))
+            self.owner[id(prm)] = cs
+            _EARLY[id(prm)] = self
+            for c in cs:
+                self.total[c] += 1
+        self._reset()
+
+    def _reset(self):
+        self.left = list(self.total)
+        self.seen = set()
+        self.launched = []          # [(chunk index, work)]
+        self.sent = [False] * len(self.bounds)
+
+    def _launch(self, c):
+        lo, hi = self.bounds[c]
+        self.sent[c] = True
+        self.launched.append((c, dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
+
+    def mark(self, prm):
+        k = id(prm)
+        if k in self.seen:
+            raise RuntimeError("EarlyExchange: a parameter was reported final twice in one step (more than one backward over this "
+                               "arena per optimizer step: the model must not opt into overlap_exchange)")
+        self.seen.add(k)
+        for c in self.owner[k]:
+            self.left[c] -= 1
+            if self.left[c] == 0:
+                self._launch(c)
+
+    def drain(self):
+        self.last_early = len(self.launched)     # chunks that went out from inside the backward (diagnostics / tests)
+        for c in range(len(self.bounds)):
+            if not self.sent[c]:
+                self._launch(c)
+        out = [(self.bounds[c][0], self.bounds[c][1], w) for c, w in self.launched]
+        self._reset()
+        return out
+
+
+def grads_final(params):
+    """Called by a fused backward schedule: the gradients of `params` are final for this step."""
+    if not _EARLY or not exchange_active():
+        return
+    for prm in params:
+        ex = _EARLY.get(id(prm))
+        if ex is not None:
+            ex.mark(prm)
+
+
 def allreduce_and_step(arena, hp, grad_scale, n_chunks=4):
     """sum-all-reduce arena.g chunk by chunk (async, RCCL stream) and run the fused optimizer on
-    each chunk as soon as its reduction has landed.  Mean over ranks = DDP semantics."""
+    each chunk as soon as its reduction has landed.  Mean over ranks = DDP semantics.
+    Chunks whose reduction was already started from inside the backward (`EarlyExchange`) are only waited for."""
     ws = world_size()
-    bounds = chunk_bounds(arena.numel, n_chunks)
-    works = [dist.all_reduce(arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi in bounds]
-    for (lo, hi), w in zip(bounds, works):
+    ex = getattr(arena, "early_exchange", None)
+    if ex is not None:
+        pending = ex.drain()
+    else:
+        bounds = chunk_bounds(arena.numel, n_chunks)
+        pending = [(lo, hi, dist.all_reduce(arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)) for lo, hi in bounds]
+    for lo, hi, w in pending:
         w.wait()  # NCCL/RCCL: makes the current stream wait, does not block the host
         arena.adamw_step(grad_scale=grad_scale / ws, lo=lo, hi=hi, **hp)
 

@@ -389,6 +389,9 @@ for mode in ("single", "rccl"):
         losses.append(float(model.get_current_losses()["G_tot"]))
     net = model.netG_A.module if hasattr(model.netG_A, "module") else model.netG_A
     out.append((losses, float(net.arena.p.double().norm()), float(net.arena.ema.double().norm())))
+    if mode == "rccl":   # the reduction of most chunks was started from inside the backward (parallel.EarlyExchange)
+        ex = net.arena.early_exchange
+        assert ex.last_early >= len(ex.bounds) - 2, (ex.last_early, len(ex.bounds), ex.total)
     parallel.FORCE_EXCHANGE = False
 dist.destroy_process_group()
 (l0, p0, e0), (l1, p1, e1) = out

@@ -144,3 +144,90 @@ def test_three_arenas_of_the_cut_step(tmp_path):
     for a, b, ref in zip(r0, r1, refs):
         assert torch.equal(a, b)
         torch.testing.assert_close(a, ref.p, rtol=1e-5, atol=1e-6)
+
+
+class _P:
+    """stand-in for an nn.Parameter (EarlyExchange keys parameters by identity)"""
+
+
+def _worker_early(rank, world, port, sizes, out):
+    """backward-overlapped exchange: parameters are reported final tail-first, group by group, while the 'backward' is still
+    writing the gradients of earlier parameters; two parameters (the embedding projections of the real model) are never
+    reported and go out with the optimizer step"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from joligen_amd import parallel
+
+    n = sum(sizes)
+    arena = FakeArena(n, seed=100 + rank)
+    params, off = [], 0
+    arena.slices = {}
+    for i, sz in enumerate(sizes):
+        arena.slices["p%d" % i] = (off, sz)
+        params.append(("p%d" % i, _P()))
+        off += sz
+    parallel.broadcast_params(arena, 0)
+    arena.early_exchange = ex = parallel.EarlyExchange(arena, params, n_chunks=6)
+    hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=True, ema_beta=None, zero_grad=True)
+    g = torch.Generator().manual_seed(11)
+    early = []
+    for step in range(3):
+        grads = torch.randn(world, n, generator=g)
+        if step == 1:       # an accumulation micro-step under no_sync: local, nothing is reported
+            with parallel.no_sync():
+                arena.g += 0.5 * grads[rank]
+                parallel.grads_final([p for _, p in params])
+            assert not ex.seen and not ex.launched
+            grads = 0.5 * torch.randn(world, n, generator=g)
+        for i in range(len(sizes) - 1, 1, -1):          # parameters 0 and 1 are never reported
+            lo, sz = arena.slices["p%d" % i]
+            arena.g[lo:lo + sz] += grads[rank, lo:lo + sz]
+            parallel.grads_final([params[i][1]])
+        for i in (0, 1):
+            lo, sz = arena.slices["p%d" % i]
+            arena.g[lo:lo + sz] += grads[rank, lo:lo + sz]
+        early.append(len(ex.launched))
+        arena.step += 1
+        parallel.allreduce_and_step(arena, hp, grad_scale=1.0)
+        assert ex.last_early == early[-1] and not ex.launched and not ex.seen
+    # reporting a parameter twice in one step is a contract violation
+    parallel.grads_final([params[-1][1]])
+    try:
+        parallel.grads_final([params[-1][1]])
+        dup = False
+    except RuntimeError:
+        dup = True
+    ex.drain()
+    torch.save(dict(p=arena.p, calls=arena.calls, early=early, dup=dup, nchunks=len(ex.bounds)), out % rank)
+    dist.destroy_process_group()
+
+
+def test_backward_overlapped_exchange(tmp_path):
+    world = 2
+    sizes = (900, 1500, 3000, 40, 5000, 7000, 64, 2048, 6000, 1000)
+    n = sum(sizes)
+    out = str(tmp_path / "e%d.pt")
+    mp.spawn(_worker_early, args=(world, _free_port(), sizes, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert torch.equal(r0["p"], r1["p"])
+    assert r0["dup"] and r1["dup"]
+    assert r0["early"] == r1["early"] and min(r0["early"]) >= r0["nchunks"] - 2 and max(r0["early"]) < r0["nchunks"]
+    # every step covers the arena exactly once (chunks in launch order: tail first)
+    per_step = len(r0["calls"]) // 3
+    for s in range(3):
+        c = sorted(r0["calls"][s * per_step:(s + 1) * per_step])
+        assert c[0][0] == 0 and c[-1][1] == n and all(c[i][1] == c[i + 1][0] for i in range(len(c) - 1))
+    assert r0["calls"][0][1] == n       # the tail chunk went first
+    ref = FakeArena(n, seed=100)
+    g = torch.Generator().manual_seed(11)
+    hp = dict(lr=1e-2, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=True)
+    for step in range(3):
+        grads = torch.randn(world, n, generator=g)
+        if step == 1:
+            ref.g += 0.5 * grads.mean(0)
+            grads = 0.5 * torch.randn(world, n, generator=g)
+        ref.g += grads.mean(0)
+        ref.step += 1
+        ref.adamw_step(**hp)
+    torch.testing.assert_close(r0["p"], ref.p, rtol=1e-5, atol=1e-6)
