@@ -25,9 +25,10 @@
 // the shifted-tap fragment reads of conv_halo.hip become conflict-free (they were 2-way for s = 1, 2).
 __device__ __forceinline__ int jg_pixperm(int r) { return r < 4 ? 2 * r : (r < 12 ? 2 * (r - 4) + 1 : 2 * (r - 8)); }
 
-template <typename T, int TM, bool PERM = false, typename PixFn, typename FlushFn>
+// rrow(lp, m): row of the residual tensor for local pixel lp / output row m (m itself, or the half-resolution row for res_up)
+template <typename T, int TM, bool PERM = false, typename PixFn, typename ResRowFn, typename FlushFn>
 __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][TM], char* scratch, int lane, int nbase,
-                                                int gimg, PixFn pix, FlushFn flush) {
+                                                int gimg, PixFn pix, ResRowFn rrow, FlushFn flush) {
   static_assert(TM % 4 == 0, "slabs of 4 pixel tiles");
   const int l15 = lane & 15, lk = lane >> 4;
   const int c8 = lane & 7, prow = lane >> 3;
@@ -78,7 +79,7 @@ __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][
         for (int q = 0; q < 8; ++q) v[q] += bias[q];
         if (res) {
           float rf[8];
-          const long mr = p.res_up ? jg_res_up_row(p, m) : m;
+          const long mr = rrow(slab * 64 + pl, m);
           unpack8<T>(*reinterpret_cast<const uint4*>(res + mr * p.ldres + nbase + c8 * 8), rf);
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += p.res_scale * rf[q];

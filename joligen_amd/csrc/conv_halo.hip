@@ -241,11 +241,15 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     __syncthreads();
   }
   const long mrow0 = ((long)b * p.H + oh0 + wm * TM) * p.W + ow0;
+  // half-resolution residual (res_up): tile origins and the wave's row offset are even, so the nearest-upsample map is two shifts
+  const int wres = p.res_up ? (p.W >> 1) : p.W, rsh = p.res_up ? 1 : 0;
+  const long rrow0 = p.res_up ? ((long)b * (p.H >> 1) + ((oh0 + wm * TM) >> 1)) * wres + (ow0 >> 1) : mrow0;
 #pragma unroll
   for (int h = 0; h < TN / 4; ++h) {     // 64 output channels of the wave tile at a time
     jg_epilogue_lds<T, TM, true>(
         p, reinterpret_cast<f32x4(&)[4][TM]>(acc[4 * h]), smc + wave * 16384, lane, n0 + wn * WN + 64 * h, b,
         [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
+        [&](int lp, long) -> long { return rrow0 + (long)((lp >> 4) >> rsh) * wres + ((lp & 15) >> rsh); },
         [&](int nch, const float* s1, const float* s2) {
           // wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block
 #pragma unroll

@@ -333,6 +333,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
       jg_epilogue_lds<T, TM>(
           q, acc, reinterpret_cast<char*>(&sm[0][0]) + wave * 16384, lane, n0 + wn * WN, p.stats ? m0 / (p.Ho * p.Wo) : 0,
           [&](int lp) -> long { return (mw + lp < p.M) ? (long)(mw + lp) : -1L; },
+          [&](int, long m) -> long { return p.res_up ? jg_res_up_row(p, m) : m; },
           [&](int nch, const float* s1, const float* s2) {
 #pragma unroll
             for (int qq = 0; qq < 8; ++qq) {
