@@ -78,6 +78,10 @@ typedef struct {
   /* res_mode 1: res is [B, Ho/2, Wo/2, Cout] and is read through the nearest-upsample map, i.e. y += res_scale * Upsample(res)
    * without the upsampled copy (ResBlock-up skip path `self.x_upd(x)`, unet_generator_attn.py:236-246).  Ho, Wo even, nbatch 1. */
   int32_t res_mode;
+  /* x_mode 1: x is [B, H/2, W/2, Cin] and the convolution runs over its nearest x2 upsample (H, W = the upsampled size, even) without
+   * the upsampled copy: `conv(Upsample(h))` of the ResBlock-up path (unet_generator_attn.py:120-140,239-246).  Halo-resident 3x3
+   * kernel only (shape limits of pad_mode 1), else JG_ERR_UNSUPPORTED. */
+  int32_t x_mode;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 
@@ -100,6 +104,7 @@ typedef struct {
   int32_t out_mode;
   float dbias_scale; /* dbias[co] += dbias_scale * sum_p dy[p][co]; 0 means 1 (a skip-path conv fed with skipw*dy) */
   int32_t pad_mode;  /* 1: x is read with mirrored borders (see jg_conv_args.pad_mode); same shape limits */
+  int32_t x_mode;    /* 1: x is the half-resolution tensor of jg_conv_args.x_mode 1 (H, W = the upsampled size); same shape limits */
 } jg_wgrad_args;
 int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream);
 

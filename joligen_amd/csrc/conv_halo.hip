@@ -105,7 +105,9 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     }
     const bool ok = pos < HALO_CH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
     const int kc = cpos ^ ((hx >> 1) & 7);   // swizzle by the COLUMN inside the halo row: the same for every row
-    aoff[rd] = ok ? (int)((((long)b * p.H + ih) * p.W + iw) * p.ldx) + kc * 8 : -1;
+    // x_up: the halo pixel (ih, iw) of the (virtual) upsampled image lives at (ih >> 1, iw >> 1) of the half-resolution tensor
+    const int ush = p.x_up ? 1 : 0;
+    aoff[rd] = ok ? (int)((((long)b * (p.H >> ush) + (ih >> ush)) * (p.W >> ush) + (iw >> ush)) * p.ldx) + kc * 8 : -1;
   }
   int boff[B_ROUNDS];
 #pragma unroll

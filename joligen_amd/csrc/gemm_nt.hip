@@ -407,7 +407,7 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
     JG_CHECK_LAUNCH();
     return JG_OK;
   }
-  if (p.reflect) return JG_ERR_UNSUPPORTED;   // mirrored borders exist only in the halo-resident kernel
+  if (p.reflect || p.x_up) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read exist only in the halo-resident kernel
   if (variant >= 2) {
     if (p.N <= 64) {
       if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);
@@ -458,6 +458,9 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.nslots = a->stats_slots > 0 ? a->stats_slots : 1;
   p.reflect = a->pad_mode == 1;
   if (a->pad_mode != 0 && a->pad_mode != 1) return JG_ERR_BAD_ARG;
+  p.x_up = a->x_mode == 1;
+  if (a->x_mode != 0 && a->x_mode != 1) return JG_ERR_BAD_ARG;
+  if (p.x_up && (p.reflect || (a->H & 1) || (a->W & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;
   p.res_up = a->res_mode == 1;
   if (a->res_mode != 0 && a->res_mode != 1) return JG_ERR_BAD_ARG;
   if (p.res_up && (!a->res || a->nbatch != 1 || (a->Ho & 1) || (a->Wo & 1))) return JG_ERR_BAD_ARG;

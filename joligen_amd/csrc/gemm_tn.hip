@@ -455,13 +455,16 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   p.dbias_scale = a->dbias_scale != 0.f ? a->dbias_scale : 1.f;
   if (a->pad_mode != 0 && a->pad_mode != 1) return JG_ERR_BAD_ARG;
   p.reflect = a->pad_mode == 1;
+  if (a->x_mode != 0 && a->x_mode != 1) return JG_ERR_BAD_ARG;
+  p.x_up = a->x_mode == 1;
+  if (p.x_up && (p.reflect || (a->H & 1) || (a->W & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;
   const char* venv = getenv("JG_WGRAD_VARIANT");
   const int variant = venv ? atoi(venv) : 4;  // 1: register transpose; 2: transposing LDS reads; 3: 2 with 128-row tiles only; 4: + halo-resident 3x3
   if (variant >= 4 && jg_wgrad_halo_try(dtype, p, a->nbatch, (hipStream_t)stream)) {
     JG_CHECK_LAUNCH();
     return JG_OK;
   }
-  if (p.reflect) return JG_ERR_UNSUPPORTED;   // mirrored borders exist only in the halo-resident kernel
+  if (p.reflect || p.x_up) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read exist only in the halo-resident kernel
   const int tilesN = (p.Ktot + 127) / 128;
   if (variant == 1) {
     dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * a->splitk);

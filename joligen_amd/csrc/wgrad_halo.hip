@@ -44,8 +44,10 @@ __device__ __forceinline__ int f4(int c) { return ((c >> 1) & 1) | (((c >> 3) & 
 // 3-bit swizzle of a 256-byte pixel row (8 blocks of 32 B)
 __device__ __forceinline__ int f8(int c) { return (c & 3) | (((c >> 3) & 1) << 2); }
 
-template <typename T, int TH, int CPW, int WMR, bool REFLECT>
+// XMODE 0: plain zero padding; 1: mirrored borders (REFLECT); 2: x is the half-resolution tensor read through the nearest-upsample map
+template <typename T, int TH, int CPW, int WMR, int XMODE>
 __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p, int ntiles, int per, int npairs, int ncot) {
+  constexpr bool REFLECT = XMODE == 1, UP = XMODE == 2;
   constexpr int NT = WMR * 256;                // WMR wave rows (output-channel groups) x 4 wave columns (16-channel ci tiles)
   constexpr int BCO = WMR * CPW * 16;          // output channels per block
   constexpr int HW_ = 18, HPX = (TH + 2) * HW_;
@@ -101,7 +103,9 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
     const int hp = pos >> 3, cpos = pos & 7;
     const int hy = hp / HW_, hx = hp - hy * HW_;
     const int chunk = (((cpos >> 1) ^ f4(hx)) << 1) | (cpos & 1);
-    a_rel[rd] = ((hy - 1) * p.W + (hx - 1)) * (int)p.ldx + chunk * 8;
+    // UP: tile origins are even, so (oh0 + hy - 1) >> 1 = oh0 / 2 + ((hy - 1) >> 1): offsets relative to the half-resolution origin
+    a_rel[rd] = UP ? (((hy - 1) >> 1) * (p.W >> 1) + ((hx - 1) >> 1)) * (int)p.ldx + chunk * 8
+                   : ((hy - 1) * p.W + (hx - 1)) * (int)p.ldx + chunk * 8;
     a_yx[rd] = (pos < HALO_CH) ? ((hy << 8) | hx) : -1;
   }
   }
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
       const int b = r2 / th;
       const int oh0 = ty * TH, ow0 = tx << 4;
       const long pix = ((long)b * p.H + oh0) * p.W + ow0;
-      const T* xb = xg + pix * p.ldx;
+      const T* xb = UP ? xg + (((long)b * (p.H >> 1) + (oh0 >> 1)) * (p.W >> 1) + (ow0 >> 1)) * p.ldx : xg + pix * p.ldx;
       const T* db = dyg + pix * p.lddy;
       const unsigned l0 = lds0 + (buf * BUF_CH + wave * 64) * 16;
   #pragma unroll
@@ -149,7 +153,8 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
             iw = JG_REFLECT1(iw, p.W);
           }
           const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-          glds16(ok ? xb + ((ih - oh0) * p.W + (iw - ow0)) * (int)p.ldx + chunk * 8 : zp, l0 + rd * NT * 16);
+          const int rel = UP ? (((ih >> 1) - (oh0 >> 1)) * (p.W >> 1) + ((iw >> 1) - (ow0 >> 1))) : ((ih - oh0) * p.W + (iw - ow0));
+          glds16(ok ? xb + rel * (int)p.ldx + chunk * 8 : zp, l0 + rd * NT * 16);
         }
       }
     
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
       const int b = r2 / th;
       const int oh0 = ty * TH, ow0 = tx << 4;
       const long pix = ((long)b * p.H + oh0) * p.W + ow0;
-      const T* xb = xg + pix * p.ldx;
+      const T* xb = UP ? xg + (((long)b * (p.H >> 1) + (oh0 >> 1)) * (p.W >> 1) + (ow0 >> 1)) * p.ldx : xg + pix * p.ldx;
       const T* db = dyg + pix * p.lddy;
       const unsigned l0 = lds0 + (buf * BUF_CH + wave * 64) * 16;
   #pragma unroll
@@ -297,14 +302,14 @@ static void pick_split(int npairs, int ntiles, int ovh, int slots, int* per_out,
   *per_out = bper; *splitk_out = bsk;
 }
 
-template <typename T, int TH, int CPW, int WMR, bool REFLECT = false>
+template <typename T, int TH, int CPW, int WMR, int XMODE = 0>
 void launch_wg(const WgP& p, hipStream_t st) {
   constexpr int BCO = WMR * CPW * 16;
   const int ncot = p.Cout / BCO, npairs = ncot * (p.Cin / 64);
   const int ntiles = p.B * (p.H / TH) * (p.W >> 4);
   int per, splitk;
   pick_split(npairs, ntiles, TH == 16 ? 6 : 10, WMR == 1 ? 512 : 256, &per, &splitk);
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, REFLECT>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot);
+  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot);
 }
 
 template <typename T>
@@ -317,7 +322,9 @@ void dispatch_wg(const WgP& p, hipStream_t st) {
   const bool big = cfg == 2 || (cfg == 0 && per1 >= 64);
   // mirrored borders (pad_mode 1) are compiled only into the 16x16 / 64-co configuration: the extra address arithmetic would push
   // the register-tight 8-row configurations into spilling
-  if (p.reflect) launch_wg<T, 16, 2, 2, true>(p, st);
+  if (p.reflect) launch_wg<T, 16, 2, 2, 1>(p, st);
+  else if (p.x_up && big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2, 2>(p, st);   // upsample-on-read: the two shapes the UNet up-blocks use
+  else if (p.x_up) launch_wg<T, 16, 2, 2, 2>(p, st);
   else if (cfg == 3) launch_wg<T, 8, 4, 1>(p, st);   // 4 waves, 64 co x 8-row tiles, 2 workgroups / CU
   else if (big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2>(p, st);
   else launch_wg<T, 16, 2, 2>(p, st);

@@ -14,6 +14,7 @@ struct WgP {
   int out_mode;
   int B;
   float dbias_scale;
+  int x_up;      // 1: x is [B, H/2, W/2, Cin], read through the nearest-upsample index map (halo kernel only)
   int reflect;   // 1: the x halo mirrors the interior at the image border (ReflectionPad2d(1) + pad-0 3x3 conv)
 };
 

@@ -57,6 +57,7 @@ NORM_BEFORE_UP = os.environ.get("JG_NORM_BEFORE_UP", "1") != "0"
 # ResBlock-down: pool(act(norm(x))) in one kernel, and the GroupNorm backward reads the pooled-resolution gradients through the
 # upsample index map (jg_gn_apply_pool / jg_gn_bwd_*_up) instead of materialising full-resolution copies
 FUSE_DOWN_POOL = os.environ.get("JG_FUSE_DOWN_POOL", "1") != "0"
+X_UP_ON_READ = os.environ.get("JG_X_UP_ON_READ", "1") != "0"
 RES_UP_ON_READ = os.environ.get("JG_RES_UP_ON_READ", "1") != "0"
 FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 
@@ -80,8 +81,15 @@ class _Pool:
 # ---------------------------------------------------------------------------------------------------
 # raw launches (no autograd): every tensor may be a channel slice of a wider buffer
 # ---------------------------------------------------------------------------------------------------
-def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res_up=False):
+def halo_ok(m, H, W):
+    """shape limits of the halo-resident 3x3 kernels (conv_halo.hip / wgrad_halo.hip): the only ones with x_mode / pad_mode"""
+    return m.R == 3 and m.S == 3 and m.pad == 1 and m.stride == 1 and m.Cin % 64 == 0 and m.Cout % 64 == 0 and H % 16 == 0 and W % 16 == 0
+
+
+def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res_up=False, x_up=False):
     B, H, W, Cin = x.shape
+    if x_up:      # x is the half-resolution tensor, the convolution runs over its nearest upsample (jg_conv_args.x_mode 1)
+        H, W = 2 * H, 2 * W
     Ho, Wo = m.out_hw(H, W)
     if out is None:
         out = torch.empty((B, Ho, Wo, m.Cout), device=x.device, dtype=x.dtype)
@@ -90,7 +98,7 @@ def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res
             ldx=_ld(x), ldw=m.R * m.S * Cin, ldy=_ld(out), bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
             ldres=_ld(res) if res is not None else 0, alpha=alpha, res_scale=res_scale,
             stats=stats if fuse else None, ldstats=stats.stride(1) // 2 if fuse else 0, stats_slots=NSLOT,
-            res_mode=1 if res_up else 0)
+            res_mode=1 if res_up else 0, x_mode=1 if x_up else 0)
     if stats is not None and not fuse:   # shapes the fused epilogue does not cover: separate statistics pass
         check(_lib.lib().jg_gn_stats_ld(_dt(out), out.data_ptr(), _ld(out), stats.data_ptr(), stats.stride(0) // 2, B, Ho * Wo,  # replica 0
                                         m.Cout, _st()), "jg_gn_stats_ld")
@@ -120,8 +128,10 @@ def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0, gn=None, pool=None
     return (out, red) if gn is not None else out
 
 
-def conv_wgrad(dy, x, m, alpha=1.0, dbias_scale=0.0):
+def conv_wgrad(dy, x, m, alpha=1.0, dbias_scale=0.0, x_up=False):
     B, H, W, Cin = x.shape
+    if x_up:
+        H, W = 2 * H, 2 * W
     _, Ho, Wo, Cout = dy.shape
     wg = m.weight.grad
     if wg is None:
@@ -131,7 +141,7 @@ def conv_wgrad(dy, x, m, alpha=1.0, dbias_scale=0.0):
     splitk = ops._wgrad_splitk(tiles, B * Ho * Wo)
     wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
              lddy=_ld(dy), ldx=_ld(x), lddw=m.R * m.S * m.Cin_real, dbias=m.bias.grad if m.bias is not None else None,
-             Cin_out=m.Cin_real, Cout_out=m.Cout_real, splitk=splitk, alpha=alpha, dbias_scale=dbias_scale)
+             Cin_out=m.Cin_real, Cout_out=m.Cout_real, splitk=splitk, alpha=alpha, dbias_scale=dbias_scale, x_mode=1 if x_up else 0)
 
 
 def gn_coef(st, hw, gamma, beta, film, G, eps):
@@ -373,14 +383,20 @@ class UNetExecutor:
             # GroupNorm + FiLM + SiLU are point-wise given the statistics, and a nearest-neighbour upsample leaves the statistics
             # unchanged: normalise the LOW-resolution conv output and upsample the activated tensor (a quarter of the pass; the
             # backward pools the gradient first and runs the GroupNorm backward at low resolution as well -- same mathematics)
-            h2 = up2(h2, 1.0)
+            # ... and the upsampled tensor itself is never written when conv2 / its weight gradient can read the low-resolution one
+            # through the upsample index map (x_mode 1 of the halo-resident kernels)
+            h2_up = X_UP_ON_READ and halo_ok(c2m, Ho, Wo)
+            if not h2_up:
+                h2 = up2(h2, 1.0)
+        else:
+            h2_up = False
         skipw = 1.0 / math.sqrt(2) if rb.efficient else 1.0
         identity = isinstance(rb.skip_connection, nn.Identity)
         sk = xs if identity else conv_fwd(xs, rb.skip_connection.meta)
         out_t, out_st = dest(B, Ho, Wo, Cout)
-        conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st, res_up=res_up)
+        conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st, res_up=res_up, x_up=h2_up)
         rec = dict(kind="res", rb=rb, x=x, ab1=ab1, mr1=mr1, a1=a1, c1=c1, ab2=ab2, mr2=mr2, h2=h2, film=film,
-                   xs=None if identity else xs, skipw=skipw, identity=identity, low2=low2)
+                   xs=None if identity else xs, skipw=skipw, identity=identity, low2=low2, h2_up=h2_up)
         rec.update(self._in_fields(X))
         self.tape.append(rec)
         return Act(out_t, out_st, Ho * Wo, len(self.tape) - 1)
@@ -458,10 +474,12 @@ class UNetExecutor:
         skipw = rec["skipw"]
         # conv2
         if rec.get("low2"):
-            dh2, red2 = pool2(conv_dgrad(dO, c2m, rec["h2"].shape), 1.0), None      # adjoint of the upsample behind GroupNorm 2
+            hb, hh, hw_, hc = rec["h2"].shape
+            full = (hb, 2 * hh, 2 * hw_, hc) if rec["h2_up"] else (hb, hh, hw_, hc)
+            dh2, red2 = pool2(conv_dgrad(dO, c2m, full), 1.0), None      # adjoint of the upsample behind GroupNorm 2
         else:
             dh2, red2 = conv_dgrad(dO, c2m, rec["h2"].shape, gn=(rec["c1"], rec["ab2"], JG_ACT_SILU), pool=self.bpool)
-        conv_wgrad(dO, rec["h2"], c2m)
+        conv_wgrad(dO, rec["h2"], c2m, x_up=rec["h2_up"])
         # GroupNorm 2 (+FiLM +SiLU)
         off, n = rb.emb_slice
         dc1 = gn_bwd(rec["c1"], dh2, rec["ab2"], rec["mr2"], gn2.weight, gn2.bias, rec["film"], gn2.num_groups, JG_ACT_SILU,

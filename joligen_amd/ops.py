@@ -82,7 +82,7 @@ def _wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode):
 
 def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
             ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
-            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0):
+            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0, x_mode=0):
     """jg_conv2d_nt with element offsets into the operand tensors."""
     a = ConvArgs()
     es = 2
@@ -102,6 +102,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     a.stats, a.ldstats, a.stats_slots = _p(stats), ldstats, stats_slots
     a.pad_mode = pad_mode
     a.res_mode = res_mode
+    a.x_mode = x_mode
     if gn_reduce is not None:   # (norm input x, pixel stride, ab coefficients, act): GroupNorm-backward reductions in the epilogue
         gx, gldx, gab, gact = gn_reduce
         a.stats_mode, a.gn_x, a.gn_ldx, a.gn_ab, a.gn_act = 1, gx.data_ptr(), gldx, gab.data_ptr(), gact
@@ -117,7 +118,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
              Cout_out=0, splitk=1, nbatch=1, nh=1, sdy=(0, 0), sx=(0, 0), sdw=(0, 0), alpha=1.0,
-             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0, dbias_scale=0.0, pad_mode=0):
+             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0, dbias_scale=0.0, pad_mode=0, x_mode=0):
     a = WgradArgs()
     a.dy = dy.data_ptr() + dy_off * 2
     a.x = x.data_ptr() + x_off * 2
@@ -132,6 +133,7 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.sdwb, a.sdwh = sdw
     a.alpha, a.out_mode, a.dbias_scale = alpha, out_mode, dbias_scale
     a.pad_mode = pad_mode
+    a.x_mode = x_mode
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()

@@ -725,3 +725,55 @@ def test_conv_half_resolution_residual(case, dtype):
     assert torch.equal(ys[0], ys[1])
     ref = F.conv2d(nchw(x).float(), w.permute(0, 3, 1, 2).float(), bias, 1, pad) + 0.7 * nchw(res_full).float()
     assert relerr(nchw(ys[0]), ref) < TOL[dtype]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", ["0", "2"])
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64), (1, 16, 48, 128, 128), (2, 32, 32, 192, 256), (1, 32, 64, 128, 384)])
+def test_conv_over_upsample_on_read(case, cfg, dtype, monkeypatch):
+    """x_mode = 1 of jg_conv_args / jg_wgrad_args: conv3x3(Upsample_nearest(x)) and its weight gradient with x at half resolution
+    (ResBlock-up path, reference unet_generator_attn.py:120-140,239-246) against the same kernels fed the materialised upsample
+    (forward: bit-identical; weight gradient: split-K atomics, fp32 noise) and against torch fp32."""
+    from joligen_amd import ops
+
+    monkeypatch.setenv("JG_WGRAD_HALO_CFG", cfg)     # 2: the 8-row x 128-channel configuration the UNet up-blocks run
+    B, H, W, Cin, Cout = case
+    d = dev()
+    x_low = nhwc(rnd((B, Cin, H // 2, W // 2), dtype, 81)).to(d)
+    x_full = x_low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2).contiguous()
+    w = rnd((Cout, Cin, 3, 3), dtype, 82, 1.0 / math.sqrt(Cin * 9)).permute(0, 2, 3, 1).contiguous().to(d)
+    bias = rnd((Cout,), torch.float32, 83).to(d)
+    dy = nhwc(rnd((B, Cout, H, W), dtype, 84)).to(d)
+    ys, dws = [], []
+    for x, mode in ((x_low, 1), (x_full, 0)):
+        y = torch.empty((B, H, W, Cout), device=d, dtype=dtype)
+        ops.conv_nt(x, w, y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=9 * Cin, ldy=Cout,
+                    bias=bias, x_mode=mode)
+        dw = torch.zeros((Cout, 3, 3, Cin), device=d, dtype=torch.float32)
+        db = torch.zeros((Cout,), device=d, dtype=torch.float32)
+        ops.wgrad_tn(dy, x, dw, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, lddy=Cout, ldx=Cin,
+                     lddw=9 * Cin, dbias=db, splitk=2, x_mode=mode)
+        ys.append(y)
+        dws.append((dw, db))
+    torch.cuda.synchronize()
+    assert torch.equal(ys[0], ys[1])
+    assert relerr(dws[0][0], dws[1][0]) < 1e-5 and relerr(dws[0][1], dws[1][1]) < 1e-5
+    xr = nchw(x_full).float().requires_grad_(False)
+    wr = w.permute(0, 3, 1, 2).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, bias, 1, 1)
+    yr.backward(nchw(dy).float())
+    assert relerr(nchw(ys[0]), yr.detach()) < TOL[dtype]
+    assert relerr(dws[0][0].permute(0, 3, 1, 2), wr.grad) < TOL[dtype]
+
+
+@pytest.mark.gpu
+def test_upsample_on_read_unsupported_shape_is_refused():
+    from joligen_amd import ops
+
+    d = dev()
+    x = torch.zeros((1, 6, 6, 32), device=d, dtype=torch.bfloat16)          # 12x12 upsampled: not a multiple of 16, Cin 32
+    w = torch.zeros((64, 3, 3, 32), device=d, dtype=torch.bfloat16)
+    y = torch.empty((1, 12, 12, 64), device=d, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="jg_conv2d_nt"):
+        ops.conv_nt(x, w, y, B=1, H=12, W=12, Cin=32, Cout=64, R=3, S=3, pad=1, stride=1, Ho=12, Wo=12, ldx=32, ldw=288, ldy=64, x_mode=1)
