@@ -82,6 +82,10 @@ typedef struct {
    * the upsampled copy: `conv(Upsample(h))` of the ResBlock-up path (unet_generator_attn.py:120-140,239-246).  Halo-resident 3x3
    * kernel only (shape limits of pad_mode 1), else JG_ERR_UNSUPPORTED. */
   int32_t x_mode;
+  /* y_mode 1: y is [B, Ho/2, Wo/2, Cout] and receives the 2x2 SUM-pool of alpha * conv(x) -- the adjoint of x_mode 1, i.e. the
+   * input gradient of `conv(Upsample(h))` w.r.t. h, without the full-resolution gradient in between.  No bias / res / stats;
+   * halo-resident 3x3 kernel only, else JG_ERR_UNSUPPORTED. */
+  int32_t y_mode;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 

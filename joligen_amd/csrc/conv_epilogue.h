@@ -26,9 +26,11 @@
 __device__ __forceinline__ int jg_pixperm(int r) { return r < 4 ? 2 * r : (r < 12 ? 2 * (r - 4) + 1 : 2 * (r - 8)); }
 
 // rrow(lp, m): row of the residual tensor for local pixel lp / output row m (m itself, or the half-resolution row for res_up)
-template <typename T, int TM, bool PERM = false, typename PixFn, typename ResRowFn, typename FlushFn>
+// prow(slab, r2, c2): y_pool (slabs of 4 image rows x 16 columns only): row of the POOLED output tensor of the slab's pooled pixel
+//   (r2 in 0..1, c2 in 0..7); the 2x2 sum of alpha * acc is stored there, no bias / residual / statistics
+template <typename T, int TM, bool PERM = false, typename PixFn, typename ResRowFn, typename PoolRowFn, typename FlushFn>
 __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][TM], char* scratch, int lane, int nbase,
-                                                int gimg, PixFn pix, ResRowFn rrow, FlushFn flush) {
+                                                int gimg, PixFn pix, ResRowFn rrow, PoolRowFn prow_fn, FlushFn flush) {
   static_assert(TM % 4 == 0, "slabs of 4 pixel tiles");
   const int l15 = lane & 15, lk = lane >> 4;
   const int c8 = lane & 7, prow = lane >> 3;
@@ -66,6 +68,24 @@ __device__ __forceinline__ void jg_epilogue_lds(const ConvP& p, f32x4 (&acc)[4][
                                p.alpha * acc[j][slab * 4 + ii][2], p.alpha * acc[j][slab * 4 + ii][3]);
         *reinterpret_cast<float4*>(scratch + pl * 256 + chunk * 16) = v;
       }
+    }
+    if (p.y_pool) {
+      // 16 pooled pixels x 8 channel octets per slab = 2 items per lane; a lane sums its 2x2 window out of the scratch
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int pp = it * 8 + prow, r2 = pp >> 3, c2 = pp & 7;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+          const int pl = (2 * r2 + (dd >> 1)) * 16 + 2 * c2 + (dd & 1);
+          const float4 a = *reinterpret_cast<const float4*>(scratch + pl * 256 + (((2 * c8) ^ (pl & 15)) << 4));
+          const float4 b = *reinterpret_cast<const float4*>(scratch + pl * 256 + (((2 * c8 + 1) ^ (pl & 15)) << 4));
+          v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+          v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        if (nok) *reinterpret_cast<uint4*>(y + prow_fn(slab, r2, c2) * p.ldy + nbase + c8 * 8) = pack8<T>(v);
+      }
+      continue;
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {

@@ -252,6 +252,9 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
         p, reinterpret_cast<f32x4(&)[4][TM]>(acc[4 * h]), smc + wave * 16384, lane, n0 + wn * WN + 64 * h, b,
         [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
         [&](int lp, long) -> long { return rrow0 + (long)((lp >> 4) >> rsh) * wres + ((lp & 15) >> rsh); },
+        [&](int slab, int r2, int c2) -> long {
+          return ((long)b * (p.H >> 1) + ((oh0 + wm * TM) >> 1) + slab * 2 + r2) * (p.W >> 1) + (ow0 >> 1) + c2;
+        },
         [&](int nch, const float* s1, const float* s2) {
           // wave partials -> LDS (ds_add_f32) -> ONE global atomic pair per channel per block
 #pragma unroll

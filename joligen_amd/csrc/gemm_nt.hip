@@ -334,6 +334,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
           q, acc, reinterpret_cast<char*>(&sm[0][0]) + wave * 16384, lane, n0 + wn * WN, p.stats ? m0 / (p.Ho * p.Wo) : 0,
           [&](int lp) -> long { return (mw + lp < p.M) ? (long)(mw + lp) : -1L; },
           [&](int, long m) -> long { return p.res_up ? jg_res_up_row(p, m) : m; },
+          [&](int, int, int) -> long { return 0L; },   // y_pool is refused before this kernel is reached
           [&](int nch, const float* s1, const float* s2) {
 #pragma unroll
             for (int qq = 0; qq < 8; ++qq) {
@@ -407,7 +408,7 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
     JG_CHECK_LAUNCH();
     return JG_OK;
   }
-  if (p.reflect || p.x_up) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read exist only in the halo-resident kernel
+  if (p.reflect || p.x_up || p.y_pool) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read / pooled stores exist only in the halo-resident kernel
   if (variant >= 2) {
     if (p.N <= 64) {
       if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);
@@ -458,6 +459,9 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.nslots = a->stats_slots > 0 ? a->stats_slots : 1;
   p.reflect = a->pad_mode == 1;
   if (a->pad_mode != 0 && a->pad_mode != 1) return JG_ERR_BAD_ARG;
+  p.y_pool = a->y_mode == 1;
+  if (a->y_mode != 0 && a->y_mode != 1) return JG_ERR_BAD_ARG;
+  if (p.y_pool && (a->bias || a->res || a->stats || a->out_f32 || (a->Ho & 1) || (a->Wo & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;
   p.x_up = a->x_mode == 1;
   if (a->x_mode != 0 && a->x_mode != 1) return JG_ERR_BAD_ARG;
   if (p.x_up && (p.reflect || (a->H & 1) || (a->W & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;

@@ -57,6 +57,7 @@ NORM_BEFORE_UP = os.environ.get("JG_NORM_BEFORE_UP", "1") != "0"
 # ResBlock-down: pool(act(norm(x))) in one kernel, and the GroupNorm backward reads the pooled-resolution gradients through the
 # upsample index map (jg_gn_apply_pool / jg_gn_bwd_*_up) instead of materialising full-resolution copies
 FUSE_DOWN_POOL = os.environ.get("JG_FUSE_DOWN_POOL", "1") != "0"
+POOL_IN_DGRAD = os.environ.get("JG_POOL_IN_DGRAD", "1") != "0"
 X_UP_ON_READ = os.environ.get("JG_X_UP_ON_READ", "1") != "0"
 RES_UP_ON_READ = os.environ.get("JG_RES_UP_ON_READ", "1") != "0"
 FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
@@ -105,7 +106,7 @@ def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res
     return out
 
 
-def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0, gn=None, pool=None):
+def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0, gn=None, pool=None, pool_out=False):
     """Input gradient of a stride-1 convolution.  `gn = (x, ab, act)`: the result is the output-gradient of a
     GroupNorm with input x / coefficients ab; its backward reductions (sum du, sum du*x) are then taken in
     this epilogue and returned as `red` [B, NSLOT, C, 2] (None when the shape is not covered: the caller
@@ -114,6 +115,9 @@ def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0, gn=None, pool=None
         raise NotImplementedError("input-gradient of strided convolutions is not implemented")
     B, H, W, Cin = x_shape
     _, Ho, Wo, Cout = dy.shape
+    if pool_out:   # the result is the 2x2 sum-pool of the input gradient (jg_conv_args.y_mode 1): adjoint of a conv over Upsample(h)
+        assert out is None and res is None and gn is None
+        out = torch.empty((B, H // 2, W // 2, Cin), device=dy.device, dtype=dy.dtype)
     if out is None:
         out = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
     red = None
@@ -124,7 +128,7 @@ def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0, gn=None, pool=None
         kw = dict(stats=red, ldstats=Cin, stats_slots=NSLOT, gn_reduce=(gx, _ld(gx), gab, gact))
     conv_nt(dy, m.w16T, out, B=B, H=Ho, W=Wo, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,
             ldx=_ld(dy), ldw=m.R * m.S * Cout, ldy=_ld(out), alpha=alpha, res=res, ldres=_ld(res) if res is not None else 0,
-            res_scale=1.0, **kw)
+            res_scale=1.0, y_mode=1 if pool_out else 0, **kw)
     return (out, red) if gn is not None else out
 
 
@@ -476,7 +480,11 @@ class UNetExecutor:
         if rec.get("low2"):
             hb, hh, hw_, hc = rec["h2"].shape
             full = (hb, 2 * hh, 2 * hw_, hc) if rec["h2_up"] else (hb, hh, hw_, hc)
-            dh2, red2 = pool2(conv_dgrad(dO, c2m, full), 1.0), None      # adjoint of the upsample behind GroupNorm 2
+            # adjoint of the upsample behind GroupNorm 2: pooled in the input-gradient epilogue when the halo kernel runs the layer
+            if POOL_IN_DGRAD and halo_ok(c2m, full[1], full[2]):
+                dh2, red2 = conv_dgrad(dO, c2m, full, pool_out=True), None
+            else:
+                dh2, red2 = pool2(conv_dgrad(dO, c2m, full), 1.0), None
         else:
             dh2, red2 = conv_dgrad(dO, c2m, rec["h2"].shape, gn=(rec["c1"], rec["ab2"], JG_ACT_SILU), pool=self.bpool)
         conv_wgrad(dO, rec["h2"], c2m, x_up=rec["h2_up"])

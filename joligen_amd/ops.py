@@ -82,7 +82,7 @@ def _wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode):
 
 def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
             ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
-            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0, x_mode=0):
+            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0, x_mode=0, y_mode=0):
     """jg_conv2d_nt with element offsets into the operand tensors."""
     a = ConvArgs()
     es = 2
@@ -103,6 +103,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     a.pad_mode = pad_mode
     a.res_mode = res_mode
     a.x_mode = x_mode
+    a.y_mode = y_mode
     if gn_reduce is not None:   # (norm input x, pixel stride, ab coefficients, act): GroupNorm-backward reductions in the epilogue
         gx, gldx, gab, gact = gn_reduce
         a.stats_mode, a.gn_x, a.gn_ldx, a.gn_ab, a.gn_act = 1, gx.data_ptr(), gldx, gab.data_ptr(), gact

@@ -777,3 +777,31 @@ def test_upsample_on_read_unsupported_shape_is_refused():
     y = torch.empty((1, 12, 12, 64), device=d, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="jg_conv2d_nt"):
         ops.conv_nt(x, w, y, B=1, H=12, W=12, Cin=32, Cout=64, R=3, S=3, pad=1, stride=1, Ho=12, Wo=12, ldx=32, ldw=288, ldy=64, x_mode=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64), (1, 16, 48, 128, 128), (2, 32, 32, 256, 192), (1, 32, 64, 384, 128), (2, 16, 16, 128, 512)])
+def test_conv_pooled_store(case, dtype):
+    """y_mode = 1 of jg_conv_args: the 2x2 sum-pool of alpha * conv3x3(x) stored at half resolution from the epilogue (adjoint of the
+    upsample-on-read convolution: input gradient of the ResBlock-up conv2 w.r.t. the low-resolution activation), against
+    torch fp32 and against pooling the materialised full-resolution result of the same kernel."""
+    from joligen_amd import ops
+    from joligen_amd.modules import unet_exec as ue
+
+    B, H, W, Cin, Cout = case
+    d = dev()
+    x = nhwc(rnd((B, Cin, H, W), dtype, 85)).to(d)
+    w = rnd((Cout, Cin, 3, 3), dtype, 86, 1.0 / math.sqrt(Cin * 9)).permute(0, 2, 3, 1).contiguous().to(d)
+    kw = dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=9 * Cin, ldy=Cout, alpha=0.5)
+    y_low = torch.full((B, H // 2, W // 2, Cout), float("nan"), device=d, dtype=dtype)
+    ops.conv_nt(x, w, y_low, y_mode=1, **kw)
+    y_full = torch.empty((B, H, W, Cout), device=d, dtype=dtype)
+    ops.conv_nt(x, w, y_full, **kw)
+    torch.cuda.synchronize()
+    ref = 4 * F.avg_pool2d(0.5 * F.conv2d(nchw(x).float(), w.permute(0, 3, 1, 2).float(), None, 1, 1), 2)
+    assert torch.isfinite(y_low.float()).all()
+    assert relerr(nchw(y_low), ref) < TOL[dtype]
+    assert relerr(y_low.float(), ue.pool2(y_full, 1.0).float()) < TOL[dtype]
+    with pytest.raises(RuntimeError, match="jg_conv2d_nt"):      # no bias / residual / statistics in this mode
+        ops.conv_nt(x, w, y_low, y_mode=1, bias=torch.zeros(Cout, device=d), **kw)
