@@ -365,8 +365,15 @@ def test_cut_checkpoints_reference_layout(golden_dir, tmp_path):
         m.set_input({"A": s["A"], "B": s["B"]})
         m.forward()
     torch.cuda.synchronize()
-    # same weights -> same output up to the summation order of the atomically accumulated InstanceNorm statistics
-    assert relerr(m1.fake_B.float(), m2.fake_B.float()) < 5e-3
+    # the loaded weights are bit-identical ...
+    for name in ("G_A", "F", "D_B_basic"):
+        sd1, sd2 = m1._net(name).state_dict(), m2._net(name).state_dict()
+        assert list(sd1.keys()) == list(sd2.keys())
+        for k in sd1:
+            assert torch.equal(sd1[k], sd2[k]), (name, k)
+    # ... and the output agrees up to the summation order of the atomically accumulated InstanceNorm statistics: a different
+    # bf16 rounding of a few activations cascades through the 9 ResnetBlocks (observed 1e-3 .. 6e-3 run to run)
+    assert relerr(m1.fake_B.float(), m2.fake_B.float()) < 2e-2
 
 
 @pytest.mark.parametrize("netG", ["resnet", "segformer_attn_conv"])
