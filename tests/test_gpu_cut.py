@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 TOL = {torch.float16: 4e-3, torch.bfloat16: 3e-2}
 # The input gradient of these ReLU + InstanceNorm stacks is ill-conditioned with respect to 16-bit rounding: rounding ONLY the
 # input and the weights to fp16 and evaluating the fp32 oracle already moves dx by 4.4 % (ReLU masks of near-zero
-# pre-activations flip; tools/dbg_cut_net.py prints it).  Outputs, feature taps and weight gradients stay tight.
+# pre-activations flip; tests/tools/dbg_cut_net.py prints it).  Outputs, feature taps and weight gradients stay tight.
 TOL_DX = {torch.float16: 0.12, torch.bfloat16: 0.35}
 
 

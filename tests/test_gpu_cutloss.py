@@ -247,7 +247,7 @@ def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
             assert abs(losses[k] - ref) <= tol * abs(ref) * (1 + it * later) + 1e-4, (it, k, losses[k], ref)
         # it = 0 is a pure forward pass.  Later iterations see weights that went through Adam's sign-like first steps: with 16-bit
         # activations the gradient DIRECTION of this ReLU / InstanceNorm stack is only good to ~10 % (fp16) / ~30 % (bf16) at
-        # random weights (tools/dbg_cut_grads.py; an fp32 oracle whose forward is merely rounded to fp16 moves by the same 10 %),
+        # random weights (tests/tools/dbg_cut_grads.py; an fp32 oracle whose forward is merely rounded to fp16 moves by the same 10 %),
         # which one optimizer step turns into a 2 - 3 % / 5 - 8 % change of the generator output.
         fb = model.fake_B.permute(0, 3, 1, 2)[:, :3].float()
         tol_fb = tol if it == 0 else (later * it if name == "segformer" else 1.0) * (4e-2 if dtype == torch.float16 else 1.2e-1)
