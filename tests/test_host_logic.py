@@ -185,12 +185,13 @@ def test_ops_refuse_cpu_tensors():
 
 def test_product_does_not_import_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
-    for dirpath, _, files in os.walk(os.path.join(ROOT, "joligen_amd")):
-        for f in files:
-            if f.endswith(".py"):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "jg_oracle" not in src and "ref_shim" not in src and "/root/reference" not in src.replace(
-                    "/root/reference/models", "").replace("/root/reference/", "REF/"), os.path.join(dirpath, f)
+    paths = [os.path.join(dirpath, f) for top in ("joligen_amd", "tools") for dirpath, _, files in os.walk(os.path.join(ROOT, top))
+             for f in files if f.endswith(".py")]
+    assert len(paths) > 20
+    for path in paths:
+        src = open(path).read()
+        assert "jg_oracle" not in src and "ref_shim" not in src and "/root/reference" not in src.replace(
+            "/root/reference/models", "").replace("/root/reference/", "REF/"), path
 
 
 def test_hot_kernels_do_not_spill(tmp_path):
