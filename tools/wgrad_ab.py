@@ -40,7 +40,6 @@ for Cin, Cout, k, S, cnt in shapes:
         vv = v.split(":")
         os.environ["JG_WGRAD_VARIANT"] = vv[0]
         os.environ["JG_WGRAD_HALO_CFG"] = vv[1] if len(vv) > 1 else "0"
-        os.environ["JG_WGRAD_HALO_BLOCKS"] = vv[2] if len(vv) > 2 else "512"
         dw = torch.zeros(Cout, k, k, Cin, device=d, dtype=torch.float32)
         db = torch.zeros(Cout, device=d, dtype=torch.float32)
 
