@@ -494,3 +494,39 @@ def test_subpixel_identity_of_conv_after_nearest_upsample():
                     acc = acc + torch.einsum("oc,bchw->bohw", wk, Lp[:, :, 1 + oy:1 + oy + H, 1 + ox:1 + ox + W])
             out[:, :, py::2, px::2] = acc
     torch.testing.assert_close(out, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_subpixel_backward_identities():
+    """The two adjoints the four-phase kernels need: with Wp[py][px][a][b] = sum of the original taps folded into
+    phase tap (a, b),
+      * input gradient at LOW resolution = sum over the 4 phases of the transposed 2x2-tap convolution of the parity sub-image
+        dO[:, :, py::2, px::2] (so the gradient of the upsampled map is never formed, 16 instead of 36 tap-MACs per pixel),
+      * dW[r][s] = sum of dWp[py][px][a][b] over the phase taps that (r, s) was folded into, where dWp is the plain weight gradient
+        of the phase convolution (parity sub-image of dO x shifted low-resolution input)."""
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(1)
+    L = torch.randn(2, 5, 6, 8, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    dO = torch.randn(2, 4, 12, 16, generator=g, dtype=torch.float64)
+    F.conv2d(F.interpolate(L, scale_factor=2, mode="nearest"), w, padding=1).backward(dO)
+    comb = {0: ((-1, [0]), (0, [1, 2])), 1: ((0, [0, 1]), (1, [2]))}
+    H, W = L.shape[2:]
+    Ld = L.detach()
+    Lp = F.pad(Ld, (1, 1, 1, 1))
+    dL = torch.zeros(2, 5, H + 2, W + 2, dtype=torch.float64)       # padded accumulator, the border is dropped
+    dW = torch.zeros_like(w)
+    for py in (0, 1):
+        for px in (0, 1):
+            sub = dO[:, :, py::2, px::2]                              # [B, Cout, H, W]: the phase's output pixels
+            for oy, ry in comb[py]:
+                for ox, rx in comb[px]:
+                    wk = w.detach()[:, :, ry][:, :, :, rx].sum((2, 3))                  # folded tap [Cout, Cin]
+                    dL[:, :, 1 + oy:1 + oy + H, 1 + ox:1 + ox + W] += torch.einsum("oc,bohw->bchw", wk, sub)
+                    dwk = torch.einsum("bohw,bchw->oc", sub, Lp[:, :, 1 + oy:1 + oy + H, 1 + ox:1 + ox + W])
+                    for r in ry:                                      # unfold: every original tap of the fold receives dWp
+                        for s in rx:
+                            dW[:, :, r, s] += dwk
+    torch.testing.assert_close(dL[:, :, 1:-1, 1:-1], L.grad, rtol=1e-12, atol=1e-12)
+    torch.testing.assert_close(dW, w.grad, rtol=1e-12, atol=1e-12)
