@@ -80,7 +80,10 @@ typedef struct {
   int32_t res_mode;
   /* x_mode 1: x is [B, H/2, W/2, Cin] and the convolution runs over its nearest x2 upsample (H, W = the upsampled size, even) without
    * the upsampled copy: `conv(Upsample(h))` of the ResBlock-up path (unet_generator_attn.py:120-140,239-246).  Halo-resident 3x3
-   * kernel only (shape limits of pad_mode 1), else JG_ERR_UNSUPPORTED. */
+   * kernel only (shape limits of pad_mode 1), else JG_ERR_UNSUPPORTED.
+   * x_mode 2: the same function in its sub-pixel form: w is the FOLDED weight tensor [4][Cout][2][2][Cin] of jg_subpixel_fold
+   * (ldw = 4 * Cin), every output phase (oh & 1, ow & 1) is a 2x2-tap convolution of the half-resolution x -- 16 instead of 36
+   * tap-MACs per input pixel.  H, W multiples of 32. */
   int32_t x_mode;
   /* y_mode 1: y is [B, Ho/2, Wo/2, Cout] and receives the 2x2 SUM-pool of alpha * conv(x) -- the adjoint of x_mode 1, i.e. the
    * input gradient of `conv(Upsample(h))` w.r.t. h, without the full-resolution gradient in between.  No bias / res / stats;
@@ -88,6 +91,10 @@ typedef struct {
   int32_t y_mode;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
+/* Folded weights of x_mode 2 from the fp32 master weights w32 [Cout][3][3][Cin]: out[py*2+px][co][a][b][ci] (dtype) = sum of the
+ * 3x3 taps that land on tap (a, b) of output phase (py, px) of conv3x3(Upsample_nearest(x)) -- per axis {w0 | w1+w2} for phase 0,
+ * {w0+w1 | w2} for phase 1 (fp32 sum, one rounding). */
+int jg_subpixel_fold(int dtype, const float* w32, void* out, int Cout, int Cin, jg_stream_t s);
 
 /* Weight gradient / batched GEMM "TN" on MFMA:
  *   dw[z][co][(r,s,ci)] (+)= alpha * sum_p dy[z][p][co] * xcol[z][p][(r,s,ci)]

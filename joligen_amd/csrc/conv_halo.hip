@@ -49,8 +49,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BN, int NT, int WAVES_M, int WAVES_N, int NABUF, int NBBUF, int MINB>
+// PHASE (sub-pixel form of conv3x3 over a nearest-x2-upsampled input, x_mode 2): p.H / p.W are the LOW-resolution dimensions of x,
+// y is [B, 2H, 2W, N].  A workgroup owns a 16x16 tile of low-resolution pixels, BN channels and ONE of the four output phases
+// (py, px): output pixel (2h + py, 2w + px) = sum over the 2x2 taps (a, b) of  Wp[py][px][a][b] . x[h + a + py - 1][w + b + px - 1],
+// i.e. halo offsets (a + py, b + px) of the same 18x18 halo tile, with the folded weights Wp = [4][N][2][2][Cin] (jg_subpixel_fold):
+// 4 instead of 9 K-steps per chunk.
+template <typename T, int BN, int NT, int WAVES_M, int WAVES_N, int NABUF, int NBBUF, int MINB, bool PHASE = false>
 __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
+  constexpr int NTAP = PHASE ? 4 : 9;
+  static_assert(!PHASE || NABUF == 1, "the phase form reloads its halo between chunks");
+  static_assert(!PHASE || NBBUF - 1 < NTAP, "weight ring prologue");
   constexpr int NWAVES = NT / 64;
   static_assert(WAVES_M * WAVES_N == NWAVES, "wave grid");
   constexpr int TM = 16 / WAVES_M;                 // 16-pixel tile rows per wave
@@ -76,6 +84,12 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     const int q = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
   }
+  int py = 0, px = 0;
+  if constexpr (PHASE) {        // the four phases of a tile are neighbours in the id order: they share the halo in L2
+    py = (id >> 1) & 1;
+    px = id & 1;
+    id >>= 2;
+  }
   const int tilesN = (p.N + BN - 1) / BN;
   const int n0 = (id % tilesN) * BN;
   const int sp = id / tilesN;
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   const int b = sp / (tw * th);
 
   const T* __restrict__ x = (const T*)p.x;
-  const T* __restrict__ w = (const T*)p.w;
+  const T* __restrict__ w = (const T*)p.w + (PHASE ? (long)(py * 2 + px) * p.N * p.ldw : 0L);
   const T* zp = reinterpret_cast<const T*>(&jg_halo_zero_page);
   typedef __attribute__((address_space(3))) char* lds_cptr;
   const unsigned lds0 = (unsigned)(size_t)(lds_cptr)(char*)&sm[0];   // LDS byte address of sm
@@ -161,7 +175,8 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       uint4 fa[TM], fb[TN];
-      const int a0 = (afrag[s3] ^ (sub * 64)) + abyte;
+      const int af = PHASE ? (s3 == 0 ? afrag[0] : (s3 == 1 ? afrag[1] : afrag[2])) : afrag[s3];   // PHASE: s3 is a run-time value
+      const int a0 = (af ^ (sub * 64)) + abyte;
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const uint4*>(smb + a0 + (i + r) * (HW_ * 128));
 #pragma unroll
@@ -174,7 +189,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   };
 
   const int nch = p.Cin >> 6;       // 64-channel chunks
-  const int nk = nch * 9;
+  const int nk = nch * NTAP;
 
   // ---- prologue: halo of chunk 0, first NBBUF-1 weight tiles -----------------------------------------
   if (!(p.dbg & 4)) {
@@ -193,7 +208,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     const int abyte = (NABUF == 2 ? (cc & 1) : 0) * (HALO_CH * 16);
     const bool next_chunk = cc + 1 < nch;
 #pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    for (int tap = 0; tap < NTAP; ++tap) {
       // 1. prefetch: weight tile of K-step k + NBBUF - 1 into the slot freed at the previous barrier
       const bool b_iss = kpre < nk;
       if (b_iss) {
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
         if (slot >= NBBUF) slot -= NBBUF;
         issue_b(slot, pre_tap * p.Cin + pre_cc * 64);
         ++kpre;
-        if (++pre_tap == 9) { pre_tap = 0; ++pre_cc; }
+        if (++pre_tap == NTAP) { pre_tap = 0; ++pre_cc; }
       }
       // 2. one LDS-DMA round of the next chunk's halo per tap
       bool a_iss = false;
@@ -210,7 +225,10 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
         a_iss = true;
       }
       // 3. MFMAs of this K-step
-      if (!(p.dbg & 2)) compute(abyte, (NABUF * HALO_CH + bslot * B_BUF) * 16, tap / 3, tap % 3);
+      if (!(p.dbg & 2)) {
+        if constexpr (PHASE) compute(abyte, (NABUF * HALO_CH + bslot * B_BUF) * 16, (tap >> 1) + py, (tap & 1) + px);
+        else compute(abyte, (NABUF * HALO_CH + bslot * B_BUF) * 16, tap / 3, tap % 3);
+      }
       // 4. the weight tile of the NEXT K-step (and, at tap 8, the whole next halo) must have landed;
       //    what was issued in this step may stay in flight (NBBUF == 3)
       if (NBBUF >= 3 && b_iss) {
@@ -242,16 +260,22 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     for (int i = tid; i < BN * 2; i += NT) sred[i] = 0.f;
     __syncthreads();
   }
-  const long mrow0 = ((long)b * p.H + oh0 + wm * TM) * p.W + ow0;
+  const long mrow0 = PHASE ? ((long)b * 2 * p.H + 2 * (oh0 + wm * TM) + py) * (2 * p.W) + 2 * ow0 + px
+                           : ((long)b * p.H + oh0 + wm * TM) * p.W + ow0;
   // half-resolution residual (res_up): tile origins and the wave's row offset are even, so the nearest-upsample map is two shifts
-  const int wres = p.res_up ? (p.W >> 1) : p.W, rsh = p.res_up ? 1 : 0;
-  const long rrow0 = p.res_up ? ((long)b * (p.H >> 1) + ((oh0 + wm * TM) >> 1)) * wres + (ow0 >> 1) : mrow0;
+  // (PHASE: the kernel's own grid IS the half resolution, the residual row of a pixel is its low-resolution index)
+  const int wres = PHASE ? p.W : (p.res_up ? (p.W >> 1) : p.W), rsh = (!PHASE && p.res_up) ? 1 : 0;
+  const long rrow0 = PHASE ? ((long)b * p.H + oh0 + wm * TM) * p.W + ow0
+                           : (p.res_up ? ((long)b * (p.H >> 1) + ((oh0 + wm * TM) >> 1)) * wres + (ow0 >> 1) : mrow0);
 #pragma unroll
   for (int h = 0; h < TN / 4; ++h) {     // 64 output channels of the wave tile at a time
     jg_epilogue_lds<T, TM, true>(
         p, reinterpret_cast<f32x4(&)[4][TM]>(acc[4 * h]), smc + wave * 16384, lane, n0 + wn * WN + 64 * h, b,
-        [&](int lp) -> long { return mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
-        [&](int lp, long) -> long { return rrow0 + (long)((lp >> 4) >> rsh) * wres + ((lp & 15) >> rsh); },
+        [&](int lp) -> long { return PHASE ? mrow0 + (long)(lp >> 4) * (4 * p.W) + 2 * (lp & 15) : mrow0 + (long)(lp >> 4) * p.W + (lp & 15); },
+        [&](int lp, long m) -> long {
+          if (PHASE && !p.res_up) return m;      // full-resolution residual: the output row itself
+          return rrow0 + (long)((lp >> 4) >> rsh) * wres + ((lp & 15) >> rsh);
+        },
         [&](int slab, int r2, int c2) -> long {
           return ((long)b * (p.H >> 1) + ((oh0 + wm * TM) >> 1) + slab * 2 + r2) * (p.W >> 1) + (ow0 >> 1) + c2;
         },
@@ -269,6 +293,12 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
     float* dst = p.stats + (((long)b * p.nslots + sp % p.nslots) * p.ldstats + n0) * 2;
     for (int i = tid; i < BN * 2; i += NT) atomicAdd(dst + i, sred[i]);
   }
+}
+
+template <typename T, int BN, int NT, int WMv, int WNv, int NABUF, int NBBUF, int MINB>
+void launch_halo_phase(const ConvP& p, hipStream_t st) {   // p.H / p.W: low-resolution grid; 4 phases per tile
+  const int tiles = p.B * (p.H >> 4) * (p.W >> 4) * ((p.N + BN - 1) / BN) * 4;
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NT, WMv, WNv, NABUF, NBBUF, MINB, true>), dim3(tiles), dim3(NT), 0, st, p);
 }
 
 template <typename T, int BN, int NT, int WMv, int WNv, int NABUF, int NBBUF, int MINB>
@@ -295,10 +325,59 @@ void dispatch_halo(const ConvP& p, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+
+// 16-bit folded weights of the sub-pixel form: out[ph = py * 2 + px][co][a][b][ci] = sum of w32[co][r][s][ci] over r in R(py, a),
+// s in R(px, b) with R(0,0) = {0}, R(0,1) = {1,2}, R(1,0) = {0,1}, R(1,1) = {2}; fp32 sum, one rounding
+template <typename T>
+__global__ __launch_bounds__(256) void subpixel_fold_kernel(const float* __restrict__ w32, T* __restrict__ out, int Cout, int Cin) {
+  const long n = (long)Cout * Cin * 16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int ci = (int)(i % Cin);
+    long t = i / Cin;
+    const int tap = (int)(t & 3);
+    t >>= 2;
+    const int co = (int)(t % Cout), ph = (int)(t / Cout);
+    const int py = ph >> 1, px = ph & 1, a = tap >> 1, b = tap & 1;
+    const int r0 = (py == 0) ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), r1 = (py == 0) ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+    const int s0 = (px == 0) ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), s1 = (px == 0) ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+    float acc = 0.f;
+    for (int r = r0; r <= r1; ++r)
+      for (int sx = s0; sx <= s1; ++sx) acc += w32[(((long)co * 3 + r) * 3 + sx) * Cin + ci];
+    out[i] = from_f32<T>(acc);
+  }
+}
+
+}  // namespace
+
+extern "C" int jg_subpixel_fold(int dtype, const float* w32, void* out, int Cout, int Cin, jg_stream_t s) {
+  if (!w32 || !out || Cout < 1 || Cin < 1) return JG_ERR_BAD_ARG;
+  const long n = (long)Cout * Cin * 16;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((subpixel_fold_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)s, w32, (T*)out, Cout, Cin););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
 bool jg_conv_halo_try(int dtype, const ConvP& p0, int nbatch, hipStream_t st) {
   ConvP p = p0;
   static const int dbg = [] { const char* e = getenv("JG_HALO_DBG"); return e ? atoi(e) : 0; }();
   p.dbg = dbg;
+  if (p.x_up == 2) {
+    // sub-pixel form: p.H / p.W arrive as the upsampled (output) size; the kernel runs on the half-resolution grid
+    if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_f32 || p.reflect || p.y_pool) return false;
+    if (p.Cin % 64 || p.N % 64 || (p.H & 31) || (p.W & 31) || p.H != p.Ho || p.W != p.Wo || p.ldw != 4L * p.Cin) return false;
+    if ((long)p.B * p.H * p.W * p.ldy >= (1L << 33) || (long)4 * p.N * p.ldw >= (1L << 31)) return false;
+    if (p.stats && p.stats_mode != 0) return false;
+    p.H >>= 1; p.W >>= 1; p.x_up = 0;
+    if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31)) return false;
+    if (dtype == JG_F16) {
+      if (p.N % 128 == 0) launch_halo_phase<f16_t, 128, 256, 2, 2, 1, 2, 2>(p, st); else launch_halo_phase<f16_t, 64, 256, 4, 1, 1, 3, 2>(p, st);
+    } else if (dtype == JG_BF16) {
+      if (p.N % 128 == 0) launch_halo_phase<bf16_t, 128, 256, 2, 2, 1, 2, 2>(p, st); else launch_halo_phase<bf16_t, 64, 256, 4, 1, 1, 3, 2>(p, st);
+    } else return false;
+    return true;
+  }
   if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_f32) return false;
   if (p.Cin % 64 || p.N % 64 || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.N * p.ldw >= (1L << 31)) return false;

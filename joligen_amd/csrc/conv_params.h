@@ -24,7 +24,8 @@ struct ConvP {
   int dbg;        // ablation switches of the dev tools (JG_HALO_DBG): 1 = no epilogue, 2 = no MFMA/LDS reads, 4 = no halo DMA
   const char* gx; long gldx; const float* gab; int gact;
   int y_pool;     // 1: y is [B, Ho/2, Wo/2, N] = 2x2 SUM-pool of alpha * conv (halo kernel only; no bias / residual / statistics)
-  int x_up;       // 1: x is [B, H/2, W/2, Cin] and is read through the nearest-upsample index map (conv over Upsample(x), halo kernel only)
+  int x_up;       // 1: x is [B, H/2, W/2, Cin] and is read through the nearest-upsample index map (conv over Upsample(x), halo kernel only);
+                  // 2: the same convolution in its sub-pixel form (four 2x2-tap phases, folded weights)
   int res_up;     // 1: res is [B, Ho/2, Wo/2, N] and is read through the nearest-upsample index map (UNet up-block skip path)
   int reflect;    // 1: out-of-image halo pixels mirror the interior (nn.ReflectionPad2d(1) in front of a pad-0 3x3 conv)
 };

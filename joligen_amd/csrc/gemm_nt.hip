@@ -462,8 +462,8 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   p.y_pool = a->y_mode == 1;
   if (a->y_mode != 0 && a->y_mode != 1) return JG_ERR_BAD_ARG;
   if (p.y_pool && (a->bias || a->res || a->stats || a->out_f32 || (a->Ho & 1) || (a->Wo & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;
-  p.x_up = a->x_mode == 1;
-  if (a->x_mode != 0 && a->x_mode != 1) return JG_ERR_BAD_ARG;
+  p.x_up = a->x_mode;      // 1: upsample-on-read, 2: sub-pixel form (w = folded weights of jg_subpixel_fold)
+  if (a->x_mode < 0 || a->x_mode > 2) return JG_ERR_BAD_ARG;
   if (p.x_up && (p.reflect || (a->H & 1) || (a->W & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;
   p.res_up = a->res_mode == 1;
   if (a->res_mode != 0 && a->res_mode != 1) return JG_ERR_BAD_ARG;

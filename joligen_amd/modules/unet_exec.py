@@ -57,6 +57,8 @@ NORM_BEFORE_UP = os.environ.get("JG_NORM_BEFORE_UP", "1") != "0"
 # ResBlock-down: pool(act(norm(x))) in one kernel, and the GroupNorm backward reads the pooled-resolution gradients through the
 # upsample index map (jg_gn_apply_pool / jg_gn_bwd_*_up) instead of materialising full-resolution copies
 FUSE_DOWN_POOL = os.environ.get("JG_FUSE_DOWN_POOL", "1") != "0"
+# forward of the up-block conv2 in its sub-pixel form (x_mode 2: 16 instead of 36 tap-MACs per low-resolution pixel)
+SUBPIXEL_CONV = os.environ.get("JG_SUBPIXEL_CONV", "1") != "0"
 POOL_IN_DGRAD = os.environ.get("JG_POOL_IN_DGRAD", "1") != "0"
 X_UP_ON_READ = os.environ.get("JG_X_UP_ON_READ", "1") != "0"
 RES_UP_ON_READ = os.environ.get("JG_RES_UP_ON_READ", "1") != "0"
@@ -87,7 +89,20 @@ def halo_ok(m, H, W):
     return m.R == 3 and m.S == 3 and m.pad == 1 and m.stride == 1 and m.Cin % 64 == 0 and m.Cout % 64 == 0 and H % 16 == 0 and W % 16 == 0
 
 
-def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res_up=False, x_up=False):
+def subpixel_ok(m, H, W):
+    """shape limits of jg_conv_args.x_mode 2 (H, W: the upsampled size)"""
+    return halo_ok(m, H, W) and H % 32 == 0 and W % 32 == 0 and m.Cin_real == m.Cin and m.Cout_real == m.Cout
+
+
+def subpixel_fold(m, dtype):
+    """folded weights [4][Cout][2][2][Cin] of the sub-pixel form from the fp32 master weights (physical [Cout][3][3][Cin])"""
+    out = torch.empty((4, m.Cout, 2, 2, m.Cin), device=m.weight.device, dtype=dtype)
+    check(_lib.lib().jg_subpixel_fold(_lib.JG_F16 if dtype == torch.float16 else _lib.JG_BF16, m.weight.data_ptr(), out.data_ptr(), m.Cout,
+                                      m.Cin, _st()), "jg_subpixel_fold")
+    return out
+
+
+def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res_up=False, x_up=False, wfold=None):
     B, H, W, Cin = x.shape
     if x_up:      # x is the half-resolution tensor, the convolution runs over its nearest upsample (jg_conv_args.x_mode 1)
         H, W = 2 * H, 2 * W
@@ -95,11 +110,13 @@ def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res
     if out is None:
         out = torch.empty((B, Ho, Wo, m.Cout), device=x.device, dtype=x.dtype)
     fuse = stats is not None and _stats_fusable(B, Ho, Wo, m.Cout)
-    conv_nt(x, m.w16, out, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
-            ldx=_ld(x), ldw=m.R * m.S * Cin, ldy=_ld(out), bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
+    # wfold: x_mode 2, the sub-pixel form of the same convolution (four 2x2-tap phases on the folded weights)
+    conv_nt(x, m.w16 if wfold is None else wfold, out, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride,
+            Ho=Ho, Wo=Wo, ldx=_ld(x), ldw=m.R * m.S * Cin if wfold is None else 4 * Cin, ldy=_ld(out),
+            bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
             ldres=_ld(res) if res is not None else 0, alpha=alpha, res_scale=res_scale,
             stats=stats if fuse else None, ldstats=stats.stride(1) // 2 if fuse else 0, stats_slots=NSLOT,
-            res_mode=1 if res_up else 0, x_mode=1 if x_up else 0)
+            res_mode=1 if res_up else 0, x_mode=(2 if wfold is not None else 1) if x_up else 0)
     if stats is not None and not fuse:   # shapes the fused epilogue does not cover: separate statistics pass
         check(_lib.lib().jg_gn_stats_ld(_dt(out), out.data_ptr(), _ld(out), stats.data_ptr(), stats.stride(0) // 2, B, Ho * Wo,  # replica 0
                                         m.Cout, _st()), "jg_gn_stats_ld")
@@ -398,7 +415,8 @@ class UNetExecutor:
         identity = isinstance(rb.skip_connection, nn.Identity)
         sk = xs if identity else conv_fwd(xs, rb.skip_connection.meta)
         out_t, out_st = dest(B, Ho, Wo, Cout)
-        conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st, res_up=res_up, x_up=h2_up)
+        wfold = subpixel_fold(c2m, h2.dtype) if (h2_up and SUBPIXEL_CONV and subpixel_ok(c2m, Ho, Wo)) else None
+        conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st, res_up=res_up, x_up=h2_up, wfold=wfold)
         rec = dict(kind="res", rb=rb, x=x, ab1=ab1, mr1=mr1, a1=a1, c1=c1, ab2=ab2, mr2=mr2, h2=h2, film=film,
                    xs=None if identity else xs, skipw=skipw, identity=identity, low2=low2, h2_up=h2_up)
         rec.update(self._in_fields(X))

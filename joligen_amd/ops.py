@@ -113,8 +113,11 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append((_conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, B * Ho * Wo if (stats is None or (R == 3 and Cin == 8 and gn_reduce is None)) else 0), ev0, ev1,
-                              2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
+        if x_mode == 2:    # sub-pixel form: 4 of the 9 tap-MACs per output pixel are executed -- count the MFMA work actually done
+            KERNEL_TIMING.append(("conv3x3_halo_kernel<subpixel>", ev0, ev1, 2.0 * B * Ho * Wo * Cout * 4 * Cin, (nbatch, B, Ho, Wo, Cin, Cout, 2)))
+        else:
+            KERNEL_TIMING.append((_conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, B * Ho * Wo if (stats is None or (R == 3 and Cin == 8 and gn_reduce is None)) else 0), ev0, ev1,
+                                  2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
 
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,

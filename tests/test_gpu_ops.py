@@ -805,3 +805,51 @@ def test_conv_pooled_store(case, dtype):
     assert relerr(y_low.float(), ue.pool2(y_full, 1.0).float()) < TOL[dtype]
     with pytest.raises(RuntimeError, match="jg_conv2d_nt"):      # no bias / residual / statistics in this mode
         ops.conv_nt(x, w, y_low, y_mode=1, bias=torch.zeros(Cout, device=d), **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 64, False), (1, 32, 64, 128, 128, True), (2, 64, 32, 192, 256, True), (1, 32, 32, 128, 192, False),
+                                  (1, 64, 64, 512, 128, True)])
+def test_conv_subpixel_form(case, dtype):
+    """x_mode = 2 of jg_conv_args: conv3x3(Upsample_nearest(x)) as four 2x2-tap phase convolutions of the half-resolution x on the
+    folded weights of jg_subpixel_fold (reference unet_generator_attn.py:120-140,239-246), with bias, half- or full-resolution
+    residual and the fused GroupNorm statistics, against torch fp32 and against the upsample-on-read 3x3 form (x_mode 1)."""
+    from joligen_amd import _lib, ops
+    from joligen_amd.modules import unet_exec as ue
+
+    B, H, W, Cin, Cout, res_low = case
+    d = dev()
+    x_low = nhwc(rnd((B, Cin, H // 2, W // 2), dtype, 61)).to(d)
+    w32 = rnd((Cout, Cin, 3, 3), torch.float32, 62, 1.0 / math.sqrt(Cin * 9)).permute(0, 2, 3, 1).contiguous().to(d)     # [Cout][3][3][Cin]
+    w16 = w32.to(dtype)
+    bias = rnd((Cout,), torch.float32, 63).to(d)
+    res = nhwc(rnd((B, Cout, H // 2, W // 2) if res_low else (B, Cout, H, W), dtype, 64)).to(d)
+    wf = torch.empty((4, Cout, 2, 2, Cin), device=d, dtype=dtype)
+    _lib.check(_lib.lib().jg_subpixel_fold(ue._dt(x_low), w32.data_ptr(), wf.data_ptr(), Cout, Cin, ue._st()), "jg_subpixel_fold")
+    # fold against its definition
+    wr = w32.double()
+    sets = {(0, 0): [0], (0, 1): [1, 2], (1, 0): [0, 1], (1, 1): [2]}
+    for py in (0, 1):
+        for px in (0, 1):
+            for a in (0, 1):
+                for b in (0, 1):
+                    ref_t = sum(wr[:, r, s, :] for r in sets[(py, a)] for s in sets[(px, b)])
+                    assert relerr(wf[py * 2 + px, :, a, b, :].double(), ref_t) < TOL[dtype]
+    kw = dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldy=Cout, bias=bias, res=res, ldres=Cout,
+              res_scale=0.7, res_mode=1 if res_low else 0, stats_slots=ue.NSLOT, ldstats=Cout)
+    outs = []
+    for mode, w, ldw in ((2, wf, 4 * Cin), (1, w16, 9 * Cin)):
+        y = torch.full((B, H, W, Cout), float("nan"), device=d, dtype=dtype)
+        st = torch.zeros((B, ue.NSLOT, Cout, 2), device=d, dtype=torch.float32)
+        ops.conv_nt(x_low, w, y, ldw=ldw, x_mode=mode, stats=st, **kw)
+        outs.append((y, st.sum(1)))
+    torch.cuda.synchronize()
+    x_full = x_low.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    r_full = res.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2) if res_low else res
+    ref = F.conv2d(nchw(x_full).float(), w32.permute(0, 3, 1, 2), bias, 1, 1) + 0.7 * nchw(r_full).float()
+    assert torch.isfinite(outs[0][0].float()).all()
+    assert relerr(nchw(outs[0][0]), ref) < TOL[dtype]
+    assert relerr(outs[0][0].float(), outs[1][0].float()) < 2 * TOL[dtype]
+    assert relerr(outs[0][1][..., 0], ref.sum((2, 3))) < 5e-3 and relerr(outs[0][1][..., 1], (ref * ref).sum((2, 3))) < TOL[dtype]
+    assert relerr(outs[0][1], outs[1][1]) < 2 * TOL[dtype]
