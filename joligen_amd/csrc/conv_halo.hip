@@ -19,6 +19,13 @@
 // k-chunk c ^ ((row >> 1) & 7), and fragment reads apply the same XOR (row = halo pixel index /
 // weight row).  MFMA: v_mfma_f32_16x16x32, weights as operand A so that a lane's 4 accumulators are
 // 4 consecutive output channels of one pixel (8-byte epilogue stores).
+//
+// Addressing modes (all decided in the prologue / epilogue, the K loop is the same code):
+//   reflect  out-of-image halo pixels fetch the mirrored interior pixel (ReflectionPad2d(1) + pad-0 conv as one launch)
+//   x_up 1   x is the half-resolution tensor: halo pixel (ih, iw) fetches (ih >> 1, iw >> 1)   -- conv over Upsample_nearest(x)
+//   x_up 2   the same function in its sub-pixel form (PHASE instantiation below): 4 taps on folded weights per output phase
+//   res_up   the residual is at half resolution and is read through the same index map in the epilogue
+//   y_pool   the epilogue stores the 2x2 sum-pool of the tile (adjoint of x_up 1 when this launch computes an input gradient)
 #include "conv_params.h"
 #include "conv_epilogue.h"
 #include <cstdlib>
