@@ -266,3 +266,58 @@ def test_cut_options_and_forced_segformer_settings():
 
         with pytest.raises(RuntimeError, match="MI355X"):
             create_model(opt, 0)
+
+
+def test_early_exchange_parameter_coverage_of_the_fused_backward():
+    """Data parallel (parallel.EarlyExchange): walking the UNet the way unet_exec's forward builds its tape, the records' own
+    parameters (`_own_params`) cover every UNet parameter EXACTLY once except the ResBlock embedding projections (their gradient
+    comes from the stacked linear behind the node); with the conditioning MLP those are the parameters that go out with the
+    optimizer step.  Checked on the CPU-built module tree + arena of an efficient and a non-efficient UNet, then driven through
+    EarlyExchange's bookkeeping (tail-first readiness, nothing reported twice, every chunk accounted for)."""
+    import torch
+    import torch.nn as nn
+
+    from joligen_amd import parallel
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.modules import unet_exec as ue
+    from joligen_amd.modules.unet_generator_attn import AttentionBlock, ResBlock
+    from joligen_amd.options import opt_from_json
+
+    for efficient, mults, nres in ((True, [1, 2], [1, 1]), (False, [1, 2, 2], [2, 1, 1])):
+        opt = opt_from_json({}, dict(G_ngf=32, G_unet_mha_channel_mults=mults, G_unet_mha_res_blocks=nres, G_unet_mha_attn_res=[16],
+                                     G_unet_mha_vit_efficient=efficient, data_crop_size=32, gpu_ids="0"))
+        net = define_G(**vars(opt))
+        arena = ParamArena(net, torch.device("cpu"), torch.bfloat16)
+        u = net.denoise_fn.model
+        recs = [dict(kind="stem", m=list(u.input_blocks[0])[0].meta)]
+        blocks = [list(b) for b in list(u.input_blocks)[1:]] + [list(u.middle_block)] + [list(b) for b in u.output_blocks]
+        for layers in blocks:
+            for layer in layers:
+                if isinstance(layer, ResBlock):
+                    recs.append(dict(kind="res", rb=layer, identity=isinstance(layer.skip_connection, nn.Identity)))
+                else:
+                    assert isinstance(layer, AttentionBlock), type(layer)
+                    recs.append(dict(kind="attn", blk=layer))
+        recs.append(dict(kind="head", gn=u.out[0].norm, m=u.out[2].meta))
+        name_of = {id(p): n for n, p in net.named_parameters()}
+        reported = [id(p) for rec in recs for p in ue._own_params(rec)]
+        assert len(reported) == len(set(reported))                                    # nothing twice
+        assert all(i in name_of for i in reported)
+        left = sorted(n for i, n in name_of.items() if i not in set(reported))
+        assert left and all(("emb_layers" in n) or ("cond_embed" in n) for n in left), left   # only the embedding path is outside the node
+        # the bookkeeping: report in backward (reverse tape) order
+        ex = parallel.EarlyExchange.__new__(parallel.EarlyExchange)
+        launched = []
+        ex._launch = lambda c, ex=ex: (ex.sent.__setitem__(c, True), launched.append(c))
+        parallel.EarlyExchange.__init__(ex, arena, list(net.named_parameters()), n_chunks=8)
+        for rec in reversed(recs):
+            for p in ue._own_params(rec):
+                ex.mark(p)
+        early = list(launched)
+        assert len(early) >= len(ex.bounds) - 3, (early, len(ex.bounds))              # the priority (embedding) group sits at the head
+        assert early == sorted(early, reverse=True) or len(set(early)) == len(early)  # tail-first, each chunk once
+        assert all(ex.left[c] == 0 for c in early) and all(ex.left[c] > 0 or ex.total[c] == 0 for c in range(len(ex.bounds)) if c not in early)
+        for k in list(parallel._EARLY):                                                # keep the module-level registry clean for other tests
+            if parallel._EARLY[k] is ex:
+                del parallel._EARLY[k]
