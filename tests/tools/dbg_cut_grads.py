@@ -10,7 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
 import torch
 
 import jg_oracle as O
-from test_gpu_cutloss import build_cut_model, relerr
+from test_gpu_5_cutloss import build_cut_model, relerr
 from test_oracle_golden import cut_ids, cut_trainer_for
 
 name = sys.argv[1] if len(sys.argv) > 1 else "config0"
