@@ -32,6 +32,15 @@ enum { JG_OUT_ATOMIC_F32 = 0, JG_OUT_STORE_F32 = 1, JG_OUT_STORE_T = 2 };
 int jg_version(void);
 const char* jg_strerror(int code);
 
+/* Dispatch switches.  Each switch is read once from the environment variable of the same name
+ * ("JG_HALO_CFG", "JG_WGRAD_HALO_CFG", "JG_CONV_VARIANT", "JG_WGRAD_VARIANT", "JG_SINKHORN_GENERIC", "JG_CONV1X1",
+ * "JG_GN_REVERSE", "JG_HALO_DBG", "JG_PERSIST64"); jg_set_tuning overrides it for the rest of the process (parity tests use
+ * it to force a tile configuration that the automatic choice only takes at bench-sized grids).  No reference counterpart:
+ * the reference delegates kernel choice to cuDNN's heuristics (torch.backends.cudnn.benchmark, train.py:38-48).
+ * Returns JG_OK / JG_ERR_BAD_ARG (unknown name); jg_get_tuning returns the current value or -1. */
+int jg_set_tuning(const char* name, int value);
+int jg_get_tuning(const char* name);
+
 /* Implicit-GEMM convolution / batched GEMM "NT" on MFMA (v_mfma_f32_16x16x32_{f16,bf16}).
  *   y[z][m][n] = alpha * sum_k A[z][m][k] * w[z][n][k] + bias[n] + res_scale * res[z][m][n]
  * with A the implicit im2col of x[z] = [B,H,W,Cin] (pixel stride ldx), m = (b,oh,ow),

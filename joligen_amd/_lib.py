@@ -50,6 +50,8 @@ class WgradArgs(C.Structure):
 SIGNATURES = {
     "jg_version": [],
     "jg_strerror": [c_i32],
+    "jg_set_tuning": [C.c_char_p, c_i32],
+    "jg_get_tuning": [C.c_char_p],
     "jg_conv2d_nt": [c_i32, C.POINTER(ConvArgs), c_p],
     "jg_conv2d_wgrad_tn": [c_i32, C.POINTER(WgradArgs), c_p],
     "jg_gn_stats": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_p],
@@ -135,20 +137,50 @@ SIGNATURES = {
 }
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source into csrc/libjg355.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_params.h"), os.path.join(CSRC, "wgrad_params.h"), os.path.join(os.path.dirname(_HERE), "include", "jg355.h")]
-    if not force and os.path.exists(LIB_PATH):
-        if os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(d) for d in deps):
-            return LIB_PATH
+def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+    """Compile every HIP source for gfx950 (hipcc cross-compiles without a GPU) into csrc/libjg355.so.
+    One object per source under csrc/build/ (compiled in parallel, rebuilt when the source or any header is newer), then one link.
+    csrc/build/BUILD_INFO.json records what was compiled by this call."""
+    import json
+    import time
+    from concurrent.futures import ThreadPoolExecutor
+
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith(".h")] + [os.path.join(os.path.dirname(_HERE), "include", "jg355.h")]
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    bdir = os.path.join(CSRC, "build")
+    os.makedirs(bdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    cflags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    todo, objs = [], []
+    for src in SOURCES:
+        sp, op = os.path.join(CSRC, src), os.path.join(bdir, src.replace(".hip", ".o"))
+        objs.append(op)
+        if force or not os.path.exists(op) or os.path.getmtime(op) < max(os.path.getmtime(sp), hdr_time):
+            todo.append((sp, op))
+
+    def cc(job):
+        sp, op = job
+        cmd = [hipcc] + cflags + ["-c", sp, "-o", op]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    t0 = time.time()
+    if todo:
+        with ThreadPoolExecutor(max_workers=jobs or min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(cc, todo))
+    relink = bool(todo) or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs)
+    if relink:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    if todo or relink:
+        with open(os.path.join(bdir, "BUILD_INFO.json"), "w") as f:
+            json.dump({"compiled": [os.path.basename(s) for s, _ in todo], "linked": relink, "seconds": round(time.time() - t0, 1),
+                       "flags": cflags, "hipcc": hipcc}, f)
     return LIB_PATH
 
 
@@ -172,6 +204,14 @@ def lib():
         fn.restype = C.c_char_p if name == "jg_strerror" else c_i32
     _lib = L
     return L
+
+
+def set_tuning(name: str, value: int):
+    """override a dispatch switch of the library for the rest of the process; returns the previous value"""
+    L = lib()
+    prev = L.jg_get_tuning(name.encode())
+    check(L.jg_set_tuning(name.encode(), int(value)), f"jg_set_tuning({name})")
+    return prev
 
 
 def check(code: int, what: str = ""):

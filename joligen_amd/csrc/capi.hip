@@ -12,3 +12,47 @@ extern "C" const char* jg_strerror(int code) {
     default: return "unknown error";
   }
 }
+
+// ---- dispatch switches --------------------------------------------------------------------------------
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+struct TuneDef { const char* env; int dflt; };
+const TuneDef kTune[JG_TUNE_COUNT] = {
+    {"JG_HALO_CFG", 0}, {"JG_WGRAD_HALO_CFG", 0}, {"JG_CONV_VARIANT", 6}, {"JG_WGRAD_VARIANT", 4}, {"JG_SINKHORN_GENERIC", 0},
+    {"JG_CONV1X1", 1}, {"JG_GN_REVERSE", 1}, {"JG_HALO_DBG", 0}, {"JG_PERSIST64", 1}};
+std::atomic<int> g_tune[JG_TUNE_COUNT];
+std::once_flag g_tune_once;
+void tune_init() {
+  for (int i = 0; i < JG_TUNE_COUNT; ++i) {
+    const char* e = getenv(kTune[i].env);
+    g_tune[i].store(e ? atoi(e) : kTune[i].dflt, std::memory_order_relaxed);
+  }
+}
+}  // namespace
+
+int jg_tune(int which) {
+  std::call_once(g_tune_once, tune_init);
+  return g_tune[which].load(std::memory_order_relaxed);
+}
+
+extern "C" int jg_set_tuning(const char* name, int value) {
+  if (!name) return JG_ERR_BAD_ARG;
+  std::call_once(g_tune_once, tune_init);
+  for (int i = 0; i < JG_TUNE_COUNT; ++i)
+    if (!strcmp(name, kTune[i].env)) {
+      g_tune[i].store(value, std::memory_order_relaxed);
+      return JG_OK;
+    }
+  return JG_ERR_BAD_ARG;
+}
+
+extern "C" int jg_get_tuning(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < JG_TUNE_COUNT; ++i)
+    if (!strcmp(name, kTune[i].env)) return jg_tune(i);
+  return -1;
+}

@@ -13,6 +13,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define JG_WAVE 64
 
+// Dispatch switches: read ONCE from the environment, overridable at run time through the C ABI
+// (jg_set_tuning, include/jg355.h) so that tests can force a kernel configuration that the automatic choice would
+// not pick at test-sized shapes.  No per-launch getenv().
+enum JgTune { JG_TUNE_HALO_CFG = 0, JG_TUNE_WGRAD_HALO_CFG, JG_TUNE_CONV_VARIANT, JG_TUNE_WGRAD_VARIANT, JG_TUNE_SINKHORN_GENERIC,
+              JG_TUNE_CONV1X1, JG_TUNE_GN_REVERSE, JG_TUNE_HALO_DBG, JG_TUNE_PERSIST64, JG_TUNE_COUNT };
+int jg_tune(int which);
+
 #define JG_CHECK_LAUNCH()                          \
   do {                                             \
     if (hipGetLastError() != hipSuccess) return JG_ERR_LAUNCH; \

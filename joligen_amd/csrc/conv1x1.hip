@@ -256,7 +256,7 @@ bool dispatch_1x1(const ConvP& p, hipStream_t st) {
 // true when the shape was handled here (gemm_nt.hip falls through to the generic kernel otherwise)
 bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   if (p.res_up || p.x_up || p.y_pool) return false;   // half-resolution residuals / inputs: LDS-staged kernels only
-  static const int off = [] { const char* e = getenv("JG_CONV1X1"); return e && atoi(e) == 0; }();
+  const bool off = jg_tune(JG_TUNE_CONV1X1) == 0;
   if (off) return false;
   if (nbatch == 1 && p.nh == 1 && p.R == 3 && p.S == 3 && p.pad == 1 && p.stride == 1 && !p.out_f32 && !(p.stats && p.stats_mode) && !p.reflect &&
       p.Cin == 8 && ((p.H * p.W) & 15) == 0 &&

@@ -316,14 +316,15 @@ void launch_halo(const ConvP& p, hipStream_t st) {
 
 template <typename T>
 void dispatch_halo(const ConvP& p, hipStream_t st) {
-  const char* e = getenv("JG_HALO_CFG");
-  const int cfg = e ? atoi(e) : 0;   // 0: auto; 1: never the 256-wide tile; 2: 8-wave 128-wide tile (A/B experiments)
+  // JG_HALO_CFG 0: auto; 1: never the 256-wide tile; 2: 8-wave 128-wide tile; 3: the 256-wide tile whenever N % 256 == 0 (parity tests
+  // force the bench's configuration at test-sized grids); 4: 64-wide tile with a 4-deep weight ring
+  const int cfg = jg_tune(JG_TUNE_HALO_CFG);
   // 256-wide tiles run one 8-wave workgroup per CU: worth it only when the grid fills whole rounds of 256
   const long b256 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.N / 256);
   const bool fill256 = p.N % 256 == 0 && (double)b256 / (double)(((b256 + 255) / 256) * 256) >= 0.85;
   // (tried: <256, 256, 2, 2, 1, 2, 1> = 4 waves x (128 px x 128 ch) with the 256 accumulator registers in AGPRs -- halves the LDS
   //  fragment traffic per MFMA, but one wave per SIMD cannot hide the halo reloads: 1000-1170 vs 1260-1430 TFLOP/s, not kept)
-  if (fill256 && cfg == 0) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
+  if ((fill256 && cfg == 0) || (cfg == 3 && p.N % 256 == 0)) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
   else if (p.N % 128 == 0 && cfg == 2) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
   else if (p.N % 128 == 0) launch_halo<T, 128, 256, 2, 2, 1, 2, 2>(p, st);   // 4 waves x (128 px x 64 ch), 2 workgroups / CU
   else if (cfg == 4) launch_halo<T, 64, 256, 4, 1, 1, 4, 2>(p, st);
@@ -368,8 +369,7 @@ extern "C" int jg_subpixel_fold(int dtype, const float* w32, void* out, int Cout
 
 bool jg_conv_halo_try(int dtype, const ConvP& p0, int nbatch, hipStream_t st) {
   ConvP p = p0;
-  static const int dbg = [] { const char* e = getenv("JG_HALO_DBG"); return e ? atoi(e) : 0; }();
-  p.dbg = dbg;
+  p.dbg = jg_tune(JG_TUNE_HALO_DBG);
   if (p.x_up == 2) {
     // sub-pixel form: p.H / p.W arrive as the upsampled (output) size; the kernel runs on the half-resolution grid
     if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_f32 || p.reflect || p.y_pool) return false;

@@ -396,8 +396,7 @@ void launch_glds(const ConvP& p, int nbatch, hipStream_t st) {
 
 template <typename T>
 int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
-  const char* venv = getenv("JG_CONV_VARIANT");
-  const int variant = venv ? atoi(venv) : 6;  // 1: register-staged 32-deep; 2..5: LDS-DMA staged (128x128x64 = 3); 6: + halo-resident 3x3
+  const int variant = jg_tune(JG_TUNE_CONV_VARIANT);  // 1: register-staged 32-deep; 2..5: LDS-DMA staged (128x128x64 = 3); 6: + halo-resident 3x3
   if (p.stats && variant < 2) return JG_ERR_UNSUPPORTED;
   // streaming (LDS-free) kernels for the HBM-bound shapes first: 1x1 at >= 64k pixels, the 8-channel 3x3 stem, 64 -> 64 3x3 at >= 1M pixels
   if (variant >= 6 && !p.reflect && jg_conv1x1_try(sizeof(T) == 2 && std::is_same<T, f16_t>::value ? JG_F16 : JG_BF16, p, nbatch, st)) {

@@ -586,7 +586,7 @@ extern "C" int jg_nce_sinkhorn_fwd(const float* S, float* K, float* u_hist, floa
                                    jg_stream_t s) {
   if (!S || !K || !u_hist || !v_hist || nimg < 1 || P < 1 || niter < 1) return JG_ERR_BAD_ARG;
   if (P > SK_MAXP) return JG_ERR_UNSUPPORTED;
-  if (P <= SKR && !getenv("JG_SINKHORN_GENERIC"))
+  if (P <= SKR && !jg_tune(JG_TUNE_SINKHORN_GENERIC))
     hipLaunchKernelGGL(sinkhorn_fwd_reg_kernel, dim3(nimg), dim3(1024), 0, (hipStream_t)s, S, K, u_hist, v_hist, P, niter, eps);
   else
     hipLaunchKernelGGL(sinkhorn_fwd_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, S, K, u_hist, v_hist, P, niter, eps);
@@ -618,7 +618,7 @@ extern "C" int jg_nce_sinkhorn_bwd(const float* K, const float* u_hist, const fl
                                    float* dS, int nimg, int P, int niter, jg_stream_t s) {
   if (!K || !u_hist || !v_hist || !gW || !ds_hist || !dr_hist || !dS || nimg < 1 || P < 1 || niter < 1) return JG_ERR_BAD_ARG;
   if (P > SK_MAXP || niter * 32 * sizeof(float) > 48 * 1024) return JG_ERR_UNSUPPORTED;
-  if (P <= SKR && !getenv("JG_SINKHORN_GENERIC")) {
+  if (P <= SKR && !jg_tune(JG_TUNE_SINKHORN_GENERIC)) {
     hipLaunchKernelGGL(sinkhorn_seed_kernel, dim3(nimg), dim3(SK_THREADS), 0, (hipStream_t)s, K, u_hist, v_hist, gW, ds_hist, dr_hist, P, niter);
     hipLaunchKernelGGL(sinkhorn_bwd_reg_kernel, dim3(nimg), dim3(1024), 0, (hipStream_t)s, K, u_hist, v_hist, ds_hist, dr_hist, P, niter);
   } else

@@ -458,7 +458,7 @@ extern "C" int jg_gn_bwd_apply_up(int dtype, const void* x, int64_t ldx, const v
   if ((add1_low && (ldadd1 < C || ldadd1 % 8)) || (add2 && (ldadd2 < C || ldadd2 % 8))) return JG_ERR_BAD_ARG;
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  static const int rev = [] { const char* e = getenv("JG_GN_REVERSE"); return e ? atoi(e) : 1; }();
+  const int rev = jg_tune(JG_TUNE_GN_REVERSE);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, true>), grid, dim3(256), 0, (hipStream_t)s,
                                                             (const T*)x, (long)ldx, (const T*)dy_low, (long)lddy, ab, pqr, (T*)dx, (long)lddx,
                                                             (const T*)add1_low, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2,
@@ -498,7 +498,7 @@ extern "C" int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const v
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   hipStream_t st = (hipStream_t)s;
-  static const int rev = [] { const char* e = getenv("JG_GN_REVERSE"); return e ? atoi(e) : 1; }();
+  const int rev = jg_tune(JG_TUNE_GN_REVERSE);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT>), grid, dim3(256), 0, st, (const T*)x,
                                                             (long)ldx, (const T*)dy, (long)lddy, ab, pqr, (T*)dx, (long)lddx,
                                                             (const T*)add1, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2,

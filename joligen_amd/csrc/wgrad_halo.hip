@@ -314,8 +314,7 @@ void launch_wg(const WgP& p, hipStream_t st) {
 
 template <typename T>
 void dispatch_wg(const WgP& p, hipStream_t st) {
-  const char* e = getenv("JG_WGRAD_HALO_CFG");
-  const int cfg = e ? atoi(e) : 0;   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co; 3: 8x16 x 64 co, 4 waves
+  const int cfg = jg_tune(JG_TUNE_WGRAD_HALO_CFG);   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co; 3: 8x16 x 64 co, 4 waves
   // the 128-channel x 8-row configuration halves the L2->LDS bytes per MFMA but doubles the atomic
   // volume: it pays once a block has >= 64 (16-row) tiles to walk
   const long per1 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.Cout / 64) * (p.Cin / 64) / 256;

@@ -150,6 +150,118 @@ def test_conv_backward(case, dtype):
     assert relerr(m.c.weight.grad, 2 * wr.grad) < TOL[dtype]
 
 
+# ---- the tile configurations the BENCH runs --------------------------------------------------------------
+# dispatch_halo / dispatch_wg choose by grid size: at bench shapes (batch 32, 256x256) the 256-wide 8-wave double-buffered
+# forward tile and the 8-row / 128-channel weight-gradient tile are the ones that run, at the small shapes above they never are.
+# jg_set_tuning forces each configuration at a test-sized grid; every forced run is compared with fp32 torch on the same rounded
+# inputs AND with the automatic configuration's result (same MFMA products, other summation order -> 2e-5).
+HALO_FORCED = [
+    # (JG_HALO_CFG, kernel instance)                                  B, H,  W,  Cin, Cout
+    (3, "conv3x3_halo_kernel<256,512,2,4,2,2,1>", (2, 32, 32, 192, 256)),    # 3 chunks: halo double buffer wraps, 2-deep weight ring
+    (3, "conv3x3_halo_kernel<256,512,2,4,2,2,1>", (1, 16, 48, 64, 512)),     # 1 chunk (no prefetch), two 256-wide channel tiles
+    (2, "conv3x3_halo_kernel<128,512,4,2,2,3,1>", (2, 32, 16, 128, 128)),
+    (4, "conv3x3_halo_kernel<64,256,4,1,1,4,2>", (2, 16, 32, 192, 64)),
+    (1, "conv3x3_halo_kernel<128,256,2,2,1,2,2>", (2, 16, 16, 192, 256)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg,inst,shape", HALO_FORCED)
+def test_conv_halo_forced_configs(cfg, inst, shape, dtype):
+    from joligen_amd import _lib
+
+    B, H, W, Cin, Cout = shape
+    x = rnd((B, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, 1.0 / math.sqrt(Cin * 9))
+    bias = rnd((Cout,), torch.float32, 3)
+    res = rnd((B, Cout, H, W), dtype, 4)
+    ref = 0.5 * F.conv2d(x.float(), w.float(), None, 1, 1) + bias.view(1, -1, 1, 1) + 0.7 * res.float()
+    d = dev()
+    args = (nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d), bias.to(d), nhwc(res).to(d), 1, 1, 0.5, 0.7)
+    y_auto = torch.ops.jg355.conv2d_nt(*args)
+    prev = _lib.set_tuning("JG_HALO_CFG", cfg)
+    try:
+        y = torch.ops.jg355.conv2d_nt(*args)
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_tuning("JG_HALO_CFG", prev)
+    assert relerr(nchw(y), ref) < TOL[dtype], (inst, relerr(nchw(y), ref))
+    assert relerr(y.float(), y_auto.float()) < 2e-3 * (1 if dtype == torch.float16 else 4), (inst, relerr(y.float(), y_auto.float()))
+
+
+def test_conv_halo_bench_dispatch_shapes():
+    """Shapes whose grid passes dispatch_halo's `fill256` test (>= 218 of 256 workgroups per round), i.e. the AUTOMATIC choice is the
+    256-wide instance the bench's deep layers run: forward with fused statistics-free epilogue and the input gradient, bf16 (the
+    bench dtype), against fp32 torch on the rounded inputs."""
+    dtype = torch.bfloat16
+    for (B, H, W, Cin, Cout) in ((14, 64, 64, 256, 256), (30, 32, 32, 512, 512)):
+        assert B * (H // 16) * (W // 16) * (Cout // 256) >= 218
+        m, arena, w_ref, b_ref = _make_conv_module(Cin, Cout, 3, 1, dtype)
+        x = rnd((B, Cin, H, W), dtype, 91)
+        gy = rnd((B, Cout, H, W), dtype, 92)
+        xr = x.float().requires_grad_(True)
+        wr = w_ref.clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, b_ref, 1, 1)
+        yr.backward(gy.float())
+        xd = nhwc(x).to(dev()).requires_grad_(True)
+        y = m.c(xd)
+        y.backward(nhwc(gy).to(dev()))
+        torch.cuda.synchronize()
+        assert relerr(nchw(y), yr.detach()) < TOL[dtype], (B, H, Cin, relerr(nchw(y), yr.detach()))
+        assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype], ("dx", relerr(nchw(xd.grad), xr.grad))
+        assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype], ("dw", relerr(m.c.weight.grad, wr.grad))
+
+
+WGRAD_FORCED = [
+    # (JG_WGRAD_HALO_CFG, instance, (B, H, W, Cin, Cout))
+    (1, "wgrad3x3_halo_kernel<16,2,2>", (2, 32, 32, 64, 128)),
+    (2, "wgrad3x3_halo_kernel<8,4,2>  (bench: 128 -> 128 at 256x256)", (2, 32, 32, 128, 128)),
+    (2, "wgrad3x3_halo_kernel<8,4,2>", (1, 64, 32, 64, 256)),
+    (3, "wgrad3x3_halo_kernel<8,4,1>", (2, 32, 32, 128, 64)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg,inst,shape", WGRAD_FORCED)
+def test_wgrad_halo_forced_configs(cfg, inst, shape, dtype):
+    from joligen_amd import _lib
+
+    B, H, W, Cin, Cout = shape
+    m, arena, w_ref, b_ref = _make_conv_module(Cin, Cout, 3, 1, dtype)
+    x = rnd((B, Cin, H, W), dtype, 11)
+    gy = rnd((B, Cout, H, W), dtype, 12)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b_ref.clone().requires_grad_(True)
+    F.conv2d(x.float(), wr, br, 1, 1).backward(gy.float())
+    xd = nhwc(x).to(dev()).requires_grad_(True)
+    prev = _lib.set_tuning("JG_WGRAD_HALO_CFG", cfg)
+    try:
+        m.c(xd).backward(nhwc(gy).to(dev()))
+        torch.cuda.synchronize()
+    finally:
+        _lib.set_tuning("JG_WGRAD_HALO_CFG", prev)
+    assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype], (inst, relerr(m.c.weight.grad, wr.grad))
+    assert relerr(m.c.bias.grad, br.grad) < TOL[dtype], (inst, relerr(m.c.bias.grad, br.grad))
+
+
+def test_wgrad_halo_bench_splitk():
+    """the weight gradient at the bench's full-resolution geometry (256x256, 64 -> 64: split-K 308 at batch 32) on a batch of 4:
+    hundreds of split-K slices accumulate through fp32 atomics; against fp32 torch on the rounded inputs"""
+    dtype = torch.bfloat16
+    B, H, W, Cin, Cout = 4, 256, 256, 64, 64
+    m, arena, w_ref, b_ref = _make_conv_module(Cin, Cout, 3, 1, dtype)
+    x = rnd((B, Cin, H, W), dtype, 13)
+    gy = rnd((B, Cout, H, W), dtype, 14)
+    wr = w_ref.clone().requires_grad_(True)
+    br = b_ref.clone().requires_grad_(True)
+    F.conv2d(x.float(), wr, br, 1, 1).backward(gy.float())
+    xd = nhwc(x).to(dev()).requires_grad_(True)
+    m.c(xd).backward(nhwc(gy).to(dev()))
+    torch.cuda.synchronize()
+    assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype], relerr(m.c.weight.grad, wr.grad)
+    assert relerr(m.c.bias.grad, br.grad) < TOL[dtype], relerr(m.c.bias.grad, br.grad)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_padded_channels(dtype):
     """stem (Cin 6 -> 8) and head (Cout 3 -> 8): padded working copies, unpadded master grads."""

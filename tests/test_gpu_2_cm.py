@@ -65,32 +65,51 @@ def test_cm_generator_vs_reference_golden(golden_dir, name, dtype_name):
     assert relerr(out[1], g["current_x"]) < TOL_OUT[dtype], relerr(out[1], g["current_x"])
 
 
+TOL_LOSS_FWD = {torch.float16: 1e-2, torch.bfloat16: 5e-2}
+COS_UPDATE = {torch.float16: 0.90, torch.bfloat16: 0.70}
+
+
 @pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
 @pytest.mark.parametrize("name", CFGS)
 def test_cm_three_steps_vs_reference_golden(golden_dir, name, dtype_name):
-    """3 x optimize_parameters() (2 UNet forwards + 1 backward, AdamW + EMA) with the reference's injected
-    (noise, timesteps): loss per step and per-parameter checksums after steps 1 and 3."""
+    """3 x optimize_parameters() (2 UNet forwards + 1 backward, AdamW + EMA) with the reference's injected (noise, timesteps),
+    TEACHER-FORCED by the CPU oracle (tests/parity_util.py; the oracle reproduces the reference fixture's loss of every iteration,
+    re-asserted here): per iteration the loss on identical weights and the parameter / EMA update against the oracle's update."""
+    import parity_util as PU
+    from test_oracle_golden import cm_cfg_of
+
     g = load(golden_dir, f"cm_step_{name}.pt")
     dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
-    model = make_model(g["cfg"], dtype_name, g["hp"])
-    model.netG_A.current_t = 0
-    lr = g["hp"]["lr"]
+    hp = g["hp"]
+    model = make_model(g["cfg"], dtype_name, hp)
+    net = model.netG_A
+    net.current_t = 0
+    sd0 = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    tr = O.OracleCMTrainer(sd0, cm_cfg_of(g["cfg"]), g["total_t"], lr=hp["lr"], beta1=hp["beta1"], beta2=hp["beta2"], eps=hp["eps"],
+                           weight_decay=hp["weight_decay"], ema_beta=hp["ema_beta"] if hp["ema"] else None, lambda_G=hp["lambda_G"],
+                           optim=hp["optim"])
+    log = []
     for it, s in enumerate(g["steps"]):
+        PU.force_state(net, {k: tr.P[k] for k in tr.param_names}, tr.m, tr.v, tr.step, tr.ema)
+        before, ref_before = PU.snapshot(net), {k: tr.P[k].clone() for k in tr.param_names}
+        ema_before = None if tr.ema is None else {k: v.clone() for k, v in tr.ema.items()}
         model.rng_injection = lambda b, s=s: (s["noise"], s["timesteps"])
         model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "A_img_paths": ["x"]})
         model.optimize_parameters()
         loss = float(model.get_current_losses()["G_tot"])
-        assert abs(loss - float(s["loss"])) < (0.03 if dtype == torch.float16 else 0.08) * abs(float(s["loss"])), (it, loss, float(s["loss"]))
-        if "param_checks" in s:
-            params = dict(model.netG_A.named_parameters())
-            ema = dict(model.netG_A_ema.named_parameters())
-            for k, ref in s["param_checks"].items():
-                v = params[k].detach().float().cpu()
-                travel = 1.05 * (it + 1) * lr * v.numel() ** 0.5     # Adam's first steps move every weight by ~lr
-                assert abs(float(v.norm() - ref[0])) < 2e-3 * float(ref[0]) + travel, (it, k)
-                ve = ema[k].detach().float().cpu()
-                assert abs(float(ve.norm() - s["ema_checks"][k][0])) < 2e-3 * float(s["ema_checks"][k][0]) + travel, (it, k)
+        loss_ref = float(tr.optimize_parameters(s["B"], s["mask"], s["noise"], s["timesteps"]))
+        assert abs(loss_ref - float(s["loss"])) < 2e-4 * abs(float(s["loss"])) + 1e-6
+        assert abs(loss - loss_ref) < TOL_LOSS_FWD[dtype] * abs(loss_ref), (it, loss, loss_ref)
+        after = PU.snapshot(net)
+        PU.check_update(f"{name} {dtype_name} it{it}", before, after, ref_before, {k: tr.P[k] for k in tr.param_names},
+                        COS_UPDATE[dtype], log=log)
+        if hp["ema"]:
+            ema = {k: v.detach().float().cpu() for k, v in model.netG_A_ema.named_parameters()}
+            PU.check_ema(f"ema it{it}", ema_before, ema, after, hp["ema_beta"], first=ema_before is None)
     assert model.netG_A.current_t == 3 * g["cfg"]["B"]
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/update_agreement_cm_{name}_{dtype_name}.txt", "w") as f:
+        f.write("\n".join(log))
 
 
 def test_cm_first_step_gradients_vs_oracle():
