@@ -249,9 +249,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: re-launch under torch.distributed.run (one rank per GPU); the ranks inherit stdout, so
+        # rank 0's JSON line is this process's last line as well
+        import socket
+        import subprocess
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or args.force_exchange:
@@ -284,7 +295,9 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    loss = float(model.get_current_losses()["G_tot"].detach())
+    # logging path of the reference (train.py:293-301): the printed loss is the mean over the ranks
+    loss = float(model.get_current_losses_reduced()["G_tot"].detach())
+    n_ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -366,7 +379,8 @@ def main():
                                    "inpainting synthetic masks, AdamW+EMA, iter_size 1 "
                                    "(example_ddpm_noglasses2glasses.json + SURVEY Appendix C overrides)",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image_size": args.size,
-                       "efficient": bool(args.efficient), "parallelism": f"dp{world}", "final_loss": round(loss, 6)},
+                       "efficient": bool(args.efficient), "parallelism": f"dp{world}", "final_loss": round(loss, 6),
+                       "n_ranks_seen": n_ranks_seen},
             "roofline": roofline, "cpu_baseline": cpu,
         }
     # RCCL prints its banner through C stdio (block-buffered when stdout is a pipe, i.e. written at exit): every rank flushes it

@@ -197,6 +197,9 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
 
   const int nch = p.Cin >> 6;       // 64-channel chunks
   const int nk = nch * NTAP;
+  static_assert(TN == 4, "one 64-channel epilogue pass per wave");
+  float bias_pre[8];                // epilogue bias of this lane, in flight during the K loop
+  jg_epilogue_bias(p, lane, n0 + wn * WN, bias_pre);
 
   // ---- prologue: halo of chunk 0, first NBBUF-1 weight tiles -----------------------------------------
   if (!(p.dbg & 4)) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
           }
         });
   }
-  if (p.stats) {
+  if (p.stats && !(p.dbg & 64)) {
     __syncthreads();
     float* dst = p.stats + (((long)b * p.nslots + sp % p.nslots) * p.ldstats + n0) * 2;
     for (int i = tid; i < BN * 2; i += NT) atomicAdd(dst + i, sred[i]);

@@ -237,6 +237,10 @@ class BaseModel:
                 out[name] = getattr(self, "loss_" + name)
         return out
 
+    def get_current_losses_reduced(self):
+        """the logging path of train.py:288-303: the current losses averaged over the ranks (one small all-reduce)"""
+        return parallel.reduce_losses(self.get_current_losses())
+
     def get_current_batch_size(self):
         return self.real_A.shape[0]
 

@@ -152,6 +152,21 @@ def broadcast_params(arena, src=0):
         arena.dirty = True
 
 
+def reduce_losses(losses):
+    """train.py:293-301 of the reference: before printing, every logged loss is all-reduced (SUM) over the ranks and divided by the
+    world size.  The reference issues one collective per loss; here the values are stacked and travel as ONE small all-reduce.
+    `losses`: OrderedDict name -> 0-dim tensor | float (BaseModel.get_current_losses()); returns the same mapping with the mean over
+    ranks (0-dim fp32 tensors on the first tensor's device).  Single process: returned unchanged."""
+    ws = world_size()
+    if ws == 1 or not losses:
+        return losses
+    dev = next((v.device for v in losses.values() if torch.is_tensor(v)), torch.device("cpu"))
+    flat = torch.stack([(v.detach().float().to(dev) if torch.is_tensor(v) else torch.tensor(float(v), device=dev)).reshape(()) for v in losses.values()])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= ws
+    return type(losses)((k, flat[i]) for i, k in enumerate(losses))
+
+
 class FlatDataParallel(torch.nn.Module):
     """`net.module` / `net.no_sync()` surface of DistributedDataParallel for code written against
     the reference (models/base_model.py:836-860,1313-1315); forward just delegates -- the

@@ -231,3 +231,33 @@ def test_backward_overlapped_exchange(tmp_path):
         ref.step += 1
         ref.adamw_step(**hp)
     torch.testing.assert_close(r0["p"], ref.p, rtol=1e-5, atol=1e-6)
+
+
+def _worker_losses(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from collections import OrderedDict
+
+    from joligen_amd import parallel
+
+    losses = OrderedDict([("G_tot", torch.tensor(1.0 + rank)), ("G_NCE", 0.5 * (rank + 1)), ("D_tot", torch.tensor(3.0 - 2 * rank))])
+    red = parallel.reduce_losses(losses)
+    torch.save({k: float(v) for k, v in red.items()}, out % rank)
+    dist.destroy_process_group()
+
+
+def test_logging_loss_allreduce(tmp_path):
+    """train.py:293-301 of the reference: the printed losses are the mean over the ranks (here one stacked all-reduce); tensors and
+    plain floats are both accepted, the key order is kept, and a single process gets its mapping back unchanged."""
+    from collections import OrderedDict
+
+    from joligen_amd import parallel
+
+    out = str(tmp_path / "l%d.pt")
+    mp.spawn(_worker_losses, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert r0 == r1 and list(r0) == ["G_tot", "G_NCE", "D_tot"]
+    assert abs(r0["G_tot"] - 1.5) < 1e-6 and abs(r0["G_NCE"] - 0.75) < 1e-6 and abs(r0["D_tot"] - 2.0) < 1e-6
+    single = OrderedDict(a=torch.tensor(2.0))
+    assert parallel.reduce_losses(single) is single
