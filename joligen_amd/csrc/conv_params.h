@@ -59,5 +59,7 @@ __device__ __forceinline__ void jg_stats_flush(float* stats, long row, int n, co
 
 // conv_halo.hip: returns true when the shape was handled by the halo-resident 3x3 kernel.
 bool jg_conv_halo_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);
+// conv_p64.hip: returns true when the shape was handled by the persistent Cin == 64 kernel (weights resident in LDS).
+bool jg_conv_p64_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);
 // conv1x1.hip: returns true when the shape was handled by the streaming (LDS-free) 1x1 kernel.
 bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);

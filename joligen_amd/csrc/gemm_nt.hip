@@ -403,6 +403,10 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
     JG_CHECK_LAUNCH();
     return JG_OK;
   }
+  if (variant >= 6 && jg_conv_p64_try(sizeof(T) == 2 && std::is_same<T, f16_t>::value ? JG_F16 : JG_BF16, p, nbatch, st)) {
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   if (variant >= 6 && jg_conv_halo_try(sizeof(T) == 2 && std::is_same<T, f16_t>::value ? JG_F16 : JG_BF16, p, nbatch, st)) {
     JG_CHECK_LAUNCH();
     return JG_OK;

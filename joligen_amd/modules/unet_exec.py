@@ -63,6 +63,11 @@ POOL_IN_DGRAD = os.environ.get("JG_POOL_IN_DGRAD", "1") != "0"
 X_UP_ON_READ = os.environ.get("JG_X_UP_ON_READ", "1") != "0"
 RES_UP_ON_READ = os.environ.get("JG_RES_UP_ON_READ", "1") != "0"
 FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
+# Weight gradients on a SECOND HIP stream.  The backward's critical chain is dgrad -> GroupNorm backward -> dgrad -> ...; the weight
+# gradient of a layer hangs off it (nothing in the chain reads it).  Launched on their own stream the MFMA-bound weight-gradient
+# kernels run underneath the HBM-bound GroupNorm-backward passes of the chain instead of in front of them.  The streams meet again at
+# the end of the backward (and before a gradient chunk leaves for the all-reduce).
+WGRAD_STREAM = os.environ.get("JG_WGRAD_STREAM", "1") != "0"
 
 
 class _Pool:
@@ -280,6 +285,31 @@ class UNetExecutor:
             self.cat_ch.append((ctot, ctot - chans[j], chans[j]))
         self.tape = None
         self._pool_need = {}
+        self._side = None          # HIP stream of the weight-gradient launches (created with the first backward)
+
+    # ---- weight gradients off the critical chain -----------------------------------------------------
+    def wgrad(self, dy, x, m, **kw):
+        """conv_wgrad on the side stream: it starts once everything launched so far on the compute stream (the producers of dy and
+        x) is done.  Both operands are marked as in use by the side stream, so the caching allocator does not hand their memory to a
+        later allocation of the compute stream while the kernel may still be reading it."""
+        if not WGRAD_STREAM:
+            return conv_wgrad(dy, x, m, **kw)
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dy.device)
+            # a gradient chunk's all-reduce is ordered behind the CURRENT stream only: the weight gradients of the side stream are
+            # brought in right before a chunk leaves (parallel.EarlyExchange._launch), not after every layer
+            parallel.PRE_LAUNCH_HOOKS.append(self.wgrad_join)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            conv_wgrad(dy, x, m, **kw)
+        dy.record_stream(self._side)
+        x.record_stream(self._side)
+
+    def wgrad_join(self):
+        """the compute stream waits for every weight gradient launched so far (end of the backward; before an all-reduce chunk)"""
+        if self._side is not None:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, xin, emb):
@@ -454,10 +484,10 @@ class UNetExecutor:
             tape[idx] = None
             dO = dout if rec["kind"] == "head" else dacts.pop(idx)
             if rec["kind"] == "stem":
-                conv_wgrad(dO, rec["xin"], rec["m"])
+                self.wgrad(dO, rec["xin"], rec["m"])
                 if need_dx:
                     self.dxin = conv_dgrad(dO, rec["m"], rec["xin"].shape)
-                parallel.grads_final(_own_params(rec))
+                self._grads_final(rec)
                 continue
             adds = []
             if rec.get("add_hs") is not None:
@@ -468,7 +498,7 @@ class UNetExecutor:
                 dX = self.res_bwd(rec, dO, adds)
             else:
                 dX = self.attn_bwd(rec, dO, adds)
-            parallel.grads_final(_own_params(rec))     # data parallel: chunks of the gradient arena start their all-reduce here
+            self._grads_final(rec)     # data parallel: chunks of the gradient arena start their all-reduce here
             if rec["cat_j"] is not None:
                 ca = rec["Ca"]
                 dacts[rec["cat_a_id"]] = dX[..., :ca]
@@ -476,15 +506,19 @@ class UNetExecutor:
             else:
                 dacts[rec["in_id"]] = dX
         assert not dacts and not dhs, (list(dacts), list(dhs))
+        self.wgrad_join()
         self._pool_need[bkey] = max(self.bpool.off, 64)
         self.bpool = None
         demb, self.demb, self.emb = self.demb, None, None
         return demb
 
+    def _grads_final(self, rec):
+        parallel.grads_final(_own_params(rec))
+
     def head_bwd(self, rec, dO, adds):
         gn, m = rec["gn"], rec["m"]
         dhn, red = conv_dgrad(dO, m, rec["hn"].shape, gn=(rec["x"], rec["ab"], JG_ACT_SILU), pool=self.bpool)
-        conv_wgrad(dO, rec["hn"], m)
+        self.wgrad(dO, rec["hn"], m)
         return gn_bwd(rec["x"], dhn, rec["ab"], rec["mr"], gn.weight, gn.bias, None, gn.num_groups, JG_ACT_SILU, adds=adds,
                       red=red)
 
@@ -505,7 +539,7 @@ class UNetExecutor:
                 dh2, red2 = pool2(conv_dgrad(dO, c2m, full), 1.0), None
         else:
             dh2, red2 = conv_dgrad(dO, c2m, rec["h2"].shape, gn=(rec["c1"], rec["ab2"], JG_ACT_SILU), pool=self.bpool)
-        conv_wgrad(dO, rec["h2"], c2m, x_up=rec["h2_up"])
+        self.wgrad(dO, rec["h2"], c2m, x_up=rec["h2_up"])
         # GroupNorm 2 (+FiLM +SiLU)
         off, n = rb.emb_slice
         dc1 = gn_bwd(rec["c1"], dh2, rec["ab2"], rec["mr2"], gn2.weight, gn2.bias, rec["film"], gn2.num_groups, JG_ACT_SILU,
@@ -519,7 +553,7 @@ class UNetExecutor:
             da1, red1 = conv_dgrad(dc1, c1m, rec["a1"].shape, gn=(x, rec["ab1"], JG_ACT_SILU), pool=self.bpool)
         else:
             da1, red1 = conv_dgrad(dc1, c1m, rec["a1"].shape), None
-        conv_wgrad(dc1, rec["a1"], c1m)
+        self.wgrad(dc1, rec["a1"], c1m)
         del dc1
         pooled = None
         if rb.down and FUSE_DOWN_POOL:
@@ -546,7 +580,7 @@ class UNetExecutor:
         if rb.updown:
             raise NotImplementedError("resampling ResBlock with a 1x1 skip convolution")
         skm = rb.skip_connection.meta
-        conv_wgrad(dO, rec["xs"], skm, alpha=skipw, dbias_scale=skipw)
+        self.wgrad(dO, rec["xs"], skm, alpha=skipw, dbias_scale=skipw)
         dxg = gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
                      red=red1)
         return conv_dgrad(dO, skm, x.shape, res=dxg, alpha=skipw)   # skipw * (dO . Wskip) + dxg in one epilogue
@@ -559,12 +593,12 @@ class UNetExecutor:
         dO4 = dO.view(B, 1, T, C) if dO.dim() == 4 else dO
         a4 = rec["a"].view(B, 1, T, C)
         da = conv_dgrad(dO4, blk.proj_out.meta, a4.shape)
-        conv_wgrad(dO4, a4, blk.proj_out.meta)
+        self.wgrad(dO4, a4, blk.proj_out.meta)
         dqkv = attn_core_bwd(rec["qkv"].view(B, T, 3 * C), rec["P"], da.view(B, T, C), blk.num_heads, rec["a"])
         xn4 = rec["xn"].view(B, 1, T, C)
         dxn, red = conv_dgrad(dqkv.view(B, 1, T, 3 * C), blk.qkv.meta, xn4.shape, gn=(x.view(B, 1, T, C), rec["ab"], JG_ACT_NONE),
                               pool=self.bpool)
-        conv_wgrad(dqkv.view(B, 1, T, 3 * C), xn4, blk.qkv.meta)
+        self.wgrad(dqkv.view(B, 1, T, 3 * C), xn4, blk.qkv.meta)
         adds = list(adds) + [(dO, 1.0)]
         return gn_bwd(x, dxn.view(B, H, W, C), rec["ab"], rec["mr"], None, None, None, C, JG_ACT_NONE, adds=adds, red=red)
 

@@ -55,6 +55,9 @@ def chunk_bounds(n, n_chunks, align=1024):
 
 # id(parameter) -> EarlyExchange that owns it (filled by EarlyExchange.__init__)
 _EARLY = {}
+# callables run right before a gradient chunk's all-reduce is enqueued: schedules that launch gradient kernels on a second stream
+# (modules/unet_exec.py: weight gradients) register their join here, because the collective is ordered behind the current stream only
+PRE_LAUNCH_HOOKS = []
 
 
 class EarlyExchange:
@@ -96,6 +99,8 @@ class EarlyExchange:
     def _launch(self, c):
         lo, hi = self.bounds[c]
         self.sent[c] = True
+        for hook in PRE_LAUNCH_HOOKS:
+            hook()
         self.launched.append((c, dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
 
     def mark(self, prm):
@@ -139,6 +144,8 @@ def allreduce_and_step(arena, hp, grad_scale, n_chunks=4):
         pending = ex.drain()
     else:
         bounds = chunk_bounds(arena.numel, n_chunks)
+        for hook in PRE_LAUNCH_HOOKS:
+            hook()
         pending = [(lo, hi, dist.all_reduce(arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)) for lo, hi in bounds]
     for lo, hi, w in pending:
         w.wait()  # NCCL/RCCL: makes the current stream wait, does not block the host

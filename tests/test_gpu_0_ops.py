@@ -262,6 +262,58 @@ def test_wgrad_halo_bench_splitk():
     assert relerr(m.c.bias.grad, br.grad) < TOL[dtype], relerr(m.c.bias.grad, br.grad)
 
 
+P64_CASES = [
+    # JG_PERSIST64 (>= 2: forced, that many spatial streams), B, H, W, Cout, with_res
+    (2, 2, 32, 48, 64, False),     # 12 tiles on 2 workgroups: 6 tiles each, both wave groups alternate
+    (5, 3, 64, 64, 128, True),     # 48 tiles x 2 channel blocks on 5 streams: ragged tile counts (10, 10, 10, 9, 9), odd and even
+    (3, 1, 48, 32, 192, True),     # 3 channel blocks, 6 tiles, 2 per stream
+    (7, 1, 16, 16, 64, True),      # a single tile: only wave group 0 ever computes
+    (1, 4, 256, 256, 64, True),    # automatic dispatch at the bench geometry (1024 tiles, 4 per workgroup)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode,B,H,W,Cout,with_res", P64_CASES)
+def test_conv_p64_persistent_kernel(mode, B, H, W, Cout, with_res, dtype):
+    """conv_p64.hip (persistent Cin == 64 kernel: weights resident in LDS, two wave groups in anti-phase): output, fused GroupNorm
+    statistics, bias / residual / alpha against fp32 torch on the rounded inputs, and against conv_halo.hip on the same launch
+    (same MFMA products per output element in the same order; the residual enters through the accumulators here and in the
+    epilogue there, so a few elements may round the other way)."""
+    from joligen_amd import _lib, ops
+
+    Cin = 64
+    x = rnd((B, H, W, Cin), dtype, 81)
+    w = (rnd((Cout, 3, 3, Cin), dtype, 82).float() / math.sqrt(9 * Cin)).to(dtype)
+    bias = rnd((Cout,), torch.float32, 83) * 0.1
+    res = rnd((B, H, W, Cout), dtype, 84) if with_res else None
+    nslots = 16
+    geo = dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=9 * Cin, ldy=Cout)
+    kw = dict(bias=bias.to(dev()), res=None if res is None else res.to(dev()), ldres=Cout, alpha=0.5, res_scale=0.7, ldstats=Cout, stats_slots=nslots)
+    xd, wd = x.to(dev()), w.to(dev())
+    out = {}
+    for m in (0, mode):
+        prev = _lib.set_tuning("JG_PERSIST64", m)
+        try:
+            y = torch.empty((B, H, W, Cout), device=dev(), dtype=dtype)
+            st = torch.zeros((B, nslots, Cout, 2), device=dev(), dtype=torch.float32)
+            ops.conv_nt(xd, wd, y, stats=st, **geo, **kw)
+            torch.cuda.synchronize()
+            out[m] = (y, st.sum(1).cpu())
+        finally:
+            _lib.set_tuning("JG_PERSIST64", prev)
+    ref = 0.5 * F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1) + bias
+    if with_res:
+        ref = ref + 0.7 * res.float()
+    y, st = out[mode]
+    assert relerr(y.float(), ref) < TOL[dtype], relerr(y.float(), ref)
+    assert relerr(st[..., 0], ref.sum((1, 2))) < 1e-3 and relerr(st[..., 1], (ref * ref).sum((1, 2))) < 1e-3
+    if with_res:
+        assert relerr(y.float(), out[0][0].float()) < (2e-4 if dtype == torch.float16 else 1.5e-3), relerr(y.float(), out[0][0].float())
+    else:
+        assert torch.equal(y, out[0][0]), relerr(y.float(), out[0][0].float())
+    assert relerr(st, out[0][1]) < 1e-5
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_padded_channels(dtype):
     """stem (Cin 6 -> 8) and head (Cout 3 -> 8): padded working copies, unpadded master grads."""

@@ -204,7 +204,7 @@ def test_hot_kernels_do_not_spill(tmp_path):
 
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     csrc = os.path.join(ROOT, "joligen_amd", "csrc")
-    for src in ("conv_halo.hip", "wgrad_halo.hip"):
+    for src in ("conv_halo.hip", "wgrad_halo.hip", "conv_p64.hip"):
         out = tmp_path / src.replace(".hip", "")
         out.mkdir()
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-c", os.path.join(csrc, src), "-o",
@@ -216,7 +216,12 @@ def test_hot_kernels_do_not_spill(tmp_path):
         names = re.findall(r"\.name:\s+(\S+)", text)
         spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
         priv = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)]
-        assert names and len(spills) >= len([n for n in names if "halo_kernel" in n])
+        assert names and len(spills) >= len([n for n in names if "halo_kernel" in n or "p64_kernel" in n])
+        if src == "conv_p64.hip":
+            # the persistent kernel sits at the 256-register limit of two waves per SIMD: a handful of loop-invariant scalars are
+            # allowed to live in scratch (reloaded twice per tile); anything more means a whole array went there
+            assert max(spills) <= 8, list(zip(names, spills, priv))
+            continue
         assert max(spills) == 0 and max(priv) == 0, list(zip(names, spills, priv))
         # occupancy budgets (512 VGPRs per SIMD lane): the 64-pixel-row forward tiles are tuned for 4 waves per SIMD, the
         # 128x512 4-wave tile for 3 -- an epilogue edit once cost the former its fourth wave (129 registers, +4.6 % time)
