@@ -223,12 +223,12 @@ def test_hot_kernels_do_not_spill(tmp_path):
             assert max(spills) <= 8, list(zip(names, spills, priv))
             continue
         assert max(spills) == 0 and max(priv) == 0, list(zip(names, spills, priv))
-        # occupancy budgets (512 VGPRs per SIMD lane): the 64-pixel-row forward tiles are tuned for 4 waves per SIMD, the
-        # 128x512 4-wave tile for 3 -- an epilogue edit once cost the former its fourth wave (129 registers, +4.6 % time)
+        # occupancy budgets (512 VGPRs per SIMD lane): LDS (66 KB per workgroup) holds the 64-wide tiles at two workgroups per CU =
+        # two waves per SIMD, the 128x512 8-wave tile at one workgroup: both stay clear of the 256-register line with room to spare
         vg = [int(v) for v in re.findall(r"\.vgpr_count:\s+(\d+)", text)]
         for nm, v in zip(names, vg):
             if "conv3x3_halo_kernel" in nm and "Li64ELi256E" in nm:
-                assert v <= 128, (nm, v)
+                assert v <= 168, (nm, v)
             if "conv3x3_halo_kernel" in nm and "Li128ELi512E" in nm:
                 assert v <= 168, (nm, v)
 
