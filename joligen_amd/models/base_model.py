@@ -244,6 +244,37 @@ class BaseModel:
     def get_current_batch_size(self):
         return self.real_A.shape[0]
 
+    # ---- visuals (:762-764, :782-806): what train.py's display / test loops call ---------------------------------------
+    def compute_visuals(self, nb_imgs):
+        """base: nothing; the diffusion models run their sampler here (`inference`)"""
+        pass
+
+    def get_current_visuals(self, nb_imgs, phase="train", test_name=""):
+        visual_ret = []
+        for i, group in enumerate(self.visual_names):
+            cur_visual = OrderedDict()
+            for name in group:
+                if phase == "test":
+                    name = name + "_test_" + test_name
+                if isinstance(name, str) and hasattr(self, name):
+                    cur_visual[name] = getattr(self, name)
+            visual_ret.append(cur_visual)
+            if self.opt.model_type not in ("cut", "cycle_gan") and i == nb_imgs - 1:      # GANs have more outputs in practice
+                break
+        return visual_ret
+
+    def _publish_visuals(self, nb_imgs, offset=0):
+        """`<name><k>` attributes of the first nb_imgs images for every entry of gen_visual_names (palette_model.py:852-862)"""
+        for name in self.gen_visual_names:
+            whole = getattr(self, name[:-1], None)
+            if whole is None:
+                continue
+            for k in range(min(nb_imgs, self.get_current_batch_size())):
+                cur = whole[k:k + 1]
+                if "mask" in name:
+                    cur = cur.squeeze(0)
+                setattr(self, name + str(offset + k), cur)
+
     # ---- checkpoints (:824-868, :957-1103) -------------------------------------------------------
     def save_networks(self, epoch):
         os.makedirs(self.save_dir, exist_ok=True)

@@ -69,6 +69,12 @@ class CMModel(BaseModel):
         self.networks_groups = [self.group_G]
         self.iter_calculator_init()
         self.rng_injection = None  # parity runs: callable(sigmas on the host) -> (noise, timesteps)
+        # visuals (cm_model.py:139-185)
+        self.gen_visual_names = ["gt_image_", "y_t_", "next_noisy_x_", "current_noisy_x_", "mask_", "output_"]
+        for k in range(opt.train_batch_size):
+            self.visual_names.append([n + str(k) for n in self.gen_visual_names])
+        self.visual_names.append([])
+        self.sampling_noises = None   # parity runs: the N(0,1) draw of every sampling sigma
 
     # cm_model.py:265-351 (4-D inputs)
     def set_input(self, data):
@@ -93,3 +99,34 @@ class CMModel(BaseModel):
         self.loss_G_tot = ops.cm_loss(r["F_next"], r["F_cur"], r["next_noisy_x"], r["current_noisy_x"], r["cs_n"], r["co_n"],
                                       r["cs_c"], r["co_c"], self.mask, r["loss_weights"], lam=self.opt.alg_diffusion_lambda_G,
                                       grad_scale=self.loss_scale)
+
+    # cm_model.py:504-657
+    SAMPLING_SIGMAS = (80.0, 24.4, 5.84, 0.9, 0.661)
+
+    @torch.no_grad()
+    def inference(self, nb_imgs, offset=0):
+        netG = self._net("G_A")
+        mask = self.mask[:nb_imgs] if self.mask is not None else None
+        y_cond = self.cond_image[:nb_imgs] if self.cond_image is not None else None
+        if self.task == "pix2pix":      # y_t must have the output's channel count: there is no ground truth to start from
+            shp = list(y_cond.shape)
+            shp[1] = netG.cm_model.out_channel
+            y_t = torch.zeros(shp, device=y_cond.device, dtype=y_cond.dtype)
+        else:
+            y_t = self.y_t[:nb_imgs]
+        self.output = netG.restoration(y_t, y_cond, self.SAMPLING_SIGMAS, mask, noises=self.sampling_noises)
+        self.fake_B = self.output
+        self.visuals = self.output
+        self._publish_visuals(nb_imgs, offset)
+
+    def compute_visuals(self, nb_imgs):
+        super().compute_visuals(nb_imgs)
+        self.inference(nb_imgs)
+
+    def get_current_visuals(self, nb_imgs, phase="train", test_name=""):
+        old = self.visual_names.copy()
+        if phase == "test":             # the noisy columns are hidden in test mode
+            self.visual_names = [[x for x in grp if "noisy" not in x] for grp in self.visual_names]
+        out = super().get_current_visuals(nb_imgs, phase, test_name)
+        self.visual_names = old
+        return out

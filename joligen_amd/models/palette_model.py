@@ -83,6 +83,16 @@ class PaletteModel(BaseModel):
         self.networks_groups = [self.group_G]
         self.iter_calculator_init()
         self.rng_injection = None  # parity runs: callable(batch_size) -> (t, u, noise) drawn on the host
+        # visuals (palette_model.py:158-198) and the sampler settings of `inference` (:281-285)
+        self.gen_visual_names = ["gt_image_", "cond_image_"] + (["y_t_", "mask_"] if self.task == "inpainting" else []) + ["output_"]
+        if opt.isTrain:
+            for k in range(min(opt.train_batch_size, getattr(opt, "output_num_images", 20))):
+                self.visual_names.append([n + str(k) for n in self.gen_visual_names])
+        self.visual_names.append([])
+        self.sample_num = 2
+        self.ddim_num_steps = getattr(opt, "alg_palette_ddim_num_steps", 10)
+        self.ddim_eta = getattr(opt, "alg_palette_ddim_eta", 0.5)
+        self.sampling_noises = None   # parity runs: per-step N(0,1) draws of the ancestral sampler
 
     # palette_model.py:287-366 (4-D inputs, no SAM masks, no reference image)
     def set_input(self, data):
@@ -119,3 +129,21 @@ class PaletteModel(BaseModel):
         for res, val in levels.items():          # palette_model.py:610-616: the per-resolution terms are logged before lambda_G
             setattr(self, "loss_G_" + res, val / lam if lam not in (0, 1) else val)
         self.loss_G_tot = loss
+
+    # palette_model.py:622-887 (inpainting / pix2pix; no per-class, reference-image or video branches)
+    @torch.no_grad()
+    def inference(self, nb_imgs, offset=0):
+        netG = self._net("G_A")
+        if self.task == "inpainting":
+            self.output, self.visuals = netG.restoration(y_cond=self.cond_image[:nb_imgs], y_t=self.y_t[:nb_imgs], y_0=self.gt_image[:nb_imgs],
+                                                         mask=self.mask[:nb_imgs], sample_num=self.sample_num, ddim_num_steps=self.ddim_num_steps,
+                                                         ddim_eta=self.ddim_eta, noises=self.sampling_noises)
+        else:
+            self.output, self.visuals = netG.restoration(y_cond=self.cond_image[:nb_imgs], sample_num=self.sample_num,
+                                                         noises=self.sampling_noises)
+        self.fake_B = self.output
+        self._publish_visuals(nb_imgs, offset)
+
+    def compute_visuals(self, nb_imgs):
+        super().compute_visuals(nb_imgs)
+        self.inference(nb_imgs)

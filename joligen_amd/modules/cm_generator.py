@@ -142,6 +142,43 @@ class CMGenerator(nn.Module):
                     num_timesteps=num_timesteps, sigmas=sigmas,
                     loss_weights=improved_loss_weighting(sigmas)[timesteps].view(-1, 1, 1, 1))
 
+    @torch.no_grad()
+    def restoration(self, y, y_cond, sigmas, mask, clip_denoised=True, noises=None):
+        """reference :504-554: multistep consistency sampling over `sigmas` (CMModel.inference uses (80, 24.4, 5.84, 0.9, 0.661)).
+        Per sigma: ONE fused kernel forms `x + s * eps` with the mask blend (fp32 NCHW) together with the UNet's 16-bit NHWC input
+        (`jg_cm_noisy`), one UNet forward on the fused schedule, one kernel for `c_skip x + c_out F` (`jg_cm_combine`).
+        `noises`: optional list with the N(0,1) draw of every sigma in loop order (parity runs); else the device RNG.  NCHW fp32."""
+        if self.arena is None:
+            raise RuntimeError("CMGenerator.jg_finalize(device) has not been called")
+        if y.dim() != 4:
+            raise NotImplementedError("video (5-D) inputs are outside the SURVEY.md 8 hot path")
+        self.arena.ensure_fresh()
+        dev = y.device
+        y = y.float()
+        m = None
+        if mask is not None:
+            m = torch.clamp(mask, min=0, max=1)                                   # removes class information from the mask
+            y = y * (1 - m).to(y.dtype)
+        cond = None if y_cond is None else y_cond.float()
+        cpad = (y.shape[1] + (0 if cond is None else cond.shape[1]) + 7) // 8 * 8
+        x = y
+        for k, sig in enumerate(sigmas):
+            sigma = torch.full((y.shape[0],), float(sig), dtype=torch.float32, device=dev)
+            eps = noises[k].to(dev).float() if noises is not None else torch.randn_like(y)
+            # first step: y + sigma eps; later steps: x + sqrt(sigma^2 - sigma_min^2) eps; then x m + (1 - m) y (x already equals y
+            # outside the mask after the previous blend, which is what the kernel blends with)
+            step = sigma if k == 0 else (sigma ** 2 - self.sigma_min ** 2) ** 0.5
+            noisy, xin = ops.cm_noisy(x, eps, step, m, cond, self.act_dtype, cpad)
+            F = self._unet(xin, sigma)
+            x = ops.cm_combine(noisy, F, skip_scaling(sigma, self.sigma_data, self.sigma_min),
+                               output_scaling(sigma, self.sigma_data, self.sigma_min))
+            if clip_denoised:
+                x = x.clamp(min=-1.0, max=1.0)
+            if m is not None:
+                mf = m.to(x.dtype)
+                x = x * mf + (1 - mf) * y
+        return x
+
     def forward(self, x, total_training_steps=50000, mask=None, x_cond=None, noise=None, timesteps=None):
         """reference :388-502 signature (plus the two injectable random draws); returns the reference's 7-tuple
         (next_x, current_x, num_timesteps, sigmas, loss_weights, next_noisy_x, current_noisy_x) in NCHW fp32.

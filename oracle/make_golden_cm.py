@@ -58,6 +58,44 @@ def build_opt(c):
     return opt
 
 
+SAMPLING_SIGMAS = (80.0, 24.4, 5.84, 0.9, 0.661)      # cm_model.py:521
+
+
+def make_sampling():
+    """CMGenerator.restoration (cm_generator.py:504-554) of the unmodified reference, multistep consistency sampling over the sigmas
+    CMModel.inference uses, with the N(0,1) draws recorded (the reference draws one randn_like per sigma from the default
+    generator)                                                                          -> cm_sampling_<cfg>.pt"""
+    os.makedirs(OUT, exist_ok=True)
+    os.chdir("/tmp")
+    from models import create_model
+
+    for name, c in TINY.items():
+        opt = build_opt(c)
+        torch.manual_seed(0)
+        model = create_model(opt, 0)
+        model.setup(opt)
+        netG = model.netG_A
+        netG.load_state_dict(O.synth_state_dict(netG.state_dict(), seed=0))
+        netG.eval()
+        data = synth_batch(c["B"], c["S"], seed=977)
+        y_t, mask = data["A"], data["B_label_mask"]
+        g = torch.Generator().manual_seed(31)
+        noises = [torch.randn(y_t.shape, generator=g) for _ in SAMPLING_SIGMAS]
+        it = iter(noises)
+        orig = torch.randn_like
+        torch.randn_like = lambda t, **kw: next(it).to(t.dtype)       # the reference's draws, in its order
+        try:
+            with torch.no_grad():
+                out = netG.restoration(y_t, None, SAMPLING_SIGMAS, mask)
+                out_noclip = None
+        finally:
+            torch.randn_like = orig
+        assert next(it, None) is None
+        torch.save(dict(cfg=c, y_t=y_t, mask=mask, sigmas=SAMPLING_SIGMAS, noises=noises, output=out),
+                   os.path.join(OUT, f"cm_sampling_{name}.pt"))
+        print(name, "restoration", tuple(out.shape), float(out.abs().mean()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     os.chdir("/tmp")
@@ -125,4 +163,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "sampling":     # the other fixtures stay untouched
+        make_sampling()
+    else:
+        main()

@@ -527,3 +527,80 @@ def test_ddpm_restoration_vs_reference_golden(golden_dir, name, dtype):
     assert torch.equal(y.cpu()[keep], g["B"][keep])
     assert relerr(y, g["y_ddim"]) < 2 * TOL_OUT[dtype], relerr(y, g["y_ddim"])
     assert relerr(ret, g["ret_ddim"]) < 2 * TOL_OUT[dtype]
+
+
+def test_palette_compute_visuals_surface(golden_dir):
+    """the display path of train.py:319-413 through the model API: compute_visuals(n) runs the sampler on the
+    current batch (palette_model.py:622-887), get_current_visuals(n) returns one OrderedDict per image with the reference's names;
+    the sampled output equals a direct restoration() call with the same draws and keeps the unmasked pixels bit-exact."""
+    g = load(golden_dir, "sampling_tiny_eff.pt")
+    c = g["cfg"]
+    model = make_model(c, "fp16", golden_dir, G_diff_n_timestep_test=g["T"])
+    B = c["B"]
+    model.set_input({"A": g["y_t0"], "B": g["B"], "B_label_mask": g["mask"], "A_img_paths": ["x"] * B})
+    model.sampling_noises = g["noises"]
+    model.compute_visuals(B)
+    vis = model.get_current_visuals(B)
+    assert len(vis) == B
+    assert list(vis[0].keys()) == ["gt_image_0", "cond_image_0", "y_t_0", "mask_0", "output_0"]
+    out = torch.cat([v[f"output_{k}"] for k, v in enumerate(vis)])
+    d = torch.device("cuda:0")
+    y, _ = model.netG_A.restoration(g["y_t0"].to(d), y_t=g["y_t0"].to(d), y_0=g["B"].to(d), mask=g["mask"].to(d), sample_num=2, noises=g["noises"])
+    assert relerr(out, y) < 1e-6
+    keep = (g["mask"] == 0).expand_as(g["B"])
+    assert torch.equal(out.cpu()[keep], g["B"][keep])
+    assert model.fake_B is model.output and tuple(vis[1]["mask_1"].shape) == tuple(g["mask"].shape[1:])
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
+def test_loss_curve_200_steps_vs_oracle(golden_dir, dtype_name):
+    """north_star: "loss curves matching the CPU reference within tolerance".  200 free-running optimize_parameters() steps
+    (AdamW + EMA, lr 2e-4) of a 3-level UNet (ngf 32, 64x64, batch 2) on HIP against the CPU oracle trainer from the same weights,
+    the same fresh synthetic batch and the same injected (t, u, noise) at every step -- NOT teacher-forced: the two weight
+    trajectories are free to separate, what must agree is the training signal.  Compared: the curves smoothed over 20 steps
+    (relative band), the mean of the last 50 steps, and that both actually learn.  The raw curves go to gpurun_out/ (committed under
+    profiles/)."""
+    import json
+
+    c = dict(ngf=32, mults=[1, 2, 4], res_blocks=[1, 1, 1], attn_res=[16], efficient=True, S=64, B=2)
+    n_steps = 200
+    model = make_model(c, dtype_name, golden_dir, train_G_ema=True)
+    net = model.netG_A
+    # the reference's zero_module() layers start at zero and a DDPM loss starts at 1: keep the deterministic synthetic weights but zero
+    # the layers the reference zeroes, so that the curve has the reference's shape (a descent from ~1)
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("out_layers.3.weight") or k.endswith("out_layers.3.bias") or ".proj_out." in k or k.endswith("model.out.2.weight") or k.endswith("model.out.2.bias"):
+            sd[k] = torch.zeros_like(sd[k])
+    net.load_state_dict(sd)
+    net.arena.refresh()
+    sd0 = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    tr = O.OraclePaletteTrainer(sd0, cfg_of(c), lr=model.opt.train_G_lr, ema_beta=model.opt.train_G_ema_beta)
+    gd, gr = torch.Generator().manual_seed(11), torch.Generator().manual_seed(12)
+    mine, ref = [], []
+    for it in range(n_steps):
+        Bimg = torch.rand(c["B"], 3, c["S"], c["S"], generator=gd) * 2 - 1
+        mask = torch.zeros(c["B"], 1, c["S"], c["S"], dtype=torch.int64)
+        h0, w0 = int(torch.randint(0, 24, (1,), generator=gd)), int(torch.randint(0, 24, (1,), generator=gd))
+        mask[:, :, h0:h0 + 32, w0:w0 + 36] = 1
+        A = Bimg * (1 - mask) + torch.randn(Bimg.shape, generator=gd) * mask
+        t, u, noise = O.draw_step_randomness(gr, Bimg, 2000)
+        model.rng_injection = lambda b, t=t, u=u, noise=noise: (t, u, noise)
+        model.set_input({"A": A, "B": Bimg, "B_label_mask": mask})
+        model.optimize_parameters()
+        mine.append(float(model.get_current_losses()["G_tot"]))
+        ref.append(float(tr.optimize_parameters(Bimg, A, mask, noise, t, u)))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/loss_curve_200_{dtype_name}.json", "w") as f:
+        json.dump({"config": c, "dtype": dtype_name, "steps": n_steps, "hip": mine, "cpu_oracle": ref}, f)
+    m, r = torch.tensor(mine), torch.tensor(ref)
+    assert torch.isfinite(m).all()
+    win = 20
+    ms, rs = m.unfold(0, win, 1).mean(1), r.unfold(0, win, 1).mean(1)
+    band = float(((ms - rs).abs() / rs).max())
+    tail = abs(float(m[-50:].mean()) - float(r[-50:].mean())) / float(r[-50:].mean())
+    # per-step losses depend on the drawn noise level far more than on the weights (both sides share it), so the curves track
+    # each other closely even after the weight trajectories have separated
+    assert band < (0.05 if dtype_name == "fp16" else 0.10), band
+    assert tail < (0.03 if dtype_name == "fp16" else 0.06), tail
+    assert float(r[-50:].mean()) < 0.8 * float(r[:10].mean()) and float(m[-50:].mean()) < 0.8 * float(m[:10].mean())

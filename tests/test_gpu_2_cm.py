@@ -147,3 +147,31 @@ def test_cm_first_step_gradients_vs_oracle():
             if float(ref.norm()) > 1e-12 and relerr(mine, ref) > 6e-2:
                 bad.append((k, relerr(mine, ref)))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
+@pytest.mark.parametrize("name", CFGS)
+def test_cm_restoration_vs_reference_golden(golden_dir, name, dtype_name):
+    """CMGenerator.restoration (cm_generator.py:504-554, 5 sigmas of CMModel.inference) and the model-level visuals surface
+    (compute_visuals / get_current_visuals, cm_model.py:504-669) against the unmodified reference's sampler output with its recorded
+    N(0,1) draws.  5 chained UNet forwards with a clamp in between: the model-level forward tolerance, not tighter."""
+    g = load(golden_dir, f"cm_sampling_{name}.pt")
+    dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
+    model = make_model(g["cfg"], dtype_name)
+    d = torch.device("cuda:0")
+    out = model.netG_A.restoration(g["y_t"].to(d), None, g["sigmas"], g["mask"].to(d), noises=g["noises"])
+    keep = (g["mask"] == 0).expand_as(g["output"])
+    assert torch.equal(out.cpu()[keep], g["y_t"][keep])                      # bit-exact mask semantics
+    e = relerr(out, g["output"])
+    assert e < 3 * TOL_OUT[dtype], e
+    # the same through the model API that train.py's display loop calls
+    B = g["cfg"]["B"]
+    model.set_input({"A": g["y_t"], "B": g["y_t"], "B_label_mask": g["mask"], "A_img_paths": ["x"] * B})
+    model.sampling_noises = g["noises"]
+    model.compute_visuals(B)
+    vis = model.get_current_visuals(B)
+    assert len(vis) == B and list(vis[0].keys()) == ["gt_image_0", "y_t_0", "mask_0", "output_0"]   # noisy columns exist only after a training step
+    assert relerr(torch.cat([v[f"output_{k}"] for k, v in enumerate(vis)]), g["output"]) < 3 * TOL_OUT[dtype]
+    assert tuple(vis[0]["mask_0"].shape) == tuple(g["mask"].shape[1:])
+    test_vis = model.get_current_visuals(B, phase="test", test_name="t")
+    assert all(not k for v in test_vis for k in v if "noisy" in k)

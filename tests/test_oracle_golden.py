@@ -153,6 +153,19 @@ def test_cm_three_steps(golden_dir, name):
                     torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
 
 
+@pytest.mark.parametrize("name", CM_CFGS)
+def test_cm_restoration(golden_dir, name):
+    """CMGenerator.restoration (multistep consistency sampling, cm_generator.py:504-554) of the unmodified reference with its N(0,1)
+    draws recorded (oracle/make_golden_cm.py sampling)"""
+    sd, _ = cm_synth_for(golden_dir, name)
+    g = load(golden_dir, f"cm_sampling_{name}.pt")
+    with torch.no_grad():
+        out = O.cm_restoration(sd, g["y_t"], g["mask"], g["sigmas"], g["noises"], cm_cfg_of(g["cfg"]))
+    torch.testing.assert_close(out, g["output"], rtol=2e-4, atol=2e-5)
+    keep = (g["mask"] == 0).expand_as(out)
+    assert torch.equal(out[keep], g["y_t"][keep])          # unmasked pixels are exact copies of the input
+
+
 # ---- DDPM sampling (restoration): oracle/make_golden_sampling.py fixtures ----------------------------------
 @pytest.mark.parametrize("name", ["tiny_eff", "tiny_attn"])
 def test_ddpm_restoration(golden_dir, name):
