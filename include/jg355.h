@@ -408,6 +408,19 @@ int jg_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H,
 int jg_adamw_ema(float* p, float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2,
                  float eps, float wd, int decoupled, int step, float grad_scale, float ema_beta, int zero_grad,
                  jg_stream_t s);
+/* The optimizer factory of train.py:51-62 as one entry point: kind 0 = torch.optim.Adam, 1 = AdamW (both = jg_adamw_ema),
+ * 2 = torch.optim.RAdam (coupled weight decay, rectification term computed on the host from `step`),
+ * 3 = Lion (util/lion_pytorch.py:60-82; uses m only, v may be NULL).  adam8bit (bitsandbytes) is not provided.
+ * skip / nskipped (optional device ints): when *skip != 0 the step is dropped -- parameters, moments and EMA untouched, gradients
+ * cleared, *nskipped += 1 -- the behaviour of torch.cuda.amp.GradScaler.step on non-finite gradients (models/base_model.py:1268-1274).
+ * jg_grad_nonfinite sets *flag = 1 if any gradient element is inf / NaN (the caller clears the flag). */
+int jg_optim_step(int kind, float* p, float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float wd, int step, float grad_scale, float ema_beta, int zero_grad, const int* skip, int* nskipped,
+                  jg_stream_t s);
+int jg_adamw_ema_skip(float* p, float* g, float* m, float* v, float* ema, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float wd, int decoupled, int step, float grad_scale, float ema_beta, int zero_grad, const int* skip,
+                      int* nskipped, jg_stream_t s);
+int jg_grad_nonfinite(const float* g, int64_t n, int* flag, jg_stream_t s);
 /* Stand-alone EMA update ema = p + beta (ema - p) (BaseModel.ema_step, models/base_model.py:1284-1297) for the
  * micro-iterations of a gradient-accumulation cycle in which the optimizer does not step. */
 int jg_ema_update(float* ema, const float* p, int64_t n, float beta, jg_stream_t s);

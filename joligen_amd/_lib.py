@@ -132,6 +132,9 @@ SIGNATURES = {
     "jg_nhwc_to_nchw_f32": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_nchw_f32_to_nhwc": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_adamw_ema": [c_p, c_p, c_p, c_p, c_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p],
+    "jg_optim_step": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_f32, c_f32, c_i32, c_p, c_p, c_p],
+    "jg_adamw_ema_skip": [c_p, c_p, c_p, c_p, c_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p, c_p, c_p],
+    "jg_grad_nonfinite": [c_p, c_i64, c_p, c_p],
     "jg_ema_update": [c_p, c_p, c_i64, c_f32, c_p],
     "jg_refresh_weights": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_p],
 }

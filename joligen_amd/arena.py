@@ -65,6 +65,8 @@ class ParamArena:
         self.v = torch.zeros(self.numel, **f32)
         self.ema = None
         self.step = 0
+        self.optim_kind = None     # jg_optim_step kind (0 adam, 1 adamw, 2 radam, 3 lion); None: adam / adamw by `decoupled`
+        self.overflow = None       # device int32 [found non-finite in this step's gradient, steps dropped so far] (fp16 only)
 
         for name, prm in ordered:
             off, n = self.slices[name]
@@ -163,19 +165,36 @@ class ParamArena:
     def zero_grad(self):
         self.g.zero_()
 
+    def enable_overflow_check(self):
+        """fp16 (static loss scale): a non-finite gradient drops the optimizer step like GradScaler.step (base_model.py:1268-1274)"""
+        if self.overflow is None:
+            self.overflow = torch.zeros(2, device=self.device, dtype=torch.int32)
+
+    def check_overflow(self):
+        """scan the (already reduced) gradient arena for inf / NaN into overflow[0]; the optimizer launches of this step read it"""
+        if self.overflow is None:
+            return
+        self.overflow[:1].zero_()
+        check(_lib.lib().jg_grad_nonfinite(self.g.data_ptr(), self.numel, self.overflow.data_ptr(), _st()), "jg_grad_nonfinite")
+
     def adamw_step(self, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale=1.0, ema_beta=None, zero_grad=True,
                    lo=0, hi=None):
-        """One fused AdamW(+EMA)(+zero_grad) launch over arena[lo:hi]; `self.step` must already be advanced."""
+        """One fused optimizer(+EMA)(+zero_grad) launch over arena[lo:hi] (Adam / AdamW / RAdam / Lion by `optim_kind`);
+        `self.step` must already be advanced."""
         hi = self.numel if hi is None else hi
         ema_ptr = None
         if ema_beta is not None:
             if self.ema is None:
                 raise RuntimeError("EMA buffer not created")
             ema_ptr = self.ema.data_ptr() + 4 * lo
-        check(_lib.lib().jg_adamw_ema(self.p.data_ptr() + 4 * lo, self.g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
-                                      self.v.data_ptr() + 4 * lo, ema_ptr, hi - lo, lr, beta1, beta2, eps, weight_decay,
-                                      int(decoupled), self.step, grad_scale, 0.0 if ema_beta is None else ema_beta,
-                                      int(zero_grad), _st()), "jg_adamw_ema")
+        kind = self.optim_kind if self.optim_kind is not None else int(bool(decoupled))
+        skip = nsk = None
+        if self.overflow is not None:
+            skip, nsk = self.overflow.data_ptr(), (self.overflow.data_ptr() + 4 if lo == 0 else None)   # count a dropped step once
+        check(_lib.lib().jg_optim_step(kind, self.p.data_ptr() + 4 * lo, self.g.data_ptr() + 4 * lo, self.m.data_ptr() + 4 * lo,
+                                       self.v.data_ptr() + 4 * lo, ema_ptr, hi - lo, lr, beta1, beta2, eps, weight_decay,
+                                       self.step, grad_scale, 0.0 if ema_beta is None else ema_beta, int(zero_grad), skip, nsk,
+                                       _st()), "jg_optim_step")
         self.dirty = True
 
     def ema_create(self):

@@ -104,12 +104,44 @@ class BaseModel:
     # ---- optimizer factory (train.py:51-62) ------------------------------------------------
     def make_optimizer(self, net, lr, betas, weight_decay, eps):
         name = self.opt.train_optim
-        if name not in ("adam", "adamw"):
-            raise NotImplementedError(f"train_optim={name!r}: only adam / adamw have a fused MI355X kernel")
+        if name not in ("adam", "adamw", "radam", "lion"):
+            raise NotImplementedError(f"train_optim={name!r}: adam / adamw / radam / lion have a fused MI355X kernel (adam8bit needs "
+                                      "bitsandbytes' blockwise quantisation maps, unavailable offline)")
         arena = net.jg_finalize(self.device, self.act_dtype)
-        opt = FusedAdamW(arena, net.parameters(), lr, betas, weight_decay, eps, decoupled=(name == "adamw"))
+        if weight_decay != 0.0:
+            # the fused kernel walks the whole arena: torch.optim skips parameters without a gradient, so a frozen slice
+            # ('freeze' / 'cv_ensemble' names, set_requires_grad) must not silently decay
+            frozen = [n for n, _ in net.named_parameters() if "freeze" in n or "cv_ensemble" in n]
+            if frozen:
+                raise NotImplementedError(f"weight decay with frozen parameters ({frozen[:3]}...) is not supported by the flat-arena optimizer")
+        opt = FusedAdamW(arena, net.parameters(), lr, betas, weight_decay, eps, decoupled=(name == "adamw"), kind=name)
         opt.grad_scale = 1.0 / self.loss_scale
+        if self.act_dtype == torch.float16:
+            arena.enable_overflow_check()
         return opt
+
+    def poll_overflow(self):
+        """fp16 loss-scale maintenance, the host half of GradScaler: the kernels drop a step with non-finite gradients on their own
+        (no host sync per step); every `jg_overflow_poll` steps (default 50) the dropped-step counters are read back, the static
+        loss scale is halved if any step was dropped since the last poll and the optimizers' step counts are corrected."""
+        every = int(getattr(self.opt, "jg_overflow_poll", 50) or 50)
+        if self.act_dtype != torch.float16 or self.niter % every != 0:
+            return
+        dropped = 0
+        for o in self.optimizers:
+            a = getattr(o, "arena", None)
+            if a is None or a.overflow is None:
+                continue
+            n = int(a.overflow[1])
+            new = n - getattr(a, "_dropped_seen", 0)
+            a._dropped_seen = n
+            a.step -= new            # a dropped step must not advance the bias correction
+            dropped += new
+        if dropped:
+            self.loss_scale = max(1.0, self.loss_scale / 2.0)
+            for o in self.optimizers:
+                o.grad_scale = 1.0 / self.loss_scale
+            print(f"[joligen_amd] {dropped} optimizer step(s) dropped on non-finite fp16 gradients: loss scale -> {self.loss_scale:g}")
 
     # ---- setup / parallel --------------------------------------------------------------------
     def setup(self, opt):
@@ -186,6 +218,7 @@ class BaseModel:
                             self.ema_step(network)
             for obj in self.objects_to_update:
                 obj.update(self.niter)
+        self.poll_overflow()
 
     def compute_step(self, optimizers_names, loss_names, group=None):
         """:1250-1282.  The EMA update of the group's networks is fused into the optimizer launch

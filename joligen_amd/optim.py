@@ -9,12 +9,19 @@ import torch
 from . import parallel
 
 
+KINDS = {"adam": 0, "adamw": 1, "radam": 2, "lion": 3}
+
+
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, arena, params, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, decoupled=True):
+    """`kind`: "adam" | "adamw" | "radam" | "lion" (train.py:51-62; adam8bit needs bitsandbytes' quantisation maps: not provided)."""
+
+    def __init__(self, arena, params, lr, betas=(0.9, 0.999), weight_decay=0.0, eps=1e-8, decoupled=True, kind=None):
         defaults = dict(lr=lr, betas=betas, weight_decay=weight_decay, eps=eps)
         super().__init__(list(params), defaults)
         self.arena = arena
         self.decoupled = decoupled
+        self.kind = kind if kind is not None else ("adamw" if decoupled else "adam")
+        arena.optim_kind = KINDS[self.kind]
         self.grad_scale = 1.0      # 1 / (loss_scale) ; the data-parallel 1/world is applied by parallel.py
         self.n_chunks = 4          # all-reduce / optimizer overlap granularity when world_size > 1
 
@@ -31,6 +38,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if parallel.exchange_active():
             parallel.allreduce_and_step(a, hp, self.grad_scale, self.n_chunks)
         else:
+            a.check_overflow()
             a.adamw_step(grad_scale=self.grad_scale, **hp)
         a.refresh()
 

@@ -39,8 +39,10 @@ DEFAULTS = dict(
     train_lr_policy="linear", train_n_epochs=100, train_n_epochs_decay=100, train_epoch_count=1,
     train_lr_decay_iters=50, train_lr_steps=[], train_feat_wavelet=False, train_metrics_list=[],
     output_display_G_attention_masks=False, output_num_images=20,
-    # joligen_amd extensions (not in the reference): activation dtype and static fp16 loss scale
-    jg_act_dtype="bf16", jg_loss_scale=0.0,
+    alg_palette_ddim_num_steps=10, alg_palette_ddim_eta=0.5,
+    # joligen_amd extensions (not in the reference): activation dtype, fp16 loss scale (0 = default) and how often (in steps) the
+    # device-side dropped-step counters are polled to back the scale off (BaseModel.poll_overflow)
+    jg_act_dtype="bf16", jg_loss_scale=0.0, jg_overflow_poll=50,
 )
 
 

@@ -139,6 +139,12 @@ def allreduce_and_step(arena, hp, grad_scale, n_chunks=4):
     each chunk as soon as its reduction has landed.  Mean over ranks = DDP semantics.
     Chunks whose reduction was already started from inside the backward (`EarlyExchange`) are only waited for."""
     ws = world_size()
+    overflow = getattr(arena, "overflow", None)
+    if overflow is not None:
+        # fp16: the step is dropped on every rank or on none.  The LOCAL gradient is scanned before it is reduced (a non-finite
+        # value survives the sum, but it would surface in one chunk only) and the flag travels as one tiny MAX all-reduce.
+        arena.check_overflow()
+        dist.all_reduce(overflow[:1], op=dist.ReduceOp.MAX)
     ex = getattr(arena, "early_exchange", None)
     if ex is not None:
         pending = ex.drain()

@@ -575,6 +575,83 @@ def test_adamw_ema_matches_torch_optim():
         assert relerr(p, pr) < 1e-6 and relerr(ema, er) < 1e-6 and relerr(v, vr) < 1e-4
 
 
+def test_radam_and_lion_match_their_references():
+    """train.py:51-62: train_optim = radam -> torch.optim.RAdam, lion -> util/lion_pytorch.py.  The fused kernels (jg_optim_step kinds
+    2 / 3, + EMA + zero_grad) against torch.optim.RAdam on CPU and a line-by-line restatement of the reference's Lion.step over 8
+    steps (RAdam switches to its rectified branch at step 6 with beta2 = 0.999)."""
+    from joligen_amd import _lib
+
+    d = dev()
+    n = 50001
+    g = torch.Generator().manual_seed(17)
+    p0 = torch.randn(n, generator=g)
+    st = torch.cuda.current_stream().cuda_stream
+    for wd in (0.0, 0.05):
+        # ---- RAdam
+        pr = torch.nn.Parameter(p0.clone())
+        ref = torch.optim.RAdam([pr], lr=2e-3, betas=(0.9, 0.999), weight_decay=wd, eps=1e-8)
+        p, m, v, ema = p0.clone().to(d), torch.zeros(n, device=d), torch.zeros(n, device=d), p0.clone().to(d)
+        er = p0.clone()
+        for step in range(1, 9):
+            gr = torch.randn(n, generator=g)
+            pr.grad = gr.clone()
+            ref.step()
+            er = pr.detach() + 0.99 * (er - pr.detach())
+            gd = (gr * 4.0).to(d)
+            _lib.check(_lib.lib().jg_optim_step(2, p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n, 2e-3, 0.9, 0.999,
+                                                1e-8, wd, step, 0.25, 0.99, 1, None, None, st))
+            assert float(gd.abs().max()) == 0.0
+            assert relerr(p, pr.detach()) < 2e-6, ("radam", wd, step, relerr(p, pr.detach()))
+        assert relerr(ema, er) < 2e-6
+        # ---- Lion (p *= 1 - lr wd; p -= lr sign(b1 m + (1 - b1) g); m = b2 m + (1 - b2) g)
+        pl, ml = p0.clone(), torch.zeros(n)
+        p, m = p0.clone().to(d), torch.zeros(n, device=d)
+        for step in range(1, 5):
+            gr = torch.randn(n, generator=g)
+            pl.mul_(1 - 1e-4 * wd)
+            upd = ml * 0.9 + gr * (1 - 0.9)
+            pl.add_(torch.sign(upd), alpha=-1e-4)
+            ml.mul_(0.99).add_(gr, alpha=1 - 0.99)
+            gd = gr.to(d)
+            _lib.check(_lib.lib().jg_optim_step(3, p.data_ptr(), gd.data_ptr(), m.data_ptr(), None, None, n, 1e-4, 0.9, 0.99, 0.0, wd, step, 1.0,
+                                                0.0, 1, None, None, st))
+        assert relerr(p, pl) < 1e-6 and relerr(m, ml) < 1e-6
+
+
+def test_optimizer_drops_step_on_nonfinite_gradient():
+    """fp16 path: jg_grad_nonfinite raises the device flag, every optimizer kind then leaves p / m / v / EMA untouched, clears the
+    gradient and counts the dropped step (GradScaler.step semantics, models/base_model.py:1268-1274); a clean gradient steps."""
+    from joligen_amd import _lib
+
+    d = dev()
+    n = 4099
+    st = torch.cuda.current_stream().cuda_stream
+    L = _lib.lib()
+    for kind in (0, 1, 2, 3):
+        p = torch.randn(n, device=d)
+        m, v, ema = torch.rand(n, device=d), torch.rand(n, device=d), torch.randn(n, device=d)
+        p0, m0, v0, e0 = p.clone(), m.clone(), v.clone(), ema.clone()
+        flag = torch.zeros(2, device=d, dtype=torch.int32)
+        for bad in (float("inf"), float("nan")):
+            gd = torch.randn(n, device=d)
+            gd[1234] = bad
+            flag[:1].zero_()
+            _lib.check(L.jg_grad_nonfinite(gd.data_ptr(), n, flag.data_ptr(), st))
+            assert int(flag[0]) == 1
+            _lib.check(L.jg_optim_step(kind, p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8,
+                                       0.01, 3, 1.0, 0.99, 1, flag.data_ptr(), flag.data_ptr() + 4, st))
+            assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0) and torch.equal(ema, e0)
+            assert float(gd.abs().nan_to_num(1.0).max()) == 0.0
+        assert int(flag[1]) == 2
+        gd = torch.randn(n, device=d)
+        flag[:1].zero_()
+        _lib.check(L.jg_grad_nonfinite(gd.data_ptr(), n, flag.data_ptr(), st))
+        assert int(flag[0]) == 0
+        _lib.check(L.jg_optim_step(kind, p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), ema.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8,
+                                   0.01, 3, 1.0, 0.99, 1, flag.data_ptr(), flag.data_ptr() + 4, st))
+        assert not torch.equal(p, p0) and int(flag[1]) == 2 and torch.isfinite(p).all()
+
+
 def test_c_abi_rejects_bad_arguments():
     from joligen_amd import _lib
 

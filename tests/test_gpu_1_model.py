@@ -529,6 +529,37 @@ def test_ddpm_restoration_vs_reference_golden(golden_dir, name, dtype):
     assert relerr(ret, g["ret_ddim"]) < 2 * TOL_OUT[dtype]
 
 
+def test_fp16_overflow_drops_step_and_backs_off_loss_scale(golden_dir):
+    """the fp16 path used a static loss scale with no overflow detection.  An absurd loss scale makes the first backward
+    overflow: the fused optimizer drops those steps on the device (weights, moments, EMA stay finite and unchanged), the poll halves
+    the scale until steps go through, and the dropped steps do not advance the bias correction."""
+    g = load(golden_dir, "palette_step_tiny_eff.pt")
+    model = make_model(g["cfg"], "fp16", golden_dir, g["hp"], jg_loss_scale=2.0 ** 40, jg_overflow_poll=1)
+    net = model.netG_A
+    w0 = net.arena.p.clone()
+    s = g["steps"][0]
+    model.rng_injection = lambda b: (s["t"], s["u"], s["noise"])
+    scales = []
+    for it in range(40):
+        model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "A_img_paths": ["x"]})
+        model.optimize_parameters()
+        scales.append(model.loss_scale)
+        if it == 0:
+            assert torch.equal(net.arena.p, w0) and net.arena.step == 0, "an overflowing step must leave the weights alone"
+            assert int(net.arena.overflow[1]) == 1
+    assert torch.isfinite(net.arena.p).all() and torch.isfinite(net.arena.m).all() and torch.isfinite(net.arena.v).all()
+    assert scales[-1] < scales[0] and not torch.equal(net.arena.p, w0), scales[-5:]
+    assert net.arena.step == 40 - int(net.arena.overflow[1])
+    # and radam / lion run through the model API
+    for name in ("radam", "lion"):
+        m2 = make_model(g["cfg"], "bf16", golden_dir, train_optim=name)
+        m2.rng_injection = lambda b: (s["t"], s["u"], s["noise"])
+        before = m2.netG_A.arena.p.clone()
+        m2.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "A_img_paths": ["x"]})
+        m2.optimize_parameters()
+        assert not torch.equal(m2.netG_A.arena.p, before) and torch.isfinite(m2.netG_A.arena.p).all()
+
+
 def test_palette_compute_visuals_surface(golden_dir):
     """the display path of train.py:319-413 through the model API: compute_visuals(n) runs the sampler on the
     current batch (palette_model.py:622-887), get_current_visuals(n) returns one OrderedDict per image with the reference's names;
@@ -546,7 +577,7 @@ def test_palette_compute_visuals_surface(golden_dir):
     out = torch.cat([v[f"output_{k}"] for k, v in enumerate(vis)])
     d = torch.device("cuda:0")
     y, _ = model.netG_A.restoration(g["y_t0"].to(d), y_t=g["y_t0"].to(d), y_0=g["B"].to(d), mask=g["mask"].to(d), sample_num=2, noises=g["noises"])
-    assert relerr(out, y) < 1e-6
+    assert relerr(out, y) < 2 * TOL_OUT[torch.float16], relerr(out, y)     # two runs differ by the order of the statistics atomics
     keep = (g["mask"] == 0).expand_as(g["B"])
     assert torch.equal(out.cpu()[keep], g["B"][keep])
     assert model.fake_B is model.output and tuple(vis[1]["mask_1"].shape) == tuple(g["mask"].shape[1:])
