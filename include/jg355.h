@@ -396,6 +396,15 @@ int jg_noise_level_embedding(const float* sigma, const float* W, float* emb, int
 int jg_noise_level_embedding_bwd(const float* sigma, const float* W, const float* demb, float* dW, int Bn, int half,
                                  jg_stream_t s);
 
+/* Device-side input pipeline of the self-supervised inpainting datasets: per image crop window (oy, ox) of size S x S out of the
+ * uint8 HWC source [B,H,W,3] (+ uint8 label mask [B,H,W], may be NULL), optional horizontal flip, ToTensor + Normalize(0.5, 0.5)
+ * (data/base_dataset.py:513-528), ToTensorMask -> int64 [B,1,S,S] (:892-917) and fill_mask_with_random
+ * (data/online_creation.py:1366-1376; data/self_supervised_labeled_mask_dataset.py:46-62):
+ *   B = (img / 255 - 0.5) / 0.5;  A = B (1 - m) + noise m,  m = (mask != 0).   win = int32 [B][3] = (oy, ox, flip).
+ * A, Bimg: fp32 NCHW [B,3,S,S]; noise: fp32 NCHW N(0,1) draws (NULL: treated as 0).  Bit-identical to the CPU transforms. */
+int jg_input_pipeline(const uint8_t* img, const uint8_t* mask, const int32_t* win, const float* noise, float* A, float* Bimg,
+                      int64_t* mask_out, int B, int H, int W, int S, jg_stream_t s);
+
 /* NHWC(T, Cpad) <-> NCHW(fp32, C) layout converters at the module boundary. */
 int jg_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);
 int jg_nchw_f32_to_nhwc(int dtype, const float* x, void* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);

@@ -129,6 +129,7 @@ SIGNATURES = {
                    c_f32, c_f32, c_f32, c_p],
     "jg_noise_level_embedding": [c_p, c_p, c_p, c_i32, c_i32, c_p],
     "jg_noise_level_embedding_bwd": [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p],
+    "jg_input_pipeline": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_nhwc_to_nchw_f32": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_nchw_f32_to_nhwc": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_adamw_ema": [c_p, c_p, c_p, c_p, c_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p],

@@ -1104,3 +1104,47 @@ extern "C" int jg_ddpm_multiscale_loss(int dtype, const float* noise, const void
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
+
+// ======================================================================================
+// Device-side input pipeline: what the reference's DataLoader workers do per image on the CPU --
+// crop (data/online_creation.py crop window), horizontal flip, ToTensor (/255) + Normalize((0.5,), (0.5,)) (data/base_dataset.py:513-528),
+// ToTensorMask -> int64 (:892-917) and the self-supervised mask fill  A = B (1 - m) + N(0,1) m,  m = (mask != 0)
+// (fill_mask_with_random, data/online_creation.py:1366-1376; data/self_supervised_labeled_mask_dataset.py:46-62) -- as ONE pass over
+// the uint8 source: 4 bytes read, 32 written per pixel.  The arithmetic keeps torchvision's operation order (x / 255 - 0.5) / 0.5 in
+// fp32, so the result is bit-identical to the CPU pipeline.
+// ======================================================================================
+namespace {
+__global__ __launch_bounds__(256) void input_pipeline_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask,
+                                                             const int32_t* __restrict__ win, const float* __restrict__ noise,
+                                                             float* __restrict__ A, float* __restrict__ Bimg,
+                                                             int64_t* __restrict__ mout, int B, int H, int W, int S) {
+  const long total = (long)B * S * S;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % S);
+    const long t = i / S;
+    const int y = (int)(t % S), b = (int)(t / S);
+    const int oy = win[b * 3], ox = win[b * 3 + 1], flip = win[b * 3 + 2];
+    const int sx = ox + (flip ? S - 1 - x : x), sy = oy + y;
+    const long sp = ((long)b * H + sy) * W + sx;
+    const int mv = mask ? (int)mask[sp] : 0;
+    mout[i] = (int64_t)mv;
+    const float m = mv != 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)img[sp * 3 + c], 255.0f), 0.5f), 0.5f);
+      const long o = (((long)b * 3 + c) * S + y) * S + x;
+      Bimg[o] = v;
+      A[o] = __fadd_rn(__fmul_rn(v, 1.0f - m), __fmul_rn(noise ? noise[o] : 0.f, m));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int jg_input_pipeline(const uint8_t* img, const uint8_t* mask, const int32_t* win, const float* noise, float* A, float* Bimg,
+                                 int64_t* mask_out, int B, int H, int W, int S, jg_stream_t s) {
+  if (!img || !win || !A || !Bimg || !mask_out || B < 1 || S < 1 || S > H || S > W) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(input_pipeline_kernel, dim3(grid_for((long)B * S * S)), dim3(256), 0, (hipStream_t)s, img, mask, win, noise, A, Bimg,
+                     mask_out, B, H, W, S);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}

@@ -309,17 +309,84 @@ class BaseModel:
                 setattr(self, name + str(offset + k), cur)
 
     # ---- checkpoints (:824-868, :957-1103) -------------------------------------------------------
-    def save_networks(self, epoch):
+    def save_networks(self, epoch, blocking=None):
+        """`<epoch>_net_<name>.pth` (+ `_ema.pth`) with the reference's keys / layout.
+        blocking=False (or opt.jg_async_checkpoint): the step loop only pays for one device -> pinned-host copy of each flat arena,
+        enqueued on a side stream; a writer thread waits for the copy, rebuilds the reference-layout state_dict from the host
+        snapshot and writes the file (tmp + rename).  `wait_checkpoints()` joins the writers (called by the next save / load)."""
+        if blocking is None:
+            blocking = not getattr(self.opt, "jg_async_checkpoint", False)
         os.makedirs(self.save_dir, exist_ok=True)
+        self.wait_checkpoints()
         for name in self.model_names:
             net = self._net(name)
-            torch.save(net.state_dict(), os.path.join(self.save_dir, "%s_net_%s.pth" % (epoch, name)))
-            if self.opt.train_G_ema:
-                ema = getattr(self, "net" + name + "_ema", None)
+            path = os.path.join(self.save_dir, "%s_net_%s.pth" % (epoch, name))
+            ema = getattr(self, "net" + name + "_ema", None) if self.opt.train_G_ema else None
+            ema_path = os.path.join(self.save_dir, "%s_net_%s_ema.pth" % (epoch, name))
+            if blocking or getattr(net, "arena", None) is None:
+                torch.save(net.state_dict(), path)
                 if ema is not None:
-                    torch.save(ema.state_dict(), os.path.join(self.save_dir, "%s_net_%s_ema.pth" % (epoch, name)))
+                    torch.save(ema.state_dict(), ema_path)
+                continue
+            self._save_async(net, path, None)
+            if ema is not None:
+                self._save_async(net, ema_path, net.arena.ema)
+
+    def _save_async(self, net, path, flat):
+        import threading
+
+        arena = net.arena
+        flat = arena.p if flat is None else flat
+        if not hasattr(self, "_ckpt_stream"):
+            self._ckpt_stream, self._ckpt_threads = torch.cuda.Stream(device=self.device), []
+        keys = getattr(arena, "_sd_keys", None)
+        if keys is None:      # key order of the reference layout (parameters and buffers interleaved in module order), computed once
+            keys = arena._sd_keys = list(net.state_dict(keep_vars=True).keys())
+        shapes = {n: tuple(prm.shape) for n, prm in net.named_parameters()}
+        host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
+        side = self._ckpt_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            host.copy_(flat, non_blocking=True)
+            bufs = {k: v.detach().to("cpu", non_blocking=True) for k, v in net.named_buffers()}
+            done = torch.cuda.Event()
+            done.record(side)
+        flat.record_stream(side)
+
+        def write():
+            done.synchronize()
+            sd = OrderedDict()
+            for k in keys:
+                if k in arena.slices:
+                    off, _ = arena.slices[k]
+                    sd[k] = arena._views(host, off, shapes[k]).clone(memory_format=torch.contiguous_format)
+                else:
+                    sd[k] = bufs[k].clone()
+            tmp = path + ".tmp"
+            torch.save(sd, tmp)
+            os.replace(tmp, path)
+
+        t = threading.Thread(target=write, daemon=False)
+        t.start()
+        self._ckpt_threads.append(t)
+
+    def wait_checkpoints(self):
+        for t in getattr(self, "_ckpt_threads", []):
+            t.join()
+        if hasattr(self, "_ckpt_threads"):
+            self._ckpt_threads = []
+
+    def export_networks(self, epoch):
+        """:870-938.  The reference exports ONNX / TorchScript for GAN generators only (palette / cm are skipped there too), by
+        loading the saved `.pth` into its own CPU modules (util/export.py).  The checkpoints written here interchange with the
+        reference, so the same exporter runs on them unchanged; this build has no CPU module graph to trace."""
+        if self.opt.model_type in ("palette", "cm"):
+            return
+        raise NotImplementedError("ONNX / TorchScript export of GAN generators: run the reference's util/export.py on the "
+                                  "<epoch>_net_G_A.pth written by save_networks (same keys and layout)")
 
     def load_networks(self, epoch, load_dir=None):
+        self.wait_checkpoints()
         load_dir = load_dir or self.save_dir
         for name in self.model_names:
             path = os.path.join(load_dir, "%s_net_%s.pth" % (epoch, name))
