@@ -17,6 +17,8 @@ import ctypes as C
 import math
 import os
 
+from typing import Optional, Tuple
+
 import torch
 
 from . import _lib
@@ -521,11 +523,11 @@ class _Upsample2Fn(torch.autograd.Function):
 
 
 def avg_pool2(x):
-    return _AvgPool2Fn.apply(x)
+    return torch.ops.jg355.resample2(x, False, 0.25)
 
 
 def upsample_nearest2(x):
-    return _Upsample2Fn.apply(x)
+    return torch.ops.jg355.resample2(x, True, 1.0)
 
 
 def copy_channels(src, soff, dst, doff, n):
@@ -664,7 +666,7 @@ class _AttnCoreFn(torch.autograd.Function):
 
 
 def attention_core(qkv, n_heads):
-    return _AttnCoreFn.apply(qkv, n_heads)
+    return torch.ops.jg355.attention_core(qkv, n_heads)[0]
 
 
 # ======================================================================================
@@ -1110,37 +1112,220 @@ def to_nhwc(x, act_dtype, cpad=None):
 
 
 # ======================================================================================
-# torch.ops.jg355.* -- the op surface north_star names (forward kernels; autograd lives above)
+# torch.ops.jg355.* -- the op surface north_star names: every op is a torch.library custom op with a fake (meta) kernel and an
+# autograd formula built from the C-ABI kernels, so the ops trace (torch.compile / FakeTensor), compose with autograd and pass
+# torch.library.opcheck.  The ops are FUNCTIONAL (gradients are returned).  The module graph uses them where a functional op costs
+# nothing (attention core, pooling, upsampling); convolutions and normalisations of the training path keep their arena-accumulating
+# autograd nodes (`_Conv2dFn`, `_GroupNormFn`, modules/unet_exec.py), whose weight / affine gradients are atomically added IN PLACE
+# into the flat gradient arena -- returning them as tensors would add a full-arena copy to every step.
 # ======================================================================================
-_TORCH_LIB = None
+def _conv_out_hw(H, W, R, S, pad, stride):
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
 
-def register_torch_ops():
-    global _TORCH_LIB
-    if _TORCH_LIB is not None:
-        return
-    tl = torch.library.Library("jg355", "DEF")
-    tl.define("conv2d_nt(Tensor x, Tensor w, Tensor? bias, Tensor? res, int pad, int stride, float alpha, float res_scale) -> Tensor")
-    tl.define("group_norm_act(Tensor x, Tensor? gamma, Tensor? beta, Tensor? film, int groups, int act, float eps) -> Tensor")
-    tl.define("attention_core(Tensor qkv, int heads) -> Tensor")
-    tl.define("avg_pool2(Tensor x) -> Tensor")
-    tl.define("upsample_nearest2(Tensor x) -> Tensor")
-
-    def _conv(x, w, bias, res, pad, stride, alpha, res_scale):
-        B, H, W, Cin = x.shape
-        Cout, R, S, _ = w.shape
-        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
-        y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
-        conv_nt(x, w, y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, pad=pad, stride=stride, Ho=Ho, Wo=Wo, ldx=Cin,
-                ldw=R * S * Cin, ldy=Cout, bias=bias, res=res, ldres=Cout, alpha=alpha, res_scale=res_scale)
-        return y
-
-    tl.impl("conv2d_nt", _conv, "CUDA")
-    tl.impl("group_norm_act", lambda x, g, b, f, G, act, eps: _GroupNormFn.apply(x, g, b, f, G, act, eps), "CUDA")
-    tl.impl("attention_core", lambda qkv, h: _AttnCoreFn.apply(qkv, h), "CUDA")
-    tl.impl("avg_pool2", lambda x: _pool(x, 0.25), "CUDA")
-    tl.impl("upsample_nearest2", lambda x: _up(x, 1.0), "CUDA")
-    _TORCH_LIB = tl
+@torch.library.custom_op("jg355::conv2d_nt", mutates_args=())
+def _op_conv2d_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], res: Optional[torch.Tensor], pad: int, stride: int,
+                  alpha: float, res_scale: float) -> torch.Tensor:
+    """x [B,H,W,Cin] 16-bit NHWC, w [Cout,R,S,Cin] 16-bit, bias fp32 [Cout], res like y: y = alpha conv(x, w) + bias + res_scale res"""
+    B, H, W, Cin = x.shape
+    Cout, R, S, _ = w.shape
+    Ho, Wo = _conv_out_hw(H, W, R, S, pad, stride)
+    y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
+    x, w = x.contiguous(), w.contiguous()
+    conv_nt(x, w, y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, pad=pad, stride=stride, Ho=Ho, Wo=Wo, ldx=Cin,
+            ldw=R * S * Cin, ldy=Cout, bias=bias, res=None if res is None else res.contiguous(), ldres=Cout, alpha=alpha, res_scale=res_scale)
+    return y
 
 
-register_torch_ops()
+@_op_conv2d_nt.register_fake
+def _(x, w, bias, res, pad, stride, alpha, res_scale):
+    B, H, W, _ = x.shape
+    Cout, R, S, _ = w.shape
+    Ho, Wo = _conv_out_hw(H, W, R, S, pad, stride)
+    return x.new_empty((B, Ho, Wo, Cout))
+
+
+@torch.library.custom_op("jg355::conv2d_wgrad", mutates_args=())
+def _op_conv2d_wgrad(dy: torch.Tensor, x: torch.Tensor, R: int, S: int, pad: int, stride: int, alpha: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dW fp32 [Cout,R,S,Cin], dbias fp32 [Cout]) of y = alpha conv(x, W) + bias for the output gradient dy"""
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    dw = torch.zeros((Cout, R, S, Cin), device=x.device, dtype=torch.float32)
+    db = torch.zeros((Cout,), device=x.device, dtype=torch.float32)
+    ktot = R * S * Cin
+    splitk = _wgrad_splitk(((Cout + 127) // 128) * ((ktot + 127) // 128), B * Ho * Wo)
+    wgrad_tn(dy.contiguous(), x.contiguous(), dw, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, pad=pad, stride=stride, Ho=Ho, Wo=Wo,
+             lddy=Cout, ldx=Cin, lddw=ktot, dbias=db, splitk=splitk, alpha=alpha)
+    return dw, db
+
+
+@_op_conv2d_wgrad.register_fake
+def _(dy, x, R, S, pad, stride, alpha):
+    return x.new_empty((dy.shape[-1], R, S, x.shape[-1]), dtype=torch.float32), x.new_empty((dy.shape[-1],), dtype=torch.float32)
+
+
+def _conv2d_nt_setup(ctx, inputs, output):
+    x, w, bias, res, pad, stride, alpha, res_scale = inputs
+    ctx.save_for_backward(x, w)
+    ctx.geo = (pad, stride, alpha, res_scale, bias is not None, res is not None)
+
+
+def _conv2d_nt_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    pad, stride, alpha, res_scale, has_bias, has_res = ctx.geo
+    if stride != 1:
+        raise NotImplementedError("jg355::conv2d_nt autograd: stride 1 only (the strided layers of the networks use their module nodes)")
+    Cout, R, S, Cin = w.shape
+    dy = dy.contiguous()
+    dx = dw = db = dres = None
+    if ctx.needs_input_grad[0]:          # input gradient = the same kernel on the flipped / transposed weights
+        wT = w.permute(3, 1, 2, 0).flip(1, 2).contiguous()
+        dx = torch.ops.jg355.conv2d_nt(dy, wT, None, None, R - 1 - pad, 1, alpha, 0.0)
+    if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+        dwf, dbf = torch.ops.jg355.conv2d_wgrad(dy, x, R, S, pad, stride, alpha)
+        dw = dwf.to(w.dtype) if ctx.needs_input_grad[1] else None
+        db = dbf if (has_bias and ctx.needs_input_grad[2]) else None
+    if has_res and ctx.needs_input_grad[3]:
+        dres = dy if res_scale == 1.0 else (dy.float() * res_scale).to(dy.dtype)
+    return dx, dw, db, dres, None, None, None, None
+
+
+_op_conv2d_nt.register_autograd(_conv2d_nt_backward, setup_context=_conv2d_nt_setup)
+
+
+@torch.library.custom_op("jg355::group_norm_act", mutates_args=())
+def _op_group_norm_act(x: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor], film: Optional[torch.Tensor],
+                       groups: int, act: int, eps: float) -> torch.Tensor:
+    """act(GroupNorm_groups(x) gamma + beta [(1 + scale) + shift]); x NHWC 16-bit (any number of middle dims), film fp32 [B, 2C]"""
+    return _GroupNormFn.forward(_NoCtx(), x.contiguous(), gamma, beta, None if film is None else film.contiguous(), groups, act, eps)
+
+
+class _NoCtx:
+    """stand-in autograd context for calling a Function's forward as a plain kernel sequence"""
+    needs_input_grad = (False,) * 8
+
+    def save_for_backward(self, *a):
+        self.saved = a
+
+
+@_op_group_norm_act.register_fake
+def _(x, gamma, beta, film, groups, act, eps):
+    return torch.empty_like(x)
+
+
+@torch.library.custom_op("jg355::group_norm_act_bwd", mutates_args=())
+def _op_group_norm_act_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: Optional[torch.Tensor], beta: Optional[torch.Tensor],
+                           film: Optional[torch.Tensor], groups: int, act: int, eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(dx, dgamma [C], dbeta [C], dfilm [B, 2C]) -- the statistics are recomputed from x (two small kernels)"""
+    L = _lib.lib()
+    x, dy = x.contiguous(), dy.contiguous()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    dev, st, dt = x.device, _st(), _dt(x)
+    f32 = dict(device=dev, dtype=torch.float32)
+    sums, ab, mr = torch.empty((B, C, 2), **f32), torch.empty((B, C, 2), **f32), torch.empty((B, groups, 2), **f32)
+    film = None if film is None else film.contiguous()
+    ldfilm = film.stride(0) if film is not None else 0
+    check(L.jg_gn_stats(dt, x.data_ptr(), sums.data_ptr(), B, HW, C, st), "jg_gn_stats")
+    check(L.jg_gn_coef(sums.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, ab.data_ptr(), mr.data_ptr(), B, HW, C, groups, eps, st), "jg_gn_coef")
+    red, pqr = torch.empty((B, C, 2), **f32), torch.empty((B, C, 3), **f32)
+    dgamma, dbeta, dfilm = torch.zeros((C,), **f32), torch.zeros((C,), **f32), torch.zeros((B, 2 * C), **f32)
+    check(L.jg_gn_bwd_reduce(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), red.data_ptr(), B, HW, C, act, st), "jg_gn_bwd_reduce")
+    check(L.jg_gn_bwd_coef(red.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, mr.data_ptr(), pqr.data_ptr(),
+                           dgamma.data_ptr() if gamma is not None else None, dbeta.data_ptr() if beta is not None else None,
+                           dfilm.data_ptr() if film is not None else None, 2 * C, B, HW, C, groups, st), "jg_gn_bwd_coef")
+    dx = torch.empty_like(x)
+    check(L.jg_gn_bwd_apply(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), pqr.data_ptr(), dx.data_ptr(), B, HW, C, act, st), "jg_gn_bwd_apply")
+    return dx, dgamma, dbeta, dfilm
+
+
+@_op_group_norm_act_bwd.register_fake
+def _(x, dy, gamma, beta, film, groups, act, eps):
+    B, C = x.shape[0], x.shape[-1]
+    f = lambda *sh: x.new_empty(sh, dtype=torch.float32)
+    return torch.empty_like(x), f(C), f(C), f(B, 2 * C)
+
+
+def _gn_setup(ctx, inputs, output):
+    x, gamma, beta, film, groups, act, eps = inputs
+    ctx.save_for_backward(x, gamma, beta, film)
+    ctx.cfg = (groups, act, eps)
+
+
+def _gn_backward(ctx, dy):
+    x, gamma, beta, film = ctx.saved_tensors
+    groups, act, eps = ctx.cfg
+    dx, dgamma, dbeta, dfilm = torch.ops.jg355.group_norm_act_bwd(x, dy, gamma, beta, film, groups, act, eps)
+    return (dx if ctx.needs_input_grad[0] else None, dgamma if (gamma is not None and ctx.needs_input_grad[1]) else None,
+            dbeta if (beta is not None and ctx.needs_input_grad[2]) else None,
+            dfilm if (film is not None and ctx.needs_input_grad[3]) else None, None, None, None)
+
+
+_op_group_norm_act.register_autograd(_gn_backward, setup_context=_gn_setup)
+
+
+@torch.library.custom_op("jg355::attention_core", mutates_args=())
+def _op_attention_core(qkv: torch.Tensor, heads: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """QKVAttentionLegacy core: qkv [B,T,3C] (legacy head layout) -> (a [B,T,C], aux) with aux = per-query logsumexp of the fused
+    kernel (head dim 32, T % 128 == 0) or the softmax probabilities of the unfused path (what the backward needs)"""
+    a, P = attn_core_fwd(qkv.contiguous(), heads)
+    return a, P
+
+
+@_op_attention_core.register_fake
+def _(qkv, heads):
+    B, T, C3 = qkv.shape
+    Cc = C3 // 3
+    a = qkv.new_empty((B, T, Cc))
+    if FLASH_ATTENTION and Cc // heads == 32 and T % 128 == 0:
+        return a, qkv.new_empty((B * heads, T), dtype=torch.float32)
+    return a, qkv.new_empty((B * heads, T, T))
+
+
+@torch.library.custom_op("jg355::attention_core_bwd", mutates_args=())
+def _op_attention_core_bwd(qkv: torch.Tensor, aux: torch.Tensor, a: torch.Tensor, da: torch.Tensor, heads: int) -> torch.Tensor:
+    return attn_core_bwd(qkv.contiguous(), aux, da, heads, a)
+
+
+@_op_attention_core_bwd.register_fake
+def _(qkv, aux, a, da, heads):
+    return torch.empty_like(qkv)
+
+
+def _attn_setup(ctx, inputs, output):
+    qkv, heads = inputs
+    a, aux = output
+    ctx.save_for_backward(qkv, aux, a)
+    ctx.heads = heads
+
+
+def _attn_backward(ctx, da, daux):
+    qkv, aux, a = ctx.saved_tensors
+    return torch.ops.jg355.attention_core_bwd(qkv, aux, a, da.contiguous(), ctx.heads), None
+
+
+_op_attention_core.register_autograd(_attn_backward, setup_context=_attn_setup)
+
+
+@torch.library.custom_op("jg355::resample2", mutates_args=())
+def _op_resample2(x: torch.Tensor, up: bool, scale: float) -> torch.Tensor:
+    """up: nearest x2 upsample times `scale`; else 2x2 SUM pool times `scale` (avg_pool = 0.25).  Each is the other's adjoint."""
+    return _up(x.contiguous(), scale) if up else _pool(x.contiguous(), scale)
+
+
+@_op_resample2.register_fake
+def _(x, up, scale):
+    B, H, W, Cc = x.shape
+    return x.new_empty((B, H * 2, W * 2, Cc)) if up else x.new_empty((B, H // 2, W // 2, Cc))
+
+
+def _resample_setup(ctx, inputs, output):
+    ctx.cfg = (inputs[1], inputs[2])
+
+
+def _resample_backward(ctx, dy):
+    up, scale = ctx.cfg
+    return torch.ops.jg355.resample2(dy.contiguous(), not up, scale), None, None
+
+
+_op_resample2.register_autograd(_resample_backward, setup_context=_resample_setup)
