@@ -351,6 +351,9 @@ int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, const void* v, 
 int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
                         float* dkf, float* dvf, void* dk, void* dv, int B, int Tq, int Tkv, int heads, int64_t ldq, int64_t ldkv, int64_t ldo,
                         float scale, jg_stream_t s);
+/* the same with align_corners selectable (1: FeatureFusionBlockMatrix of the projected discriminator, projected_d/blocks.py:276-287) */
+int jg_bilinear2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, int align_corners, jg_stream_t s);
+int jg_bilinear2_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, int align_corners, jg_stream_t s);
 int jg_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, jg_stream_t s);
 int jg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, jg_stream_t s);
 int jg_bn_coef(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* ab, float* mr, int B,
@@ -362,6 +365,23 @@ int jg_attn_compose_fwd(int dtype, const void* img, const void* logits, const vo
 int jg_attn_compose_bwd(int dtype, const void* img, const void* logits, const void* xin, const void* dout, void* dimg, void* dlogits, void* dxin,
                         int B, int S, int f, int na, int ni, int nc, int ldimg, int ldl, int ldx, int ldo, jg_stream_t s);
 int jg_scale(int dtype, const void* x, const float* scale, const void* res, void* y, int B, int64_t HW, int C, int per_channel, jg_stream_t s);
+
+/* Projected discriminator (models/modules/projected_d/discriminator.py:13-77,166-286; blocks.py:11-13,182-200).
+ * Spectral normalisation (torch.nn.utils.spectral_norm, one power iteration per training forward) of a convolution whose fp32 master
+ * W is [Cout][R][S][Cin]:  v = normalize(W^T u), u = normalize(W v), sigma = u . W v  (u [Cout], v [Cin*RS] in the REFERENCE's
+ * weight.view(Cout, -1) order, both updated in place; ws: >= RS*Cin + Cout + 2 floats);
+ * jg_spectral_weights writes the 16-bit working copies of W / sigma (straight, and flipped + transposed for the input gradient);
+ * jg_spectral_wgrad_fix turns the gradient w.r.t. W_sn into the gradient w.r.t. W (u, v constant) and ADDS it to g:
+ *   g += (dWsn - <dWsn, W_sn> u v^T) / sigma          (ws: 1 float).
+ * jg_hinge_loss: gan_mode "projected" (models/modules/loss.py:77-84): mode 0 mean relu(1 - p), 1 mean relu(1 + p), 2 mean(-p) over
+ * the cvalid leading channels of an NHWC logit map; *loss += scale * value, dpred = grad_scale * scale * d value / d pred. */
+int jg_spectral_power_iter(const float* W, float* u, float* v, float* sigma, float* ws, int Cout, int RS, int Cin, float eps, jg_stream_t s);
+int jg_spectral_weights(int dtype, const float* W, const float* sigma, void* w16, void* w16T, int Cout, int RS, int Cin, int CoutP, int CinP,
+                        jg_stream_t s);
+int jg_spectral_wgrad_fix(const float* dWsn, const float* W, const float* u, const float* v, const float* sigma, float* g, float* ws, int Cout,
+                          int RS, int Cin, jg_stream_t s);
+int jg_hinge_loss(int dtype, const void* pred, float* loss, void* dpred, int64_t npix, int cpad, int cvalid, int mode, float scale,
+                  float grad_scale, jg_stream_t s);
 
 /* One DDPM ancestral sampling step after the UNet (DiffusionGenerator.p_sample / p_mean_variance, restoration_ddpm:
  * models/modules/diffusion_generator.py:187-284, predict_start_from_noise / q_posterior: diffusion_utils.py:122-137):

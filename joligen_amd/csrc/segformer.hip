@@ -460,14 +460,16 @@ __global__ __launch_bounds__(64) void attn_smallkv_bwd_kernel(const T* __restric
 }
 
 // ---- bilinear resize, align_corners = False (aten upsample_bilinear2d): src = (dst + 0.5) * in / out - 0.5, clamped at 0 ------------
+// ALIGN (align_corners = True, FeatureFusionBlockMatrix of the projected discriminator): src = dst * (in - 1) / (out - 1)
+template <bool ALIGN = false>
 __device__ __forceinline__ void bil_coord(int o, int in, int out, int& i0, int& i1, float& w1) {
-  float s = ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
+  float s = ALIGN ? (out > 1 ? (float)o * ((float)(in - 1) / (float)(out - 1)) : 0.f) : ((float)o + 0.5f) * ((float)in / (float)out) - 0.5f;
   s = s < 0.f ? 0.f : s;
   i0 = (int)s;
   i1 = i0 + (i0 < in - 1 ? 1 : 0);
   w1 = s - (float)i0;
 }
-template <typename T>
+template <typename T, bool ALIGN = false>
 __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo, long ldy) {
   const int c8n = C >> 3;
   const long total = (long)B * Ho * Wo * c8n;
@@ -479,8 +481,8 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
     const int oy = p % Ho, b = p / Ho;
     int y0, y1, x0, x1;
     float wy, wx;
-    bil_coord(oy, H, Ho, y0, y1, wy);
-    bil_coord(ox, W, Wo, x0, x1, wx);
+    bil_coord<ALIGN>(oy, H, Ho, y0, y1, wy);
+    bil_coord<ALIGN>(ox, W, Wo, x0, x1, wx);
     float a[8], bq[8], c[8], d[8], o8[8];
     const T* xb = x + (long)b * H * W * C + c8 * 8;
     unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y0 * W + x0) * C), a);
@@ -493,7 +495,7 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
   }
 }
 // adjoint as a gather: an input pixel collects from the output pixels whose two source rows / columns include it
-template <typename T>
+template <typename T, bool ALIGN = false>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, long lddy) {
   const int c8n = C >> 3;
   const long total = (long)B * H * W * c8n;
@@ -507,18 +509,19 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    const int oy_lo = max(0, (iy - 1) * fy), oy_hi = min(Ho - 1, (iy + 2) * fy);
-    const int ox_lo = max(0, (ix - 1) * fx), ox_hi = min(Wo - 1, (ix + 2) * fx);
+    // (align_corners: the footprint of an input pixel shifts by up to one output pixel against the half-pixel rule -> one more each way)
+    const int oy_lo = max(0, (iy - 1) * fy - (ALIGN ? fy : 0)), oy_hi = min(Ho - 1, (iy + 2) * fy + (ALIGN ? fy : 0));
+    const int ox_lo = max(0, (ix - 1) * fx - (ALIGN ? fx : 0)), ox_hi = min(Wo - 1, (ix + 2) * fx + (ALIGN ? fx : 0));
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1;
       float wy;
-      bil_coord(oy, H, Ho, y0, y1, wy);
+      bil_coord<ALIGN>(oy, H, Ho, y0, y1, wy);
       const float ky = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
       if (ky == 0.f) continue;
       for (int ox = ox_lo; ox <= ox_hi; ++ox) {
         int x0, x1;
         float wx;
-        bil_coord(ox, W, Wo, x0, x1, wx);
+        bil_coord<ALIGN>(ox, W, Wo, x0, x1, wx);
         const float kx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
         if (kx == 0.f) continue;
         float f[8];
@@ -804,19 +807,37 @@ extern "C" int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, cons
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
-extern "C" int jg_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, jg_stream_t s) {
+extern "C" int jg_bilinear2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, int align_corners,
+                                jg_stream_t s) {
   if (!x || !y || C < 8 || C % 8 || ldy < C || ldy % 8 || H < 1 || W < 1 || Ho < 1 || Wo < 1) return JG_ERR_BAD_ARG;
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T>), dim3(grid_for((long)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)s,
-                                              (const T*)x, (T*)y, B, H, W, C, Ho, Wo, (long)ldy););
+  if (align_corners) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, true>), dim3(grid_for((long)B * Ho * Wo * (C / 8))), dim3(256), 0,
+                                                (hipStream_t)s, (const T*)x, (T*)y, B, H, W, C, Ho, Wo, (long)ldy););
+  } else {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_fwd_kernel<T, false>), dim3(grid_for((long)B * Ho * Wo * (C / 8))), dim3(256), 0,
+                                                (hipStream_t)s, (const T*)x, (T*)y, B, H, W, C, Ho, Wo, (long)ldy););
+  }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, jg_stream_t s) {
+  return jg_bilinear2_fwd(dtype, x, y, B, H, W, C, Ho, Wo, ldy, 0, s);
+}
+extern "C" int jg_bilinear2_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, int align_corners,
+                                jg_stream_t s) {
+  if (!dy || !dx || C < 8 || C % 8 || lddy < C || lddy % 8 || Ho < H || Wo < W) return JG_ERR_BAD_ARG;   // up-sampling only
+  if (align_corners) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, true>), dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0,
+                                                (hipStream_t)s, (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, (long)lddy););
+  } else {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, false>), dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0,
+                                                (hipStream_t)s, (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, (long)lddy););
+  }
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
 extern "C" int jg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, jg_stream_t s) {
-  if (!dy || !dx || C < 8 || C % 8 || lddy < C || lddy % 8 || Ho < H || Wo < W) return JG_ERR_BAD_ARG;   // up-sampling only
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T>), dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0, (hipStream_t)s,
-                                              (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, (long)lddy););
-  JG_CHECK_LAUNCH();
-  return JG_OK;
+  return jg_bilinear2_bwd(dtype, dy, dx, B, H, W, C, Ho, Wo, lddy, 0, s);
 }
 extern "C" int jg_bn_coef(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* ab, float* mr,
                           int B, int HW, int C, float eps, float momentum, int training, jg_stream_t s) {

@@ -59,9 +59,10 @@ class CUTModel(BaseModel):
             raise NotImplementedError(f"G_netG={opt.G_netG!r}: the CUT path is built for the resnet and segformer_attn_conv generators")
         if "segformer" in opt.G_netG:           # cut_model.py:205-210: enforced by the reference
             opt.alg_cut_nce_layers, opt.alg_cut_nce_T = "0,1,2,3", 0.2
-        if list(opt.D_netDs) != ["basic"]:
-            raise NotImplementedError(f"D_netDs={opt.D_netDs!r}: only the 'basic' PatchGAN is built (projected_d needs pretrained "
-                                      "timm backbones, unavailable offline)")
+        bad = [d for d in opt.D_netDs if d not in ("basic", "projected_d")]
+        if bad or not opt.D_netDs:
+            raise NotImplementedError(f"D_netDs={opt.D_netDs!r}: 'basic' (PatchGAN) and 'projected_d' are built ('vision_aided' and the "
+                                      "depth / mask / sam / temporal discriminators need pretrained networks)")
         if opt.alg_cut_netF != "mlp_sample":
             raise NotImplementedError(f"alg_cut_netF={opt.alg_cut_netF!r}")
         if opt.alg_cut_nce_loss not in ("monce", "patchnce"):
@@ -87,9 +88,19 @@ class CUTModel(BaseModel):
         if opt.isTrain:
             self.netF = PatchSampleF(use_mlp=True, init_type=opt.model_init_type, init_gain=opt.model_init_gain, nc=opt.alg_cut_netF_nc)
             self.netF.set_device(self.device)
-            self.netD_B_basic = NLayerDiscriminator(opt.model_output_nc, opt.D_ndf, n_layers=opt.D_n_layers)
-            self.discriminators_names = ["D_B_basic"]
-            self.model_names += ["F", "D_B_basic"]
+            # gan_networks.define_D (:330-446): one network per entry of D_netDs, named D_B_<entry>
+            self.discriminators_names = []
+            for d in opt.D_netDs:
+                if d == "basic":
+                    net = NLayerDiscriminator(opt.model_output_nc, opt.D_ndf, n_layers=opt.D_n_layers)
+                else:
+                    from ..modules.projected_d import ProjectedDiscriminator
+
+                    net = ProjectedDiscriminator(getattr(opt, "D_proj_network_type", "efficientnet"), interp=getattr(opt, "D_proj_interp", -1),
+                                                 img_size=opt.data_crop_size)
+                setattr(self, "netD_B_" + d, net)
+                self.discriminators_names.append("D_B_" + d)
+            self.model_names += ["F"] + self.discriminators_names
             # base_model.py:115-118; forward_GAN (base_gan_model.py:170-173) also pushes the real images through pools on every
             # iteration: they feed only the metrics, but they consume host random draws BEFORE the fake pool does
             self.real_A_pool, self.real_B_pool = ImagePool(opt.train_pool_size), ImagePool(opt.train_pool_size)
@@ -100,19 +111,31 @@ class CUTModel(BaseModel):
                       eps=opt.train_optim_eps)
             self.optimizer_G = self.make_optimizer(self.netG_A, **kw)
             kw["lr"] = opt.train_D_lr
-            self.optimizer_D = self.make_optimizer(self.netD_B_basic, **kw)
-            self.optimizers += [self.optimizer_D, self.optimizer_G]
-            self.D_B_basic_loss_calculator = DiscriminatorGANLoss(self.netD_B_basic, self.device, opt.train_gan_mode,
-                                                                  opt.dataaug_D_label_smooth)
-            self.objects_to_update.append(self.D_B_basic_loss_calculator)
+            # the reference chains every discriminator's parameters into ONE Adam (cut_model.py:378-395); one fused optimizer per
+            # discriminator arena with the same hyper-parameters is the same update
+            optD = []
+            for dn in self.discriminators_names:
+                o = self.make_optimizer(getattr(self, "net" + dn), **kw)
+                setattr(self, "optimizer_" + dn, o)
+                optD.append("optimizer_" + dn)
+                self.optimizers.append(o)
+                # base_gan_model.set_discriminators_info (:538-640): projected discriminators always train with the hinge objective
+                mode = "projected" if "projected" in dn else opt.train_gan_mode
+                calc = DiscriminatorGANLoss(getattr(self, "net" + dn), self.device, mode, opt.dataaug_D_label_smooth)
+                setattr(self, dn + "_loss_calculator", calc)
+                self.objects_to_update.append(calc)
+            self.optimizer_D = getattr(self, optD[0])
+            self.optimizers.append(self.optimizer_G)
             self.group_G = NetworkGroup(networks_to_optimize=["G_A", "F"], forward_functions=["forward"],
                                         backward_functions=["compute_G_loss"], loss_names_list=["loss_names_G"],
                                         optimizer=["optimizer_G", "optimizer_F"], loss_backward=["loss_G_tot"], networks_to_ema=["G_A"])
-            self.group_D = NetworkGroup(networks_to_optimize=["D_B_basic"], forward_functions=None, backward_functions=["compute_D_loss"],
-                                        loss_names_list=["loss_names_D"], optimizer=["optimizer_D"], loss_backward=["loss_D_tot"])
+            self.group_D = NetworkGroup(networks_to_optimize=list(self.discriminators_names), forward_functions=None,
+                                        backward_functions=["compute_D_loss"], loss_names_list=["loss_names_D"], optimizer=optD,
+                                        loss_backward=["loss_D_tot"])
             self.networks_groups = [self.group_G, self.group_D]
-            self.loss_names_G = ["G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_basic"] if opt.alg_cut_nce_idt else ["G_tot", "G_NCE", "G_GAN_D_B_basic"]
-            self.loss_names_D = ["D_tot", "D_GAN_D_B_basic"]
+            self.loss_names_G = (["G_tot", "G_NCE", "G_NCE_Y"] if opt.alg_cut_nce_idt else ["G_tot", "G_NCE"]) + \
+                ["G_GAN_" + dn for dn in self.discriminators_names]
+            self.loss_names_D = ["D_tot"] + ["D_GAN_" + dn for dn in self.discriminators_names]
             self.loss_names = self.loss_names_G + self.loss_names_D
             self.loss_functions_G = ["compute_G_loss_GAN", "compute_G_loss_cut"]
             self.iter_calculator_init()
@@ -169,10 +192,12 @@ class CUTModel(BaseModel):
         self.loss_G_tot = _ScaleGradFn.apply(self.loss_G_tot, self.loss_scale)
 
     def compute_G_loss_GAN(self):
-        """base_gan_model.py:421-503 for one 'basic' discriminator on domain B."""
-        lossf = self.D_B_basic_loss_calculator
-        self.loss_G_GAN_D_B_basic = self.opt.alg_gan_lambda * lossf.compute_loss_G(self._net("D_B_basic"), self.real_B, self.fake_B)
-        self.loss_G_tot = self.loss_G_tot + self.loss_G_GAN_D_B_basic
+        """base_gan_model.py:421-503: lambda_GAN * compute_loss_G of every discriminator on domain B."""
+        for dn in self.discriminators_names:
+            lossf = getattr(self, dn + "_loss_calculator")
+            val = self.opt.alg_gan_lambda * lossf.compute_loss_G(self._net(dn), self.real_B, self.fake_B)
+            setattr(self, "loss_G_GAN_" + dn, val)
+            self.loss_G_tot = self.loss_G_tot + val
 
     def compute_G_loss_cut(self):
         """cut_model.py:708-837 (NCE + identity NCE)."""
@@ -211,7 +236,11 @@ class CUTModel(BaseModel):
 
     # ---- discriminator loss (base_gan_model.py:341-419) ------------------------------------------------------------------
     def compute_D_loss(self):
-        fake = self.fake_B_pool.query(self.fake_B)
-        lossf = self.D_B_basic_loss_calculator
-        self.loss_D_GAN_D_B_basic = lossf.compute_loss_D(self._net("D_B_basic"), self.real_B, fake, None)
-        self.loss_D_tot = _ScaleGradFn.apply(self.loss_D_GAN_D_B_basic, self.loss_scale)
+        """base_gan_model.py:341-419: every discriminator draws ITS OWN fake batch from the history pool (compute_D_loss_generic)."""
+        tot = 0
+        for dn in self.discriminators_names:
+            fake = self.fake_B_pool.query(self.fake_B)
+            val = getattr(self, dn + "_loss_calculator").compute_loss_D(self._net(dn), self.real_B, fake, None)
+            setattr(self, "loss_D_GAN_" + dn, val)
+            tot = tot + val
+        self.loss_D_tot = _ScaleGradFn.apply(tot, self.loss_scale)

@@ -1,6 +1,9 @@
 """GAN objectives of the CUT path on the HIP ops: /root/reference/models/modules/loss.py `GANLoss` (:11-85) for
-gan_mode='lsgan' (the train_gan_mode default) and `DiscriminatorGANLoss` (:249-313) without APA / D-diffusion augmentation.
-Predictions are NHWC logit maps whose channel 0 is valid (PatchGAN output padded to 8 channels)."""
+gan_mode='lsgan' (the train_gan_mode default: MSE against 1 / 0) and 'projected' (the hinge objective :77-84 that
+`set_discriminators_info` forces for projected discriminators, base_gan_model.py:544-545), and `DiscriminatorGANLoss` (:249-313)
+without APA / D-diffusion augmentation.
+lsgan predictions are NHWC logit maps whose channel 0 is valid (PatchGAN output padded to 8 channels); projected predictions are the
+concatenated logits [B, N] of the mini-discriminators (every element valid)."""
 from __future__ import annotations
 
 import torch.nn as nn
@@ -11,13 +14,17 @@ from .. import ops
 class GANLoss(nn.Module):
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
         super().__init__()
-        if gan_mode != "lsgan":
-            raise NotImplementedError(f"gan mode {gan_mode!r}: only 'lsgan' is built (vanilla / wgangp / projected are not)")
+        if gan_mode not in ("lsgan", "projected"):
+            raise NotImplementedError(f"gan mode {gan_mode!r}: 'lsgan' and 'projected' (hinge) are built (vanilla / wgangp are not)")
         self.gan_mode = gan_mode
         self.real_label, self.fake_label = float(target_real_label), float(target_fake_label)
 
     def __call__(self, prediction, target_is_real, relu=True):
-        """loss.py:59-71: nn.MSELoss()(prediction, label.expand_as(prediction))."""
+        """loss.py:59-85: lsgan: nn.MSELoss()(prediction, label.expand_as(prediction)); projected: hinge (`relu`) / -mean (generator)."""
+        if self.gan_mode == "projected":
+            from .projected_d import hinge_loss
+
+            return hinge_loss(prediction, target_is_real, relu)
         return ops.lsgan_loss(prediction, self.real_label if target_is_real else self.fake_label)
 
 

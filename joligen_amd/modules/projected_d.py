@@ -1,0 +1,392 @@
+"""Projected discriminator on the HIP ops: mirror of /root/reference/models/modules/projected_d/discriminator.py (`SingleDisc` :13-77,
+`MultiScaleD` :166-230, `ProjectedDiscriminator` :233-286), projector.py (`Proj` :490-589, `_make_scratch_ccm/_csm` :15-48,
+`_make_efficientnet` :51-59) and blocks.py (`conv2d` = spectral_norm(nn.Conv2d) :11-13, `NormLayer` :28-32, `DownBlock` :182-200,
+`FeatureFusionBlockMatrix` :248-287) for the convolutional ("efficientnet") variant, `proj_type` 2, `cout` 64, `expand` True.
+
+What is and is not here
+  * The frozen feature network's BACKBONE in the reference is a pretrained timm model (`tf_efficientnet_lite0`): neither timm nor its
+    weights are available offline, so the backbone is a STAND-IN with the same interface -- four stages at strides 4 / 8 / 16 / 32 with
+    tf_efficientnet_lite0's feature widths (24 / 40 / 112 / 320), built from `conv_stem`, `bn1`, `blocks[0:9]` exactly the way
+    `_make_efficientnet` slices a timm EfficientNet (`StandInEfficientNet` below; the same torch module, handed to the UNMODIFIED
+    reference through a stubbed `timm.create_model`, produced the fixtures).  Everything downstream of the backbone is the reference's
+    arithmetic: cross-channel mixing (1x1 convs), cross-scale mixing (add -> bilinear x2, align_corners -> 1x1 conv, top-down), the
+    four spectral-norm / GroupNorm / LeakyReLU mini-discriminators, the concatenated logits, and the hinge objective.
+  * state_dict() keys follow the reference (`freeze_feature_network.scratch.layer0_ccm.weight`,
+    `discriminator.mini_discs.0.main.0.main.0.weight_orig / weight_u / weight_v`, ...).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from .._lib import check
+from ..ops import JG_ACT_LRELU, _dt, _p, _st, conv_nt, wgrad_tn
+from .layers import JGConv2d, JGConvNd
+
+TF_EFFICIENTNET_LITE0_WIDTHS = (24, 40, 112, 320)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# small autograd nodes
+# ---------------------------------------------------------------------------------------------------------------------
+class _Bilinear2Fn(torch.autograd.Function):
+    """F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=align) on an NHWC map (up-sampling)."""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty((B, Ho, Wo, C), device=x.device, dtype=x.dtype)
+        check(_lib.lib().jg_bilinear2_fwd(_dt(x), x.data_ptr(), y.data_ptr(), B, H, W, C, Ho, Wo, C, int(align), _st()), "jg_bilinear2_fwd")
+        ctx.geo = (H, W, Ho, Wo, int(align))
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        H, W, Ho, Wo, align = ctx.geo
+        dy = dy.contiguous()
+        B, C = dy.shape[0], dy.shape[-1]
+        dx = torch.empty((B, H, W, C), device=dy.device, dtype=dy.dtype)
+        check(_lib.lib().jg_bilinear2_bwd(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, H, W, C, Ho, Wo, C, align, _st()), "jg_bilinear2_bwd")
+        return dx, None, None, None
+
+
+def bilinear(x, Ho, Wo, align_corners):
+    return _Bilinear2Fn.apply(x, Ho, Wo, align_corners)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpby(a.contiguous(), 1.0, b.contiguous(), 1.0)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class _HingeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, mode, scale):
+        pred = pred.contiguous()
+        loss = torch.zeros((), device=pred.device, dtype=torch.float32)
+        dpred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().jg_hinge_loss(_dt(pred), pred.data_ptr(), loss.data_ptr(), _p(dpred), pred.numel(), 1, 1, mode, scale, 1.0, _st()),
+              "jg_hinge_loss")
+        ctx.dpred = dpred
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        dpred, ctx.dpred = ctx.dpred, None
+        return ops.axpby(dpred, 1.0, None, 0.0, alpha_dev=g.reshape(1).float(), out=dpred), None, None
+
+
+def hinge_loss(pred, target_is_real, relu=True, scale=1.0):
+    """GANLoss("projected") (models/modules/loss.py:77-84) on a logits tensor whose every element is valid:
+    relu: mean relu(1 - p) (real) / mean relu(1 + p) (fake);  not relu (generator): mean(-p)."""
+    mode = (0 if target_is_real else 1) if relu else 2
+    return _HingeFn.apply(pred, mode, float(scale))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# spectral-norm convolution (blocks.py:11-13)
+# ---------------------------------------------------------------------------------------------------------------------
+class _SpectralConvFn(torch.autograd.Function):
+    """y = conv(x, W / sigma) + bias with torch.nn.utils.spectral_norm semantics: one power iteration per TRAINING forward (u, v
+    updated in place), sigma = u . W v; the gradient reaches W through 1 / sigma as well, with u and v held constant.
+    Every forward owns the 16-bit copies of ITS W / sigma (a discriminator runs twice per step -- real and fake -- before one
+    backward, each time with a new sigma)."""
+
+    @staticmethod
+    def forward(ctx, x, weight_orig, bias, mod):
+        L = _lib.lib()
+        m = mod.meta
+        x = x.contiguous()
+        B, H, W_, Cin = x.shape
+        assert Cin == m.Cin, (Cin, m.Cin)
+        dev = x.device
+        K = m.R * m.S * m.Cin_real
+        sigma = torch.empty(1, device=dev, dtype=torch.float32)
+        Wp = weight_orig.data_ptr()            # arena slice: physical [Cout][R][S][Cin] fp32
+        if mod.training:
+            ws = torch.empty(K + m.Cout_real + 2, device=dev, dtype=torch.float32)
+            check(L.jg_spectral_power_iter(Wp, mod.weight_u.data_ptr(), mod.weight_v.data_ptr(), sigma.data_ptr(), ws.data_ptr(), m.Cout_real,
+                                           m.R * m.S, m.Cin_real, 1e-12, _st()), "jg_spectral_power_iter")
+        else:       # eval: sigma from the stored vectors (torch.nn.utils.spectral_norm does not iterate in eval mode)
+            Wl = weight_orig.detach().reshape(m.Cout_real, -1)
+            sigma.copy_(torch.dot(mod.weight_u, Wl @ mod.weight_v).reshape(1))
+        w16 = torch.empty((m.Cout, m.R, m.S, m.Cin), device=dev, dtype=x.dtype)
+        w16T = torch.empty((m.Cin, m.R, m.S, m.Cout), device=dev, dtype=x.dtype) if ctx.needs_input_grad[0] else None
+        check(L.jg_spectral_weights(_dt(x), Wp, sigma.data_ptr(), w16.data_ptr(), _p(w16T), m.Cout_real, m.R * m.S, m.Cin_real, m.Cout, m.Cin,
+                                    _st()), "jg_spectral_weights")
+        Ho, Wo = m.out_hw(H, W_)
+        y = torch.empty((B, Ho, Wo, m.Cout), device=dev, dtype=x.dtype)
+        conv_nt(x, w16, y, B=B, H=H, W=W_, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo, ldx=Cin,
+                ldw=m.R * m.S * Cin, ldy=m.Cout, bias=m.bias_pad if m.bias_pad is not None else bias)
+        ctx.save_for_backward(x, w16T, sigma, mod.weight_u.clone(), mod.weight_v.clone())
+        ctx.mod = mod
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w16T, sigma, u, v = ctx.saved_tensors
+        mod = ctx.mod
+        m = mod.meta
+        L = _lib.lib()
+        dy = dy.contiguous()
+        B, H, W_, Cin = x.shape
+        _, Ho, Wo, Cout = dy.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            if m.stride != 1:     # stride-s input gradient = stride-1 convolution over the zero-dilated dy (ops.conv2d_dgrad)
+                Hd, Wd = H + 2 * m.pad - m.R + 1, W_ + 2 * m.pad - m.S + 1
+                dyd = ops.dilate2d(dy, Hd, Wd, m.stride)
+                conv_nt(dyd, w16T, dx, B=B, H=Hd, W=Wd, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W_,
+                        ldx=Cout, ldw=m.R * m.S * Cout, ldy=Cin)
+            else:
+                conv_nt(dy, w16T, dx, B=B, H=Ho, W=Wo, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W_,
+                        ldx=Cout, ldw=m.R * m.S * Cout, ldy=Cin)
+        if ctx.needs_input_grad[1]:
+            wg = mod.weight_orig.grad
+            if wg is None:
+                raise RuntimeError("spectral conv weight has no arena-backed .grad")
+            K = m.R * m.S * m.Cin_real
+            dwsn = torch.zeros((m.Cout_real, K), device=dy.device, dtype=torch.float32)
+            ktot = m.R * m.S * Cin
+            splitk = ops._wgrad_splitk(((Cout + 127) // 128) * ((ktot + 127) // 128), B * Ho * Wo)
+            wgrad_tn(dy, x, dwsn, B=B, H=H, W=W_, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo, lddy=Cout, ldx=Cin,
+                     lddw=K, dbias=mod.bias.grad if mod.bias is not None else None, Cin_out=m.Cin_real, Cout_out=m.Cout_real, splitk=splitk)
+            ws = torch.empty(1, device=dy.device, dtype=torch.float32)
+            check(L.jg_spectral_wgrad_fix(dwsn.data_ptr(), mod.weight_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), wg.data_ptr(),
+                                          ws.data_ptr(), m.Cout_real, m.R * m.S, m.Cin_real, _st()), "jg_spectral_wgrad_fix")
+        return dx, None, None, None
+
+
+class SpectralConv2d(nn.Module, JGConvNd):
+    """`spectral_norm(nn.Conv2d(...))` of blocks.py:11-13 with the state_dict layout of torch.nn.utils.spectral_norm: parameters
+    `bias`, `weight_orig`; buffers `weight_u` [Cout], `weight_v` [Cin * k * k]."""
+
+    jg_wname = "weight_orig"
+
+    def __init__(self, cin, cout, k, stride, padding, bias=True):
+        super().__init__()
+        ref = nn.Conv2d(cin, cout, k, stride, padding, bias=bias)          # the reference's default initialisation
+        if bias:
+            self.bias = nn.Parameter(ref.bias.detach().clone())
+        else:
+            self.register_parameter("bias", None)
+        self.weight_orig = nn.Parameter(ref.weight.detach().clone())
+        u = nn.functional.normalize(torch.randn(cout), dim=0, eps=1e-12)
+        v = nn.functional.normalize(torch.randn(cin * k * k), dim=0, eps=1e-12)
+        self.register_buffer("weight_u", u)
+        self.register_buffer("weight_v", v)
+        self.needs_dgrad = True
+        self.jg_padding, self.jg_stride = padding, stride
+
+    def forward(self, x):
+        if self.meta is None:
+            raise RuntimeError("SpectralConv2d used before ParamArena finalisation")
+        return _SpectralConvFn.apply(x, self.weight_orig, self.bias, self)
+
+
+class DownBlock(nn.Module):
+    """blocks.py:182-200 (not separable): spectral conv 4x4 s2 p1 -> GroupNorm(c // 2, c) -> LeakyReLU(0.2)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.main = nn.Sequential(SpectralConv2d(cin, cout, 4, 2, 1), nn.GroupNorm(cout // 2, cout), nn.LeakyReLU(0.2, inplace=True))
+
+    def forward(self, x):
+        conv, gn = self.main[0], self.main[1]
+        return ops.group_norm(conv(x), gn.num_groups, gn.weight, gn.bias, None, JG_ACT_LRELU, gn.eps)
+
+
+CHANNEL_DICT = {4: 512, 8: 512, 16: 256, 32: 128, 64: 64, 128: 64, 256: 32, 512: 16, 1024: 8}
+
+
+class SingleDisc(nn.Module):
+    """discriminator.py:13-77 (head None, not separable, not patch)."""
+
+    def __init__(self, nc, start_sz=256, end_sz=8):
+        super().__init__()
+        nfc = dict(CHANNEL_DICT)
+        if start_sz not in nfc:          # sizes that are not powers of two: the closest entry (:36-39)
+            start_sz = min(nfc, key=lambda s: abs(s - start_sz))
+        self.start_sz = start_sz
+        nfc[start_sz] = nc
+        layers = []
+        while start_sz > end_sz:
+            layers.append(DownBlock(nfc[start_sz], nfc[start_sz // 2]))
+            start_sz //= 2
+        layers.append(SpectralConv2d(nfc[end_sz], 1, 4, 1, 0, bias=False))
+        self.main = nn.Sequential(*layers)
+
+    def forward(self, x):
+        for layer in self.main:
+            x = layer(x)
+        return x                          # [B, h, w, 8] logits, channel 0 valid
+
+
+class MultiScaleD(nn.Module):
+    """discriminator.py:166-230 (conv = True, 4 discriminators, no conditioning): logits of the mini-discriminators flattened and
+    concatenated, [B, sum h_i w_i]."""
+
+    def __init__(self, channels, resolutions, num_discs=4):
+        super().__init__()
+        self.mini_discs = nn.ModuleDict({str(i): SingleDisc(nc=c, start_sz=r, end_sz=8)
+                                         for i, (c, r) in enumerate(zip(channels[:num_discs], resolutions[:num_discs]))})
+
+    def forward(self, features):
+        outs = []
+        for k, disc in self.mini_discs.items():
+            lg = disc(features[k])
+            outs.append(lg[..., 0].reshape(lg.shape[0], -1))
+        return torch.cat(outs, dim=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# frozen feature network
+# ---------------------------------------------------------------------------------------------------------------------
+class StandInEfficientNet(nn.Module):
+    """torch stand-in for timm's `tf_efficientnet_lite0` with the attributes `_make_efficientnet` (projector.py:51-59) slices:
+    conv_stem, bn1, blocks[0:2] -> stride 4 / 24 ch; blocks[2:3] -> stride 8 / 40; blocks[3:5] -> stride 16 / 112; blocks[5:9] ->
+    stride 32 / 320.  Used AS IS (torch, CPU) by oracle/make_golden_projd.py to drive the unmodified reference."""
+
+    def __init__(self):
+        super().__init__()
+        w = TF_EFFICIENTNET_LITE0_WIDTHS
+
+        def stage(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, 4, 2, 1), nn.LeakyReLU(0.2))
+
+        self.conv_stem = nn.Conv2d(3, 16, 4, 2, 1)
+        self.bn1 = nn.LeakyReLU(0.2)
+        self.blocks = nn.Sequential(nn.Identity(), stage(16, w[0]), stage(w[0], w[1]), nn.Identity(), stage(w[1], w[2]), nn.Identity(),
+                                    nn.Identity(), nn.Identity(), stage(w[2], w[3]))
+
+
+class _Stage(nn.Module):
+    """one `pretrained.layer<i>` Sequential of the stand-in on the HIP ops (same child indices as the reference's slices)"""
+
+    def __init__(self, items):
+        super().__init__()
+        for i, it in enumerate(items):
+            self.add_module(str(i), it)
+
+    def forward(self, x):
+        for mod in self.children():
+            x = _run_plain(mod, x)
+        return x
+
+
+def _run_plain(mod, x):
+    if isinstance(mod, JGConv2d):
+        return mod(x)
+    if isinstance(mod, nn.LeakyReLU):
+        return ops.activation(x, JG_ACT_LRELU)
+    if isinstance(mod, nn.Identity):
+        return x
+    if isinstance(mod, (nn.Sequential, _Stage)):
+        for sub in mod.children():
+            x = _run_plain(sub, x)
+        return x
+    raise NotImplementedError(type(mod))
+
+
+def _hip_stage(cin, cout):
+    return nn.Sequential(JGConv2d(cin, cout, 4, padding=1, stride=2), nn.LeakyReLU(0.2))
+
+
+class FeatureFusionBlockMatrix(nn.Module):
+    """blocks.py:248-287: (x0 [+ x1]) -> bilinear x2 (align_corners=True) -> 1x1 conv to features // 2 when `expand`."""
+
+    def __init__(self, features, expand=False):
+        super().__init__()
+        self.out_conv = JGConv2d(features, features // 2 if expand else features, 1)
+
+    def forward(self, *xs):
+        out = xs[0] if len(xs) == 1 else _AddFn.apply(xs[0], xs[1])
+        out = bilinear(out, 2 * out.shape[1], 2 * out.shape[2], True)
+        return self.out_conv(out)
+
+
+class Proj(nn.Module):
+    """projector.py:490-589 with proj_type 2: frozen backbone -> CCM (1x1 convs to cout * (1, 2, 4, 8)) -> CSM (top-down fusion)."""
+
+    def __init__(self, cout=64, expand=True, interp=256):
+        super().__init__()
+        w = TF_EFFICIENTNET_LITE0_WIDTHS
+        pre = nn.Module()
+        pre.layer0 = _Stage([JGConv2d(3, 16, 4, padding=1, stride=2), nn.LeakyReLU(0.2), nn.Identity(), _hip_stage(16, w[0])])
+        pre.layer1 = _Stage([_hip_stage(w[0], w[1])])
+        pre.layer2 = _Stage([nn.Identity(), _hip_stage(w[1], w[2])])
+        pre.layer3 = _Stage([nn.Identity(), nn.Identity(), nn.Identity(), _hip_stage(w[2], w[3])])
+        self.pretrained = pre
+        ccm = [cout, cout * 2, cout * 4, cout * 8] if expand else [cout] * 4
+        sc = nn.Module()
+        for i in range(4):
+            setattr(sc, f"layer{i}_ccm", JGConv2d(w[i], ccm[i], 1))
+        sc.layer3_csm = FeatureFusionBlockMatrix(ccm[3], expand=expand)
+        sc.layer2_csm = FeatureFusionBlockMatrix(ccm[2], expand=expand)
+        sc.layer1_csm = FeatureFusionBlockMatrix(ccm[1], expand=expand)
+        sc.layer0_csm = FeatureFusionBlockMatrix(ccm[0])
+        self.scratch = sc
+        self.CHANNELS = [cout, cout, cout * 2, cout * 4] if expand else [cout] * 4
+        self.RESOLUTIONS = [2 * (interp // s) for s in (4, 8, 16, 32)]       # the CSM doubles every map (projector.py:484-486)
+
+    def forward(self, x):
+        p, s = self.pretrained, self.scratch
+        o0 = p.layer0(x)
+        o1 = p.layer1(o0)
+        o2 = p.layer2(o1)
+        o3 = p.layer3(o2)
+        c0, c1, c2, c3 = s.layer0_ccm(o0), s.layer1_ccm(o1), s.layer2_ccm(o2), s.layer3_ccm(o3)
+        m3 = s.layer3_csm(c3)
+        m2 = s.layer2_csm(m3, c2)
+        m1 = s.layer1_csm(m2, c1)
+        m0 = s.layer0_csm(m1, c0)
+        return {"0": m0, "1": m1, "2": m2, "3": m3}
+
+
+class ProjectedDiscriminator(nn.Module):
+    """discriminator.py:233-286.  forward(x: [B, S, S, 8] 16-bit NHWC image, 3 valid channels) -> logits [B, N]."""
+
+    def __init__(self, projector_model="efficientnet", interp=-1, img_size=256, cout=64, expand=True):
+        super().__init__()
+        if projector_model != "efficientnet":
+            raise NotImplementedError(f"D_proj_network_type={projector_model!r}: the convolutional ('efficientnet') projector is built; the "
+                                      "ViT / CLIP / DINOv2 / SegFormer feature networks need pretrained weights that are not available offline")
+        self.interp = interp
+        size = interp if interp > 0 else img_size
+        self.freeze_feature_network = Proj(cout=cout, expand=expand, interp=size)
+        self.freeze_feature_network.requires_grad_(False)
+        self.discriminator = MultiScaleD(self.freeze_feature_network.CHANNELS, self.freeze_feature_network.RESOLUTIONS)
+        self.arena = None
+
+    def train(self, mode=True):
+        self.freeze_feature_network.train(False)
+        self.discriminator.train(mode)
+        self.training = mode
+        return self
+
+    def jg_finalize(self, device, act_dtype):
+        from ..arena import ParamArena
+
+        if self.arena is None:
+            self.act_dtype = act_dtype
+            self.arena = ParamArena(self, device, act_dtype, priority=())
+        return self.arena
+
+    def forward(self, x):
+        if self.arena is not None:
+            self.arena.ensure_fresh()
+        if self.interp > 0 and (x.shape[1] != self.interp or x.shape[2] != self.interp):
+            x = bilinear(x, self.interp, self.interp, False)
+        feats = self.freeze_feature_network(x)
+        return self.discriminator(feats)

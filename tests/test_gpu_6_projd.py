@@ -1,0 +1,251 @@
+"""GPU parity tests of the projected discriminator: spectral-norm convolution, bilinear (align_corners) resize,
+hinge objective, and the whole ProjectedDiscriminator (stand-in backbone -> CCM -> CSM -> four mini-discriminators) against the fixture
+recorded from the unmodified reference (oracle/make_golden_projd.py) and against the CPU oracle."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import jg_oracle as O
+from test_oracle_golden import projd_run_oracle, projd_state
+
+pytestmark = pytest.mark.gpu
+D0 = "cuda:0"
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("align", [True, False])
+def test_bilinear_align_corners(dtype, align):
+    from joligen_amd.modules.projected_d import bilinear
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 24, 7, 9, generator=g).to(dtype)
+    gy = torch.randn(2, 24, 14, 18, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    yr = F.interpolate(xr, size=(14, 18), mode="bilinear", align_corners=align)
+    yr.backward(gy.float())
+    xd = x.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True)
+    y = bilinear(xd, 14, 18, align)
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(D0))
+    assert relerr(y.permute(0, 3, 1, 2), yr.detach()) < TOL[dtype]
+    assert relerr(xd.grad.permute(0, 3, 1, 2), xr.grad) < 2 * TOL[dtype], relerr(xd.grad.permute(0, 3, 1, 2), xr.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_hinge_loss(dtype):
+    from joligen_amd.modules.projected_d import hinge_loss
+
+    g = torch.Generator().manual_seed(2)
+    p = (torch.randn(3, 100, generator=g) * 1.5).to(dtype)
+    for real, relu in ((True, True), (False, True), (True, False)):
+        pr = p.float().requires_grad_(True)
+        lo = O.hinge_loss(pr, real, relu)
+        (lo * 3.0).backward()
+        pd = p.to(D0).requires_grad_(True)
+        l = hinge_loss(pd, real, relu)
+        (l * 3.0).backward()
+        assert abs(float(l) - float(lo)) < 1e-5 * abs(float(lo)) + 1e-6
+        assert relerr(pd.grad, pr.grad) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,stride,pad,bias", [(64, 128, 4, 2, 1, True), (256, 1, 4, 1, 0, False)])
+def test_spectral_conv_vs_torch(cin, cout, k, stride, pad, bias, dtype):
+    """spectral_norm(nn.Conv2d) of blocks.py:11-13: two training forwards (two power iterations, each with its own sigma) followed by
+    one backward through both -- output, input gradient, gradient w.r.t. weight_orig (through 1 / sigma) and bias, and the updated
+    u / v, against torch.nn.utils.spectral_norm on the rounded inputs."""
+    import torch.nn as nn
+
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.modules.projected_d import SpectralConv2d
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = SpectralConv2d(cin, cout, k, stride, pad, bias=bias)
+
+    torch.manual_seed(3)
+    m = M()
+    ref = torch.nn.utils.spectral_norm(nn.Conv2d(cin, cout, k, stride, pad, bias=bias))
+    with torch.no_grad():
+        ref.weight_orig.copy_(m.c.weight_orig.to(dtype).float())
+        m.c.weight_orig.copy_(ref.weight_orig)
+        ref.weight_u.copy_(m.c.weight_u)
+        ref.weight_v.copy_(m.c.weight_v)
+        if bias:
+            ref.bias.copy_(m.c.bias)
+    ParamArena(m, D0, dtype, priority=()).refresh()
+    m.train()
+    ref.train()
+    g = torch.Generator().manual_seed(4)
+    S = 16
+    xs = [torch.randn(2, cin, S, S, generator=g).to(dtype) for _ in range(2)]
+    outs, outs_r, xds, xrs = [], [], [], []
+    for x in xs:
+        xd = x.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True)
+        xr = x.float().requires_grad_(True)
+        outs.append(m.c(xd))
+        outs_r.append(ref(xr))
+        xds.append(xd)
+        xrs.append(xr)
+    gys = [torch.randn(outs_r[0].shape, generator=g).to(dtype) for _ in range(2)]
+    sum((o * gy.float()).sum() for o, gy in zip(outs_r, gys)).backward()
+    cp = outs[0].shape[-1]
+    for o, gy in zip(outs, gys):
+        gyp = torch.zeros(gy.shape[0], gy.shape[2], gy.shape[3], cp, dtype=dtype)
+        gyp[..., :cout] = gy.permute(0, 2, 3, 1)
+        o.backward(gyp.to(D0))
+    torch.cuda.synchronize()
+    for o, orf in zip(outs, outs_r):
+        assert relerr(o.permute(0, 3, 1, 2)[:, :cout], orf.detach()) < TOL[dtype]
+    for xd, xr in zip(xds, xrs):
+        assert relerr(xd.grad.permute(0, 3, 1, 2), xr.grad) < 2 * TOL[dtype], relerr(xd.grad.permute(0, 3, 1, 2), xr.grad)
+    assert relerr(m.c.weight_orig.grad, ref.weight_orig.grad) < 2 * TOL[dtype], relerr(m.c.weight_orig.grad, ref.weight_orig.grad)
+    if bias:
+        assert relerr(m.c.bias.grad, ref.bias.grad) < 2 * TOL[dtype]
+    assert relerr(m.c.weight_u, ref.weight_u) < 1e-5 and relerr(m.c.weight_v, ref.weight_v) < 1e-5
+
+
+def build_projd(g, dtype, seed=5):
+    from joligen_amd.modules.projected_d import ProjectedDiscriminator
+
+    c = g["cfg"]
+    net = ProjectedDiscriminator("efficientnet", interp=c["interp"], img_size=c["S"])
+    assert list(net.state_dict().keys()) == g["keys"]
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(g["shapes"][k]), k
+    net.load_state_dict(projd_state(g, seed))
+    net.jg_finalize(torch.device(D0), dtype)
+    net.train()
+    return net
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_projected_discriminator_vs_reference_golden(golden_dir, dtype):
+    """The fixture's sequence on HIP: D(real), D(fake) (training forwards: spectral-norm power iterations), the hinge discriminator
+    loss and the gradient of all 44 trainable tensors, then the generator-side loss and its gradient w.r.t. the fake image through the
+    frozen feature network (stand-in backbone, CCM, CSM).  state_dict keys / shapes are the reference's."""
+    from joligen_amd import ops
+    from joligen_amd.modules.projected_d import hinge_loss
+
+    g = load(golden_dir, "projd.pt")
+    net = build_projd(g, dtype)
+    for n, p in net.named_parameters():
+        p.requires_grad_(not n.startswith("freeze"))
+    real = ops.to_nhwc(g["real"].to(D0), dtype, 8)
+    fake = ops.to_nhwc(g["fake"].to(D0), dtype, 8)
+    pred_real = net(real)
+    pred_fake = net(fake)
+    assert tuple(pred_real.shape) == tuple(g["pred_real"].shape)
+    tol = 6e-3 if dtype == torch.float16 else 4e-2
+    assert relerr(pred_real, g["pred_real"]) < tol, relerr(pred_real, g["pred_real"])
+    loss_D = (hinge_loss(pred_real, True) + hinge_loss(pred_fake, False)) * 0.5
+    assert abs(float(loss_D) - float(g["loss_D"])) < tol * abs(float(g["loss_D"]))
+    net.arena.g.zero_()
+    loss_D.backward()
+    torch.cuda.synchronize()
+    bad = []
+    P = dict(net.named_parameters())
+    for k, ref in g["grad_checks"].items():
+        v = P[k].grad.detach().float().cpu()
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        t = 4 * tol * float(ref[0]) + 1e-7
+        if abs(float(mine[0] - ref[0])) > t or abs(float(mine[1] - ref[1])) > 2 * t * max(1.0, v.numel() ** 0.5 / 4):
+            bad.append((k, mine.tolist(), ref.tolist()))
+    assert not bad, bad[:6]
+    sd = net.state_dict()
+    for k, ref in g["uv_mid"].items():
+        v = sd[k].float().cpu()
+        assert abs(float(v.norm()) - float(ref[0])) < 1e-4 and abs(float((v * O.projection_vector(k, v.shape)).sum()) - float(ref[1])) < 5e-3, k
+    # generator side: gradient to the image through the frozen feature network (no parameter gradient is produced there)
+    fk = ops.to_nhwc(g["fake"].to(D0), dtype, 8).requires_grad_(True)
+    loss_G = hinge_loss(net(fk), True, relu=False)
+    assert abs(float(loss_G) - float(g["loss_G"])) < tol * abs(float(g["loss_G"])) + 2e-3
+    loss_G.backward()
+    dfk = fk.grad.permute(0, 3, 1, 2)[:, :3].float()
+    assert relerr(dfk, g["dfake"]) < (0.05 if dtype == torch.float16 else 0.2), relerr(dfk, g["dfake"])
+    for n, p in net.named_parameters():
+        if n.startswith("freeze"):
+            assert not p.requires_grad
+
+
+def test_projected_discriminator_first_step_vs_oracle(golden_dir):
+    """per-parameter gradients (not just checksums) of the discriminator loss against the CPU oracle on fp16-representable weights"""
+    from joligen_amd import ops
+    from joligen_amd.modules.projected_d import hinge_loss
+
+    dtype = torch.float16
+    g = load(golden_dir, "projd.pt")
+    g = dict(g, real=g["real"].half().float(), fake=g["fake"].half().float())
+    P0 = {k: (v.half().float() if (torch.is_floating_point(v) and not k.endswith(("weight_u", "weight_v"))) else v) for k, v in projd_state(g).items()}
+    from joligen_amd.modules.projected_d import ProjectedDiscriminator
+
+    net = ProjectedDiscriminator("efficientnet", interp=g["cfg"]["interp"], img_size=g["cfg"]["S"])
+    net.load_state_dict(P0)
+    net.jg_finalize(torch.device(D0), dtype)
+    net.train()
+    for n, p in net.named_parameters():
+        p.requires_grad_(not n.startswith("freeze"))
+    r = projd_run_oracle({k: v.clone() for k, v in P0.items()}, g)
+    real, fake = ops.to_nhwc(g["real"].to(D0), dtype, 8), ops.to_nhwc(g["fake"].to(D0), dtype, 8)
+    loss_D = (hinge_loss(net(real), True) + hinge_loss(net(fake), False)) * 0.5
+    net.arena.g.zero_()
+    loss_D.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss_D) - float(r["loss_D"])) < 6e-3 * abs(float(r["loss_D"]))
+    errs = []
+    for k, p in net.named_parameters():
+        if k in r["grads"]:
+            errs.append((relerr(p.grad, r["grads"][k]), k))
+    errs.sort(reverse=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_table_projd.txt", "w") as f:
+        f.write("\n".join(f"{e:10.3e} {k}" for e, k in errs))
+    assert errs[0][0] < 0.1, errs[:6]
+    assert errs[len(errs) // 2][0] < 0.03, errs[len(errs) // 2]
+
+
+def test_cut_model_with_projected_and_basic_discriminators():
+    """BASELINE configs[2]'s discriminator set through the model API (D_netDs = [projected_d, basic], the example_gan_*.json choice):
+    the step runs, every loss the reference logs exists and is finite, the projected discriminator trains with the hinge objective,
+    its frozen feature network does not move, both discriminators and the generator do."""
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    cfg = {"model_type": "cut", "G": {"netG": "resnet", "ngf": 32, "nblocks": 2}, "D": {"netDs": ["projected_d", "basic"], "ndf": 32, "proj_interp": 128},
+           "data": {"crop_size": 64, "load_size": 64}, "train": {"batch_size": 2, "G_ema": True}}
+    model = create_model(opt_from_json(cfg, overrides={"jg_act_dtype": "bf16", "gpu_ids": "0"}), 0)
+    g = torch.Generator().manual_seed(2)
+    data = {"A": torch.rand(2, 3, 64, 64, generator=g) * 2 - 1, "B": torch.rand(2, 3, 64, 64, generator=g) * 2 - 1}
+    torch.manual_seed(0)
+    model.data_dependent_initialize(data)
+    assert model.discriminators_names == ["D_B_projected_d", "D_B_basic"]
+    assert model.D_B_projected_d_loss_calculator.gan_mode == "projected" and model.D_B_basic_loss_calculator.gan_mode == "lsgan"
+    before = {n: {k: p.detach().clone() for k, p in getattr(model, "net" + n).named_parameters()} for n in ("G_A", "D_B_projected_d", "D_B_basic")}
+    for _ in range(2):
+        model.set_input(data)
+        model.optimize_parameters()
+    torch.cuda.synchronize()
+    losses = {k: float(v) for k, v in model.get_current_losses().items()}
+    assert set(losses) == {"G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_projected_d", "G_GAN_D_B_basic", "D_tot", "D_GAN_D_B_projected_d", "D_GAN_D_B_basic"}
+    assert all(math.isfinite(v) for v in losses.values()), losses
+    assert abs(losses["D_tot"] - losses["D_GAN_D_B_projected_d"] - losses["D_GAN_D_B_basic"]) < 1e-3 * abs(losses["D_tot"]) + 1e-4
+    for n, params in before.items():
+        cur = dict(getattr(model, "net" + n).named_parameters())
+        moved = [k for k, p0 in params.items() if not torch.equal(cur[k].detach(), p0)]
+        frozen = [k for k in params if k.startswith("freeze")]
+        assert all(k not in moved for k in frozen), [k for k in frozen if k in moved][:3]
+        assert len(moved) >= 0.8 * (len(params) - len(frozen)), (n, len(moved), len(params))

@@ -414,3 +414,49 @@ def test_segformer_generator(golden_dir, name):
         sd_eval.update({k: v for k, v in g["bn_after"].items()})
         out_eval, _ = O.segformer_generator_attn(sd_eval, g["x"], rand=None)
         torch.testing.assert_close(out_eval, g["out_eval"], rtol=1e-4, atol=1e-5)
+
+
+# ---- projected discriminator (a21 / a24): oracle/make_golden_projd.py fixture ---------------------------------------------------------
+def projd_state(g, seed=5):
+    return O.synth_state_dict({k: torch.empty(g["shapes"][k]) for k in g["keys"]}, seed=seed)
+
+
+def projd_run_oracle(P, g):
+    """the fixture's sequence: loss_D = (hinge(D(real), real) + hinge(D(fake), fake)) / 2 with its parameter gradients, then the
+    generator-side loss -mean(D(fake)) with its gradient to the image; three training forwards = three power iterations"""
+    train = [k for k in P if k.startswith("discriminator.") and not (k.endswith("weight_u") or k.endswith("weight_v"))]
+    for k in train:
+        P[k] = P[k].clone().requires_grad_(True)
+    interp = g["cfg"]["interp"]
+    pred_real = O.projected_discriminator(P, g["real"], interp)
+    pred_fake = O.projected_discriminator(P, g["fake"], interp)
+    loss_D = (O.hinge_loss(pred_real, True) + O.hinge_loss(pred_fake, False)) * 0.5
+    grads = dict(zip(train, torch.autograd.grad(loss_D, [P[k] for k in train])))
+    uv_mid = {k: v.clone() for k, v in P.items() if k.endswith("weight_u") or k.endswith("weight_v")}
+    fk = g["fake"].clone().requires_grad_(True)
+    loss_G = O.hinge_loss(O.projected_discriminator(P, fk, interp), True, relu=False)
+    (dfake,) = torch.autograd.grad(loss_G, fk)
+    uv_after = {k: v.clone() for k, v in P.items() if k.endswith("weight_u") or k.endswith("weight_v")}
+    return dict(pred_real=pred_real.detach(), loss_D=loss_D.detach(), grads=grads, uv_mid=uv_mid, loss_G=loss_G.detach(), dfake=dfake,
+                uv_after=uv_after)
+
+
+def test_projected_discriminator(golden_dir):
+    """the CPU restatement of Proj (CCM / CSM), MultiScaleD / SingleDisc / DownBlock with spectral norm, and the hinge losses against
+    the unmodified reference run over the stand-in backbone"""
+    g = load(golden_dir, "projd.pt")
+    r = projd_run_oracle(projd_state(g), g)
+    torch.testing.assert_close(r["pred_real"], g["pred_real"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(r["loss_D"], g["loss_D"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(r["loss_G"], g["loss_G"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(r["dfake"], g["dfake"], rtol=1e-3, atol=1e-7)
+    assert set(r["grads"]) == set(g["grad_checks"])
+    for k, ref in g["grad_checks"].items():
+        v = r["grads"][k]
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        torch.testing.assert_close(mine, ref, rtol=2e-4, atol=2e-4 * float(ref[0]) + 1e-7, msg=k)
+    for name in ("uv_mid", "uv_after"):
+        for k, ref in g[name].items():
+            v = r[name][k]
+            mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+            torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-5, msg=(name, k))
