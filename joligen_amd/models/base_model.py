@@ -393,7 +393,9 @@ class BaseModel:
             state_dict = torch.load(path, map_location="cpu")
             if hasattr(state_dict, "_metadata"):
                 del state_dict._metadata
-            self._net(name).load_state_dict(state_dict, strict=not getattr(self.opt, "model_load_no_strictness", False))
+            # :1098-1103: the reference passes `strict=self.opt.model_load_no_strictness` (non-strict unless the flag is set -- the
+            # flag's name says the opposite, the call is what reference checkpoints rely on)
+            self._net(name).load_state_dict(state_dict, strict=bool(getattr(self.opt, "model_load_no_strictness", False)))
 
 
 class _EmaView:

@@ -73,6 +73,13 @@ class CUTModel(BaseModel):
                 raise NotImplementedError(f"{flag} is outside the SURVEY.md 8 hot path")
         if opt.alg_cut_lambda_SRC > 0 or [s for s in opt.alg_cut_supervised_loss if s] or opt.dataaug_D_noise > 0:
             raise NotImplementedError("SRC / supervised / noisy-D terms are outside the built path")
+        # options that select ANOTHER network than the one built here must not be dropped silently: the generator /
+        # PatchGAN below are the InstanceNorm, no-dropout, no-spectral-norm variants of gan_networks.define_G / define_D
+        for name, built in (("G_dropout", False), ("D_dropout", False), ("D_spectral", False), ("G_spectral", False),
+                            ("G_norm", "instance"), ("D_norm", "instance")):
+            val = getattr(opt, name, built)
+            if val != built and not (name.endswith("_norm") and "segformer" in opt.G_netG and name == "G_norm"):
+                raise NotImplementedError(f"{name}={val!r}: only {built!r} is built for the CUT networks")
         self.nce_layers = [int(i) for i in str(opt.alg_cut_nce_layers).split(",")]
         if "segformer" in opt.G_netG:            # gan_networks.py:177-187
             from ..modules.segformer import SegformerGenerator_attn

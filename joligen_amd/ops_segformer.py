@@ -179,6 +179,28 @@ def resize_concat(xs, Ho, Wo):
 
 
 # ---- BatchNorm2d (+ ReLU) on the GroupNorm kernels ---------------------------------------------------------------------------------------
+# Multi-GPU: the reference converts every BatchNorm to SyncBatchNorm before wrapping the network in DDP (models/base_model.py:725-737):
+# the batch statistics -- and the two reductions of the backward -- are taken over the GLOBAL batch.  Here the per-(image, channel)
+# sums of the local batch are reduced over the images, all-reduced (one [C, 2] message per BatchNorm and direction) and fed to the
+# same coefficient kernels as "one image of world * B * HW pixels".  FORCE_SYNC_BN runs that path with a single rank (tests).
+FORCE_SYNC_BN = False
+
+
+def _sync_active(training):
+    from . import parallel
+
+    return training and (parallel.world_size() > 1 or FORCE_SYNC_BN)
+
+
+def _all_reduce_sum(t):
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return dist.get_world_size()
+    return 1
+
+
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
@@ -191,22 +213,32 @@ class _BatchNormFn(torch.autograd.Function):
         ab = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
         mr = torch.empty((C, 2), device=dev, dtype=torch.float32)
         sums = None
+        sync = _sync_active(training)
+        world = 1
         if training:
             sums = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
             check(L.jg_gn_stats(dt, x.data_ptr(), sums.data_ptr(), B, HW, C, st), "jg_gn_stats")
-        check(L.jg_bn_coef(_p(sums), weight.data_ptr(), bias.data_ptr(), _p(running_mean), _p(running_var), ab.data_ptr(), mr.data_ptr(), B, HW, C,
-                           eps, momentum, int(training), st), "jg_bn_coef")
+        if sync:
+            tot = sums.sum(0, keepdim=True).contiguous()         # [1, C, 2]: the local batch as one "image"
+            world = _all_reduce_sum(tot)
+            ab1 = torch.empty((1, C, 2), device=dev, dtype=torch.float32)
+            check(L.jg_bn_coef(tot.data_ptr(), weight.data_ptr(), bias.data_ptr(), _p(running_mean), _p(running_var), ab1.data_ptr(), mr.data_ptr(), 1,
+                               world * B * HW, C, eps, momentum, 1, st), "jg_bn_coef")
+            ab.copy_(ab1.expand(B, C, 2))
+        else:
+            check(L.jg_bn_coef(_p(sums), weight.data_ptr(), bias.data_ptr(), _p(running_mean), _p(running_var), ab.data_ptr(), mr.data_ptr(), B, HW, C,
+                               eps, momentum, int(training), st), "jg_bn_coef")
         y = torch.empty_like(x)
         check(L.jg_gn_apply(dt, x.data_ptr(), ab.data_ptr(), y.data_ptr(), B, HW, C, act, st), "jg_gn_apply")
         ctx.save_for_backward(x, ab, mr, weight)
-        ctx.cfg = (training, act, weight.grad, bias.grad)
+        ctx.cfg = (training, act, weight.grad, bias.grad, sync, world)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, ab, mr, weight = ctx.saved_tensors
-        training, act, gw, gb = ctx.cfg
+        training, act, gw, gb, sync, world = ctx.cfg
         L = _lib.lib()
         dy = dy.contiguous()
         B, C = x.shape[0], x.shape[-1]
@@ -218,8 +250,22 @@ class _BatchNormFn(torch.autograd.Function):
         if want_p and (gw is None or gb is None):
             raise RuntimeError("BatchNorm parameters have no arena-backed .grad")
         check(L.jg_gn_bwd_reduce(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), red.data_ptr(), B, HW, C, act, st), "jg_gn_bwd_reduce")
-        check(L.jg_bn_bwd_coef(red.data_ptr(), weight.data_ptr(), mr.data_ptr(), pqr.data_ptr(), _p(gw) if want_p else None, _p(gb) if want_p else None,
-                               B, HW, C, int(training), st), "jg_bn_bwd_coef")
+        if sync:
+            # dgamma / dbeta: the LOCAL reductions (the data-parallel gradient exchange averages them over the ranks like every other
+            # parameter gradient); dx: the reductions of the GLOBAL batch
+            if want_p:
+                scratch = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
+                check(L.jg_bn_bwd_coef(red.data_ptr(), weight.data_ptr(), mr.data_ptr(), scratch.data_ptr(), _p(gw), _p(gb), B, HW, C, 1, st),
+                      "jg_bn_bwd_coef")
+            tot = red.sum(0, keepdim=True).contiguous()
+            _all_reduce_sum(tot)
+            pqr1 = torch.empty((1, C, 3), device=dev, dtype=torch.float32)
+            check(L.jg_bn_bwd_coef(tot.data_ptr(), weight.data_ptr(), mr.data_ptr(), pqr1.data_ptr(), None, None, 1, world * B * HW, C, 1, st),
+                  "jg_bn_bwd_coef")
+            pqr.copy_(pqr1.expand(B, C, 3))
+        else:
+            check(L.jg_bn_bwd_coef(red.data_ptr(), weight.data_ptr(), mr.data_ptr(), pqr.data_ptr(), _p(gw) if want_p else None,
+                                   _p(gb) if want_p else None, B, HW, C, int(training), st), "jg_bn_bwd_coef")
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -229,7 +275,8 @@ class _BatchNormFn(torch.autograd.Function):
 
 def batch_norm(x, bn, act=JG_ACT_NONE):
     """nn.BatchNorm2d `bn` (affine, running statistics) followed by an optional fused activation; train mode uses the batch statistics
-    and updates the running ones in place (momentum 0.1, unbiased variance), like the reference."""
+    (of the global batch when several ranks train: SyncBatchNorm semantics) and updates the running ones in place (momentum 0.1,
+    unbiased variance), like the reference."""
     training = bn.training
     if training and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1

@@ -159,10 +159,16 @@ def allreduce_and_step(arena, hp, grad_scale, n_chunks=4):
 
 
 def broadcast_params(arena, src=0):
-    """DDP's constructor broadcast: every rank starts from rank `src`'s parameters."""
+    """DDP's constructor broadcast: every rank starts from rank `src`'s parameters AND buffers (BatchNorm running statistics,
+    spectral-norm vectors, noise schedules: `_sync_module_states` covers both in DistributedDataParallel)."""
     if world_size() > 1:
         dist.broadcast(arena.p, src)
         arena.dirty = True
+        module = getattr(arena, "module", None)
+        if module is not None:
+            for b in module.buffers():
+                if b is not None and b.numel() > 0:
+                    dist.broadcast(b, src)
 
 
 def reduce_losses(losses):

@@ -210,3 +210,38 @@ def test_segformer_generator_vs_reference_golden(golden_dir, name, dtype):
     with torch.no_grad():
         oe = net(x.detach())
     assert relerr(oe.permute(0, 3, 1, 2)[:, :3], g["out_eval"]) < 3 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_sync_batchnorm_path_matches_local_path(dtype):
+    """under data parallelism the reference's BatchNorm layers are SyncBatchNorm (base_model.py:725-737).  The synchronised
+    path (local sums -> [C, 2] all-reduce -> coefficient kernels over "one image of world * B * HW pixels"; local dgamma / dbeta, global
+    dx reductions) run with a single rank must reproduce the plain path: output, input gradient, affine gradients, running statistics."""
+    import torch.nn as nn
+
+    from joligen_amd import ops_segformer as S
+    from joligen_amd.ops import JG_ACT_RELU
+
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(8)
+    x = (torch.randn(3, 12, 10, 64, generator=g) * 1.5 + 0.3).to(dtype)
+    gy = torch.randn(3, 12, 10, 64, generator=g).to(dtype)
+    res = {}
+    for sync in (False, True):
+        bn = nn.BatchNorm2d(64).to(d)
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.1 * torch.randn(64, generator=g.manual_seed(9)))
+            bn.bias.copy_(0.1 * torch.randn(64, generator=g))
+        bn.weight.grad, bn.bias.grad = torch.zeros_like(bn.weight), torch.zeros_like(bn.bias)
+        bn.train()
+        S.FORCE_SYNC_BN = sync
+        try:
+            xd = x.to(d).requires_grad_(True)
+            y = S.batch_norm(xd, bn, JG_ACT_RELU)
+            y.backward(gy.to(d))
+            torch.cuda.synchronize()
+        finally:
+            S.FORCE_SYNC_BN = False
+        res[sync] = (y.detach().float(), xd.grad.float(), bn.weight.grad.clone(), bn.bias.grad.clone(), bn.running_mean.clone(), bn.running_var.clone())
+    for a, b in zip(res[True], res[False]):
+        assert relerr(a, b) < 1e-5, relerr(a, b)
