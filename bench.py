@@ -114,6 +114,17 @@ def usable_cores():
     return max(1, n)
 
 
+def _reference_ratio_note():
+    """the port-vs-reference ratio measured once in the build container (oracle/measure_reference_cpu.py; /root/reference does not
+    exist on the GPU box, so the timed CPU leg is the oracle PORT of the reference step)"""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_reference_vs_port.json")))
+        return (f"; kind=port: the unmodified reference itself measured {r['reference_img_per_s']} images/s against {r['port_img_per_s']} for this "
+                f"port on the build container's {r['cores']} cores (port / reference = {r['port_over_reference']}x)")
+    except Exception:
+        return ""
+
+
 def cpu_baseline_subprocess(args, timeout_s=240):
     """Run the CPU leg in a child process with a hard wall-clock bound so that bench.py always
     finishes within minutes whatever the host looks like."""
@@ -125,7 +136,10 @@ def cpu_baseline_subprocess(args, timeout_s=240):
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in out.stdout.splitlines():
             if line.startswith("{"):
-                return json.loads(line)
+                res = json.loads(line)
+                if args.model == "palette":
+                    res["sample"] += _reference_ratio_note()
+                return res
         return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
                 "sample": "cpu leg failed: " + out.stderr[-300:]}
     except subprocess.TimeoutExpired:
@@ -334,19 +348,22 @@ def main():
         dom = max(per, key=lambda k: per[k][1])
         n, tsum, fsum = per[dom]
         achieved = fsum / tsum / 1e12
-        # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-        # profiles/r01_pmc_hbm_traffic.md) of this same command, committed as profiles/r01_pmc.json
-        traffic = None
+        # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM") of
+        # this same command on the build named in profiles/r02_pmc_hbm_traffic.md, committed as profiles/r02_pmc.json.  PMC counters
+        # cannot be read from inside the timed process: this is the committed measurement of the same kernel, not of this run.
+        traffic, traffic_src = None, None
         try:
             if args.model != "palette":
                 raise KeyError("the committed PMC passes were taken on the palette_model command")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
             traffic = round(pmc[dom.split("<")[0]]["bytes_per_launch"], 1)
+            traffic_src = pmc.get("_meta", {}).get("build", "profiles/r02_pmc.json")
         except Exception:
             pass
         roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
                     "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_hbm_traffic.md)",
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; committed PMC passes of " + str(traffic_src)
+                                    + ", profiles/r02_pmc_hbm_traffic.md; MFMA-busy counters of the same build: profiles/r02_mfma_busy.md)",
                     "launches_per_step": n // 2, "avg_launch_us": round(tsum / n * 1e6, 2),
                     "avg_flops_per_launch": round(fsum / n, 1), "time_per_step_ms": round(tsum / 2 * 1e3, 3),
                     "other_kernels": {}}
