@@ -74,7 +74,8 @@ def build_model(args, rank, local_rank, world):
               checkpoints_dir="/tmp/jg_bench_ckpt/")
     if args.model == "cut":
         # cut_model: resnet_9blocks / SegFormer-attn G + basic PatchGAN D + mlp_sample F, MoNCE, nce_idt, lsgan (example_gan_*.json shape)
-        ov = dict(model_type="cut", G_netG=args.netG, G_ngf=64, G_nblocks=9, D_netDs=["basic"], D_ndf=64, data_crop_size=args.size,
+        ov = dict(model_type="cut", G_netG=args.netG, G_ngf=64, G_nblocks=9, D_netDs=args.netDs.split(","), D_ndf=64, D_proj_interp=args.size,
+                  data_crop_size=args.size,
                   data_load_size=args.size, train_batch_size=args.batch, train_iter_size=1, train_optim="adam", train_G_ema=True,
                   train_G_ema_beta=0.999, gpu_ids=",".join(str(i) for i in range(world)), jg_act_dtype=args.dtype, name="bench",
                   checkpoints_dir="/tmp/jg_bench_ckpt/")
@@ -248,6 +249,7 @@ def main():
     ap.add_argument("--efficient", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--netG", default="resnet", help="--model cut only: resnet (BASELINE configs[0] generator, 9 blocks) | segformer_attn_conv (configs[2])")
+    ap.add_argument("--netDs", default="basic", help="--model cut only: comma list out of basic, projected_d (BASELINE configs[2]: projected_d,basic)")
     ap.add_argument("--model", default="palette", choices=["palette", "cm", "cut"],
                     help="palette = BASELINE configs[1] (the bench line); cm = the consistency-model step of configs[4] (same UNet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -389,7 +391,7 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"cut_model, {args.netG} G (ngf 64, 9 blocks) + basic PatchGAN D + mlp_sample F, MoNCE, nce_idt, lsgan, "
+            "config": {"workload": (f"cut_model, {args.netG} G (ngf 64, 9 blocks) + D_netDs [{args.netDs}] (projected_d: stand-in backbone, DESIGN.md 14) + mlp_sample F, MoNCE, nce_idt, lsgan / hinge, "
                                     f"{args.size}x{args.size}, batch {args.batch}/GPU, Adam x3 + EMA, iter_size 1") if args.model == "cut" else
                                    f"{'palette_model DDPM' if args.model == 'palette' else 'cm_model consistency'}, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
                                    f"res_blocks[2,2,2,2] mid-attn 16x32, {args.size}x{args.size}, batch {args.batch}/GPU, "

@@ -11,23 +11,28 @@ namespace {
 
 __device__ __forceinline__ int kref(int k, int RS, int Cin) { return (k % Cin) * RS + k / Cin; }
 
-// t[k] = sum_r W[r][k] u[r];  nrm[0] += |t|^2
+// t[k] += sum over a slice of 16 rows of W[r][k] u[r]   (t zeroed by the caller; grid = column blocks x row slices: a 512 x 4096
+// matrix gives 512 blocks instead of 16)
 __global__ __launch_bounds__(256) void sn_wtu_kernel(const float* __restrict__ W, const float* __restrict__ u, float* __restrict__ t,
-                                                     float* __restrict__ nrm, int Cout, int K) {
+                                                     int Cout, int K) {
   const int k = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 16, r1 = min(Cout, r0 + 16);
+  if (k >= K) return;
   float acc = 0.f;
-  if (k < K)
-    for (int r = 0; r < Cout; ++r) acc += W[(long)r * K + k] * u[r];
-  if (k < K) t[k] = acc;
-  float sq = wave_sum(acc * acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(nrm, sq);
+  for (int r = r0; r < r1; ++r) acc += W[(long)r * K + k] * u[r];
+  atomicAdd(t + k, acc);
 }
-// s[r] = sum_k W[r][k] t[k] / max(|t|, eps);  nrm[1] += |s|^2          (one wave per row)
+// s[r] = sum_k W[r][k] t[k] / max(|t|, eps);  nrm[1] += |s|^2          (one wave per row; every wave recomputes |t|^2 -- K <= 4096 --
+// and the first one publishes it in nrm[0])
 __global__ __launch_bounds__(256) void sn_wv_kernel(const float* __restrict__ W, const float* __restrict__ t, float* __restrict__ s,
                                                     float* __restrict__ nrm, int Cout, int K, float eps) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (r >= Cout) return;
-  const float inv = 1.0f / fmaxf(sqrtf(nrm[0]), eps);
+  float tt = 0.f;
+  for (int k = lane; k < K; k += 64) tt += t[k] * t[k];
+  tt = wave_sum(tt);
+  if (r == 0 && lane == 0) nrm[0] = tt;
+  const float inv = 1.0f / fmaxf(sqrtf(tt), eps);
   float acc = 0.f;
   for (int k = lane; k < K; k += 64) acc += W[(long)r * K + k] * (t[k] * inv);
   acc = wave_sum(acc);
@@ -120,8 +125,8 @@ extern "C" int jg_spectral_power_iter(const float* W, float* u, float* v, float*
   float* t = ws;
   float* sv = ws + K;
   float* nrm = ws + K + Cout;
-  if (hipMemsetAsync(nrm, 0, 2 * sizeof(float), (hipStream_t)s) != hipSuccess) return JG_ERR_LAUNCH;
-  hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)s, W, u, t, nrm, Cout, K);
+  if (hipMemsetAsync(ws, 0, (size_t)(K + Cout + 2) * sizeof(float), (hipStream_t)s) != hipSuccess) return JG_ERR_LAUNCH;
+  hipLaunchKernelGGL(sn_wtu_kernel, dim3((K + 255) / 256, (Cout + 15) / 16), dim3(256), 0, (hipStream_t)s, W, u, t, Cout, K);
   hipLaunchKernelGGL(sn_wv_kernel, dim3((Cout + 3) / 4), dim3(256), 0, (hipStream_t)s, W, t, sv, nrm, Cout, K, eps);
   hipLaunchKernelGGL(sn_finish_kernel, dim3(grid1(K, 64)), dim3(256), 0, (hipStream_t)s, t, sv, nrm, u, v, sigma, Cout, RS, Cin, eps);
   JG_CHECK_LAUNCH();
