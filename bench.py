@@ -171,6 +171,10 @@ def cpu_baseline(args):
             from joligen_amd.modules.segformer import SegformerGenerator_attn
             netG = SegformerGenerator_attn(None, None, 3, S, 10, 1)
             layers, T = [0, 1, 2, 3], 0.2
+        elif "resnet_attn" in args.netG:
+            from joligen_amd.modules.resnet_attn_generator import ResnetGenerator_attn
+            netG = ResnetGenerator_attn(3, 3, 10, 1, 64, n_blocks=9, mobile=args.netG.startswith("mobile"))
+            layers, T = [0, 4, 8, 12, 16], 0.07
         else:
             from joligen_amd.modules.resnet_generator import ResnetGenerator
             netG = ResnetGenerator(3, 3, 64, n_blocks=9)
@@ -181,10 +185,10 @@ def cpu_baseline(args):
         sdF = {k: v.detach().float() for k, v in netF.state_dict().items()}
         sdD = {k: v.detach().float() for k, v in NLayerDiscriminator(3, 64).state_dict().items()}
         tr = O.OracleCUTTrainer(sdG, sdF, sdD, 9, layers, num_patches=256, T=T, monce=True, pool_size=50, pool_rng=random.Random(0),
-                                ema_beta=0.999, gen="segformer" if seg else "resnet")
+                                ema_beta=0.999, gen="segformer" if seg else (args.netG if "resnet_attn" in args.netG else "resnet"))
         A, Bm = batch["A"], batch["B"]
         with torch.no_grad():
-            hw = [f.shape[2] * f.shape[3] for f in (O.segformer_backbone(sdG, A) if seg else O.resnet_encoder(sdG, A, 9, layers)[1])]
+            hw = [f.shape[2] * f.shape[3] for f in (O.segformer_backbone(sdG, A) if seg else tr._feats(sdG, A))]
         times = []
         for it in range(9):
             ids = [[torch.randperm(n, generator=gen)[:min(256, n)] for n in hw] for _ in range(2)]
@@ -248,7 +252,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--efficient", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
-    ap.add_argument("--netG", default="resnet", help="--model cut only: resnet (BASELINE configs[0] generator, 9 blocks) | segformer_attn_conv (configs[2])")
+    ap.add_argument("--netG", default="resnet", help="--model cut only: resnet (BASELINE configs[0] generator, 9 blocks) | segformer_attn_conv (configs[2]) | resnet_attn | "
+                         "mobile_resnet_attn (examples/example_gan_horse2zebra.json)")
     ap.add_argument("--netDs", default="basic", help="--model cut only: comma list out of basic, projected_d (BASELINE configs[2]: projected_d,basic)")
     ap.add_argument("--model", default="palette", choices=["palette", "cm", "cut"],
                     help="palette = BASELINE configs[1] (the bench line); cm = the consistency-model step of configs[4] (same UNet)")

@@ -91,6 +91,7 @@ SIGNATURES = {
     "jg_act_fwd": [c_i32, c_p, c_p, c_i64, c_i32, c_p],
     "jg_act_bwd": [c_i32, c_p, c_p, c_p, c_i64, c_i32, c_p],
     "jg_reflect_pad2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_crop2d": [c_i32, c_p, c_p] + [c_i32] * 9 + [c_p],
     "jg_reflect_pad2d_bwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dilate2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_subsample2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],

@@ -439,6 +439,29 @@ __global__ void act_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy
 
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
+// interior crop of an NHWC tensor (y = x[:, top:top+Ho, left:left+Wo]) and its adjoint (zero outside the window): the mobile
+// (depth-wise separable) residual blocks run reflect-pad -> zero-padded depth-wise conv -> crop
+template <typename T, bool ADJ>
+__global__ void crop_kernel(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C, int top, int left, int Ho, int Wo) {
+  const int noct = C / 8;
+  const int Hd = ADJ ? H : Ho, Wd = ADJ ? W : Wo;
+  const long total = (long)B * Hd * Wd * noct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int co = i % noct;
+    long t = i / noct;
+    const int w = t % Wd; t /= Wd;
+    const int h = t % Hd;
+    const int b = t / Hd;
+    if (ADJ) {
+      const int oh = h - top, ow = w - left;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (oh >= 0 && oh < Ho && ow >= 0 && ow < Wo) v = *reinterpret_cast<const uint4*>(src + ((((long)b * Ho + oh) * Wo + ow) * noct + co) * 8);
+      *reinterpret_cast<uint4*>(dst + i * 8) = v;
+    } else {
+      *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(src + ((((long)b * H + h + top) * W + w + left) * noct + co) * 8);
+    }
+  }
+}
 // nn.ReflectionPad2d(pad), NHWC: y[b, i, j] = x[b, refl(i - pad), refl(j - pad)]
 template <typename T>
 __global__ void reflect_pad_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C, int pad) {
@@ -1018,6 +1041,21 @@ extern "C" int jg_reflect_pad2d_bwd(int dtype, const void* dy, void* dx, int B, 
   const long total = (long)B * H * W * (C / 8);
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((reflect_pad_bwd_kernel<T>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s,
                                               (const T*)dy, (T*)dx, B, H, W, C, pad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_crop2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int top, int left, int Ho, int Wo, int adjoint,
+                         jg_stream_t s) {
+  // adjoint = 0: y[B, Ho, Wo, C] = x[B, H, W, C] window; adjoint = 1: y[B, H, W, C] = x[B, Ho, Wo, C] placed at (top, left), zero elsewhere
+  if (!x || !y || C % 8 || top < 0 || left < 0 || Ho < 1 || Wo < 1 || top + Ho > H || left + Wo > W) return JG_ERR_BAD_ARG;
+  const long total = (long)B * (adjoint ? (long)H * W : (long)Ho * Wo) * (C / 8);
+  if (adjoint) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((crop_kernel<T, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                                (T*)y, B, H, W, C, top, left, Ho, Wo););
+  } else {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((crop_kernel<T, false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                                (T*)y, B, H, W, C, top, left, Ho, Wo););
+  }
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -55,8 +55,9 @@ class CUTModel(BaseModel):
             # the 1/T = 14x of the contrastive logits makes these gradients ~2 orders larger than the diffusion path's:
             # 65536 overflows fp16 activation gradients, 1024 keeps both ends of the range
             self.loss_scale = 1024.0
-        if opt.G_netG not in ("resnet", "resnet_9blocks", "resnet_6blocks", "segformer_attn_conv"):
-            raise NotImplementedError(f"G_netG={opt.G_netG!r}: the CUT path is built for the resnet and segformer_attn_conv generators")
+        if opt.G_netG not in ("resnet", "resnet_9blocks", "resnet_6blocks", "segformer_attn_conv", "resnet_attn", "mobile_resnet_attn"):
+            raise NotImplementedError(f"G_netG={opt.G_netG!r}: the CUT path is built for the resnet, resnet_attn, mobile_resnet_attn and "
+                                      "segformer_attn_conv generators")
         if "segformer" in opt.G_netG:           # cut_model.py:205-210: enforced by the reference
             opt.alg_cut_nce_layers, opt.alg_cut_nce_T = "0,1,2,3", 0.2
         bad = [d for d in opt.D_netDs if d not in ("basic", "projected_d")]
@@ -88,6 +89,15 @@ class CUTModel(BaseModel):
                                                   img_size=opt.data_crop_size, nb_mask_attn=getattr(opt, "G_attn_nb_mask_attn", 10),
                                                   nb_mask_input=getattr(opt, "G_attn_nb_mask_input", 1), final_conv=True,
                                                   padding_type=opt.G_padding_type)
+        elif "resnet_attn" in opt.G_netG:        # gan_networks.py:150-176
+            from ..modules.resnet_attn_generator import ResnetGenerator_attn
+
+            if getattr(opt, "train_feat_wavelet", False):
+                raise NotImplementedError("train_feat_wavelet (wavelet feature space) is outside the built path")
+            self.netG_A = ResnetGenerator_attn(opt.model_input_nc, opt.model_output_nc, getattr(opt, "G_attn_nb_mask_attn", 10),
+                                               getattr(opt, "G_attn_nb_mask_input", 1), opt.G_ngf, n_blocks=opt.G_nblocks,
+                                               padding_type=opt.G_padding_type, mobile=opt.G_netG.startswith("mobile"),
+                                               twice_resnet_blocks=getattr(opt, "G_backward_compatibility_twice_resnet_blocks", False))
         else:
             self.netG_A = ResnetGenerator(opt.model_input_nc, opt.model_output_nc, opt.G_ngf, n_blocks=opt.G_nblocks,
                                           padding_type=opt.G_padding_type)

@@ -457,6 +457,33 @@ def reflect_pad2d(x, pad):
     return _ReflectPadFn.apply(x, pad)
 
 
+class _CropFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, top, left, Ho, Wo):
+        _require_cuda(x)
+        x = x.contiguous()
+        B, H, W, Cc = x.shape
+        y = torch.empty(B, Ho, Wo, Cc, device=x.device, dtype=x.dtype)
+        check(_lib.lib().jg_crop2d(_dt(x), x.data_ptr(), y.data_ptr(), B, H, W, Cc, top, left, Ho, Wo, 0, _st()), "jg_crop2d")
+        ctx.cfg = (H, W, top, left)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        H, W, top, left = ctx.cfg
+        dy = dy.contiguous()
+        B, Ho, Wo, Cc = dy.shape
+        dx = torch.empty(B, H, W, Cc, device=dy.device, dtype=dy.dtype)
+        check(_lib.lib().jg_crop2d(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, top, left, Ho, Wo, 1, _st()), "jg_crop2d")
+        return dx, None, None, None, None
+
+
+def crop2d(x, top, left, Ho, Wo):
+    """x[:, top:top+Ho, left:left+Wo] on NHWC (adjoint: zero-filled placement)."""
+    return _CropFn.apply(x, top, left, Ho, Wo)
+
+
 class _ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act):

@@ -30,6 +30,9 @@ STEP_CFGS = {
     # BASELINE.json configs[2] shape with the buildable discriminator: SegFormer-attn G (MiT-b0 + ResnetDecoder tail) + basic D + MoNCE
     "segformer": dict(netG="segformer_attn_conv", ngf=64, n_blocks=9, ndf=16, S=64, B=2, nce_layers="0,1,2,3", num_patches=64, nce_loss="monce",
                       pool=2, iters=3),
+    # attention ResNet generator with depth-wise separable blocks (G_netG = mobile_resnet_attn); nce ids >= n_blocks tap nothing
+    "mobile_attn": dict(netG="mobile_resnet_attn", ngf=16, n_blocks=3, ndf=16, S=64, B=2, nce_layers="0,1,2,8", num_patches=64, nce_loss="monce",
+                        pool=2, iters=3),
     "patchnce": dict(ngf=16, n_blocks=3, ndf=16, S=32, B=1, nce_layers="0,4,8,12", num_patches=32, nce_loss="patchnce", pool=1, iters=3),
 }
 

@@ -1158,3 +1158,18 @@ def test_conv_subpixel_form(case, dtype):
     assert relerr(outs[0][0].float(), outs[1][0].float()) < 2 * TOL[dtype]
     assert relerr(outs[0][1][..., 0], ref.sum((2, 3))) < 5e-3 and relerr(outs[0][1][..., 1], (ref * ref).sum((2, 3))) < TOL[dtype]
     assert relerr(outs[0][1], outs[1][1]) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_crop2d_and_adjoint(dtype):
+    """window crop of an NHWC tensor and its zero-filling adjoint: index ops, bit exact"""
+    from joligen_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 11, 14, 16, generator=g).to(dtype).cuda().requires_grad_(True)
+    y = ops.crop2d(x, 2, 3, 7, 9)
+    assert torch.equal(y, x[:, 2:9, 3:12])
+    r = torch.randn(2, 7, 9, 16, generator=g).to(dtype).cuda()
+    y.backward(r)
+    ref = torch.zeros_like(x)
+    ref[:, 2:9, 3:12] = r
+    assert torch.equal(x.grad, ref)

@@ -75,6 +75,36 @@ def test_resnet_generator_vs_reference_golden(golden_dir, name, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["plain", "mobile"])
+def test_resnet_attn_generator_vs_reference_golden(golden_dir, name, dtype):
+    """G_netG = resnet_attn / mobile_resnet_attn (oracle/make_golden_resattn.py: unmodified reference module): output of the
+    attention composition, the tapped block features (ids beyond the blocks tap nothing), input and parameter gradients"""
+    from joligen_amd import ops
+    from joligen_amd.modules.resnet_attn_generator import ResnetGenerator_attn
+
+    g = load(golden_dir, f"resattn_{name}.pt")
+    c = g["cfg"]
+    net = ResnetGenerator_attn(3, 3, c["nb_mask_attn"], c["nb_mask_input"], c["ngf"], n_blocks=c["n_blocks"], mobile=g["mobile"])
+    assert list(net.state_dict().keys()) == g["keys"]
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == g["shapes"]
+    net.load_state_dict(O.synth_state_dict(net.state_dict(), seed=0))
+    d = torch.device("cuda:0")
+    net.jg_finalize(d, dtype)
+    x = ops.to_nhwc(g["x"].to(d), dtype, 8).requires_grad_(True)
+    out = net(x)
+    assert relerr(nchw(out, 3), g["out"]) < TOL[dtype], relerr(nchw(out, 3), g["out"])
+    out.backward(ops.to_nhwc(g["R"].to(d), dtype, 8))
+    torch.cuda.synchronize()
+    assert relerr(nchw(x.grad, 3), g["dx"]) < TOL_DX[dtype], relerr(nchw(x.grad, 3), g["dx"])
+    check_grads(net, g["grad_checks"], 3 * TOL[dtype], dtype)
+    with torch.no_grad():
+        feats = net.get_feats(x.detach(), g["nce_layers"])
+    assert len(feats) == len(g["feats"]) == 2 and net.feat_channels(g["nce_layers"]) == [64, 64]
+    for f, ref in zip(feats, g["feats"]):
+        assert relerr(nchw(f, ref.shape[1]), ref) < TOL[dtype], (tuple(ref.shape), relerr(nchw(f, ref.shape[1]), ref))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("name", ["small", "wide"])
 def test_nlayer_discriminator_vs_reference_golden(golden_dir, name, dtype):
     from joligen_amd import ops

@@ -216,6 +216,8 @@ def _zero_grad_bias(G_keys, gen):
     def skip(k):
         if gen == "segformer":      # the tail's convolutions carry no bias (BatchNorm follows); BatchNorm's own bias has a real gradient
             return k.endswith("in_proj_bias")
+        if "resnet_attn" in gen:    # the two last convolutions (image / attention logits) are not followed by a normalisation
+            return k.endswith(".bias") and not k.startswith("deconv3_")
         return k.endswith(".bias")
     return skip
 
@@ -235,7 +237,7 @@ COS_UPDATE = {torch.float16: 0.80, torch.bfloat16: 0.55}
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("name", ["monce", "patchnce", "config0", "segformer"])
+@pytest.mark.parametrize("name", ["monce", "patchnce", "config0", "segformer", "mobile_attn"])
 def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
     """N x CUTModel.optimize_parameters() against the reference's fixtures, TEACHER-FORCED (tests/parity_util.py): the CPU oracle
     trainer -- which reproduces the reference's losses of every iteration to 2e-4 (re-asserted here) -- hands its complete state
@@ -243,7 +245,7 @@ def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
     checks a single step: all five losses and fake_B on identical weights (forward tolerance), and the G / F / D parameter updates
     against the oracle's updates (direction + length), instead of a trajectory bound fitted to one box."""
     import parity_util as PU
-    from test_oracle_golden import cut_trainer_for
+    from test_oracle_golden import cut_gen, cut_ntaps, cut_trainer_for
 
     g = load(golden_dir, f"cutstep_{name}.pt")
     c = g["cfg"]
@@ -256,8 +258,8 @@ def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
     tr, rng_ref = cut_trainer_for(g)
     rng = ReplayRandom([d for s in g["steps"] for d in s["pool_draws"]])
     model.set_pool_rng(rng)
-    nl = len(c["nce_layers"].split(","))
-    gen = "segformer" if name == "segformer" else "resnet"
+    nl = cut_ntaps(c)
+    gen = cut_gen(c)
     tol = TOL_LOSS_FWD[dtype]
     log = []
     for it, s in enumerate(g["steps"]):
@@ -298,13 +300,13 @@ def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
         f.write("\n".join(log))
 
 
-@pytest.mark.parametrize("name", ["monce", "segformer"])
+@pytest.mark.parametrize("name", ["monce", "segformer", "mobile_attn"])
 def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
     """first G-group backward on identical (fp16-representable) weights and inputs: per-parameter gradients of G and F against the
     CPU oracle's autograd (includes the k-side path through the negatives and the Sinkhorn reverse sweep; for the SegFormer
     generator: MiT backbone, both heads, the BatchNorm decoder tail and the attention composition, with the reference's recorded
     DropPath / Dropout2d draws).  Per-parameter relative error and cosine; the table goes to gpurun_out/."""
-    from test_oracle_golden import cut_trainer_for
+    from test_oracle_golden import cut_gen, cut_ntaps, cut_trainer_for
     dtype = torch.float16
     g = load(golden_dir, f"cutstep_{name}.pt")
     c = g["cfg"]
@@ -317,7 +319,7 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
     model.netG_A.load_state_dict(sdG)
     model.netD_B_basic.load_state_dict(sdD)
     model.netF.load_state_dict(sdF)
-    nl = len(c["nce_layers"].split(","))
+    nl = cut_ntaps(c)
     ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
     model.patch_ids_injection = lambda call, shapes: [i.to(D0) for i in (ids_ab if call == 0 else ids_idt)]
     if s.get("uniforms"):
@@ -339,7 +341,7 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
     tr.pool.rng = tr.real_pools[0].rng = tr.real_pools[1].rng = random.Random(0)
     tr.step(A, Bi, ids_ab, ids_idt, uniforms=s.get("uniforms") or None)
     ls = model.loss_scale
-    gen = "segformer" if name == "segformer" else "resnet"
+    gen = cut_gen(c)
     skip = _zero_grad_bias(tr.G, gen)
     bad, errs, table = [], [], []
     for net, key in ((model.netG_A, "G"), (model.netF, "F")):

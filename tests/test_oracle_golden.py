@@ -224,6 +224,26 @@ def test_cut_networks(golden_dir, name):
         torch.testing.assert_close(mine, ref, rtol=1e-3, atol=1e-3 * float(ref[0]) + 1e-5, msg=k)
 
 
+# ---- attention ResNet generators (resnet_attn / mobile_resnet_attn): oracle/make_golden_resattn.py fixtures --------
+@pytest.mark.parametrize("name", ["plain", "mobile"])
+def test_resnet_attn_generator(golden_dir, name):
+    g = load(golden_dir, f"resattn_{name}.pt")
+    c = g["cfg"]
+    P = {k: v.clone().requires_grad_(True) for k, v in O.synth_state_dict({k: torch.empty(g["shapes"][k]) for k in g["keys"]}, 0).items()}
+    x = g["x"].clone().requires_grad_(True)
+    out, feats = O.resnet_attn_generator(P, x, c["n_blocks"], g["mobile"], c["nb_mask_attn"], c["nb_mask_input"], g["nce_layers"])
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+    assert len(feats) == len(g["feats"]) == 2          # ids beyond the blocks tap nothing
+    for a, b in zip(feats, g["feats"]):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5)
+    (out * g["R"]).sum().backward()
+    torch.testing.assert_close(x.grad, g["dx"], rtol=1e-3, atol=1e-4)
+    for k, ref in g["grad_checks"].items():
+        v = P[k].grad
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        torch.testing.assert_close(mine, ref, rtol=1e-3, atol=1e-3 * float(ref[0]) + 1e-5, msg=k)
+
+
 # ---- CUT losses and training step: oracle/make_golden_cutstep.py fixtures (unmodified reference modules / CUTModel) --------
 class ReplayRandom:
     """replays the recorded python-`random` draws of the reference's image pools, checking the call kinds"""
@@ -304,8 +324,19 @@ def cut_trainer_for(g):
     tr = O.OracleCUTTrainer(sdG, sdF, sdD, c["n_blocks"], [int(i) for i in c["nce_layers"].split(",")], num_patches=c["num_patches"],
                             T=hp["T"], monce=c["nce_loss"] == "monce", lambda_NCE=hp["lambda_NCE"], lambda_GAN=hp["lambda_GAN"],
                             lr_G=hp["lr_G"], lr_D=hp["lr_D"], beta1=hp["beta1"], beta2=hp["beta2"], eps=hp["eps"], pool_size=c["pool"],
-                            pool_rng=rng, ema_beta=hp["ema_beta"], gen="segformer" if "segformer" in c.get("netG", "") else "resnet")
+                            pool_rng=rng, ema_beta=hp["ema_beta"], gen=cut_gen(c))
     return tr, rng
+
+
+def cut_gen(c):
+    n = c.get("netG", "resnet")
+    return "segformer" if "segformer" in n else (n if "resnet_attn" in n else "resnet")
+
+
+def cut_ntaps(c):
+    """number of features get_feats returns: the attention ResNets tap block indices only (resnet_generator.py:504-515)"""
+    ids = [int(i) for i in c["nce_layers"].split(",")]
+    return len([i for i in ids if 0 <= i < c["n_blocks"]]) if "resnet_attn" in c.get("netG", "") else len(ids)
 
 
 def cut_ids(step, nlayers, num_patches):
@@ -316,12 +347,12 @@ def cut_ids(step, nlayers, num_patches):
     return ids[:nlayers], ids[nlayers:]
 
 
-@pytest.mark.parametrize("name", ["monce", "patchnce", "config0", "segformer"])
+@pytest.mark.parametrize("name", ["monce", "patchnce", "config0", "segformer", "mobile_attn"])
 def test_cut_steps(golden_dir, name):
     g = load(golden_dir, f"cutstep_{name}.pt")
     c = g["cfg"]
     tr, rng = cut_trainer_for(g)
-    nl = len(c["nce_layers"].split(","))
+    nl = cut_ntaps(c)
     for it, s in enumerate(g["steps"]):
         ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
         losses = tr.step(s["A"], s["B"], ids_ab, ids_idt, uniforms=s.get("uniforms") or None)
