@@ -491,3 +491,76 @@ def test_projected_discriminator(golden_dir):
             v = r[name][k]
             mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
             torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-5, msg=(name, k))
+
+
+# ---- rounding yardstick: fp32 reference arithmetic with 16-bit storage between layers ----------------------------------------
+YARD_C2 = dict(ngf=64, mults=[1, 2, 4, 8], res_blocks=[2, 2, 2, 2], attn_res=[16], efficient=True, S=256, B=1)
+YARD_MED = dict(ngf=32, mults=[1, 2, 4], res_blocks=[1, 1, 1], attn_res=[16], efficient=True, S=64, B=2)
+YARD_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_rounding_yardstick.json")
+
+
+def rounding_yardstick(c, seed=5):
+    """first-step loss / noise_hat / per-parameter gradient distance between the plain fp32 oracle and the same oracle with every
+    inter-layer activation, every back-propagated activation gradient and the weights rounded to fp16 / bf16 (oracle/jg_oracle.py
+    `activation_rounding`): what a perfect 16-bit execution of this network is allowed to differ by.  Same inputs, same error
+    measure (incl. the analytic-zero bias floor) as tests/test_gpu_1_model.py::_first_step_vs_oracle."""
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    ov = dict(G_ngf=c["ngf"], G_unet_mha_channel_mults=c["mults"], G_unet_mha_res_blocks=c["res_blocks"], G_unet_mha_attn_res=c["attn_res"],
+              G_unet_mha_vit_efficient=c["efficient"], data_crop_size=c["S"], train_batch_size=c["B"])
+    net = define_G(**vars(opt_from_json({}, ov)))
+    sd = O.synth_state_dict(net.state_dict(), seed=0)
+    cfg = O.UNetCfg(in_channel=6, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"], attn_res=c["attn_res"],
+                    channel_mults=c["mults"], efficient=c["efficient"])
+    B, S = c["B"], c["S"]
+    g = torch.Generator().manual_seed(seed)
+    Bimg = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+    mask = torch.zeros(B, 1, S, S, dtype=torch.int64)
+    mask[:, :, S // 6:(5 * S) // 8, S // 3:(7 * S) // 9] = 1
+    A = Bimg * (1 - mask) + torch.randn(B, 3, S, S, generator=g) * mask
+    t, u, noise = O.draw_step_randomness(torch.Generator().manual_seed(9), Bimg, 2000)
+    tr = O.OraclePaletteTrainer(sd, cfg, ema_beta=None)
+    loss_ref, grads_ref, nh_ref = tr.loss_and_grads(Bimg, A, mask, noise, t, u)
+    ref_norms = {k: float(v.norm()) for k, v in grads_ref.items()}
+    out = {}
+    for name, dt, eps16 in (("fp16", torch.float16, 2.0 ** -10), ("bf16", torch.bfloat16, 2.0 ** -7)):
+        sd16 = {k: (v.to(dt).float() if (torch.is_floating_point(v) and v.dim() >= 3) else v) for k, v in sd.items()}   # conv weights: 16-bit copies
+        tr16 = O.OraclePaletteTrainer(sd16, cfg, ema_beta=None)
+        tr16.grad_scale = 65536.0 if dt == torch.float16 else 1.0       # the static fp16 loss scale of the HIP path (base_model.py)
+        with O.activation_rounding(dt):
+            loss, grads, nh = tr16.loss_and_grads(Bimg, A, mask, noise, t, u)
+        errs = []
+        for k, gr in grads_ref.items():
+            floor = 0.0
+            if k.endswith(".bias") and (k[:-4] + "weight") in ref_norms:
+                floor = 16.0 * eps16 * ref_norms[k[:-4] + "weight"]
+            errs.append(float((grads[k] - gr).norm() / (gr.norm() + floor + 1e-12)))
+        errs.sort()
+        out[name] = dict(loss_rel=abs(float(loss) - float(loss_ref)) / float(loss_ref),
+                         noise_hat_rel=float((nh - nh_ref).norm() / nh_ref.norm()),
+                         grad_median=errs[len(errs) // 2], grad_p90=errs[int(len(errs) * 0.9)], grad_worst=errs[-1])
+    return out
+
+
+def test_rounding_yardstick():
+    """Measured rounding floor of the BASELINE shape (C2, batch 1) and of the 64x64 test shape; the committed file is what the GPU
+    tolerances are compared with (tests/test_gpu_1_model.py::test_tolerances_vs_rounding_yardstick).  Regenerate with
+    JG_WRITE_YARDSTICK=1."""
+    import json
+
+    res = {"c2_256": rounding_yardstick(YARD_C2), "medium_64": rounding_yardstick(YARD_MED)}
+    for shape in res.values():
+        assert shape["fp16"]["grad_median"] < shape["bf16"]["grad_median"]        # 3 more mantissa bits
+        assert 0 < shape["fp16"]["noise_hat_rel"] < 1e-2 and 0 < shape["bf16"]["noise_hat_rel"] < 1e-1
+    if os.environ.get("JG_WRITE_YARDSTICK"):
+        res["_meta"] = "oracle/jg_oracle.py activation_rounding(dtype): fp32 arithmetic, 16-bit storage of activations, activation gradients and conv weights"
+        with open(YARD_FILE, "w") as f:
+            json.dump(res, f, indent=1)
+    committed = json.load(open(YARD_FILE))
+    for shape, r in res.items():
+        if shape.startswith("_"):
+            continue
+        for dt in ("fp16", "bf16"):
+            for k, v in r[dt].items():
+                assert abs(v - committed[shape][dt][k]) <= 0.25 * committed[shape][dt][k] + 1e-6, (shape, dt, k, v, committed[shape][dt][k])
