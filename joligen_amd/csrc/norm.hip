@@ -418,11 +418,11 @@ extern "C" int jg_gn_apply(int dtype, const void* x, const float* ab, void* y, i
   return jg_gn_apply_ld(dtype, x, C, ab, y, C, B, HW, C, act, s);
 }
 
-extern "C" int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
-                                   float* red, int B, int HW, int C, int act, jg_stream_t s) {
+static int gn_bwd_reduce_ld_impl(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
+                                 float* red, int B, int HW, int C, int act, jg_stream_t s, bool zero) {
   if (!x || !dy || !ab || !red || bad_shape(B, HW, C) || ldx < C || lddy < C || (ldx % 8) || (lddy % 8)) return JG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  if (hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
+  if (zero && hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
   const int mult = red_mult(B, HW, C);
   const Map mp = make_map_red(C, mult);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
@@ -433,12 +433,22 @@ extern "C" int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const 
   return JG_OK;
 }
 
-extern "C" int jg_gn_bwd_reduce_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
-                                   float* red, int B, int H, int W, int C, int act, jg_stream_t s) {
+extern "C" int jg_gn_bwd_reduce_ld(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
+                                   float* red, int B, int HW, int C, int act, jg_stream_t s) {
+  return gn_bwd_reduce_ld_impl(dtype, x, ldx, dy, lddy, ab, red, B, HW, C, act, s, true);
+}
+// the same, ACCUMULATING into `red` (the caller hands over zeroed rows of a pool it clears once per backward pass)
+extern "C" int jg_gn_bwd_reduce_ld_acc(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab,
+                                       float* red, int B, int HW, int C, int act, jg_stream_t s) {
+  return gn_bwd_reduce_ld_impl(dtype, x, ldx, dy, lddy, ab, red, B, HW, C, act, s, false);
+}
+
+static int gn_bwd_reduce_up_impl(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
+                                 float* red, int B, int H, int W, int C, int act, jg_stream_t s, bool zero) {
   const int HW = H * W;
   if (!x || !dy_low || !ab || !red || bad_shape(B, HW, C) || (H & 1) || (W & 1) || ldx < C || lddy < C || (ldx % 8) || (lddy % 8)) return JG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
-  if (hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
+  if (zero && hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
   const int mult = red_mult(B, HW, C);
   const Map mp = make_map_red(C, mult);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
@@ -447,6 +457,15 @@ extern "C" int jg_gn_bwd_reduce_up(int dtype, const void* x, int64_t ldx, const 
                                                             (long)ldx, (const T*)dy_low, (long)lddy, ab, red, HW, C, mult, W, dy_scale);););
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+
+extern "C" int jg_gn_bwd_reduce_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
+                                   float* red, int B, int H, int W, int C, int act, jg_stream_t s) {
+  return gn_bwd_reduce_up_impl(dtype, x, ldx, dy_low, lddy, dy_scale, ab, red, B, H, W, C, act, s, true);
+}
+extern "C" int jg_gn_bwd_reduce_up_acc(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale,
+                                       const float* ab, float* red, int B, int H, int W, int C, int act, jg_stream_t s) {
+  return gn_bwd_reduce_up_impl(dtype, x, ldx, dy_low, lddy, dy_scale, ab, red, B, H, W, C, act, s, false);
 }
 
 extern "C" int jg_gn_bwd_apply_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,

@@ -85,6 +85,15 @@ class _Pool:
         self.off += n
         return v
 
+    def take_rows(self, B, C):
+        """[B, C, 2] zeroed rows (the reductions of a stand-alone GroupNorm backward)"""
+        n = B * C * 2
+        if self.off + n > self.buf.numel():
+            return None
+        v = self.buf[self.off:self.off + n].view(B, C, 2)
+        self.off += n
+        return v
+
 
 # ---------------------------------------------------------------------------------------------------
 # raw launches (no autograd): every tensor may be a channel slice of a wider buffer
@@ -188,7 +197,7 @@ def gn_apply(x, ab, act):
     return y
 
 
-def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=(), red=None, pooled=None):
+def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=(), red=None, pooled=None, pool=None):
     """dx = GroupNorm-backward(x, dy) + sum_i scale_i * add_i  (at most two addends, fused).
     `red`: reductions already accumulated by the convolution that produced dy ([B, NSLOT, C, 2]).
     `pooled`: (dy_scale, low_add): dy (and the optional addend `low_add` = (tensor, scale)) live at the 2x2-POOLED resolution; the
@@ -201,13 +210,16 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
     nslots = NSLOT
     if red is None:
         nslots = 1
-        red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        red = pool.take_rows(B, C) if pool is not None else None      # zeroed once per backward pass: no memset launch per layer
+        up, ld = (L.jg_gn_bwd_reduce_up_acc, L.jg_gn_bwd_reduce_ld_acc) if red is not None else (L.jg_gn_bwd_reduce_up, L.jg_gn_bwd_reduce_ld)
+        if red is None:
+            red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
         if pooled is not None:
-            check(L.jg_gn_bwd_reduce_up(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), pooled[0], ab.data_ptr(), red.data_ptr(),
-                                        B, H, W, C, act, _st()), "jg_gn_bwd_reduce_up")
+            check(up(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), pooled[0], ab.data_ptr(), red.data_ptr(), B, H, W, C, act, _st()),
+                  "jg_gn_bwd_reduce_up")
         else:
-            check(L.jg_gn_bwd_reduce_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), red.data_ptr(), B, HW, C,
-                                        act, _st()), "jg_gn_bwd_reduce_ld")
+            check(ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), red.data_ptr(), B, HW, C, act, _st()),
+                  "jg_gn_bwd_reduce_ld")
     dgamma = gamma.grad if gamma is not None else None
     dbeta = beta.grad if beta is not None else None
     if gamma is not None and dgamma is None:
@@ -520,7 +532,7 @@ class UNetExecutor:
         dhn, red = conv_dgrad(dO, m, rec["hn"].shape, gn=(rec["x"], rec["ab"], JG_ACT_SILU), pool=self.bpool)
         self.wgrad(dO, rec["hn"], m)
         return gn_bwd(rec["x"], dhn, rec["ab"], rec["mr"], gn.weight, gn.bias, None, gn.num_groups, JG_ACT_SILU, adds=adds,
-                      red=red)
+                      red=red, pool=self.bpool)
 
     def res_bwd(self, rec, dO, adds):
         rb = rec["rb"]
@@ -543,7 +555,7 @@ class UNetExecutor:
         # GroupNorm 2 (+FiLM +SiLU)
         off, n = rb.emb_slice
         dc1 = gn_bwd(rec["c1"], dh2, rec["ab2"], rec["mr2"], gn2.weight, gn2.bias, rec["film"], gn2.num_groups, JG_ACT_SILU,
-                     dfilm=self.demb[:, off:off + n], red=red2)
+                     dfilm=self.demb[:, off:off + n], red=red2, pool=self.bpool)
         del dh2
         if rb.up and rb.efficient and not rec.get("low2"):
             dc1 = pool2(dc1, 1.0)          # backward of the nearest upsample that follows conv1
@@ -576,13 +588,13 @@ class UNetExecutor:
             else:
                 adds.append((pool2(dO, skipw), 1.0))
             return gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
-                          red=red1, pooled=pooled)
+                          red=red1, pooled=pooled, pool=self.bpool)
         if rb.updown:
             raise NotImplementedError("resampling ResBlock with a 1x1 skip convolution")
         skm = rb.skip_connection.meta
         self.wgrad(dO, rec["xs"], skm, alpha=skipw, dbias_scale=skipw)
         dxg = gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
-                     red=red1)
+                     red=red1, pool=self.bpool)
         return conv_dgrad(dO, skm, x.shape, res=dxg, alpha=skipw)   # skipw * (dO . Wskip) + dxg in one epilogue
 
     def attn_bwd(self, rec, dO, adds):
@@ -600,7 +612,7 @@ class UNetExecutor:
                               pool=self.bpool)
         self.wgrad(dqkv.view(B, 1, T, 3 * C), xn4, blk.qkv.meta)
         adds = list(adds) + [(dO, 1.0)]
-        return gn_bwd(x, dxn.view(B, H, W, C), rec["ab"], rec["mr"], None, None, None, C, JG_ACT_NONE, adds=adds, red=red)
+        return gn_bwd(x, dxn.view(B, H, W, C), rec["ab"], rec["mr"], None, None, None, C, JG_ACT_NONE, adds=adds, red=red, pool=self.bpool)
 
 
 def _own_params(rec):
