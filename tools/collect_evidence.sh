@@ -10,7 +10,7 @@ export TMPDIR=/tmp
 BUILD="csrc sha1 $(cat joligen_amd/csrc/*.hip joligen_amd/csrc/*.h | sha1sum | cut -c1-12)"   # .git does not travel to the box
 echo "build $BUILD" > $O/${TAG}_evidence.log
 if [ "$2" != "quick" ]; then
-  timeout 900 python -m pytest tests -q -m gpu > $O/${TAG}_gpu_pytest_full.log 2>&1
+  timeout 900 python -m pytest tests -v -m gpu -p no:cacheprovider > $O/${TAG}_gpu_pytest_full.log 2>&1
   tail -3 $O/${TAG}_gpu_pytest_full.log >> $O/${TAG}_evidence.log
 fi
 python bench.py 2> $O/${TAG}_bench.err | tail -1 > $O/${TAG}_bench_line.json
