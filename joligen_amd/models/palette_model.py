@@ -59,8 +59,17 @@ class PaletteModel(BaseModel):
             raise NotImplementedError("only alg_diffusion_cond_image_creation='y_t' is implemented")
         if opt.alg_palette_loss not in ("MSE", "L1", "multiscale_MSE", "multiscale_L1"):
             raise NotImplementedError(f"alg_palette_loss={opt.alg_palette_loss!r}")
-        if opt.alg_diffusion_dropout_prob > 0:
-            raise NotImplementedError("alg_diffusion_dropout_prob > 0 (classifier-free guidance) is not implemented")
+        if opt.alg_diffusion_dropout_prob > 0 and "class" not in opt.alg_diffusion_cond_embed:
+            raise NotImplementedError("alg_diffusion_dropout_prob > 0 needs a class embedding to drop (mask conditioning is not built)")
+        if opt.isTrain and opt.alg_diffusion_dropout_prob > 0 and not getattr(opt, "_jg_dropout_class_added", False):
+            # PaletteModel.after_parse (palette_model.py:102-107): one more class, the unconditioned one
+            opt.f_s_semantic_nclasses += 1
+            opt.cls_semantic_nclasses += 1
+            opt._jg_dropout_class_added = True
+        if getattr(opt, "alg_diffusion_generate_per_class", False):
+            raise NotImplementedError("alg_diffusion_generate_per_class visuals are not built")
+        self.num_classes = max(opt.f_s_semantic_nclasses, opt.cls_semantic_nclasses)      # :149-151
+        self.drop_injection = None      # parity runs: callable(B) -> the uniform draws of the conditioning dropout
         if opt.G_nblocks == 9 and "resnet" not in opt.G_netG:
             opt.G_nblocks = 2  # palette_model.py:199-203
 
@@ -107,7 +116,7 @@ class PaletteModel(BaseModel):
             self.y_t = a
             self.gt_image = data["B"].to(self.device, non_blocking=True)
             self.mask = None
-        self.cls = None
+        self.cls = data["B_label_cls"].to(self.device).long() if "B_label_cls" in data else None      # :368-371
         self.cond_image = self.y_t
         self.batch_size = self.cond_image.shape[0]
         self.real_A = self.cond_image
@@ -120,8 +129,17 @@ class PaletteModel(BaseModel):
         if self.rng_injection is not None:
             t, u, noise = self.rng_injection(y_0.shape[0])
             noise = noise.to(self.device)
+        cls = self.cls
+        if self.opt.alg_diffusion_dropout_prob > 0.0 and cls is not None:
+            # :565-584: the conditioning of a random subset of the batch is replaced by the highest ("unconditioned") class; the draw
+            # precedes the generator's (t, u, noise) draws on the same RNG stream
+            r = self.drop_injection(y_0.shape[0]).to(self.device) if self.drop_injection is not None else torch.rand(y_0.shape[0], device=self.device)
+            drop = r < self.opt.alg_diffusion_dropout_prob
+            cls = torch.where(drop, torch.full_like(cls, self.num_classes - 1), cls)
+            if mask is not None:     # :573-579: every mask pixel of a dropped sample becomes the highest class too (clamped to 1 downstream)
+                mask = torch.where(drop.view(-1, 1, 1, 1).expand(mask.shape), torch.full_like(mask, self.num_classes - 1), mask)
         net = self._net("G_A")
-        noise, noise_hat, min_snr_w, _ = net.forward_nhwc(y_0, y_cond, mask, noise, t, u)
+        noise, noise_hat, min_snr_w, _ = net.forward_nhwc(y_0, y_cond, mask, noise, t, u, cls=cls)
         w = min_snr_w if self.opt.alg_palette_minsnr else None
         loss, levels = ops.ddpm_loss(noise_hat, noise.float(), mask, w, lam=self.opt.alg_diffusion_lambda_G,
                                      grad_scale=self.loss_scale, lossname=self.opt.alg_palette_loss)
@@ -134,12 +152,13 @@ class PaletteModel(BaseModel):
     @torch.no_grad()
     def inference(self, nb_imgs, offset=0):
         netG = self._net("G_A")
+        cls = self.cls[:nb_imgs] if self.cls is not None else None        # palette_model.py:739-760 (no per-class generation)
         if self.task == "inpainting":
             self.output, self.visuals = netG.restoration(y_cond=self.cond_image[:nb_imgs], y_t=self.y_t[:nb_imgs], y_0=self.gt_image[:nb_imgs],
-                                                         mask=self.mask[:nb_imgs], sample_num=self.sample_num, ddim_num_steps=self.ddim_num_steps,
-                                                         ddim_eta=self.ddim_eta, noises=self.sampling_noises)
+                                                         mask=self.mask[:nb_imgs], sample_num=self.sample_num, cls=cls,
+                                                         ddim_num_steps=self.ddim_num_steps, ddim_eta=self.ddim_eta, noises=self.sampling_noises)
         else:
-            self.output, self.visuals = netG.restoration(y_cond=self.cond_image[:nb_imgs], sample_num=self.sample_num,
+            self.output, self.visuals = netG.restoration(y_cond=self.cond_image[:nb_imgs], sample_num=self.sample_num, cls=cls,
                                                          noises=self.sampling_noises)
         self.fake_B = self.output
         self._publish_visuals(nb_imgs, offset)

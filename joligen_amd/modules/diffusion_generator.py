@@ -54,21 +54,47 @@ def set_new_noise_schedule(model, phase):
     model.register_buffer("posterior_mean_coef2_" + phase, to_torch((1.0 - gammas_prev) * np.sqrt(alphas) / (1.0 - gammas)))
 
 
+class LabelEmbedder(nn.Module):
+    """palette_denoise_fn.py:14-32: nn.Embedding(num_classes, hidden, max_norm=1.0, scale_grad_by_freq=True).  The lookup of B rows
+    is host-level plumbing on torch's device ops (renormalisation of the looked-up rows in place, gather, and a dense gradient that
+    autograd accumulates into the arena-backed `.grad`)."""
+
+    def __init__(self, num_classes, hidden_size):
+        super().__init__()
+        self.embedding_table = nn.Embedding(num_classes, hidden_size, max_norm=1.0, scale_grad_by_freq=True)
+        self.num_classes = num_classes
+
+    def forward(self, labels):
+        if not labels.is_cuda:
+            raise RuntimeError("LabelEmbedder: labels must live on the GPU (no CPU fallback)")
+        return self.embedding_table(labels)
+
+
 class PaletteDenoiseFn(nn.Module):
-    """palette_denoise_fn.py:35-115 with `conditioning == ""` (class / mask / ref embeddings are
-    outside SURVEY.md 8: all off in the BASELINE configs)."""
+    """palette_denoise_fn.py:35-115 for `conditioning` in {"", "class"}: with "class" the label embedding (cond_embed_dim // 2 wide) is
+    concatenated to the noise-level embedding (:99-103).  Mask conditioning (a per-pixel embedding concatenated to the UNet input) and
+    reference conditioning (CLIP / ImageBind image encoders) are not built: off in every BASELINE config."""
 
     def __init__(self, model, cond_embed_dim, ref_embed_net, conditioning, nclasses):
         super().__init__()
-        if conditioning:
-            raise NotImplementedError(f"alg_diffusion_cond_embed={conditioning!r} is not implemented (SURVEY.md 8: off)")
+        tokens = set(t for t in str(conditioning).replace(",", "_").split("_") if t)
+        if tokens - {"class"}:
+            raise NotImplementedError(f"alg_diffusion_cond_embed={conditioning!r}: only '' and 'class' are implemented")
         self.model = model
         self.conditioning = conditioning
         self.cond_embed_dim = cond_embed_dim
         self.ref_embed_net = ref_embed_net
+        if "class" in conditioning:
+            self.netl_embedder_class = LabelEmbedder(nclasses, cond_embed_dim // 2)
+            nn.init.normal_(self.netl_embedder_class.embedding_table.weight, std=0.02)
 
     def forward(self, input, embed_noise_level, cls=None, mask=None, ref=None):
-        return self.model(input, embed_noise_level)
+        embedding = embed_noise_level
+        if "class" in self.conditioning:
+            if cls is None:
+                raise RuntimeError("alg_diffusion_cond_embed='class' needs the class labels (B_label_cls)")
+            embedding = torch.cat((embed_noise_level, self.netl_embedder_class(cls).to(embed_noise_level.dtype)), dim=1)
+        return self.model(input, embedding)
 
 
 class DiffusionGenerator(nn.Module):
@@ -83,7 +109,8 @@ class DiffusionGenerator(nn.Module):
         set_new_noise_schedule(model=self.denoise_fn.model, phase="train")
         set_new_noise_schedule(model=self.denoise_fn.model, phase="test")
         self.cond_embed_dim = cond_embed_dim
-        self.cond_embed_gammas = cond_embed_dim
+        # :66-69: half of the embedding belongs to the class / reference embedding when one is configured
+        self.cond_embed_gammas = cond_embed_dim // 2 if any(c in self.denoise_fn.conditioning for c in ("class", "ref")) else cond_embed_dim
         self.cond_embed = nn.Sequential(
             nn.Linear(self.cond_embed_gammas, self.cond_embed_gammas),
             nn.SiLU(),
@@ -136,7 +163,7 @@ class DiffusionGenerator(nn.Module):
         snr = torch.pow(model.sqrt_recip_gammas_train.gather(-1, t) / model.sqrt_recipm1_gammas_train.gather(-1, t), 2)
         return (torch.minimum(snr, 5.0 * torch.ones_like(snr)) / snr).view(-1, 1, 1, 1)
 
-    def forward_nhwc(self, y_0, y_cond, mask, noise, t=None, u=None):
+    def forward_nhwc(self, y_0, y_cond, mask, noise, t=None, u=None, cls=None):
         """The training forward with the UNet output left in NHWC 16-bit (8 channels, 3 valid).
         Returns (noise fp32 NCHW, noise_hat NHWC 16-bit, min_snr_w [B,1,1,1], t)."""
         if self.arena is None:
@@ -152,12 +179,14 @@ class DiffusionGenerator(nn.Module):
         emb = self.compute_gammas(sample_gammas)
         xin = ops.ddpm_prepare(y_0.float(), y_cond.float(), noise.float(), mask, sample_gammas.view(-1).contiguous(),
                                self.act_dtype, cpad=8)
-        noise_hat = self.denoise_fn(xin, emb, cls=None, mask=mask, ref=None)
+        noise_hat = self.denoise_fn(xin, emb, cls=cls, mask=mask, ref=None)
         return noise, noise_hat, self.min_snr_weight(t), t
 
     def forward(self, y_0, y_cond, mask, noise, cls=None, ref=None, dropout_prob=0.0, t=None, u=None):
         """reference :457-521 signature; returns (noise, noise_hat, min_snr_loss_weight) NCHW fp32."""
-        noise, nh, w, _ = self.forward_nhwc(y_0, y_cond, mask, noise, t, u)
+        if ref is not None:
+            raise NotImplementedError("reference-image conditioning is not built")
+        noise, nh, w, _ = self.forward_nhwc(y_0, y_cond, mask, noise, t, u, cls=cls)
         return noise, ops.to_nchw_f32(nh, y_0.shape[1]), w
 
     # ---- sampling (reference :83-284) ---------------------------------------------------------
@@ -171,8 +200,9 @@ class DiffusionGenerator(nn.Module):
         Returns (y_t, ret_arr) like the reference, NCHW fp32."""
         if self.sampling_method not in ("ddpm", "ddim"):
             raise NotImplementedError(f"sampling method {self.sampling_method!r}")
-        if guidance_scale > 0.0 or cls is not None or ref is not None:
-            raise NotImplementedError("classifier-free guidance / class / reference conditioning are outside SURVEY.md 8")
+        if guidance_scale > 0.0 or ref is not None:
+            # (the reference's guided branch calls denoise_fn(..., cls=None), which cannot concatenate a class embedding: :214-227)
+            raise NotImplementedError("classifier-free guidance / reference conditioning are not built")
         if self.arena is None:
             raise RuntimeError("DiffusionGenerator.jg_finalize(device) has not been called")
         self.arena.ensure_fresh()
@@ -204,7 +234,7 @@ class DiffusionGenerator(nn.Module):
                 prev = int(tseq[-2 - i]) if i != ddim_num_steps - 1 else -1
                 t = torch.full((b,), ti, device=dev, dtype=torch.long)
                 emb = self.compute_gammas(model.gammas_test.gather(-1, t).view(b, 1))
-                nh = self.denoise_fn(xin, emb)
+                nh = self.denoise_fn(xin, emb, cls=cls)
                 gamma_t = model.gammas_test.gather(-1, t)
                 gamma_p = model.gammas_prev_test.gather(-1, torch.full((b,), prev + 1, device=dev, dtype=torch.long))
                 sigma = ddim_eta * torch.sqrt((1 - gamma_p) / (1 - gamma_t) * (1 - gamma_t / gamma_p))
@@ -223,7 +253,7 @@ class DiffusionGenerator(nn.Module):
         for step, i in enumerate(reversed(range(T))):
             t = torch.full((b,), i, device=dev, dtype=torch.long)
             emb = self.compute_gammas(model.gammas_test.gather(-1, t).view(b, 1))
-            nh = self.denoise_fn(xin, emb)
+            nh = self.denoise_fn(xin, emb, cls=cls)
             coef = torch.stack([model.sqrt_recip_gammas_test.gather(-1, t), model.sqrt_recipm1_gammas_test.gather(-1, t),
                                 model.posterior_mean_coef1_test.gather(-1, t), model.posterior_mean_coef2_test.gather(-1, t),
                                 (0.5 * model.posterior_log_variance_clipped_test.gather(-1, t)).exp()], dim=1).contiguous()

@@ -564,3 +564,74 @@ def test_rounding_yardstick():
         for dt in ("fp16", "bf16"):
             for k, v in r[dt].items():
                 assert abs(v - committed[shape][dt][k]) <= 0.25 * committed[shape][dt][k] + 1e-6, (shape, dt, k, v, committed[shape][dt][k])
+
+
+# ---- class-conditioned palette_model (alg_diffusion_cond_embed = "class"): oracle/make_golden_cond.py fixture -------------------
+def cls_state(g, T_test=None):
+    sched = {}
+    ref_sd = {}
+    for k in g["keys"]:
+        leaf = k.split(".")[-1]
+        if O._is_buffer(k):
+            phase = "train" if leaf.endswith("_train") else "test"
+            n = g["shapes"][k][0]
+            if (phase, n) not in sched:
+                sched[(phase, n)] = O.noise_schedule_buffers(phase, n)
+            ref_sd[k] = sched[(phase, n)][leaf]
+        else:
+            ref_sd[k] = torch.empty(g["shapes"][k])
+    sd = O.synth_state_dict(ref_sd, seed=0)
+    row, scale = g["table_row_scale"]
+    sd["denoise_fn.netl_embedder_class.embedding_table.weight"][row] *= scale      # a row longer than max_norm
+    return sd
+
+
+def palette_conditioning_dropout(drop_u, p, num_classes, cls, mask):
+    """compute_palette_loss (palette_model.py:565-584): for the dropped samples BOTH conditionings are replaced by the highest class --
+    the class label, and every pixel of the mask (which, clamped to [0, 1] downstream, makes the whole image of that sample "masked")."""
+    drop = drop_u < p
+    cls = torch.where(drop, torch.full_like(cls, num_classes - 1), cls)
+    mask = torch.where(drop.reshape(-1, 1, 1, 1).expand(mask.shape), torch.full_like(mask, num_classes - 1), mask)
+    return cls, mask
+
+
+def test_palette_class_conditioning(golden_dir):
+    g = load(golden_dir, "palette_cls_tiny.pt")
+    c = g["cfg"]
+    cfg = cfg_of(c)
+    assert g["num_classes"] == c["nclasses"] + 1            # the unconditioned class of the conditioning dropout
+    # generator forward with labels; the looked-up row longer than max_norm is renormalised in place
+    sd = cls_state(g)
+    f = g["fwd"]
+    k = "denoise_fn.netl_embedder_class.embedding_table.weight"
+    assert float(sd[k][2].norm()) > 1.0
+    with torch.no_grad():
+        _, noise_hat, w, _ = O.diffusion_generator_forward(sd, f["B"], f["A"], f["mask"], f["noise"], f["t"], f["u"], cfg, cls=f["cls"])
+    torch.testing.assert_close(noise_hat, f["noise_hat"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(sd[k][2].norm(), f["table_row2_norm_after"], rtol=1e-5, atol=1e-6)
+    assert float(sd[k][2].norm()) <= 1.0 + 1e-5
+    # three optimizer steps with the conditioning dropout
+    sd = cls_state(g)
+    hp = g["hp"]
+    tr = O.OraclePaletteTrainer(sd, cfg, lr=hp["lr"], beta1=hp["beta1"], beta2=hp["beta2"], eps=hp["eps"], weight_decay=hp["weight_decay"],
+                                ema_beta=hp["ema_beta"], lambda_G=hp["lambda_G"], optim=hp["optim"])
+    for it, s in enumerate(g["steps"]):
+        cls, mask = palette_conditioning_dropout(s["drop_u"], c["dropout_prob"], g["num_classes"], s["cls"], s["mask"])
+        loss = tr.optimize_parameters(s["B"], s["A"], mask, s["noise"], s["t"], s["u"], cls=cls)
+        torch.testing.assert_close(loss, s["loss"], rtol=2e-4, atol=1e-6)
+        if "param_checks" in s:
+            for kk, ref in s["param_checks"].items():
+                v = tr.P[kk]
+                mine = torch.stack([v.norm(), (v * O.projection_vector(kk, v.shape)).sum()])
+                torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=kk)
+            for kk, ref in s["ema_checks"].items():
+                v = tr.ema[kk]
+                mine = torch.stack([v.norm(), (v * O.projection_vector(kk, v.shape)).sum()])
+                torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=kk)
+    # sampling with labels
+    sd = cls_state(g)
+    sm = g["sampling"]
+    with torch.no_grad():
+        y, ret = O.ddpm_restoration(sd, sm["A"], sm["y_t0"], sm["B"], sm["mask"], sm["noises"], cfg, sample_num=2, cls=sm["cls"])
+    torch.testing.assert_close(y, sm["y_out"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(ret, sm["ret"], rtol=1e-4, atol=1e-5)
