@@ -59,8 +59,8 @@ class PaletteModel(BaseModel):
             raise NotImplementedError("only alg_diffusion_cond_image_creation='y_t' is implemented")
         if opt.alg_palette_loss not in ("MSE", "L1", "multiscale_MSE", "multiscale_L1"):
             raise NotImplementedError(f"alg_palette_loss={opt.alg_palette_loss!r}")
-        if opt.alg_diffusion_dropout_prob > 0 and "class" not in opt.alg_diffusion_cond_embed:
-            raise NotImplementedError("alg_diffusion_dropout_prob > 0 needs a class embedding to drop (mask conditioning is not built)")
+        if "ref" in opt.alg_diffusion_cond_embed:
+            raise NotImplementedError("reference-image conditioning needs CLIP / ImageBind encoders (not built)")
         if opt.isTrain and opt.alg_diffusion_dropout_prob > 0 and not getattr(opt, "_jg_dropout_class_added", False):
             # PaletteModel.after_parse (palette_model.py:102-107): one more class, the unconditioned one
             opt.f_s_semantic_nclasses += 1
@@ -130,12 +130,13 @@ class PaletteModel(BaseModel):
             t, u, noise = self.rng_injection(y_0.shape[0])
             noise = noise.to(self.device)
         cls = self.cls
-        if self.opt.alg_diffusion_dropout_prob > 0.0 and cls is not None:
+        if self.opt.alg_diffusion_dropout_prob > 0.0:
             # :565-584: the conditioning of a random subset of the batch is replaced by the highest ("unconditioned") class; the draw
             # precedes the generator's (t, u, noise) draws on the same RNG stream
             r = self.drop_injection(y_0.shape[0]).to(self.device) if self.drop_injection is not None else torch.rand(y_0.shape[0], device=self.device)
             drop = r < self.opt.alg_diffusion_dropout_prob
-            cls = torch.where(drop, torch.full_like(cls, self.num_classes - 1), cls)
+            if cls is not None:
+                cls = torch.where(drop, torch.full_like(cls, self.num_classes - 1), cls)
             if mask is not None:     # :573-579: every mask pixel of a dropped sample becomes the highest class too (clamped to 1 downstream)
                 mask = torch.where(drop.view(-1, 1, 1, 1).expand(mask.shape), torch.full_like(mask, self.num_classes - 1), mask)
         net = self._net("G_A")

@@ -71,15 +71,16 @@ class LabelEmbedder(nn.Module):
 
 
 class PaletteDenoiseFn(nn.Module):
-    """palette_denoise_fn.py:35-115 for `conditioning` in {"", "class"}: with "class" the label embedding (cond_embed_dim // 2 wide) is
-    concatenated to the noise-level embedding (:99-103).  Mask conditioning (a per-pixel embedding concatenated to the UNet input) and
-    reference conditioning (CLIP / ImageBind image encoders) are not built: off in every BASELINE config."""
+    """palette_denoise_fn.py:35-115 for `conditioning` made of "class" and / or "mask" (the reference tests substrings: "class_mask"
+    selects both): with "class" the label embedding (cond_embed_dim // 2 wide) is concatenated to the noise-level embedding (:99-103);
+    with "mask" a per-pixel label embedding (cond_embed_dim wide, looked up from the semantic mask) is concatenated to the UNet INPUT
+    (:108-112, define_G adds cond_embed_dim input channels).  Reference-image conditioning (CLIP / ImageBind encoders) is not built."""
 
     def __init__(self, model, cond_embed_dim, ref_embed_net, conditioning, nclasses):
         super().__init__()
         tokens = set(t for t in str(conditioning).replace(",", "_").split("_") if t)
-        if tokens - {"class"}:
-            raise NotImplementedError(f"alg_diffusion_cond_embed={conditioning!r}: only '' and 'class' are implemented")
+        if tokens - {"class", "mask"}:
+            raise NotImplementedError(f"alg_diffusion_cond_embed={conditioning!r}: '', 'class', 'mask' and 'class_mask' are implemented")
         self.model = model
         self.conditioning = conditioning
         self.cond_embed_dim = cond_embed_dim
@@ -87,13 +88,29 @@ class PaletteDenoiseFn(nn.Module):
         if "class" in conditioning:
             self.netl_embedder_class = LabelEmbedder(nclasses, cond_embed_dim // 2)
             nn.init.normal_(self.netl_embedder_class.embedding_table.weight, std=0.02)
+        if "mask" in conditioning:
+            self.netl_embedder_mask = LabelEmbedder(nclasses, cond_embed_dim)
+            nn.init.normal_(self.netl_embedder_mask.embedding_table.weight, std=0.02)
 
     def forward(self, input, embed_noise_level, cls=None, mask=None, ref=None):
+        """input: [B, H, W, Cpad] 16-bit NHWC holding the (y_cond, y_noisy) channels first"""
         embedding = embed_noise_level
         if "class" in self.conditioning:
             if cls is None:
                 raise RuntimeError("alg_diffusion_cond_embed='class' needs the class labels (B_label_cls)")
             embedding = torch.cat((embed_noise_level, self.netl_embedder_class(cls).to(embed_noise_level.dtype)), dim=1)
+        if "mask" in self.conditioning:
+            if mask is None:
+                raise RuntimeError("alg_diffusion_cond_embed='mask' needs the semantic mask (B_label_mask)")
+            B, H, W, _ = input.shape
+            D = self.cond_embed_dim
+            real = self.model.in_channel - D              # the image channels in front (y_cond, y_noisy)
+            pad = (-self.model.in_channel) % 8
+            me = self.netl_embedder_mask(mask.long().reshape(B, H * W)).view(B, H, W, D).to(input.dtype)
+            parts = [input[..., :real], me]
+            if pad:
+                parts.append(torch.zeros((B, H, W, pad), device=input.device, dtype=input.dtype))
+            input = torch.cat(parts, dim=-1)
         return self.model(input, embedding)
 
 
@@ -234,7 +251,7 @@ class DiffusionGenerator(nn.Module):
                 prev = int(tseq[-2 - i]) if i != ddim_num_steps - 1 else -1
                 t = torch.full((b,), ti, device=dev, dtype=torch.long)
                 emb = self.compute_gammas(model.gammas_test.gather(-1, t).view(b, 1))
-                nh = self.denoise_fn(xin, emb, cls=cls)
+                nh = self.denoise_fn(xin, emb, cls=cls, mask=mask)
                 gamma_t = model.gammas_test.gather(-1, t)
                 gamma_p = model.gammas_prev_test.gather(-1, torch.full((b,), prev + 1, device=dev, dtype=torch.long))
                 sigma = ddim_eta * torch.sqrt((1 - gamma_p) / (1 - gamma_t) * (1 - gamma_t / gamma_p))
@@ -253,7 +270,7 @@ class DiffusionGenerator(nn.Module):
         for step, i in enumerate(reversed(range(T))):
             t = torch.full((b,), i, device=dev, dtype=torch.long)
             emb = self.compute_gammas(model.gammas_test.gather(-1, t).view(b, 1))
-            nh = self.denoise_fn(xin, emb, cls=cls)
+            nh = self.denoise_fn(xin, emb, cls=cls, mask=mask)
             coef = torch.stack([model.sqrt_recip_gammas_test.gather(-1, t), model.sqrt_recipm1_gammas_test.gather(-1, t),
                                 model.posterior_mean_coef1_test.gather(-1, t), model.posterior_mean_coef2_test.gather(-1, t),
                                 (0.5 * model.posterior_log_variance_clipped_test.gather(-1, t)).exp()], dim=1).contiguous()

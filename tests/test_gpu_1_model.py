@@ -53,7 +53,8 @@ def overrides_of(c, **extra):
 
 
 def cfg_of(c):
-    return O.UNetCfg(in_channel=6, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"],
+    extra = c.get("cond_embed_dim", 0) if "mask" in c.get("cond", "") else 0       # mask conditioning widens the UNet input
+    return O.UNetCfg(in_channel=6 + extra, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"],
                      attn_res=c["attn_res"], channel_mults=c["mults"], efficient=c["efficient"])
 
 
@@ -714,7 +715,7 @@ def test_device_input_pipeline_bit_exact(golden_dir):
 def _cls_model(g, dtype_name, golden_dir, hp=None, **extra):
     from test_oracle_golden import cls_state
     c = g["cfg"]
-    model = make_model(c, dtype_name, golden_dir, hp, alg_diffusion_cond_embed="class", alg_diffusion_cond_embed_dim=c["cond_embed_dim"],
+    model = make_model(c, dtype_name, golden_dir, hp, alg_diffusion_cond_embed=c["cond"], alg_diffusion_cond_embed_dim=c["cond_embed_dim"],
                        alg_diffusion_dropout_prob=c["dropout_prob"], f_s_semantic_nclasses=c["nclasses"], cls_semantic_nclasses=c["nclasses"],
                        G_diff_n_timestep_test=g["sampling"]["T"], **extra)
     net = model.netG_A
@@ -726,32 +727,35 @@ def _cls_model(g, dtype_name, golden_dir, hp=None, **extra):
 
 
 @pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
-def test_palette_class_conditioning_vs_reference_golden(golden_dir, dtype_name):
-    """LabelEmbedder (max_norm renormalisation in place, scale_grad_by_freq) concatenated to a half-width noise-level embedding, the
-    conditioning dropout of compute_palette_loss (labels AND mask of the dropped samples -> highest class), sampling with labels:
+@pytest.mark.parametrize("tag", ["cls", "mask"])
+def test_palette_class_conditioning_vs_reference_golden(golden_dir, tag, dtype_name):
+    """cls: LabelEmbedder (max_norm renormalisation in place, scale_grad_by_freq) concatenated to a half-width noise-level embedding;
+    mask: a per-pixel label embedding concatenated to the UNet input (38 input channels, gradient through the stem convolution into
+    the table); both: the conditioning dropout of compute_palette_loss (labels AND mask of the dropped samples -> highest class), sampling:
     generator forward and DDPM restoration against the reference's outputs, 3 teacher-forced optimizer steps against the CPU oracle
     (which reproduces the reference's losses and parameter checksums of these iterations: tests/test_oracle_golden.py)."""
     import parity_util as PU
     from test_oracle_golden import cls_state, palette_conditioning_dropout
 
-    g = load(golden_dir, "palette_cls_tiny.pt")
+    g = load(golden_dir, f"palette_{tag}_tiny.pt")
     c, hp = g["cfg"], g["hp"]
     dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
     model = _cls_model(g, dtype_name, golden_dir, hp)
     net = model.netG_A
     d = torch.device("cuda:0")
-    k = "denoise_fn.netl_embedder_class.embedding_table.weight"
+    k = g["table_key"]
+    dev = lambda v: None if v is None else v.to(d)
     # forward
     f = g["fwd"]
     with torch.no_grad():
-        noise, noise_hat, w = net(f["B"].to(d), f["A"].to(d), f["mask"].to(d), f["noise"].to(d), cls=f["cls"].to(d), t=f["t"], u=f["u"])
+        noise, noise_hat, w = net(f["B"].to(d), f["A"].to(d), f["mask"].to(d), f["noise"].to(d), cls=dev(f["cls"]), t=f["t"], u=f["u"])
     assert relerr(noise_hat, f["noise_hat"]) < TOL_OUT[dtype], relerr(noise_hat, f["noise_hat"])
     row_norm = float(net.state_dict()[k][2].norm())
     assert abs(row_norm - float(f["table_row2_norm_after"])) < 1e-5, row_norm       # renormalised in place, like nn.Embedding(max_norm=1)
     # sampling with labels
     sm = g["sampling"]
     net.load_state_dict(cls_state(g))
-    y, ret = net.restoration(sm["A"].to(d), y_t=sm["y_t0"].to(d), y_0=sm["B"].to(d), mask=sm["mask"].to(d), sample_num=2, cls=sm["cls"].to(d),
+    y, ret = net.restoration(sm["A"].to(d), y_t=sm["y_t0"].to(d), y_0=sm["B"].to(d), mask=sm["mask"].to(d), sample_num=2, cls=dev(sm["cls"]),
                              noises=sm["noises"])
     assert relerr(y, sm["y_out"]) < 2 * TOL_OUT[dtype], relerr(y, sm["y_out"])
     assert relerr(ret, sm["ret"]) < 2 * TOL_OUT[dtype]
@@ -765,7 +769,10 @@ def test_palette_class_conditioning_vs_reference_golden(golden_dir, dtype_name):
         before, ref_before = PU.snapshot(net), {kk: tr.P[kk].clone() for kk in tr.param_names}
         model.rng_injection = lambda b, s=s: (s["t"], s["u"], s["noise"])
         model.drop_injection = lambda b, s=s: s["drop_u"]
-        model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "B_label_cls": s["cls"], "A_img_paths": ["x"]})
+        data = {"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "A_img_paths": ["x"]}
+        if s["cls"] is not None:
+            data["B_label_cls"] = s["cls"]
+        model.set_input(data)
         model.optimize_parameters()
         loss = float(model.get_current_losses()["G_tot"])
         cls, mask = palette_conditioning_dropout(s["drop_u"], c["dropout_prob"], g["num_classes"], s["cls"], s["mask"])
@@ -773,9 +780,9 @@ def test_palette_class_conditioning_vs_reference_golden(golden_dir, dtype_name):
         assert abs(loss_ref - float(s["loss"])) < 2e-4 * abs(float(s["loss"])) + 1e-6
         assert abs(loss - loss_ref) < TOL_LOSS_FWD[dtype] * abs(loss_ref), (it, loss, loss_ref)
         after = PU.snapshot(net)
-        PU.check_update(f"cls {dtype_name} it{it}", before, after, ref_before, {kk: tr.P[kk] for kk in tr.param_names}, COS_UPDATE[dtype], log=log)
+        PU.check_update(f"{tag} {dtype_name} it{it}", before, after, ref_before, {kk: tr.P[kk] for kk in tr.param_names}, COS_UPDATE[dtype], log=log)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/update_agreement_palette_cls_{dtype_name}.txt", "w") as fh:
+    with open(f"gpurun_out/update_agreement_palette_{tag}_{dtype_name}.txt", "w") as fh:
         fh.write("\n".join(log))
 
 
@@ -807,3 +814,33 @@ def test_palette_class_embedding_gradient_vs_oracle(golden_dir):
     for kk in ("cond_embed.0.weight", "cond_embed.2.weight"):
         e = relerr(dict(net.named_parameters())[kk].grad / model.loss_scale, grads_ref[kk])
         assert e < TOL_GRAD[torch.float16], (kk, e)
+
+
+def test_palette_mask_embedding_gradient_vs_oracle(golden_dir):
+    """first-step gradient of the per-pixel mask-embedding table (through the input gradient of the 38-channel stem convolution; rows
+    scaled by 1 / their pixel count in the batch, unused classes zero) and of the stem weights against the CPU oracle"""
+    g = load(golden_dir, "palette_mask_tiny.pt")
+    c = g["cfg"]
+    model = _cls_model(g, "fp16", golden_dir, g["hp"], train_G_ema=False)
+    net = model.netG_A
+    s = g["steps"][0]
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    tr = O.OraclePaletteTrainer(sd, cfg_of(c), ema_beta=None)
+    loss_ref, grads_ref, _ = tr.loss_and_grads(s["B"], s["A"], s["mask"], s["noise"], s["t"], s["u"])
+    model.rng_injection = lambda b: (s["t"], s["u"], s["noise"])
+    model.drop_injection = lambda b: torch.ones(b)
+    model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"]})
+    model.compute_palette_loss()
+    model.loss_G_tot.backward()
+    torch.cuda.synchronize()
+    assert abs(float(model.loss_G_tot) - float(loss_ref)) < 5e-3 * float(loss_ref)
+    k = g["table_key"]
+    mine = dict(net.named_parameters())[k].grad.detach().float().cpu() / model.loss_scale
+    ref = grads_ref[k]
+    used = sorted(set(int(v) for v in s["mask"].unique()))
+    unused = [i for i in range(ref.shape[0]) if i not in used]
+    assert float(ref[used].norm()) > 0 and float(ref[unused].abs().max()) == 0.0 and float(mine[unused].abs().max()) == 0.0
+    assert relerr(mine[used], ref[used]) < 2 * TOL_GRAD[torch.float16], relerr(mine[used], ref[used])
+    kk = "denoise_fn.model.input_blocks.0.0.weight"
+    e = relerr(dict(net.named_parameters())[kk].grad / model.loss_scale, grads_ref[kk])
+    assert e < TOL_GRAD[torch.float16], e

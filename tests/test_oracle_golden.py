@@ -11,7 +11,9 @@ CFGS = ["tiny_eff", "tiny_noeff", "tiny_attn"]
 
 
 def cfg_of(c):
-    return O.UNetCfg(in_channel=6, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"],
+    # mask conditioning (alg_diffusion_cond_embed containing "mask") adds cond_embed_dim input channels (diffusion_networks.py:112-113)
+    extra = c.get("cond_embed_dim", 0) if "mask" in c.get("cond", "") else 0
+    return O.UNetCfg(in_channel=6 + extra, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"],
                      attn_res=c["attn_res"], channel_mults=c["mults"], efficient=c["efficient"])
 
 
@@ -582,7 +584,7 @@ def cls_state(g, T_test=None):
             ref_sd[k] = torch.empty(g["shapes"][k])
     sd = O.synth_state_dict(ref_sd, seed=0)
     row, scale = g["table_row_scale"]
-    sd["denoise_fn.netl_embedder_class.embedding_table.weight"][row] *= scale      # a row longer than max_norm
+    sd[g["table_key"]][row] *= scale      # a row longer than max_norm
     return sd
 
 
@@ -590,20 +592,22 @@ def palette_conditioning_dropout(drop_u, p, num_classes, cls, mask):
     """compute_palette_loss (palette_model.py:565-584): for the dropped samples BOTH conditionings are replaced by the highest class --
     the class label, and every pixel of the mask (which, clamped to [0, 1] downstream, makes the whole image of that sample "masked")."""
     drop = drop_u < p
-    cls = torch.where(drop, torch.full_like(cls, num_classes - 1), cls)
+    if cls is not None:
+        cls = torch.where(drop, torch.full_like(cls, num_classes - 1), cls)
     mask = torch.where(drop.reshape(-1, 1, 1, 1).expand(mask.shape), torch.full_like(mask, num_classes - 1), mask)
     return cls, mask
 
 
-def test_palette_class_conditioning(golden_dir):
-    g = load(golden_dir, "palette_cls_tiny.pt")
+@pytest.mark.parametrize("tag", ["cls", "mask"])
+def test_palette_conditioning(golden_dir, tag):
+    g = load(golden_dir, f"palette_{tag}_tiny.pt")
     c = g["cfg"]
     cfg = cfg_of(c)
     assert g["num_classes"] == c["nclasses"] + 1            # the unconditioned class of the conditioning dropout
-    # generator forward with labels; the looked-up row longer than max_norm is renormalised in place
+    # generator forward with the conditioning; the looked-up row longer than max_norm is renormalised in place
     sd = cls_state(g)
     f = g["fwd"]
-    k = "denoise_fn.netl_embedder_class.embedding_table.weight"
+    k = g["table_key"]
     assert float(sd[k][2].norm()) > 1.0
     with torch.no_grad():
         _, noise_hat, w, _ = O.diffusion_generator_forward(sd, f["B"], f["A"], f["mask"], f["noise"], f["t"], f["u"], cfg, cls=f["cls"])
@@ -628,7 +632,7 @@ def test_palette_class_conditioning(golden_dir):
                 v = tr.ema[kk]
                 mine = torch.stack([v.norm(), (v * O.projection_vector(kk, v.shape)).sum()])
                 torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=kk)
-    # sampling with labels
+    # sampling with the conditioning
     sd = cls_state(g)
     sm = g["sampling"]
     with torch.no_grad():
