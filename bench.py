@@ -18,8 +18,11 @@ Extra objects on the JSON line:
                   implicit-GEMM 3x3 convolution, forward + input-gradient):
                   achieved = algorithmic FLOPs per launch (2*M*N*K) / average launch duration, both
                   from HIP events recorded around EVERY launch on the launch stream during a
-                  separate instrumented pass of 2 steps (the timed region carries no events);
-                  peak = 2500 TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md).
+                  separate instrumented pass of 2 steps (the timed region carries no events) with the
+                  weight-gradient side stream off, i.e. one kernel on the GPU at a time (what rocprofv3's
+                  PMC passes see; `avg_launch_us_overlapped` = the same launches with the side stream on);
+                  peak = 2500 TFLOP/s dense bf16 MFMA (MI355X_MICROARCH.md); traffic = HBM bytes per launch
+                  from the committed rocprofv3 PMC passes of the same command (profiles/r02_pmc.json).
   cpu_baseline -- the CPU oracle (oracle/jg_oracle.py, a torch-CPU-fp32 port of the reference
                   step) timed on this box's host cores on a bounded sample (rank 0, N == 1 only).
 """
