@@ -707,6 +707,287 @@ __global__ void scale_kernel(const T* __restrict__ x, const float* __restrict__ 
 }
 
 // fp32 [n] -> T [n] (the dk / dv accumulators)
+// ---- attention backward for T_kv <= 64 on the matrix cores -------------------------------------------------------------------------------
+// EfficientMultiheadAttention after the spatial reduction has 64 keys at every stage of a 256 x 256 input (backbone.py:293-313) against
+// 64 ... 4096 queries.  The scalar kernel above spends 14 K FMA per query on the vector unit at one wave per workgroup; here a WAVE
+// owns a 64-query tile and every product is a v_mfma_f32_16x16x32 (head dim 32 = one k-step):
+//   S^T = K Q^T, dP^T = V dO^T        operands straight from global memory (16-byte rows of K / V as A, of Q / dO as B)
+//   P = exp(S scale - lse), dS = P (dP - D) scale, D = rowsum(dO . O)     in the accumulator layout (4 consecutive keys x 1 query)
+//   dQ^T = K^T dS^T, dK^T += Q^T dS, dV^T += dO^T P        second stage: P / dS in 16 bit through LDS in the two orientations the
+//                                                           operands need, Q^T / dO^T / K^T as transposed LDS copies
+// dK / dV stay in accumulator registers over all tiles of the wave, the four waves of a block are summed through LDS and ONE wave issues
+// the fp32 atomics (the scalar kernel's bottleneck at T_q = 4096: 64 workgroups per image hitting the same 4096 addresses).
+// LDS rows are 72 elements (144 B) apart: the 16 rows of a ds_read_b128 group start in 16 different bank quads.
+constexpr int KV64_LD = 72;
+constexpr int KV64_WAVE_ELEMS = (3 * 64 + 2 * 32) * KV64_LD;      // dS [q][k], dS^T [k][q], P^T [k][q], Q^T [c][q], dO^T [c][q]
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kv64_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                            const T* __restrict__ o, const T* __restrict__ dout, const float* __restrict__ lse,
+                                                            T* __restrict__ dq, float* __restrict__ dkf, float* __restrict__ dvf, int Tq, int Tkv,
+                                                            int heads, long ldq, long ldkv, long ldo, float scale, int tiles_per_wave) {
+  __shared__ __attribute__((aligned(16))) T sm[4 * KV64_WAVE_ELEMS + 32 * KV64_LD];
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  T* sKt = sm + 4 * KV64_WAVE_ELEMS;                 // [32 c][64 k], shared by the block
+  T* sdS = sm + wave * KV64_WAVE_ELEMS;              // [64 q][64 k]
+  T* sdSt = sdS + 64 * KV64_LD;                      // [64 k][64 q]
+  T* sPt = sdSt + 64 * KV64_LD;                      // [64 k][64 q]
+  T* sQt = sPt + 64 * KV64_LD;                       // [32 c][64 q]
+  T* sdOt = sQt + 32 * KV64_LD;                      // [32 c][64 q]
+  const T* kb = k + (long)b * Tkv * ldkv + h * 32;
+  const T* vb = v + (long)b * Tkv * ldkv + h * 32;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  {   // K^T for the whole block: thread = (key, 8-channel chunk)
+    const int key = tid >> 2, c0 = (tid & 3) * 8;
+    float f[8];
+    unpack8<T>(key < Tkv ? *reinterpret_cast<const uint4*>(kb + (long)key * ldkv + c0) : zero4, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sKt[(c0 + e) * KV64_LD + key] = from_f32<T>(f[e]);
+  }
+  // A operands of the first stage: rows of K and V (key l15 + 16 kt, channels kg * 8 .. + 7), kept for every tile of this wave
+  uint4 fk[4], fv[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = kt * 16 + l15;
+    fk[kt] = key < Tkv ? *reinterpret_cast<const uint4*>(kb + (long)key * ldkv + kg * 8) : zero4;
+    fv[kt] = key < Tkv ? *reinterpret_cast<const uint4*>(vb + (long)key * ldkv + kg * 8) : zero4;
+  }
+  f32x4 dKa[2][4], dVa[2][4];      // dK^T / dV^T: [channel tile][key tile], rows = 4 consecutive channels, column = key
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) dKa[ct][kt] = dVa[ct][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  const int ntiles = (Tq + 63) / 64;
+  for (int it = 0; it < tiles_per_wave; ++it) {        // the same trip count for every wave: the barriers below are block-wide
+    const int tile = (blockIdx.x * 4 + wave) * tiles_per_wave + it;
+    const int q0 = tile * 64;
+    const bool live = tile < ntiles;
+    // ---- this tile's Q / dO rows (B operands), D and lse per query, transposed copies --------------------------------------------
+    uint4 fq[4], fdo[4];
+    float Dq[4], Lq[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int qi = q0 + qt * 16 + l15;
+      const bool ok = live && qi < Tq;
+      const long row = ((long)b * Tq + (ok ? qi : 0));
+      fq[qt] = ok ? *reinterpret_cast<const uint4*>(q + row * ldq + h * 32 + kg * 8) : zero4;
+      fdo[qt] = ok ? *reinterpret_cast<const uint4*>(dout + row * ldo + h * 32 + kg * 8) : zero4;
+      const uint4 fo = ok ? *reinterpret_cast<const uint4*>(o + row * ldo + h * 32 + kg * 8) : zero4;
+      float a[8], d8[8], o8[8];
+      unpack8<T>(fq[qt], a);
+      unpack8<T>(fdo[qt], d8);
+      unpack8<T>(fo, o8);
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        part += d8[e] * o8[e];
+        sQt[(kg * 8 + e) * KV64_LD + qt * 16 + l15] = from_f32<T>(a[e]);
+        sdOt[(kg * 8 + e) * KV64_LD + qt * 16 + l15] = from_f32<T>(d8[e]);
+      }
+      part += __shfl_xor(part, 16);
+      part += __shfl_xor(part, 32);
+      Dq[qt] = part;
+      Lq[qt] = ok ? lse[((long)b * heads + h) * Tq + qi] : 0.f;
+    }
+    // ---- first stage: S^T and dP^T tiles, P / dS to LDS ---------------------------------------------------------------------------
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 st = Mfma<T>::run(fk[kt], fq[qt], z);       // rows: keys kt*16 + 4*kg + i, column: query qt*16 + l15
+        const f32x4 dpt = Mfma<T>::run(fv[kt], fdo[qt], z);
+        const int qloc = qt * 16 + l15;
+        const bool qok = live && q0 + qloc < Tq;
+        float pv[4], dsv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = kt * 16 + kg * 4 + i;
+          const float p = (qok && key < Tkv) ? expf(st[i] * scale - Lq[qt]) : 0.f;
+          pv[i] = p;
+          dsv[i] = p * (dpt[i] - Dq[qt]) * scale;
+          sPt[key * KV64_LD + qloc] = from_f32<T>(p);
+          sdSt[key * KV64_LD + qloc] = from_f32<T>(dsv[i]);
+        }
+        *reinterpret_cast<uint2*>(sdS + qloc * KV64_LD + kt * 16 + kg * 4) = pack4<T>(dsv[0], dsv[1], dsv[2], dsv[3]);
+      }
+    }
+    __syncthreads();
+    // ---- second stage ----------------------------------------------------------------------------------------------------------------
+    // dQ^T [c][q] = sum_k K^T[c][k] dS[q][k]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      uint4 ka[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) ka[ks] = *reinterpret_cast<const uint4*>(sKt + (ct * 16 + l15) * KV64_LD + ks * 32 + kg * 8);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc = Mfma<T>::run(ka[ks], *reinterpret_cast<const uint4*>(sdS + (qt * 16 + l15) * KV64_LD + ks * 32 + kg * 8), acc);
+        const int qi = q0 + qt * 16 + l15;
+        if (live && qi < Tq)
+          *reinterpret_cast<uint2*>(dq + ((long)b * Tq + qi) * ldq + h * 32 + ct * 16 + kg * 4) = pack4<T>(acc[0], acc[1], acc[2], acc[3]);
+      }
+    }
+    // dK^T [c][k] += sum_q Q^T[c][q] dS^T[k][q];   dV^T [c][k] += sum_q dO^T[c][q] P^T[k][q]
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      uint4 qa[2], da[2];
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        qa[qs] = *reinterpret_cast<const uint4*>(sQt + (ct * 16 + l15) * KV64_LD + qs * 32 + kg * 8);
+        da[qs] = *reinterpret_cast<const uint4*>(sdOt + (ct * 16 + l15) * KV64_LD + qs * 32 + kg * 8);
+      }
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+          dKa[ct][kt] = Mfma<T>::run(qa[qs], *reinterpret_cast<const uint4*>(sdSt + (kt * 16 + l15) * KV64_LD + qs * 32 + kg * 8), dKa[ct][kt]);
+          dVa[ct][kt] = Mfma<T>::run(da[qs], *reinterpret_cast<const uint4*>(sPt + (kt * 16 + l15) * KV64_LD + qs * 32 + kg * 8), dVa[ct][kt]);
+        }
+      }
+    }
+    __syncthreads();      // the next tile overwrites this wave's LDS tiles
+  }
+  // ---- block reduction of dK / dV: waves 1..3 park their accumulators in (their own, now free) LDS region, wave 0 adds and issues atomics
+  float* red = reinterpret_cast<float*>(sm + wave * KV64_WAVE_ELEMS);      // [2][2 ct][4 kt][64 lanes][4]: 16 KB of the wave's 36 KB
+  if (wave != 0) {
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        *reinterpret_cast<f32x4*>(red + (((0 * 2 + ct) * 4 + kt) * 64 + lane) * 4) = dKa[ct][kt];
+        *reinterpret_cast<f32x4*>(red + (((1 * 2 + ct) * 4 + kt) * 64 + lane) * 4) = dVa[ct][kt];
+      }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int H32 = heads * 32;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        f32x4 sk = dKa[ct][kt], sv = dVa[ct][kt];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+          const float* rw = reinterpret_cast<const float*>(sm + w * KV64_WAVE_ELEMS);
+          const f32x4 a = *reinterpret_cast<const f32x4*>(rw + (((0 * 2 + ct) * 4 + kt) * 64 + lane) * 4);
+          const f32x4 c2 = *reinterpret_cast<const f32x4*>(rw + (((1 * 2 + ct) * 4 + kt) * 64 + lane) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            sk[i] += a[i];
+            sv[i] += c2[i];
+          }
+        }
+        const int key = kt * 16 + l15;
+        if (key < Tkv) {
+          float* dkp = dkf + ((long)b * Tkv + key) * H32 + h * 32 + ct * 16 + kg * 4;
+          float* dvp = dvf + ((long)b * Tkv + key) * H32 + h * 32 + ct * 16 + kg * 4;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            atomicAdd(dkp + i, sk[i]);
+            atomicAdd(dvp + i, sv[i]);
+          }
+        }
+      }
+  }
+}
+
+// forward of the same attention on the matrix cores: S^T = K Q^T per 64-query tile of a wave, softmax over the 64 keys of a query column
+// (16 values per lane, the rest two xor-shuffles away), P in 16 bit through LDS, O^T = V^T P^T
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kv64_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
+                                                            T* __restrict__ o, float* __restrict__ lse, int Tq, int Tkv, int heads, long ldq,
+                                                            long ldkv, long ldo, float scale, int tiles_per_wave) {
+  __shared__ __attribute__((aligned(16))) T sm[4 * 64 * KV64_LD + 32 * KV64_LD];
+  const int h = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, kg = lane >> 4;
+  T* sP = sm + wave * 64 * KV64_LD;                  // [64 q][64 k] of this wave
+  T* sVt = sm + 4 * 64 * KV64_LD;                    // [32 c][64 k], shared by the block
+  const T* kb = k + (long)b * Tkv * ldkv + h * 32;
+  const T* vb = v + (long)b * Tkv * ldkv + h * 32;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  {
+    const int key = tid >> 2, c0 = (tid & 3) * 8;
+    float f[8];
+    unpack8<T>(key < Tkv ? *reinterpret_cast<const uint4*>(vb + (long)key * ldkv + c0) : zero4, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sVt[(c0 + e) * KV64_LD + key] = from_f32<T>(f[e]);
+  }
+  uint4 fk[4];
+#pragma unroll
+  for (int kt = 0; kt < 4; ++kt) {
+    const int key = kt * 16 + l15;
+    fk[kt] = key < Tkv ? *reinterpret_cast<const uint4*>(kb + (long)key * ldkv + kg * 8) : zero4;
+  }
+  __syncthreads();
+  const int ntiles = (Tq + 63) / 64;
+  for (int it = 0; it < tiles_per_wave; ++it) {
+    const int tile = (blockIdx.x * 4 + wave) * tiles_per_wave + it;
+    const int q0 = tile * 64;
+    const bool live = tile < ntiles;
+    float linv[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int qi = q0 + qt * 16 + l15;
+      const bool ok = live && qi < Tq;
+      const uint4 fq = ok ? *reinterpret_cast<const uint4*>(q + ((long)b * Tq + qi) * ldq + h * 32 + kg * 8) : zero4;
+      f32x4 st[4];
+      float m = -3.0e38f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        st[kt] = Mfma<T>::run(fk[kt], fq, (f32x4){0.f, 0.f, 0.f, 0.f});      // rows: keys kt*16 + 4*kg + i, column: query qt*16 + l15
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          st[kt][i] = (kt * 16 + kg * 4 + i < Tkv) ? st[kt][i] * scale : -3.0e38f;
+          m = fmaxf(m, st[kt][i]);
+        }
+      }
+      m = fmaxf(m, __shfl_xor(m, 16));
+      m = fmaxf(m, __shfl_xor(m, 32));
+      float l = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        float pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pv[i] = (kt * 16 + kg * 4 + i < Tkv) ? expf(st[kt][i] - m) : 0.f;
+          l += pv[i];
+        }
+        *reinterpret_cast<uint2*>(sP + (qt * 16 + l15) * KV64_LD + kt * 16 + kg * 4) = pack4<T>(pv[0], pv[1], pv[2], pv[3]);
+      }
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      linv[qt] = 1.0f / l;
+      if (ok && lse && kg == 0) lse[((long)b * heads + h) * Tq + qi] = m + logf(l);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      uint4 va[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) va[ks] = *reinterpret_cast<const uint4*>(sVt + (ct * 16 + l15) * KV64_LD + ks * 32 + kg * 8);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          acc = Mfma<T>::run(va[ks], *reinterpret_cast<const uint4*>(sP + (qt * 16 + l15) * KV64_LD + ks * 32 + kg * 8), acc);
+        const int qi = q0 + qt * 16 + l15;
+        if (live && qi < Tq)
+          *reinterpret_cast<uint2*>(o + ((long)b * Tq + qi) * ldo + h * 32 + ct * 16 + kg * 4) =
+              pack4<T>(acc[0] * linv[qt], acc[1] * linv[qt], acc[2] * linv[qt], acc[3] * linv[qt]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ void f32_to_t_kernel(const float* __restrict__ x, T* __restrict__ y, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = from_f32<T>(x[i]);
@@ -773,8 +1054,12 @@ extern "C" int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, cons
   if (Tkv > AKV_MAX || B > 65535 || heads > 65535) return JG_ERR_UNSUPPORTED;
   const dim3 grid((Tq + 63) / 64, heads, B);
   if (Tkv <= 64) {
-    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_fwd_kernel<T, 64>), grid, dim3(64), 0, (hipStream_t)s, (const T*)q, (const T*)k,
-                                                (const T*)v, (T*)o, lse, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo, scale););
+    const int ntiles = (Tq + 63) / 64;
+    int tpw = 1;
+    while (tpw < 8 && (long)((ntiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) * heads * B >= 512) tpw *= 2;
+    const dim3 gridm((ntiles + 4 * tpw - 1) / (4 * tpw), heads, B);
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_kv64_fwd_kernel<T>), gridm, dim3(256), 0, (hipStream_t)s, (const T*)q, (const T*)k,
+                                                (const T*)v, (T*)o, lse, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo, scale, tpw););
   } else {
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_fwd_kernel<T, AKV_MAX>), grid, dim3(64), 0, (hipStream_t)s, (const T*)q, (const T*)k,
                                                 (const T*)v, (T*)o, lse, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo, scale););
@@ -792,7 +1077,16 @@ extern "C" int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, cons
   if (hipMemsetAsync(dkf, 0, nkv * sizeof(float), st) != hipSuccess || hipMemsetAsync(dvf, 0, nkv * sizeof(float), st) != hipSuccess)
     return JG_ERR_LAUNCH;
   const dim3 grid((Tq + 63) / 64, heads, B);
-  if (Tkv <= 64) {
+  if (Tkv <= 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0) {
+    // matrix-core kernel: a wave per 64-query tile, 4 waves per block; tiles per wave chosen so that the grid still has >= 512 blocks
+    const int ntiles = (Tq + 63) / 64;
+    int tpw = 1;
+    while (tpw < 8 && (long)((ntiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) * heads * B >= 512) tpw *= 2;
+    const dim3 gridm((ntiles + 4 * tpw - 1) / (4 * tpw), heads, B);
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_kv64_bwd_kernel<T>), gridm, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
+                                                (const T*)o, (const T*)dout, lse, (T*)dq, dkf, dvf, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo,
+                                                scale, tpw););
+  } else if (Tkv <= 64) {
     const dim3 grid4((Tq + 63) / 64, heads, B);       // QT = 1 query tile per block
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_smallkv_bwd_kernel<T, 64>), grid4, dim3(64), 0, st, (const T*)q, (const T*)k, (const T*)v,
                                                 (const T*)o, (const T*)dout, lse, (T*)dq, dkf, dvf, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo,
