@@ -303,6 +303,10 @@ int jg_l2norm_fwd(const float* x, float* y, float* nrm, int64_t R, int D, float 
 int jg_l2norm_bwd(const float* y, const float* nrm, const float* dy, float* dx, int64_t R, int D, float eps, jg_stream_t s);
 int jg_lsgan_loss(int dtype, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
                   float grad_scale, jg_stream_t s);
+/* GANLoss (loss.py:59-76) with mode 0 "lsgan" (= jg_lsgan_loss), 1 "vanilla" (nn.BCEWithLogitsLoss against the label `target`), 2 "wgangp"
+ * (-mean for real / +mean for fake; the reference never adds the gradient penalty) */
+int jg_gan_loss(int dtype, int mode, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
+                float grad_scale, jg_stream_t s);
 
 /* Strided, batched fp32 GEMM: C[z][m][n] = alpha sum_k actA(A[z][m][k]) actB(B[z][n][k]) + bias[n], then
  * C *= act'(E[z][m][n]) (E shares C's strides), then C += beta C_old.  Element strides s??, batch strides b?.

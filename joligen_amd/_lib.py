@@ -105,6 +105,7 @@ SIGNATURES = {
     "jg_l2norm_fwd": [c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
     "jg_l2norm_bwd": [c_p, c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
     "jg_lsgan_loss": [c_i32, c_p, c_f32, c_p, c_p, c_i64, c_i32, c_f32, c_f32, c_p],
+    "jg_gan_loss": [c_i32, c_i32, c_p, c_f32, c_p, c_p, c_i64, c_i32, c_f32, c_f32, c_p],
     "jg_sgemm": [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64, c_i64, c_i64, c_i32, c_i64, c_i64,
                  c_i64, c_f32, c_f32, c_i32, c_i32, c_i32, c_p],
     "jg_row_axpy": [c_p, c_p, c_p, c_i64, c_i32, c_p],

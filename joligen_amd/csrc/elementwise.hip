@@ -609,19 +609,35 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
   for (int d = lane; d < D; d += 64) dx[row * D + d] = (dy[row * D + d] - (clamped ? 0.f : y[row * D + d] * acc)) / n;
 }
 
-// GANLoss "lsgan" (loss.py:69-76,80-85): loss += scale * mean((pred - target)^2) over the FIRST channel of a [*, Cpad] logit
-// map; dpred = grad_scale * scale * 2 (pred - target) / N in channel 0, zero in the padding channels
-template <typename T>
-__global__ __launch_bounds__(256) void lsgan_loss_kernel(const T* __restrict__ pred, float target, float* __restrict__ loss,
-                                                         T* __restrict__ dpred, long Npix, int Cpad, float scale, float grad_scale) {
+// GANLoss (loss.py:59-76) on the FIRST channel of a [*, Cpad] logit map, loss += scale * mean(f(pred)), dpred = grad_scale * scale * f'(pred) / N in
+// channel 0 and zero in the padding channels.  MODE 0 "lsgan": f = (x - target)^2 (nn.MSELoss);  1 "vanilla": f = BCE-with-logits against
+// the label `target` = max(x, 0) - x target + log(1 + exp(-|x|)) (nn.BCEWithLogitsLoss);  2 "wgangp": f = -x for real (target >= 0.5), +x for fake
+// (the reference never adds its gradient penalty: cal_gradient_penalty has no caller).
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void gan_loss_kernel(const T* __restrict__ pred, float target, float* __restrict__ loss,
+                                                       T* __restrict__ dpred, long Npix, int Cpad, float scale, float grad_scale) {
   __shared__ float s_part[4];
   float acc = 0.f;
   const float invN = 1.0f / (float)Npix;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < Npix; i += (long)gridDim.x * blockDim.x) {
-    const float d = to_f32(pred[i * Cpad]) - target;
-    acc += d * d;
+    const float x = to_f32(pred[i * Cpad]);
+    float f, df;
+    if (MODE == 0) {
+      const float d = x - target;
+      f = d * d;
+      df = 2.0f * d;
+    } else if (MODE == 1) {
+      const float e = expf(-fabsf(x));
+      f = fmaxf(x, 0.f) - x * target + log1pf(e);
+      df = (x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e)) - target;      // sigmoid(x) - target
+    } else {
+      const float sgn = target >= 0.5f ? -1.0f : 1.0f;
+      f = sgn * x;
+      df = sgn;
+    }
+    acc += f;
     if (dpred) {
-      dpred[i * Cpad] = from_f32<T>(grad_scale * scale * 2.0f * d * invN);
+      dpred[i * Cpad] = from_f32<T>(grad_scale * scale * df * invN);
       for (int c = 1; c < Cpad; ++c) dpred[i * Cpad + c] = from_f32<T>(0.f);
     }
   }
@@ -1114,13 +1130,26 @@ extern "C" int jg_l2norm_bwd(const float* y, const float* nrm, const float* dy, 
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
-extern "C" int jg_lsgan_loss(int dtype, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
-                             float grad_scale, jg_stream_t s) {
-  if (!pred || !loss || Npix < 1 || Cpad < 1) return JG_ERR_BAD_ARG;
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((lsgan_loss_kernel<T>), dim3(grid_for(Npix, 256, 256)), dim3(256), 0, (hipStream_t)s,
-                                              (const T*)pred, target, loss, (T*)dpred, (long)Npix, Cpad, scale, grad_scale););
+extern "C" int jg_gan_loss(int dtype, int mode, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
+                           float grad_scale, jg_stream_t s) {
+  if (!pred || !loss || Npix < 1 || Cpad < 1 || mode < 0 || mode > 2) return JG_ERR_BAD_ARG;
+  const dim3 grid(grid_for(Npix, 256, 256));
+  if (mode == 0) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_loss_kernel<T, 0>), grid, dim3(256), 0, (hipStream_t)s, (const T*)pred, target, loss, (T*)dpred,
+                                                (long)Npix, Cpad, scale, grad_scale););
+  } else if (mode == 1) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_loss_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)s, (const T*)pred, target, loss, (T*)dpred,
+                                                (long)Npix, Cpad, scale, grad_scale););
+  } else {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gan_loss_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)s, (const T*)pred, target, loss, (T*)dpred,
+                                                (long)Npix, Cpad, scale, grad_scale););
+  }
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+extern "C" int jg_lsgan_loss(int dtype, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
+                             float grad_scale, jg_stream_t s) {
+  return jg_gan_loss(dtype, 0, pred, target, loss, dpred, Npix, Cpad, scale, grad_scale, s);
 }
 
 extern "C" int jg_ddpm_multiscale_loss(int dtype, const float* noise, const void* noise_hat, const int64_t* mask, const float* w,

@@ -1,5 +1,6 @@
 """GAN objectives of the CUT path on the HIP ops: /root/reference/models/modules/loss.py `GANLoss` (:11-85) for
-gan_mode='lsgan' (the train_gan_mode default: MSE against 1 / 0) and 'projected' (the hinge objective :77-84 that
+gan_mode='lsgan' (the train_gan_mode default: MSE against 1 / 0), 'vanilla' (BCE with logits), 'wgangp' (-/+ mean; the reference never
+adds its gradient penalty) and 'projected' (the hinge objective :77-84 that
 `set_discriminators_info` forces for projected discriminators, base_gan_model.py:544-545), and `DiscriminatorGANLoss` (:249-313)
 without APA / D-diffusion augmentation.
 lsgan predictions are NHWC logit maps whose channel 0 is valid (PatchGAN output padded to 8 channels); projected predictions are the
@@ -14,8 +15,8 @@ from .. import ops
 class GANLoss(nn.Module):
     def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
         super().__init__()
-        if gan_mode not in ("lsgan", "projected"):
-            raise NotImplementedError(f"gan mode {gan_mode!r}: 'lsgan' and 'projected' (hinge) are built (vanilla / wgangp are not)")
+        if gan_mode not in ("lsgan", "vanilla", "wgangp", "projected"):
+            raise NotImplementedError("gan mode %s not implemented" % gan_mode)
         self.gan_mode = gan_mode
         self.real_label, self.fake_label = float(target_real_label), float(target_fake_label)
 
@@ -25,7 +26,9 @@ class GANLoss(nn.Module):
             from .projected_d import hinge_loss
 
             return hinge_loss(prediction, target_is_real, relu)
-        return ops.lsgan_loss(prediction, self.real_label if target_is_real else self.fake_label)
+        if self.gan_mode == "wgangp":       # :72-76: the sign is the label, whatever real_label / fake_label are
+            return ops.gan_loss(prediction, "wgangp", 1.0 if target_is_real else 0.0)
+        return ops.gan_loss(prediction, self.gan_mode, self.real_label if target_is_real else self.fake_label)
 
 
 class DiscriminatorGANLoss(nn.Module):

@@ -895,17 +895,20 @@ def patch_nce_loss(q, k, nimg, T, num_patches, monce=False):
     return _PatchNCEFn.apply(q, k, nimg, float(T), float(num_patches - 1), bool(monce))
 
 
+GAN_MODES = {"lsgan": 0, "vanilla": 1, "wgangp": 2}
+
+
 class _LSGANLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target, scale):
+    def forward(ctx, pred, target, scale, mode=0):
         _require_cuda(pred)
         pred = pred.contiguous()
         cpad = pred.shape[-1]
         npix = pred.numel() // cpad
         loss = torch.zeros((), device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
-        check(_lib.lib().jg_lsgan_loss(_dt(pred), pred.data_ptr(), target, loss.data_ptr(), _p(dpred), npix, cpad, scale, 1.0, _st()),
-              "jg_lsgan_loss")
+        check(_lib.lib().jg_gan_loss(_dt(pred), mode, pred.data_ptr(), target, loss.data_ptr(), _p(dpred), npix, cpad, scale, 1.0, _st()),
+              "jg_gan_loss")
         ctx.dpred = dpred
         return loss
 
@@ -913,12 +916,18 @@ class _LSGANLossFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         dpred, ctx.dpred = ctx.dpred, None
-        return axpby(dpred, 1.0, None, 0.0, alpha_dev=g.reshape(1).float(), out=dpred), None, None
+        return axpby(dpred, 1.0, None, 0.0, alpha_dev=g.reshape(1).float(), out=dpred), None, None, None
 
 
 def lsgan_loss(pred, target, scale=1.0):
     """GANLoss('lsgan') (loss.py:69-71): scale * mean((pred[..., 0] - target)^2) on an NHWC logit map whose channel 0 is valid."""
-    return _LSGANLossFn.apply(pred, float(target), float(scale))
+    return _LSGANLossFn.apply(pred, float(target), float(scale), 0)
+
+
+def gan_loss(pred, mode, target, scale=1.0):
+    """GANLoss(mode) for mode in lsgan / vanilla / wgangp (loss.py:59-76) on an NHWC logit map whose channel 0 is valid; `target` is the label
+    (real_label / fake_label)."""
+    return _LSGANLossFn.apply(pred, float(target), float(scale), GAN_MODES[mode])
 
 
 # ======================================================================================

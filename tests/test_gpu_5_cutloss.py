@@ -185,6 +185,36 @@ def test_lsgan_vs_reference_golden(golden_dir, dtype):
         assert abs(float(loss) - float(ls[lk])) < 2e-2 * abs(float(ls[lk]))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode", ["vanilla", "wgangp", "lsgan"])
+def test_gan_loss_modes_vs_torch(mode, dtype):
+    """GANLoss('vanilla' | 'wgangp' | 'lsgan') (loss.py:59-76) through the module API against the same torch formulas in fp32 on the
+    16-bit-rounded logits (incl. label smoothing 0.9 for the real label, large |x| for the stable BCE form)"""
+    from joligen_amd import ops
+    from joligen_amd.modules.loss import GANLoss
+
+    g = torch.Generator().manual_seed(8)
+    pred16 = (torch.randn(3, 1, 14, 14, generator=g) * 6.0).to(dtype)
+    crit = GANLoss(mode, target_real_label=0.9)
+    for is_real in (True, False):
+        p = ops.to_nhwc(pred16.float().to(D0), dtype, 8).requires_grad_(True)
+        loss = crit(p, is_real)
+        (loss * 2.0).backward()
+        pr = pred16.float().requires_grad_(True)
+        label = torch.full_like(pr, 0.9 if is_real else 0.0)
+        if mode == "vanilla":
+            lo = torch.nn.functional.binary_cross_entropy_with_logits(pr, label)
+        elif mode == "lsgan":
+            lo = torch.nn.functional.mse_loss(pr, label)
+        else:
+            lo = -pr.mean() if is_real else pr.mean()
+        (lo * 2.0).backward()
+        assert abs(float(loss) - float(lo)) < 1e-5 * abs(float(lo)) + 1e-6, (mode, is_real, float(loss), float(lo))
+        mine = p.grad.permute(0, 3, 1, 2).float().cpu()
+        assert relerr(mine[:, :1], pr.grad) < (2e-3 if dtype == torch.float16 else 1e-2)
+        assert float(mine[:, 1:].abs().max()) == 0.0
+
+
 def test_image_pool_replays_reference_draws():
     from joligen_amd.util.image_pool import ImagePool
     rr = random.Random(4)
