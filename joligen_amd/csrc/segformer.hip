@@ -684,6 +684,139 @@ __global__ void attn_compose_bwd_kernel(const T* __restrict__ img, const T* __re
   }
 }
 
+// pixel-parallel forms of the two kernels above (one lane per PIXEL, the f x f lanes of an attention cell side by side; 16-byte loads /
+// stores of the pixel's channels; the cell's logit gradient is a shuffle reduction over its lanes).  The cell-per-thread kernels walk
+// f^2 pixels x 35 scattered 2-byte accesses per thread: 1.0 ms / 0.3 ms per launch at 32 x 256^2 against ~0.1 ms of HBM time.
+// Requirements: f in {1, 2, 4, 8}, ldimg / ldx / ldo / ldl multiples of 8, ldimg <= 64, ldl <= 16, nc <= 8.
+template <typename T>
+__device__ __forceinline__ void acomp_softmax(const T* __restrict__ lrow, int ldl, int na, int ni, float* a, float& ain) {
+  float lg[16];
+  unpack8<T>(*reinterpret_cast<const uint4*>(lrow), lg);
+  if (ldl > 8) unpack8<T>(*reinterpret_cast<const uint4*>(lrow + 8), lg + 8);
+  float m = -3.0e38f, l = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (k < na) m = fmaxf(m, lg[k]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    a[k] = k < na ? expf(lg[k] - m) : 0.f;
+    l += a[k];
+  }
+  ain = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    a[k] /= l;
+    if (k >= ni && k < na) ain += a[k];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_compose_fwd_px_kernel(const T* __restrict__ img, const T* __restrict__ logits, const T* __restrict__ xin,
+                                                                   T* __restrict__ out, int B, int S, int f, int na, int ni, int nc, int ldimg,
+                                                                   int ldl, int ldx, int ldo) {
+  const int Sa = S / f, ff = f * f;
+  const long total = (long)B * S * S;
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long cell = t / ff;
+  const int sub = (int)(t % ff), dy = sub / f, dx = sub % f;
+  const int ax = cell % Sa, ay = (cell / Sa) % Sa, b = (int)(cell / ((long)Sa * Sa));
+  const long p = ((long)b * S + ay * f + dy) * S + ax * f + dx;
+  float a[16], ain;
+  acomp_softmax<T>(logits + cell * ldl, ldl, na, ni, a, ain);
+  float xv[8], o[8];
+  unpack8<T>(*reinterpret_cast<const uint4*>(xin + p * ldx), xv);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o[c] = c < nc ? xv[c] * ain : 0.f;
+  for (int j = 0; j < ldimg / 8; ++j) {
+    float v[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(img + p * ldimg + j * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = j * 8 + e;
+      if (ci < nc * ni) {
+        const int k = ci / nc, c = ci - k * nc;
+        float ak = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ak = q == k ? a[q] : ak;      // register array: select, do not index
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += q == c ? v[e] * ak : 0.f;
+      }
+    }
+  }
+  *reinterpret_cast<uint4*>(out + p * ldo) = pack8<T>(o);
+  for (int j = 1; j < ldo / 8; ++j) *reinterpret_cast<uint4*>(out + p * ldo + j * 8) = make_uint4(0u, 0u, 0u, 0u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_compose_bwd_px_kernel(const T* __restrict__ img, const T* __restrict__ logits, const T* __restrict__ xin,
+                                                                   const T* __restrict__ dout, T* __restrict__ dimg, T* __restrict__ dlogits,
+                                                                   T* __restrict__ dxin, int B, int S, int f, int na, int ni, int nc, int ldimg,
+                                                                   int ldl, int ldx, int ldo) {
+  const int Sa = S / f, ff = f * f;
+  const long total = (long)B * S * S;       // a multiple of ff, and ff divides 64: a cell never straddles waves or the grid end
+  const long t = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long cell = t / ff;
+  const int sub = (int)(t % ff), dy = sub / f, dx = sub % f;
+  const int ax = cell % Sa, ay = (cell / Sa) % Sa, b = (int)(cell / ((long)Sa * Sa));
+  const long p = ((long)b * S + ay * f + dy) * S + ax * f + dx;
+  float a[16], ain;
+  acomp_softmax<T>(logits + cell * ldl, ldl, na, ni, a, ain);
+  float g[8], xv[8], da[16];
+  unpack8<T>(*reinterpret_cast<const uint4*>(dout + p * ldo), g);
+  unpack8<T>(*reinterpret_cast<const uint4*>(xin + p * ldx), xv);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) da[k] = 0.f;
+  float dain = 0.f, dx8[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    if (c >= nc) g[c] = 0.f;
+    dain += g[c] * xv[c];
+    dx8[c] = g[c] * ain;
+  }
+  if (dxin) {
+    *reinterpret_cast<uint4*>(dxin + p * ldx) = pack8<T>(dx8);
+    for (int j = 1; j < ldx / 8; ++j) *reinterpret_cast<uint4*>(dxin + p * ldx + j * 8) = make_uint4(0u, 0u, 0u, 0u);
+  }
+  for (int j = 0; j < ldimg / 8; ++j) {
+    float v[8], d8[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(img + p * ldimg + j * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ci = j * 8 + e;
+      d8[e] = 0.f;
+      if (ci < nc * ni) {
+        const int k = ci / nc, c = ci - k * nc;
+        float gc = 0.f, ak = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gc = q == c ? g[q] : gc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) ak = q == k ? a[q] : ak;
+        d8[e] = gc * ak;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) da[q] += q == k ? gc * v[e] : 0.f;
+      }
+    }
+    *reinterpret_cast<uint4*>(dimg + p * ldimg + j * 8) = pack8<T>(d8);
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k >= ni && k < na) da[k] += dain;
+    for (int o = 1; o < ff; o <<= 1) da[k] += __shfl_xor(da[k], o);      // the cell's lanes are an aligned group of ff
+  }
+  if (sub == 0) {
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dot += a[k] * da[k];
+    float dl[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) dl[k] = k < na ? a[k] * (da[k] - dot) : 0.f;
+    *reinterpret_cast<uint4*>(dlogits + cell * ldl) = pack8<T>(dl);
+    if (ldl > 8) *reinterpret_cast<uint4*>(dlogits + cell * ldl + 8) = pack8<T>(dl + 8);
+  }
+}
+
 // y[b][p][c] = x * s[b] (DropPath) or x * s[b][c] (Dropout2d), optionally + res (the identity branch)
 template <typename T>
 __global__ void scale_kernel(const T* __restrict__ x, const float* __restrict__ s, const T* __restrict__ res, T* __restrict__ y, int B, long HW,
@@ -1149,10 +1282,22 @@ extern "C" int jg_bn_bwd_coef(const float* red, const float* gamma, const float*
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
+static bool acomp_px_ok(int f, int na, int nc, int ldimg, int ldl, int ldx, int ldo, long npix) {
+  const bool fok = f == 1 || f == 2 || f == 4 || f == 8;
+  return fok && na <= 16 && nc <= 8 && ldimg % 8 == 0 && ldimg <= 64 && ldl % 8 == 0 && ldl <= 16 && ldx % 8 == 0 && ldo % 8 == 0 &&
+         npix < (1L << 31) * 256;
+}
 extern "C" int jg_attn_compose_fwd(int dtype, const void* img, const void* logits, const void* xin, void* out, int B, int S, int f, int na, int ni,
                                    int nc, int ldimg, int ldl, int ldx, int ldo, jg_stream_t s) {
   if (!img || !logits || !xin || !out || B < 1 || S < 1 || f < 1 || S % f || na < 1 || na > ACOMP_MAX || ni < 0 || ni > na || nc < 1) return JG_ERR_BAD_ARG;
   if (ldimg < nc * ni || ldl < na || ldx < nc || ldo < nc) return JG_ERR_BAD_ARG;
+  if (acomp_px_ok(f, na, nc, ldimg, ldl, ldx, ldo, (long)B * S * S)) {
+    const long total = (long)B * S * S;
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_compose_fwd_px_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                                                (const T*)img, (const T*)logits, (const T*)xin, (T*)out, B, S, f, na, ni, nc, ldimg, ldl, ldx, ldo););
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_compose_fwd_kernel<T>), dim3(grid_for((long)B * (S / f) * (S / f), 64)), dim3(64), 0, (hipStream_t)s,
                                               (const T*)img, (const T*)logits, (const T*)xin, (T*)out, B, S, f, na, ni, nc, ldimg, ldl, ldx, ldo););
   JG_CHECK_LAUNCH();
@@ -1162,6 +1307,14 @@ extern "C" int jg_attn_compose_bwd(int dtype, const void* img, const void* logit
                                    void* dxin, int B, int S, int f, int na, int ni, int nc, int ldimg, int ldl, int ldx, int ldo, jg_stream_t s) {
   if (!img || !logits || !xin || !dout || !dimg || !dlogits || B < 1 || S < 1 || f < 1 || S % f || na < 1 || na > ACOMP_MAX || ni < 0 || ni > na)
     return JG_ERR_BAD_ARG;
+  if (acomp_px_ok(f, na, nc, ldimg, ldl, ldx, ldo, (long)B * S * S)) {
+    const long total = (long)B * S * S;
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_compose_bwd_px_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s,
+                                                (const T*)img, (const T*)logits, (const T*)xin, (const T*)dout, (T*)dimg, (T*)dlogits, (T*)dxin, B, S,
+                                                f, na, ni, nc, ldimg, ldl, ldx, ldo););
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_compose_bwd_kernel<T>), dim3(grid_for((long)B * (S / f) * (S / f), 64)), dim3(64), 0, (hipStream_t)s,
                                               (const T*)img, (const T*)logits, (const T*)xin, (const T*)dout, (T*)dimg, (T*)dlogits, (T*)dxin, B, S, f,
                                               na, ni, nc, ldimg, ldl, ldx, ldo););
