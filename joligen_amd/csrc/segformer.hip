@@ -240,7 +240,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restric
   }
   for (int i = threadIdx.x; i < C * 10; i += 256) s_acc[i] = 0.f;
   __syncthreads();
-  if (act) {
+  // lanes of a wave that hold the same channel chunk (lane % c8n, when c8n is a power of two below 64) are summed by xor-shuffles first;
+  // inactive pixel lanes contribute zeros.  Every lane of the wave takes part in the shuffles.
+  const bool p2 = (c8n & (c8n - 1)) == 0 && c8n < 64;
+  if (p2) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        for (int o = c8n; o < 64; o <<= 1) aw[j][t] += __shfl_xor(aw[j][t], o);
+      for (int o = c8n; o < 64; o <<= 1) ab[j] += __shfl_xor(ab[j], o);
+    }
+  }
+  if (p2 ? (int)(threadIdx.x & 63) < c8n : act) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
