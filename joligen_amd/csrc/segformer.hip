@@ -125,7 +125,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   // per-channel partials of the block: lanes with the same `sub` (over rows-in-wave and the 4 waves) add up in LDS
   for (int i = threadIdx.x; i < 1024; i += 256) (&s_red[0][0])[i] = 0.f;
   __syncthreads();
-  if (act) {
+  // the rows of a wave that share a channel octet (lane % lpr, lpr a power of two) are summed by xor-shuffles first
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    for (int o = lpr; o < 64; o <<= 1) {
+      ag[j] += __shfl_xor(ag[j], o);
+      ab[j] += __shfl_xor(ab[j], o);
+    }
+  if (act && lane < lpr) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       atomicAdd(&s_red[0][sub * 8 + j], ag[j]);
@@ -1159,9 +1166,11 @@ extern "C" int jg_layernorm_fwd(int dtype, const void* x, const float* gamma, co
 extern "C" int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, void* dx, float* dgamma,
                                 float* dbeta, int64_t R, int C, jg_stream_t s) {
   if (!x || !dy || !gamma || !mr || R < 1 || C < 8 || C % 8 || C > 512 || (!dgamma != !dbeta)) return JG_ERR_BAD_ARG;
+  // (with the parameter gradients every block ends with 2 C global atomics onto the same addresses: 256 blocks instead of 1024 keep
+  //  that chain short -- it, not the streaming, set the 20 us floor of this launch)
   const int lpr = lanes_per_row(C);
   const long waves = (R + 64 / lpr - 1) / (64 / lpr);
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, dgamma ? 256 : 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
                                               (const T*)dy, gamma, mr, (T*)dx, dgamma, dbeta, (long)R, C, lpr););
   JG_CHECK_LAUNCH();
   return JG_OK;
