@@ -16,9 +16,70 @@ inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// nn.GELU() (exact form) = x Phi(x), Phi(x) = (1 + erf(x / sqrt 2)) / 2.  erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, three orders
+// below the 16-bit rounding of the stored activation) instead of the branchy 1-ulp library erff: its exponential e^{-x^2/2} is the one
+// the derivative's density term needs as well, so gelu' costs one exp + one rcp.  (The library calls made the depth-wise backward
+// VALU-bound: ~600 instructions per 8-channel pixel chunk.)
+__device__ __forceinline__ float gelu_phi_parts(float x, float& e) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  e = __expf(-ax * ax);                                    // e^{-x^2 / 2}
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * e;                   // erf(|x| / sqrt 2)
+  return 0.5f * (1.0f + (x < 0.f ? -erf_abs : erf_abs));   // Phi(x)
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float e;
+  return x * gelu_phi_parts(x, e);
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+  float e;
+  const float phi = gelu_phi_parts(x, e);
+  return phi + x * 0.3989422804014327f * e;
+}
+
+// the nine 16-byte neighbour loads of a 3x3 window issued back to back with ONE wait, as a single asm statement (clang puts an ordinary
+// load next to its first use, and the old per-tap `continue` on the image border made every tap its own L2 round trip: a 17 MB launch took
+// 65 us).  Out-of-image taps read a clamped (valid) address and are zeroed afterwards.
+typedef unsigned dw_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dw_load9(uint4 (&v)[9], const void* const (&p)[9]) {
+  dw_u32x4 r[9];
+  asm volatile("global_load_dwordx4 %0, %9, off\n\tglobal_load_dwordx4 %1, %10, off\n\tglobal_load_dwordx4 %2, %11, off\n\t"
+               "global_load_dwordx4 %3, %12, off\n\tglobal_load_dwordx4 %4, %13, off\n\tglobal_load_dwordx4 %5, %14, off\n\t"
+               "global_load_dwordx4 %6, %15, off\n\tglobal_load_dwordx4 %7, %16, off\n\tglobal_load_dwordx4 %8, %17, off\n\t"
+               "s_waitcnt vmcnt(0)"
+               : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8])
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8])
+               : "memory");
+#pragma unroll
+  for (int i = 0; i < 9; ++i) v[i] = make_uint4(r[i].x, r[i].y, r[i].z, r[i].w);
+}
+// the same with two more rows in front (the backward's dy and pre-activation of the centre pixel)
+__device__ __forceinline__ void dw_load11(uint4 (&v)[11], const void* const (&p)[11]) {
+  dw_u32x4 r[11];
+  asm volatile("global_load_dwordx4 %0, %11, off\n\tglobal_load_dwordx4 %1, %12, off\n\tglobal_load_dwordx4 %2, %13, off\n\t"
+               "global_load_dwordx4 %3, %14, off\n\tglobal_load_dwordx4 %4, %15, off\n\tglobal_load_dwordx4 %5, %16, off\n\t"
+               "global_load_dwordx4 %6, %17, off\n\tglobal_load_dwordx4 %7, %18, off\n\tglobal_load_dwordx4 %8, %19, off\n\t"
+               "global_load_dwordx4 %9, %20, off\n\tglobal_load_dwordx4 %10, %21, off\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]),
+                 "=&v"(r[10])
+               : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]), "v"(p[8]), "v"(p[9]), "v"(p[10])
+               : "memory");
+#pragma unroll
+  for (int i = 0; i < 11; ++i) v[i] = make_uint4(r[i].x, r[i].y, r[i].z, r[i].w);
+}
+// window of pixel (py, px) of an [H, W, C] image row-major at `base` (pointer to the centre pixel's chunk): pointers + validity of the 9 taps
+template <typename T, bool FLIP>
+__device__ __forceinline__ void dw_window(const T* centre, int px, int py, int H, int W, int C, const void* (&ptr)[9], bool (&ok)[9]) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      const int dy = FLIP ? 1 - r : r - 1, dx = FLIP ? 1 - sx : sx - 1;
+      const bool in = (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W;
+      ok[r * 3 + sx] = in;
+      ptr[r * 3 + sx] = in ? centre + ((long)dy * W + dx) * C : centre;
+    }
 }
 
 // ---- LayerNorm over C (multiple of 8, <= 512): LPR lanes per row, 64 / LPR rows per wave ---------------------------------
@@ -153,19 +214,18 @@ __device__ __forceinline__ void dw_apply(const T* __restrict__ x, const float (&
                                          int C, int c8, float* acc) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = bs ? bs[j] : 0.f;
+  const void* ptr[9];
+  bool ok[9];
+  dw_window<T, FLIP>(x + p * C + c8 * 8, px, py, H, W, C, ptr, ok);
+  uint4 v[9];
+  dw_load9(v, ptr);
 #pragma unroll
-  for (int r = 0; r < 3; ++r) {
-    const int dy = FLIP ? 1 - r : r - 1;
-    if ((unsigned)(py + dy) >= (unsigned)H) continue;
+  for (int t = 0; t < 9; ++t) {
+    float f[8];
+    unpack8<T>(v[t], f);
+    const float m = ok[t] ? 1.f : 0.f;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int dx = FLIP ? 1 - s : s - 1;
-      if ((unsigned)(px + dx) >= (unsigned)W) continue;
-      float f[8];
-      unpack8<T>(*reinterpret_cast<const uint4*>(x + (p + (long)dy * W + dx) * C + c8 * 8), f);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += f[j] * wr[j][r * 3 + s];
-    }
+    for (int j = 0; j < 8; ++j) acc[j] += f[j] * m * wr[j][t];
   }
 }
 template <typename T>
@@ -218,11 +278,21 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restric
   if (act) {
     for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb) {
       const int px = p % W, py = (p / W) % H;
+      const void* ptr9[9];
+      bool ok[9];
+      dw_window<T, false>(x + p * C + c8 * 8, px, py, H, W, C, ptr9, ok);
+      const void* ptr[11];
+      ptr[0] = dy + p * C + c8 * 8;
+      ptr[1] = gelu ? pre + p * C + c8 * 8 : dy + p * C + c8 * 8;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) ptr[2 + t] = ptr9[t];
+      uint4 v[11];
+      dw_load11(v, ptr);        // one round trip per pixel: dy, pre and the 3x3 window of x
       float d[8];
-      unpack8<T>(*reinterpret_cast<const uint4*>(dy + p * C + c8 * 8), d);
+      unpack8<T>(v[0], d);
       if (gelu) {
         float q[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(pre + p * C + c8 * 8), q);
+        unpack8<T>(v[1], q);
 #pragma unroll
         for (int j = 0; j < 8; ++j) d[j] *= gelu_grad_f(q[j]);
       }
@@ -230,18 +300,12 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restric
 #pragma unroll
       for (int j = 0; j < 8; ++j) ab[j] += d[j];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int iy = py + r - 1;
-        if ((unsigned)iy >= (unsigned)H) continue;
+      for (int t = 0; t < 9; ++t) {
+        float f[8];
+        unpack8<T>(v[2 + t], f);
+        const float m = ok[t] ? 1.f : 0.f;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const int ix = px + s - 1;
-          if ((unsigned)ix >= (unsigned)W) continue;
-          float f[8];
-          unpack8<T>(*reinterpret_cast<const uint4*>(x + (p + (long)(r - 1) * W + (s - 1)) * C + c8 * 8), f);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) aw[j][r * 3 + s] += d[j] * f[j];
-        }
+        for (int j = 0; j < 8; ++j) aw[j][t] += d[j] * (f[j] * m);
       }
     }
   }
