@@ -388,7 +388,9 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
             rel = err / (float(ref.norm()) + floor + 1e-30)
             errs.append(rel)
             table.append(f"{rel:10.3e} cos={cos:7.4f} ref={float(ref.norm()):10.3e} mine={float(mine.norm()):10.3e} floor={floor:9.2e} {key}.{k}")
-            if rel > 0.15:
+            # per tensor: direction first (a wrong kernel shows as a cosine well below 0.98; the 16-bit noise of this stack keeps every
+            # tensor at >= 0.989 over all builds of round 2), then the noise amplitude with head-room over the observed 0.12 - 0.15 band
+            if rel > 0.20 or (float(ref.norm()) > 10 * floor and float(ref.norm()) > 1e-6 and cos < 0.98):
                 bad.append((key, k, rel, cos, float(ref.norm()), floor))
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/grad_table_cut_{name}.txt", "w") as f:
