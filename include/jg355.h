@@ -188,6 +188,12 @@ int jg_gn_apply_pool(int dtype, const void* x, int64_t ldx, const float* ab, voi
  * add2 (optional) is a full-resolution addend as in jg_gn_bwd_apply_ld. */
 int jg_gn_bwd_reduce_up(int dtype, const void* x, int64_t ldx, const void* dy_low, int64_t lddy, float dy_scale, const float* ab,
                         float* red, int B, int H, int W, int C, int act, jg_stream_t s);
+/* jg_gn_bwd_apply_ld / _up with the coefficient step of jg_gn_bwd_coef inside (one launch fewer per GroupNorm backward): (P, Q, R) are derived per
+ * workgroup from `red` ([B][C][2], one slot), gamma / beta / FiLM and mr; dgamma / dbeta / dfilm come out as from jg_gn_bwd_coef. */
+int jg_gn_bwd_apply_fc(int dtype, int up, const void* x, int64_t ldx, const void* dy, int64_t lddy, float dy_scale, const float* ab, const float* red,
+                       const float* gamma, const float* beta, const float* film, int64_t ldfilm, const float* mr, float* dgamma, float* dbeta,
+                       float* dfilm, int64_t lddfilm, int G, void* dx, int64_t lddx, const void* add1, int64_t ldadd1, float scale1,
+                       const void* add2, int64_t ldadd2, float scale2, int B, int H, int W, int C, int act, jg_stream_t s);
 /* jg_gn_bwd_reduce_ld / _up ACCUMULATING into `red` instead of clearing it first: the UNet executor hands over zeroed rows of a pool it
  * clears once per backward pass (57 memset launches per step fewer) */
 int jg_gn_bwd_reduce_ld_acc(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab, float* red, int B, int HW,

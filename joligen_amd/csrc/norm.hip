@@ -297,18 +297,61 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ red, int nslots, co
   }
 }
 
+// FC ("fused coefficients"): the pass derives its own (P, Q, R) from the reductions instead of reading them from a coefficient kernel's
+// output -- what gn_bwd_coef_kernel computes per (image, channel), done once per workgroup for the image it works on (2 C floats of `red`
+// through LDS); the workgroup of pixel chunk 0 also emits the parameter / FiLM gradients.  One launch fewer per GroupNorm backward: next to
+// the weight-gradient stream a 6 us coefficient kernel waited ~50 us for a free slot (3 ms of every step).
+struct GnFc {
+  const float* red;      // [B][C][2]: sum du, sum du x
+  const float* gamma;
+  const float* beta;
+  const float* film;     // [B][ldfilm]: scale | shift, or null
+  const float* mr;       // [B][G][2]: mean, rstd
+  float* dgamma;
+  float* dbeta;
+  float* dfilm;
+  long ldfilm, lddfilm;
+  int G;
+};
+
 // UP: dy AND add1 are low-resolution ([B, H/2, W/2, C]) and read through the nearest-upsample index map (see gn_bwd_reduce_kernel)
-template <typename T, int ACT, bool UP = false>
+template <typename T, int ACT, bool UP = false, bool FC = false>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                            long lddy, const float* __restrict__ ab,
                                                            const float* __restrict__ pqr, T* __restrict__ dx, long lddx,
                                                            const T* __restrict__ add1, long ldadd1, float sc1,
                                                            const T* __restrict__ add2, long ldadd2, float sc2, int HW,
-                                                           int C, int rev, int W = 0, float dysc = 1.f) {
+                                                           int C, int rev, int W = 0, float dysc = 1.f, GnFc fc = GnFc()) {
+  __shared__ float s_sm[FC ? 2 * 256 : 2];      // group sums SM1 | SM2 (G <= 256)
   const Map mp = make_map(C);
   // reversed traversal: the pass runs right behind gn_bwd_reduce over the same (x, dy); walking from the END
   // re-reads what the reduction touched last and is still resident in the 256 MB Infinity Cache
   const int tid = threadIdx.x, b = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+  if (FC) {
+    const int G = fc.G, cpg = C / G;
+    for (int i = tid; i < 2 * G; i += 256) s_sm[i] = 0.f;
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      const int g = c / cpg;
+      const float gam = fc.gamma ? fc.gamma[c] : 1.f;
+      const float f = fc.film ? 1.f + fc.film[(long)b * fc.ldfilm + c] : 1.f;
+      const float A1 = fc.red[((long)b * C + c) * 2], A2 = fc.red[((long)b * C + c) * 2 + 1];
+      const float mean = fc.mr[((long)b * G + g) * 2], rstd = fc.mr[((long)b * G + g) * 2 + 1];
+      atomicAdd(&s_sm[g], gam * f * A1);
+      atomicAdd(&s_sm[G + g], gam * f * rstd * (A2 - mean * A1));
+      if (blockIdx.x == 0) {       // once per image: parameter and FiLM gradients (gn_bwd_coef_kernel's side outputs)
+        if (fc.dgamma) atomicAdd(&fc.dgamma[c], f * rstd * (A2 - mean * A1));
+        if (fc.dbeta) atomicAdd(&fc.dbeta[c], f * A1);
+        if (fc.dfilm) {
+          const float a0 = rstd * gam;
+          const float b0 = (fc.beta ? fc.beta[c] : 0.f) - mean * a0;
+          fc.dfilm[(long)b * fc.lddfilm + c] = a0 * A2 + b0 * A1;
+          fc.dfilm[(long)b * fc.lddfilm + C + c] = A1;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (tid >= mp.active) return;
   const int co = tid % mp.noct, pl = tid / mp.noct;
   float a[8], bb[8], P[8], Q[8], R[8];
@@ -317,9 +360,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const long o = (long)b * C + co * 8 + q;
     a[q] = ab[o * 2];
     bb[q] = ab[o * 2 + 1];
-    P[q] = pqr[o * 3];
-    Q[q] = pqr[o * 3 + 1];
-    R[q] = pqr[o * 3 + 2];
+    if (FC) {
+      const int c = co * 8 + q, G = fc.G, cpg = C / G, g = c / cpg;
+      const float n = (float)HW * (float)cpg;
+      const float mean = fc.mr[((long)b * G + g) * 2], rstd = fc.mr[((long)b * G + g) * 2 + 1];
+      const float M1 = s_sm[g] / n, M2 = s_sm[G + g] / n;
+      const float gam = fc.gamma ? fc.gamma[c] : 1.f;
+      const float f = fc.film ? 1.f + fc.film[(long)b * fc.ldfilm + c] : 1.f;
+      P[q] = f * gam * rstd;
+      Q[q] = -rstd * rstd * M2;
+      R[q] = -rstd * M1 + mean * rstd * rstd * M2;
+    } else {
+      P[q] = pqr[o * 3];
+      Q[q] = pqr[o * 3 + 1];
+      R[q] = pqr[o * 3 + 2];
+    }
   }
   const int pbeg = (rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * mp.chunk;
   const int pend = min(HW, pbeg + mp.chunk);
@@ -482,6 +537,38 @@ extern "C" int jg_gn_bwd_apply_up(int dtype, const void* x, int64_t ldx, const v
                                                             (const T*)x, (long)ldx, (const T*)dy_low, (long)lddy, ab, pqr, (T*)dx, (long)lddx,
                                                             (const T*)add1_low, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2,
                                                             HW, C, rev, W, dy_scale);););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+// GroupNorm backward, second pass WITH its coefficient step (no jg_gn_bwd_coef launch): dx = du P + x Q + R (+ addends) with (P, Q, R) derived
+// in the kernel from `red` (one slot), gamma / beta / FiLM and (mean, rstd); dgamma / dbeta / dfilm are produced as by jg_gn_bwd_coef.
+// up != 0: dy (and add1) live at the 2x2-pooled resolution (jg_gn_bwd_apply_up's addressing, dy_scale applied on read).
+extern "C" int jg_gn_bwd_apply_fc(int dtype, int up, const void* x, int64_t ldx, const void* dy, int64_t lddy, float dy_scale, const float* ab,
+                                  const float* red, const float* gamma, const float* beta, const float* film, int64_t ldfilm, const float* mr,
+                                  float* dgamma, float* dbeta, float* dfilm, int64_t lddfilm, int G, void* dx, int64_t lddx, const void* add1,
+                                  int64_t ldadd1, float scale1, const void* add2, int64_t ldadd2, float scale2, int B, int H, int W, int C,
+                                  int act, jg_stream_t s) {
+  const int HW = H * W;
+  if (!x || !dy || !ab || !red || !mr || !dx || bad_shape(B, HW, C) || G < 1 || G > 256 || C % G) return JG_ERR_BAD_ARG;
+  if (up && ((H & 1) || (W & 1))) return JG_ERR_BAD_ARG;
+  if (ldx < C || lddy < C || lddx < C || (ldx % 8) || (lddy % 8) || (lddx % 8)) return JG_ERR_BAD_ARG;
+  if ((add1 && (ldadd1 < C || ldadd1 % 8)) || (add2 && (ldadd2 < C || ldadd2 % 8))) return JG_ERR_BAD_ARG;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  const int rev = jg_tune(JG_TUNE_GN_REVERSE);
+  GnFc fc{red, gamma, beta, film, mr, dgamma, dbeta, dfilm, (long)ldfilm, (long)lddfilm, G};
+  if (up) {
+    JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, true, true>), grid, dim3(256), 0, (hipStream_t)s,
+                                                              (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, (const float*)nullptr, (T*)dx,
+                                                              (long)lddx, (const T*)add1, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2,
+                                                              scale2, HW, C, rev, W, dy_scale, fc);););
+  } else {
+    JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, false, true>), grid, dim3(256), 0, (hipStream_t)s,
+                                                              (const T*)x, (long)ldx, (const T*)dy, (long)lddy, ab, (const float*)nullptr, (T*)dx,
+                                                              (long)lddx, (const T*)add1, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2,
+                                                              scale2, HW, C, rev, 0, 1.f, fc);););
+  }
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

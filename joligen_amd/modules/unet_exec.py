@@ -68,6 +68,10 @@ FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 # kernels run underneath the HBM-bound GroupNorm-backward passes of the chain instead of in front of them.  The streams meet again at
 # the end of the backward (and before a gradient chunk leaves for the all-reduce).
 WGRAD_STREAM = os.environ.get("JG_WGRAD_STREAM", "1") != "0"
+# GroupNorm backward: coefficient step inside the apply pass (jg_gn_bwd_apply_fc, 57 launches per step fewer).  Measured 51.9 vs 51.6 ms
+# (A/B on one box): the ~50 us a 6 us coefficient kernel spends waiting next to the weight-gradient stream is paid by the next kernel
+# instead, and the per-workgroup prologue costs what the launch saved -- off by default, kept for single-stream configurations.
+FUSE_GN_COEF = os.environ.get("JG_FUSE_GN_COEF", "0") != "0"
 
 
 class _Pool:
@@ -224,6 +228,28 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
     dbeta = beta.grad if beta is not None else None
     if gamma is not None and dgamma is None:
         raise RuntimeError("norm weight has no arena-backed .grad")
+    if FUSE_GN_COEF and nslots == 1 and G <= 256:
+        # the coefficient step runs inside the apply pass (jg_gn_bwd_apply_fc): one launch fewer per GroupNorm backward
+        if out is None:
+            out = torch.empty((B, H, W, C), device=dev, dtype=x.dtype)
+        adds = list(adds)
+        if pooled is not None:
+            if len(adds) > 1:
+                raise RuntimeError("at most one full-resolution addend next to the pooled one")
+            a1, s1 = pooled[1] if pooled[1] is not None else (None, 0.0)
+            a2, s2 = adds[0] if adds else (None, 0.0)
+        else:
+            if len(adds) > 2:
+                raise RuntimeError("at most two fused gradient addends")
+            a1, s1 = adds[0] if len(adds) > 0 else (None, 0.0)
+            a2, s2 = adds[1] if len(adds) > 1 else (None, 0.0)
+        check(L.jg_gn_bwd_apply_fc(dt, int(pooled is not None), x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy),
+                                   pooled[0] if pooled is not None else 1.0, ab.data_ptr(), red.data_ptr(), _p(gamma), _p(beta), _p(film),
+                                   film.stride(0) if film is not None else 0, mr.data_ptr(), _p(dgamma), _p(dbeta), _p(dfilm),
+                                   dfilm.stride(0) if dfilm is not None else 0, G, out.data_ptr(), _ld(out), _p(a1),
+                                   _ld(a1) if a1 is not None else 0, s1, _p(a2), _ld(a2) if a2 is not None else 0, s2, B, H, W, C, act, _st()),
+              "jg_gn_bwd_apply_fc")
+        return out
     check(L.jg_gn_bwd_coef_slots(red.data_ptr(), nslots, _p(gamma), _p(beta), _p(film),
                                  film.stride(0) if film is not None else 0, mr.data_ptr(), pqr.data_ptr(), _p(dgamma),
                                  _p(dbeta), _p(dfilm), dfilm.stride(0) if dfilm is not None else 0, B, HW, C, G, _st()),

@@ -896,3 +896,34 @@ def test_full_size_batch32_step_equals_single_sample_steps(golden_dir, dtype_nam
             if float(b_.norm()) > 0 and relerr(a, b_) > (3e-2 if fp16 else 0.15):
                 bad.append((name, relerr(a, b_)))
     assert not bad, bad[:8]
+
+
+@pytest.mark.parametrize("efficient", [True, False])
+def test_gn_backward_with_fused_coefficients(golden_dir, efficient, monkeypatch):
+    """jg_gn_bwd_apply_fc (coefficient step inside the apply pass; plain, FiLM, pooled-gradient and addend forms all occur in this
+    network) against the three-launch form: same input gradient, embedding gradient and gradient arena"""
+    from joligen_amd import ops
+    from joligen_amd.modules import unet_exec
+
+    c = dict(ngf=64, mults=[1, 2], res_blocks=[1, 1], attn_res=[2], efficient=efficient, S=64, B=2)
+    dtype = torch.float16
+    net, _ = build_net(c, dtype, golden_dir)
+    unet = net.denoise_fn.model
+    net.arena.ensure_fresh()
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    x0 = ops.to_nhwc(torch.randn(c["B"], 6, c["S"], c["S"], generator=g).to(d), dtype, 8)
+    emb0 = torch.randn(c["B"], unet.cond_embed_dim, generator=g).to(d)
+    R = ops.to_nhwc(torch.randn(c["B"], 3, c["S"], c["S"], generator=g).to(d), dtype, 8)
+    res = {}
+    for fc in (False, True):
+        monkeypatch.setattr(unet_exec, "FUSE_GN_COEF", fc)
+        net.arena.g.zero_()
+        x = x0.clone().requires_grad_(True)
+        emb = emb0.clone().requires_grad_(True)
+        unet(x, emb).backward(R)
+        torch.cuda.synchronize()
+        res[fc] = (x.grad.float(), emb.grad.clone(), net.arena.g.clone())
+    for i, name in enumerate(("dx", "demb", "gradient arena")):
+        e = relerr(res[True][i], res[False][i])
+        assert e < 5e-3, (name, e)        # same arithmetic, other summation orders (fp32 atomics) in front of fp16 stores
