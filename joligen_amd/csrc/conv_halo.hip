@@ -217,24 +217,6 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   for (int cc = 0; cc < nch; ++cc) {
     const int abyte = (NABUF == 2 ? (cc & 1) : 0) * (HALO_CH * 16);
     const bool next_chunk = cc + 1 < nch;
-    if (p.dbg & 128) {
-      // timing experiment only (wrong results): what an in-LDS "normalise on load" pass would cost -- every 16-byte chunk of the landed
-      // halo goes through a*x + b and SiLU in place (per-channel coefficients would come from a small LDS table; constants here), then
-      // one more barrier before the first tap reads it
-      char* hb = reinterpret_cast<char*>(&sm[0]) + abyte;
-      for (int i = tid; i < HALO_CH; i += NT) {
-        float f[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(hb + i * 16), f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float u = 1.0009765625f * f[e] + 0.001f * (float)e;
-          f[e] = u / (1.0f + __expf(-u));
-        }
-        *reinterpret_cast<uint4*>(hb + i * 16) = pack8<T>(f);
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes are done
-      __builtin_amdgcn_s_barrier();
-    }
 #pragma unroll
     for (int tap = 0; tap < NTAP; ++tap) {
       // 1. prefetch: weight tile of K-step k + NBBUF - 1 into the slot freed at the previous barrier
