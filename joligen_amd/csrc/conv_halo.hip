@@ -28,7 +28,9 @@
 //   y_pool   the epilogue stores the 2x2 sum-pool of the tile (adjoint of x_up 1 when this launch computes an input gradient)
 #include "conv_params.h"
 #include "conv_epilogue.h"
+#include "mfma_pipe.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -61,9 +63,15 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 // (py, px): output pixel (2h + py, 2w + px) = sum over the 2x2 taps (a, b) of  Wp[py][px][a][b] . x[h + a + py - 1][w + b + px - 1],
 // i.e. halo offsets (a + py, b + px) of the same 18x18 halo tile, with the folded weights Wp = [4][N][2][2][Cin] (jg_subpixel_fold):
 // 4 instead of 9 K-steps per chunk.
-template <typename T, int BN, int NT, int WAVES_M, int WAVES_N, int NABUF, int NBBUF, int MINB, bool PHASE = false>
+//
+// PIPE: the K loop in its software-pipelined form (mfma_pipe.h): the fragment reads of sub-step s + 1 (and, across the per-step barrier,
+// the pixel fragments of the next K-step -- the halo is stable for a whole chunk) are in flight under the MFMAs of sub-step s; only the
+// four weight-fragment reads that follow a barrier are exposed.  Same LDS images, same accumulators, bit-identical results.
+template <typename T, int BN, int NT, int WAVES_M, int WAVES_N, int NABUF, int NBBUF, int MINB, bool PHASE = false, int PIPE_MODE = 0>
 __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   constexpr int NTAP = PHASE ? 4 : 9;
+  constexpr bool PIPE = PIPE_MODE != 0;
+  static_assert(!PIPE || !PHASE, "the pipelined K loop covers the 9-tap form");
   static_assert(!PHASE || NABUF == 1, "the phase form reloads its halo between chunks");
   static_assert(!PHASE || NBBUF - 1 < NTAP, "weight ring prologue");
   constexpr int NWAVES = NT / 64;
@@ -77,7 +85,8 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   static_assert(NABUF == 1 || A_ROUNDS <= 9, "halo prefetch is spread over the 9 taps");
   static_assert(NBBUF >= 2 && NBBUF <= 5, "weight ring depth");
 
-  __shared__ uint4 sm[NABUF * HALO_CH + NBBUF * B_BUF];
+  // PIPE: the block's BN bias values are parked behind the ring (the pipelined loop has no registers to carry them across)
+  __shared__ uint4 sm[NABUF * HALO_CH + NBBUF * B_BUF + (PIPE ? BN / 4 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -199,7 +208,12 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   const int nk = nch * NTAP;
   static_assert(TN == 4, "one 64-channel epilogue pass per wave");
   float bias_pre[8];                // epilogue bias of this lane, in flight during the K loop
-  jg_epilogue_bias(p, lane, n0 + wn * WN, bias_pre);
+  float* sbias = reinterpret_cast<float*>(&sm[NABUF * HALO_CH + NBBUF * B_BUF]);
+  if constexpr (PIPE) {
+    for (int i = tid; i < BN; i += NT) sbias[i] = (p.bias && n0 + i < p.N) ? p.bias[n0 + i] : 0.f;   // visible after the prologue barrier
+  } else {
+    jg_epilogue_bias(p, lane, n0 + wn * WN, bias_pre);
+  }
 
   // ---- prologue: halo of chunk 0, first NBBUF-1 weight tiles -----------------------------------------
   if (!(p.dbg & 4)) {
@@ -214,6 +228,86 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   int kpre = NBBUF - 1;             // K-step whose weight tile is issued next
   int pre_tap = NBBUF - 1, pre_cc = 0;
   int bslot = 0;                    // ring slot of the current K-step
+  if constexpr (PIPE) {
+    static_assert(TM == 8 && TN == 4 && NTAP == 9, "the pipelined K loop is written for 128-pixel x 64-channel wave tiles");
+    static_assert(NABUF == 1 || A_ROUNDS <= 7, "the last halo piece must have been waited for (vmcnt(0) of tap >= A_ROUNDS) before tap 8 reads the buffer");
+    constexpr int RS = HW_ * 128;   // one halo row down
+    u32x4 faP[8], faQ[8], fb[5];     // weight fragments: k-half 0 (fbP) in fb[0..3]; k-half 1 (fbQ) re-uses fb[0], fb[1], fb[2] as they die, + fb[4]
+    // LDS-side order of one K-step (P = k-half 0, Q = k-half 1; every group = 8 MFMAs of one weight fragment):
+    //   [faP in flight from the previous step]  fbP[0..3] | G(P,0)+faQ[0..3] | G(P,1)+faQ[4..7] | G(P,2)+fbQ[0,1] | G(P,3)+fbQ[2,3]
+    //   | G(Q,0)+faP'[0..3] | G(Q,1)+faP'[4..7] | G(Q,2) | G(Q,3) | vmcnt | barrier          (faP' = pixel fragments of the NEXT step)
+    // LDS returns in order, so the lgkmcnt in front of each group is the number of reads issued after the fragment it needs.
+    auto read_fa = [&](unsigned abyte) {      // pixel fragments of (tap 0, k-half 0)
+      const unsigned a0 = lds0 + abyte + afrag[0];
+      jg_rd4<0, RS, 2 * RS, 3 * RS>(faP[0], faP[1], faP[2], faP[3], a0);
+      jg_rd4<4 * RS, 5 * RS, 6 * RS, 7 * RS>(faP[4], faP[5], faP[6], faP[7], a0);
+    };
+    auto kstep = [&](auto tapc, int cc, bool next_chunk) {
+      constexpr int tap = decltype(tapc)::value;
+      constexpr int r = tap / 3, s3 = tap % 3;
+      constexpr int ntap = (tap + 1) % 9, nr = ntap / 3, ns3 = ntap % 3;
+      const unsigned abyte = (NABUF == 2 ? (cc & 1) : 0) * (HALO_CH * 16);
+      // halo buffer the NEXT step reads: the other one after tap 8 (it has landed: its last LDS-DMA round went out at tap <= 5 and
+      // every wave has waited for a younger weight tile and passed two barriers since).  With a single halo buffer the fragments
+      // prefetched at tap 8 are dropped and re-read after the reload (below).
+      const unsigned nbyte = (NABUF == 2 && tap == 8) ? ((cc + 1) & 1) * (HALO_CH * 16) : abyte;
+      const unsigned bbyte = (NABUF * HALO_CH + bslot * B_BUF) * 16;
+      const unsigned b0 = lds0 + bbyte + bfrag[0], b1 = lds0 + bbyte + (bfrag[0] ^ 64);
+      const unsigned a1 = lds0 + abyte + (afrag[s3] ^ 64), an = lds0 + nbyte + afrag[ns3];
+      if (!(p.dbg & 1024)) jg_rd4<0, 2048, 4096, 6144>(fb[0], fb[1], fb[2], fb[3], b0);   // dbg 1024: timing without the exposed post-barrier reads
+      // weight tile of K-step k + NBBUF - 1 into the slot freed at the previous barrier; one halo round of the next chunk.
+      // (measured, profiles/r03_halo_pipe_ablation.txt: spreading the pieces between the MFMA groups, staggering them between the two waves
+      // of a SIMD, or leaving the halo piece in flight across the barrier are all slower than issuing them right here)
+      const bool b_iss = kpre < nk && !(p.dbg & 128);
+      int slot = bslot + NBBUF - 1;
+      if (slot >= NBBUF) slot -= NBBUF;
+      const int koff = pre_tap * p.Cin + pre_cc * 64;
+      if (kpre < nk) {
+        ++kpre;
+        if (++pre_tap == NTAP) { pre_tap = 0; ++pre_cc; }
+      }
+      const bool a_iss = NABUF == 2 && tap < A_ROUNDS && next_chunk && tap * NT + wave * 64 < HALO_CH && !(p.dbg & 4);
+      if (b_iss) issue_b(slot, koff);
+      if (a_iss) issue_a_round((cc + 1) & 1, cc + 1, tap);
+      jg_g8r4<T, 3, (0 + r) * RS, (1 + r) * RS, (2 + r) * RS, (3 + r) * RS>(acc[0], fb[0], faP, faQ[0], faQ[1], faQ[2], faQ[3], a1);
+      jg_g8r4<T, 6, (4 + r) * RS, (5 + r) * RS, (6 + r) * RS, (7 + r) * RS>(acc[1], fb[1], faP, faQ[4], faQ[5], faQ[6], faQ[7], a1);
+      jg_g8r2<T, 9, 0, 2048>(acc[2], fb[2], faP, fb[0], fb[1], b1);
+      jg_g8r2<T, 10, 4096, 6144>(acc[3], fb[3], faP, fb[2], fb[4], b1);
+      jg_g8r4<T, 3, (0 + nr) * RS, (1 + nr) * RS, (2 + nr) * RS, (3 + nr) * RS>(acc[0], fb[0], faQ, faP[0], faP[1], faP[2], faP[3], an);
+      jg_g8r4<T, 6, (4 + nr) * RS, (5 + nr) * RS, (6 + nr) * RS, (7 + nr) * RS>(acc[1], fb[1], faQ, faP[4], faP[5], faP[6], faP[7], an);
+      jg_g8r0<T, 9>(acc[2], fb[2], faQ);
+      jg_g8r0<T, 8>(acc[3], fb[4], faQ);
+      if (NBBUF >= 3 && b_iss) {
+        if (a_iss) wait_vmcnt<(NBBUF - 2) * B_ROUNDS + 1>(); else wait_vmcnt<(NBBUF - 2) * B_ROUNDS>();
+      } else {
+        wait_vmcnt<0>();
+      }
+      if (!(p.dbg & 512)) __builtin_amdgcn_s_barrier();      // dbg 512: timing without the per-step barrier (only meaningful with 128 + 4)
+      if (++bslot == NBBUF) bslot = 0;
+    };
+    read_fa(0);
+    for (int cc = 0; cc < nch; ++cc) {
+      const bool next_chunk = cc + 1 < nch;
+      kstep(std::integral_constant<int, 0>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 1>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 2>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 3>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 4>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 5>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 6>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 7>{}, cc, next_chunk);
+      kstep(std::integral_constant<int, 8>{}, cc, next_chunk);
+      if (NABUF == 1 && next_chunk) {
+#pragma unroll
+        for (int rd = 0; rd < A_ROUNDS; ++rd) issue_a_round(0, cc + 1, rd);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        read_fa(0);
+      }
+    }
+    // the last MFMAs are still in the pipe when the epilogue's first VALU reads the accumulators: the compiler does not see them
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+  } else
   for (int cc = 0; cc < nch; ++cc) {
     const int abyte = (NABUF == 2 ? (cc & 1) : 0) * (HALO_CH * 16);
     const bool next_chunk = cc + 1 < nch;
@@ -277,6 +371,10 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
   const int wres = PHASE ? p.W : (p.res_up ? (p.W >> 1) : p.W), rsh = (!PHASE && p.res_up) ? 1 : 0;
   const long rrow0 = PHASE ? ((long)b * p.H + oh0 + wm * TM) * p.W + ow0
                            : (p.res_up ? ((long)b * (p.H >> 1) + ((oh0 + wm * TM) >> 1)) * wres + (ow0 >> 1) : mrow0);
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bias_pre[q] = sbias[wn * WN + (lane & 7) * 8 + q];
+  }
 #pragma unroll
   for (int h = 0; h < TN / 4; ++h) {     // 64 output channels of the wave tile at a time
     jg_epilogue_lds<T, TM, true>(
@@ -296,7 +394,8 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
             atomicAdd(&sred[(nch - n0 + q) * 2], s1[q]);
             atomicAdd(&sred[(nch - n0 + q) * 2 + 1], s2[q]);
           }
-        });
+        },
+        PIPE ? bias_pre : nullptr);
   }
   if (p.stats && !(p.dbg & 64)) {
     __syncthreads();
@@ -311,10 +410,10 @@ void launch_halo_phase(const ConvP& p, hipStream_t st) {   // p.H / p.W: low-res
   hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NT, WMv, WNv, NABUF, NBBUF, MINB, true>), dim3(tiles), dim3(NT), 0, st, p);
 }
 
-template <typename T, int BN, int NT, int WMv, int WNv, int NABUF, int NBBUF, int MINB>
+template <typename T, int BN, int NT, int WMv, int WNv, int NABUF, int NBBUF, int MINB, int PIPE = 0>
 void launch_halo(const ConvP& p, hipStream_t st) {
   const int tiles = p.B * (p.H >> 4) * (p.W >> 4) * ((p.N + BN - 1) / BN);
-  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NT, WMv, WNv, NABUF, NBBUF, MINB>), dim3(tiles), dim3(NT), 0, st, p);
+  hipLaunchKernelGGL((conv3x3_halo_kernel<T, BN, NT, WMv, WNv, NABUF, NBBUF, MINB, false, PIPE>), dim3(tiles), dim3(NT), 0, st, p);
 }
 
 template <typename T>
@@ -327,9 +426,16 @@ void dispatch_halo(const ConvP& p, hipStream_t st) {
   const bool fill256 = p.N % 256 == 0 && (double)b256 / (double)(((b256 + 255) / 256) * 256) >= 0.85;
   // (tried: <256, 256, 2, 2, 1, 2, 1> = 4 waves x (128 px x 128 ch) with the 256 accumulator registers in AGPRs -- halves the LDS
   //  fragment traffic per MFMA, but one wave per SIMD cannot hide the halo reloads: 1000-1170 vs 1260-1430 TFLOP/s, not kept)
-  if ((fill256 && cfg == 0) || (cfg == 3 && p.N % 256 == 0)) launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
+  // JG_HALO_PIPE (1): software-pipelined K loop (mfma_pipe.h) for the configurations with 128-pixel x 64-channel wave tiles; 0 = the
+  // compiler-scheduled loop (A/B, tools/halo_pipe_ab.py)
+  const int pipe = jg_tune(JG_TUNE_HALO_PIPE);
+  if ((fill256 && cfg == 0) || (cfg == 3 && p.N % 256 == 0)) {
+    if (pipe) launch_halo<T, 256, 512, 2, 4, 2, 2, 1, 1>(p, st); else launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
+  }
   else if (p.N % 128 == 0 && cfg == 2) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
-  else if (p.N % 128 == 0) launch_halo<T, 128, 256, 2, 2, 1, 2, 2>(p, st);   // 4 waves x (128 px x 64 ch), 2 workgroups / CU
+  else if (p.N % 128 == 0) {   // 4 waves x (128 px x 64 ch), 2 workgroups / CU
+    if (pipe) launch_halo<T, 128, 256, 2, 2, 1, 2, 2, 1>(p, st); else launch_halo<T, 128, 256, 2, 2, 1, 2, 2>(p, st);
+  }
   else if (cfg == 4) launch_halo<T, 64, 256, 4, 1, 1, 4, 2>(p, st);
   else launch_halo<T, 64, 256, 4, 1, 1, 3, 2>(p, st);
 }

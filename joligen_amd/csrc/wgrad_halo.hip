@@ -21,6 +21,7 @@
 // applied to the SOURCE chunk index (cdna_hip_programming.md 5.4 rule 21).
 #include "conv_params.h"
 #include "wgrad_params.h"
+#include "mfma_pipe.h"
 #include <cstdlib>
 
 namespace {
@@ -45,8 +46,15 @@ __device__ __forceinline__ int f4(int c) { return ((c >> 1) & 1) | (((c >> 3) & 
 __device__ __forceinline__ int f8(int c) { return (c & 3) | (((c >> 3) & 1) << 2); }
 
 // XMODE 0: plain zero padding; 1: mirrored borders (REFLECT); 2: x is the half-resolution tensor read through the nearest-upsample map
-template <typename T, int TH, int CPW, int WMR, int XMODE>
-__global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p, int ntiles, int per, int npairs, int ncot) {
+//
+// PIPE: the MFMA loop of a tile in software-pipelined form.  hipcc orders a sub-step as {reads of a few taps; s_waitcnt; 2 MFMAs; ...}: with
+// only CPW MFMAs per weight-side fragment the LDS latency of every tap is exposed (SQ_VALU_MFMA_BUSY 0.37 for the 16-row tile,
+// profiles/r02_mfma_busy.md).  Here the (sub-step, tap) pairs of a tile form ONE flat sequence of 9 * NSUB steps; the halo fragment of
+// step i + LOOKAHEAD is requested before the MFMAs of step i are issued, and the dy fragments of the next sub-step at the start of the
+// current one.  The MFMAs are `asm volatile` statements (with a memory clobber), which pins the source order of reads and MFMAs; the
+// reads stay compiler-visible builtins, so every s_waitcnt lgkmcnt(N) is still the compiler's (LDS returns in order: exact counts).
+template <typename T, int TH, int CPW, int WMR, int XMODE, bool PIPE = false>
+__global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p, int ntiles, int per, int npairs, int ncot, int dbg) {
   constexpr bool REFLECT = XMODE == 1, UP = XMODE == 2;
   constexpr int NT = WMR * 256;                // WMR wave rows (output-channel groups) x 4 wave columns (16-channel ci tiles)
   constexpr int BCO = WMR * CPW * 16;          // output channels per block
@@ -229,14 +237,48 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
   for (int t = t0; t < t1; ++t) {
     const int buf = (t - t0) & 1;
     const bool more = t + 1 < t1;
-    if (more) issue_tile(t + 1, buf ^ 1);
-    if (more) {
+    if (more && !(dbg & 4)) issue_tile(t + 1, buf ^ 1);      // JG_HALO_DBG 4: timing without the per-tile LDS-DMA (first tile only)
+    if (more && !(dbg & 4)) {
       if (partial) wait_vmcnt<D_ROUNDS + A_FULL + 1>(); else wait_vmcnt<D_ROUNDS + A_FULL>();
     } else {
       wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
     const int boff = buf * (BUF_CH * 16);
+    if (dbg & 2) {                                            // JG_HALO_DBG 2: timing without the MFMAs and fragment reads
+      __builtin_amdgcn_s_barrier();
+      continue;
+    }
+    if constexpr (PIPE) {
+      constexpr int LA = CPW >= 4 ? 3 : 5;          // steps of lookahead: a step is CPW MFMAs (x 2 waves per SIMD) = 64 .. 128 cycles
+      constexpr int NSTEP = NSUB * 9;
+      auto load_fb = [&](int step) -> uint4 {
+        const int sub = step / 9, t9 = step % 9, r = t9 / 3, s3 = t9 % 3;
+        return tr_frag(boff + bbase[s3][0] + (2 * sub + r) * (HW_ * 128), boff + bbase[s3][1] + (2 * sub + r) * (HW_ * 128));
+      };
+      uint4 ring[LA + 1], fa[2][CPW];
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) fa[0][i] = tr_frag(boff + abase[i][0], boff + abase[i][1]);
+#pragma unroll
+      for (int s = 0; s < LA; ++s) ring[s] = load_fb(s);
+#pragma unroll
+      for (int step = 0; step < NSTEP; ++step) {
+        const int sub = step / 9, t9 = step % 9;
+        if (step + LA < NSTEP) ring[(step + LA) % (LA + 1)] = load_fb(step + LA);
+        if (t9 == 1 && sub + 1 < NSUB) {       // dy fragments of the next sub-step: 8 steps ahead of their first use
+#pragma unroll
+          for (int i = 0; i < CPW; ++i)
+            fa[(sub + 1) & 1][i] = tr_frag(boff + abase[i][0] + (sub + 1) * 32 * DY_ROWB, boff + abase[i][1] + (sub + 1) * 32 * DY_ROWB);
+        }
+        if (t9 == 0 && do_bias) {
+#pragma unroll
+          for (int i = 0; i < CPW; ++i) jg_mfma_pinned<T>(accb[i], fa[sub & 1][i], ones);
+        }
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) jg_mfma_pinned<T>(acc[t9][i], fa[sub & 1][i], ring[step % (LA + 1)]);
+      }
+      asm volatile("s_nop 7" ::: "memory");     // the compiler does not see the MFMAs: keep its next VALU write off their operands
+    } else
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
       uint4 fa[CPW];
@@ -259,6 +301,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
   }
 
   // ---- epilogue: D row = co = g*4 + q, col = ci = i16 ----------------------------------------------------
+  if (dbg & 1) return;      // JG_HALO_DBG 1: timing without the atomic epilogue (tools/wgrad_pipe_ab.py --dbg)
   float* dw = (float*)p.dw;
   const int ci = ci0 + wn * 16 + i16;
   if (ci < p.Cin_out) {
@@ -304,12 +347,15 @@ static void pick_split(int npairs, int ntiles, int ovh, int slots, int* per_out,
 
 template <typename T, int TH, int CPW, int WMR, int XMODE = 0>
 void launch_wg(const WgP& p, hipStream_t st) {
+  // JG_WGRAD_PIPE (1): the software-pipelined MFMA loop for the CPW == 2 tiles (the CPW == 4 tiles have no registers left for the ring)
+  const bool pipe = CPW == 2 && jg_tune(JG_TUNE_WGRAD_PIPE) != 0;
   constexpr int BCO = WMR * CPW * 16;
   const int ncot = p.Cout / BCO, npairs = ncot * (p.Cin / 64);
   const int ntiles = p.B * (p.H / TH) * (p.W >> 4);
   int per, splitk;
   pick_split(npairs, ntiles, TH == 16 ? 6 : 10, WMR == 1 ? 512 : 256, &per, &splitk);
-  hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot);
+  if (pipe) hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE, CPW == 2>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot, jg_tune(JG_TUNE_HALO_DBG));
+  else hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot, jg_tune(JG_TUNE_HALO_DBG));
 }
 
 template <typename T>

@@ -189,6 +189,73 @@ def test_conv_halo_forced_configs(cfg, inst, shape, dtype):
     assert relerr(y.float(), y_auto.float()) < 2e-3 * (1 if dtype == torch.float16 else 4), (inst, relerr(y.float(), y_auto.float()))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg,shape", [(3, (2, 32, 32, 192, 256)), (3, (1, 16, 48, 64, 512)), (1, (2, 16, 16, 192, 256)), (1, (3, 32, 16, 64, 128)),
+                                       (3, (2, 16, 16, 576, 256))])
+def test_conv_halo_pipelined_loop_is_bit_identical(cfg, shape, dtype):
+    """JG_HALO_PIPE 1 (software-pipelined K loop, csrc/mfma_pipe.h: hand-placed ds_read / MFMA order, counted lgkmcnt) against the
+    compiler-scheduled loop: the same MFMAs on the same fragments in the same order -> torch.equal, with bias, residual and the fused
+    GroupNorm statistics; 1 / 3 / 9 chunks (halo double buffer wraps, single-buffer reload), both wave-tile configurations."""
+    from joligen_amd import _lib, ops
+
+    B, H, W, Cin, Cout = shape
+    d = dev()
+    x = nhwc(rnd((B, Cin, H, W), dtype, 1)).to(d)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, 1.0 / math.sqrt(Cin * 9)).permute(0, 2, 3, 1).contiguous().to(d)
+    bias = rnd((Cout,), torch.float32, 3).to(d)
+    res = nhwc(rnd((B, Cout, H, W), dtype, 4)).to(d)
+    out = {}
+    prev_cfg = _lib.set_tuning("JG_HALO_CFG", cfg)
+    prev = _lib.set_tuning("JG_HALO_PIPE", 0)
+    try:
+        for pipe in (0, 1):
+            _lib.set_tuning("JG_HALO_PIPE", pipe)
+            y = torch.full((B, H, W, Cout), float("nan"), device=d, dtype=dtype)
+            st = torch.zeros(B, 4, Cout, 2, device=d)
+            ops.conv_nt(x, w, y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=9 * Cin, ldy=Cout,
+                        bias=bias, res=res, ldres=Cout, alpha=0.5, res_scale=0.7, stats=st, ldstats=Cout, stats_slots=4)
+            torch.cuda.synchronize()
+            out[pipe] = (y, st.sum(1))
+    finally:
+        _lib.set_tuning("JG_HALO_PIPE", prev)
+        _lib.set_tuning("JG_HALO_CFG", prev_cfg)
+    assert torch.isfinite(out[1][0].float()).all()
+    assert torch.equal(out[0][0], out[1][0]), float((out[0][0].float() - out[1][0].float()).abs().max())
+    assert relerr(out[1][1], out[0][1]) < 1e-5        # statistics: fp32 atomics, order differs between runs
+    ref = 0.5 * F.conv2d(nchw(x).float().cpu(), w.permute(0, 3, 1, 2).float().cpu(), None, 1, 1) + bias.cpu().view(1, -1, 1, 1) + 0.7 * nchw(res).float().cpu()
+    assert relerr(nchw(out[1][0]), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_halo_pipelined_loop(dtype):
+    """JG_WGRAD_PIPE 1 (fragment reads LOOKAHEAD steps ahead of their MFMAs, the MFMAs pinned as asm statements) against the
+    compiler-scheduled loop of wgrad3x3_halo_kernel<16,2,2>: the same products, split-K atomics in another order -> 2e-6 on fp32."""
+    from joligen_amd import _lib
+
+    B, H, W, Cin, Cout = 2, 32, 48, 128, 64
+    x = rnd((B, Cin, H, W), dtype, 11)
+    gy = rnd((B, Cout, H, W), dtype, 12)
+    got = {}
+    prev_cfg = _lib.set_tuning("JG_WGRAD_HALO_CFG", 1)
+    prev = _lib.set_tuning("JG_WGRAD_PIPE", 0)
+    try:
+        for pipe in (0, 1):
+            _lib.set_tuning("JG_WGRAD_PIPE", pipe)
+            m, arena, w_ref, b_ref = _make_conv_module(Cin, Cout, 3, 1, dtype)
+            xd = nhwc(x).to(dev()).requires_grad_(True)
+            m.c(xd).backward(nhwc(gy).to(dev()))
+            torch.cuda.synchronize()
+            got[pipe] = (m.c.weight.grad.clone(), m.c.bias.grad.clone(), w_ref, b_ref)
+    finally:
+        _lib.set_tuning("JG_WGRAD_PIPE", prev)
+        _lib.set_tuning("JG_WGRAD_HALO_CFG", prev_cfg)
+    assert relerr(got[1][0], got[0][0]) < 2e-6 and relerr(got[1][1], got[0][1]) < 2e-6
+    wr = got[1][2].clone().requires_grad_(True)
+    br = got[1][3].clone().requires_grad_(True)
+    F.conv2d(x.float(), wr, br, 1, 1).backward(gy.float())
+    assert relerr(got[1][0], wr.grad) < TOL[dtype] and relerr(got[1][1], br.grad) < TOL[dtype]
+
+
 def test_conv_halo_bench_dispatch_shapes():
     """Shapes whose grid passes dispatch_halo's `fill256` test (>= 218 of 256 workgroups per round), i.e. the AUTOMATIC choice is the
     256-wide instance the bench's deep layers run: forward with fused statistics-free epilogue and the input gradient, bf16 (the
