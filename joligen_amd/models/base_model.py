@@ -111,7 +111,7 @@ class BaseModel:
         if weight_decay != 0.0:
             # the fused kernel walks the whole arena: torch.optim skips parameters without a gradient, so a frozen slice
             # ('freeze' / 'cv_ensemble' names, set_requires_grad) must not silently decay
-            frozen = [n for n, _ in net.named_parameters() if "freeze" in n or "cv_ensemble" in n]
+            frozen = [n for n, prm in net.named_parameters() if "freeze" in n or "cv_ensemble" in n or not prm.requires_grad]
             if frozen:
                 raise NotImplementedError(f"weight decay with frozen parameters ({frozen[:3]}...) is not supported by the flat-arena optimizer")
         opt = FusedAdamW(arena, net.parameters(), lr, betas, weight_decay, eps, decoupled=(name == "adamw"), kind=name)
@@ -121,11 +121,17 @@ class BaseModel:
         return opt
 
     def poll_overflow(self):
-        """fp16 loss-scale maintenance, the host half of GradScaler: the kernels drop a step with non-finite gradients on their own
-        (no host sync per step); every `jg_overflow_poll` steps (default 50) the dropped-step counters are read back, the static
-        loss scale is halved if any step was dropped since the last poll and the optimizers' step counts are corrected."""
+        """fp16 loss-scale maintenance, the host half of torch.cuda.amp.GradScaler (reference base_model.py:89-90,1268-1274): the
+        kernels drop a step with non-finite gradients on their own (no host sync per step); every `jg_overflow_poll` OPTIMIZER steps
+        (default 50) the dropped-step counters are read back.  A dropped step halves the loss scale (backoff_factor 0.5) and is taken
+        out of the optimizers' bias-correction step count; `jg_loss_scale_growth_interval` clean optimizer steps in a row (default
+        2000, GradScaler's growth_interval) double it again (growth_factor 2).  The scale only changes on an accumulation boundary
+        (niter % train_iter_size == 0): gradients already in the arena were scaled with the old value.
+        Approximation, documented: between a dropped step and the poll that sees it (< jg_overflow_poll steps) the bias correction runs
+        one step ahead per drop (torch steps `step` only on applied updates)."""
         every = int(getattr(self.opt, "jg_overflow_poll", 50) or 50)
-        if self.act_dtype != torch.float16 or self.niter % every != 0:
+        iter_size = max(1, int(getattr(self.opt, "train_iter_size", 1) or 1))
+        if self.act_dtype != torch.float16 or self.niter % iter_size != 0 or (self.niter // iter_size) % every != 0:
             return
         dropped = 0
         for o in self.optimizers:
@@ -137,11 +143,18 @@ class BaseModel:
             a._dropped_seen = n
             a.step -= new            # a dropped step must not advance the bias correction
             dropped += new
+        growth = int(getattr(self.opt, "jg_loss_scale_growth_interval", 2000) or 2000)
         if dropped:
+            self._clean_steps = 0
             self.loss_scale = max(1.0, self.loss_scale / 2.0)
-            for o in self.optimizers:
-                o.grad_scale = 1.0 / self.loss_scale
             print(f"[joligen_amd] {dropped} optimizer step(s) dropped on non-finite fp16 gradients: loss scale -> {self.loss_scale:g}")
+        else:
+            self._clean_steps = getattr(self, "_clean_steps", 0) + every
+            if self._clean_steps >= growth:
+                self._clean_steps = 0
+                self.loss_scale = min(self.loss_scale * 2.0, 2.0 ** 24)
+        for o in self.optimizers:
+            o.grad_scale = 1.0 / self.loss_scale
 
     # ---- setup / parallel --------------------------------------------------------------------
     def setup(self, opt):
@@ -345,13 +358,20 @@ class BaseModel:
         shapes = {n: tuple(prm.shape) for n, prm in net.named_parameters()}
         host = torch.empty(flat.shape, dtype=flat.dtype, pin_memory=True)
         side = self._ckpt_stream
+        # The snapshot is taken ON THE COMPUTE STREAM (one device-to-device copy of the flat arena, ~0.1 ms for 237 MB): the next
+        # optimize_parameters() updates arena.p / arena.ema in place and is ordered behind this clone, so the file can never mix
+        # step N and step N + 1.  Only the slow device -> host copy (and the file write) leave the critical path.
+        snap = flat.clone()
+        bsnap = {k: v.detach().clone() for k, v in net.named_buffers()}
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            host.copy_(flat, non_blocking=True)
-            bufs = {k: v.detach().to("cpu", non_blocking=True) for k, v in net.named_buffers()}
+            host.copy_(snap, non_blocking=True)
+            bufs = {k: v.to("cpu", non_blocking=True) for k, v in bsnap.items()}
             done = torch.cuda.Event()
             done.record(side)
-        flat.record_stream(side)
+        snap.record_stream(side)
+        for v in bsnap.values():
+            v.record_stream(side)
 
         def write():
             done.synchronize()

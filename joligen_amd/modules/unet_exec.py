@@ -17,6 +17,7 @@ Parameter gradients are accumulated by the kernels straight into the arena (`par
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 
@@ -338,11 +339,22 @@ class UNetExecutor:
             # a gradient chunk's all-reduce is ordered behind the CURRENT stream only: the weight gradients of the side stream are
             # brought in right before a chunk leaves (parallel.EarlyExchange._launch), not after every layer
             parallel.PRE_LAUNCH_HOOKS.append(self.wgrad_join)
+            # ... and an EARLY chunk (launched from inside this backward) is enqueued FROM the side stream: ordered behind every weight
+            # gradient launched so far without the compute stream waiting for them (parallel.LAUNCH_CONTEXTS)
+            parallel.LAUNCH_CONTEXTS.append(self.exchange_context)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             conv_wgrad(dy, x, m, **kw)
         dy.record_stream(self._side)
         x.record_stream(self._side)
+
+    @contextlib.contextmanager
+    def exchange_context(self):
+        """launch context of a gradient chunk that leaves from inside the backward: the side stream first waits for the compute stream
+        (norm / bias gradients of the chunk are produced there), then the collective is enqueued with the side stream current"""
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            yield
 
     def wgrad_join(self):
         """the compute stream waits for every weight gradient launched so far (end of the backward; before an all-reduce chunk)"""

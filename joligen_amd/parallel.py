@@ -58,6 +58,42 @@ _EARLY = {}
 # callables run right before a gradient chunk's all-reduce is enqueued: schedules that launch gradient kernels on a second stream
 # (modules/unet_exec.py: weight gradients) register their join here, because the collective is ordered behind the current stream only
 PRE_LAUNCH_HOOKS = []
+# context-manager factories entered around the LAUNCH of an early chunk (EarlyExchange._launch).  The UNet executor registers one that
+# enqueues the collective from its weight-gradient stream (after making that stream wait for the compute stream): the chunk is then
+# ordered behind the weight gradients WITHOUT the compute stream having to wait for them -- joining the two streams before every chunk
+# (round 2) serialised exactly the overlap the second stream exists for.  Empty: the PRE_LAUNCH_HOOKS join is used instead.
+LAUNCH_CONTEXTS = []
+# "fp32" (default) | "bf16": wire format of the gradient chunks (JG_GRAD_WIRE).  bf16 halves the bytes on xGMI (237 -> 119 MB per step
+# for the 59 M-parameter UNet): the chunk is rounded into a bf16 staging buffer, summed by RCCL in bf16 and widened back into the fp32
+# gradient arena before the optimizer reads it (the optimizer state stays fp32).  The rounding is that of one more bf16 hop on a gradient
+# that was computed from bf16 activations; off by default, the reference's DDP reduces fp32.
+import os as _os
+GRAD_WIRE = _os.environ.get("JG_GRAD_WIRE", "fp32")
+# per-step diagnostics of the exchange (bench.py --gpus N prints them per rank): CUDA events around the wait + optimizer loop of
+# allreduce_and_step, i.e. the time the compute stream spent on the exposed part of the exchange plus the chunked optimizer
+TIMING = None       # set to [] to collect (ev_begin, ev_end) pairs
+
+
+def _launch_allreduce(buf):
+    """async all-reduce(SUM) of a slice of the fp32 gradient arena, in the configured wire format; returns an object with .wait()"""
+    if GRAD_WIRE == "bf16" and buf.dtype == torch.float32:
+        wire = buf.to(torch.bfloat16)
+        work = dist.all_reduce(wire, op=dist.ReduceOp.SUM, async_op=True)
+        return _WireWork(work, wire, buf)
+    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+
+class _WireWork:
+    """work handle of a reduced-precision chunk: wait() = wait for the collective, then widen the sum back into the fp32 arena slice"""
+
+    def __init__(self, work, wire, dst):
+        self.work, self.wire, self.dst = work, wire, dst
+
+    def wait(self):
+        self.work.wait()
+        if self.wire.is_cuda:      # the staging buffer may have been allocated on the launching (weight-gradient) stream
+            self.wire.record_stream(torch.cuda.current_stream())
+        self.dst.copy_(self.wire)
 
 
 class EarlyExchange:
@@ -99,9 +135,16 @@ class EarlyExchange:
     def _launch(self, c):
         lo, hi = self.bounds[c]
         self.sent[c] = True
-        for hook in PRE_LAUNCH_HOOKS:
-            hook()
-        self.launched.append((c, dist.all_reduce(self.arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)))
+        if LAUNCH_CONTEXTS:
+            with contextlib.ExitStack() as stack:
+                for make in LAUNCH_CONTEXTS:
+                    stack.enter_context(make())
+                work = _launch_allreduce(self.arena.g[lo:hi])
+        else:
+            for hook in PRE_LAUNCH_HOOKS:
+                hook()
+            work = _launch_allreduce(self.arena.g[lo:hi])
+        self.launched.append((c, work))
 
     def mark(self, prm):
         k = id(prm)
@@ -140,22 +183,41 @@ def allreduce_and_step(arena, hp, grad_scale, n_chunks=4):
     Chunks whose reduction was already started from inside the backward (`EarlyExchange`) are only waited for."""
     ws = world_size()
     overflow = getattr(arena, "overflow", None)
-    if overflow is not None:
-        # fp16: the step is dropped on every rank or on none.  The LOCAL gradient is scanned before it is reduced (a non-finite
-        # value survives the sum, but it would surface in one chunk only) and the flag travels as one tiny MAX all-reduce.
+    # every gradient kernel launched on another stream is joined FIRST: from here on the whole arena is final on the current stream
+    # (the overflow scan below reads all of it, and the chunks that have not left yet are enqueued behind the current stream)
+    for hook in PRE_LAUNCH_HOOKS:
+        hook()
+    ex = getattr(arena, "early_exchange", None)
+    if overflow is not None and (ex is None or not ex.launched):
+        # fp16: the step is dropped on every rank or on none.  No chunk has left yet: the LOCAL gradient is scanned before it is
+        # reduced and the flag travels as one tiny MAX all-reduce.
         arena.check_overflow()
         dist.all_reduce(overflow[:1], op=dist.ReduceOp.MAX)
-    ex = getattr(arena, "early_exchange", None)
+        overflow = None
     if ex is not None:
         pending = ex.drain()
     else:
-        bounds = chunk_bounds(arena.numel, n_chunks)
-        for hook in PRE_LAUNCH_HOOKS:
-            hook()
-        pending = [(lo, hi, dist.all_reduce(arena.g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)) for lo, hi in bounds]
-    for lo, hi, w in pending:
-        w.wait()  # NCCL/RCCL: makes the current stream wait, does not block the host
-        arena.adamw_step(grad_scale=grad_scale / ws, lo=lo, hi=hi, **hp)
+        pending = [(lo, hi, _launch_allreduce(arena.g[lo:hi])) for lo, hi in chunk_bounds(arena.numel, n_chunks)]
+    timed = TIMING is not None and torch.cuda.is_available() and arena.g.is_cuda
+    if timed:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    if overflow is not None:
+        # chunks went out from inside the backward (EarlyExchange): some slices are being summed in place right now, so the scan runs
+        # on the REDUCED arena, after every chunk has landed -- a non-finite value of any rank survives the sum, every rank scans the
+        # same reduced values and takes the same decision without a flag exchange.  The optimizer chunks then run back to back.
+        for lo, hi, w in pending:
+            w.wait()
+        arena.check_overflow()
+        for lo, hi, w in pending:
+            arena.adamw_step(grad_scale=grad_scale / ws, lo=lo, hi=hi, **hp)
+    else:
+        for lo, hi, w in pending:
+            w.wait()  # NCCL/RCCL: makes the current stream wait, does not block the host
+            arena.adamw_step(grad_scale=grad_scale / ws, lo=lo, hi=hi, **hp)
+    if timed:
+        ev1.record()
+        TIMING.append((ev0, ev1))
 
 
 def broadcast_params(arena, src=0):

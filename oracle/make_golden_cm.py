@@ -23,7 +23,7 @@ import torch  # noqa: E402
 import jg_oracle as O  # noqa: E402
 from make_golden import checks, synth_batch  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("JG_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")   # JG_GOLDEN_OUT: tests/test_oracle_golden.py::test_fixtures_regenerate
 
 TINY = {
     "tiny_eff": dict(ngf=32, mults=[1, 2], res_blocks=[1, 1], attn_res=[16], efficient=True, S=16, B=2),
@@ -163,7 +163,8 @@ def main():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sampling":     # the other fixtures stay untouched
+    if len(sys.argv) > 1 and sys.argv[1] == "sampling":     # only cm_sampling_*.pt
         make_sampling()
-    else:
+    else:                                                   # every cm_*.pt fixture
         main()
+        make_sampling()

@@ -17,7 +17,7 @@ import torch.nn as nn  # noqa: E402
 import jg_oracle as O  # noqa: E402
 from make_golden import checks  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("JG_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")   # JG_GOLDEN_OUT: tests/test_oracle_golden.py::test_fixtures_regenerate
 CFGS = {"small": dict(ngf=16, n_blocks=2, ndf=16, S=32, B=2), "wide": dict(ngf=64, n_blocks=3, ndf=64, S=32, B=1)}
 NCE_LAYERS = [0, 4, 8, 10, 11]
 

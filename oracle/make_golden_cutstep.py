@@ -20,19 +20,25 @@ ref_shim.install()
 import torch  # noqa: E402
 
 import jg_oracle as O  # noqa: E402
+
+REAL_RAND = torch.rand        # step_fixtures() swaps torch.rand for the SegFormer uniform recorder while a model runs
 from make_golden import checks  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("JG_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")   # JG_GOLDEN_OUT: tests/test_oracle_golden.py::test_fixtures_regenerate
 STEP_CFGS = {
     "monce": dict(ngf=16, n_blocks=2, ndf=16, S=32, B=2, nce_layers="0,4,8,10,11", num_patches=64, nce_loss="monce", pool=2, iters=4),
     # BASELINE.json configs[0]: cut_model, resnet_9blocks G + basic D, 128x128, batch 1 (example_gan_horse2zebra.json shape)
     "config0": dict(ngf=64, n_blocks=9, ndf=64, S=128, B=1, nce_layers="0,4,8,12,16", num_patches=256, nce_loss="monce", pool=50, iters=2),
     # BASELINE.json configs[2] shape with the buildable discriminator: SegFormer-attn G (MiT-b0 + ResnetDecoder tail) + basic D + MoNCE
+    # batch_rand="recorder": the committed segformer / mobile_attn fixtures were generated AFTER the uniform recorder was added, with
+    # batch() drawing A / B through the recorder's torch.rand (its generator, seed 31) instead of Generator(seed); the three older
+    # fixtures drew them with the real torch.rand.  The key pins which one each fixture used, so that every committed file regenerates
+    # bit-exact from this script (tests/test_oracle_golden.py::test_fixtures_regenerate); the inputs are stored in the fixture either way.
     "segformer": dict(netG="segformer_attn_conv", ngf=64, n_blocks=9, ndf=16, S=64, B=2, nce_layers="0,1,2,3", num_patches=64, nce_loss="monce",
-                      pool=2, iters=3),
+                      pool=2, iters=3, batch_rand="recorder"),
     # attention ResNet generator with depth-wise separable blocks (G_netG = mobile_resnet_attn); nce ids >= n_blocks tap nothing
     "mobile_attn": dict(netG="mobile_resnet_attn", ngf=16, n_blocks=3, ndf=16, S=64, B=2, nce_layers="0,1,2,8", num_patches=64, nce_loss="monce",
-                        pool=2, iters=3),
+                        pool=2, iters=3, batch_rand="recorder"),
     "patchnce": dict(ngf=16, n_blocks=3, ndf=16, S=32, B=1, nce_layers="0,4,8,12", num_patches=32, nce_loss="patchnce", pool=1, iters=3),
 }
 
@@ -128,9 +134,9 @@ def build_opt(c):
     return opt
 
 
-def batch(B, S, seed):
+def batch(B, S, seed, rand=REAL_RAND):
     g = torch.Generator().manual_seed(seed)
-    return {"A": torch.rand(B, 3, S, S, generator=g) * 2 - 1, "B": torch.rand(B, 3, S, S, generator=g) * 2 - 1,
+    return {"A": rand(B, 3, S, S, generator=g) * 2 - 1, "B": rand(B, 3, S, S, generator=g) * 2 - 1,
             "A_img_paths": ["synthetic"] * B, "B_img_paths": ["synthetic"] * B}
 
 
@@ -161,7 +167,8 @@ def step_fixtures():
         urec = Recorder(31)
         torch.rand, F.dropout2d = urec.rand, urec.dropout2d
         try:
-            data0 = batch(c["B"], c["S"], 500)
+            brand = urec.rand if c.get("batch_rand") == "recorder" else REAL_RAND
+            data0 = batch(c["B"], c["S"], 500, brand)
             model.data_dependent_initialize(data0)
             sdG = O.synth_state_dict(model.netG_A.state_dict(), seed=0)
             sdD = O.synth_state_dict(model.netD_B_basic.state_dict(), seed=1)
@@ -171,7 +178,7 @@ def step_fixtures():
             model.netF.load_state_dict(sdF)
             steps = []
             for it in range(c["iters"]):
-                data = batch(c["B"], c["S"], 500 + it)
+                data = batch(c["B"], c["S"], 500 + it, brand)
                 model.set_input(data)
                 perms.clear()
                 n_log, n_u = len(rr.log), len(urec.log)
@@ -179,7 +186,9 @@ def step_fixtures():
                 model.optimize_parameters()
                 losses = {k: float(v) for k, v in model.get_current_losses().items()}
                 rec = dict(A=data["A"], B=data["B"], perms=[p[: c["num_patches"]].clone() for p in perms], pool_draws=list(rr.log[n_log:]), losses=losses,
-                           fake_B=model.fake_B.detach().clone(), uniforms=[u.clone() for u in urec.log[n_u:]])
+                           fake_B=model.fake_B.detach().clone())
+                if c.get("batch_rand") == "recorder":      # the fixtures written since the recorder exists carry the DropPath / Dropout2d uniforms
+                    rec["uniforms"] = [u.clone() for u in urec.log[n_u:]]
                 if it in (0, c["iters"] - 1):
                     rec["G_checks"] = checks(dict(model.netG_A.named_parameters()))
                     rec["F_checks"] = checks(dict(model.netF.named_parameters()))
@@ -193,7 +202,7 @@ def step_fixtures():
             ref_pool.random = random
         hp = dict(lr_G=opt.train_G_lr, lr_D=opt.train_D_lr, beta1=opt.train_beta1, beta2=opt.train_beta2, eps=opt.train_optim_eps,
                   ema_beta=opt.train_G_ema_beta, T=opt.alg_cut_nce_T, lambda_NCE=opt.alg_cut_lambda_NCE, lambda_GAN=opt.alg_gan_lambda)
-        torch.save(dict(cfg=c, hp=hp, steps=steps, keysG=list(sdG.keys()), shapesG={k: tuple(v.shape) for k, v in sdG.items()},
+        torch.save(dict(cfg={k: v for k, v in c.items() if k != "batch_rand"}, hp=hp, steps=steps, keysG=list(sdG.keys()), shapesG={k: tuple(v.shape) for k, v in sdG.items()},
                         keysD=list(sdD.keys()), shapesD={k: tuple(v.shape) for k, v in sdD.items()}, keysF=list(sdF.keys()),
                         shapesF={k: tuple(v.shape) for k, v in sdF.items()}, loss_names=list(model.loss_names)),
                    os.path.join(OUT, f"cutstep_{name}.pt"))

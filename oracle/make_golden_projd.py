@@ -27,7 +27,7 @@ import torch  # noqa: E402
 import jg_oracle as O  # noqa: E402
 from make_golden import checks  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("JG_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # JG_GOLDEN_OUT: tests/test_oracle_golden.py::test_fixtures_regenerate
 
 
 def main():

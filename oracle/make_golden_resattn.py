@@ -15,7 +15,7 @@ import torch  # noqa: E402
 import jg_oracle as O  # noqa: E402
 from make_golden import checks  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("JG_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")   # JG_GOLDEN_OUT: tests/test_oracle_golden.py::test_fixtures_regenerate
 CFG = dict(ngf=16, n_blocks=3, S=64, B=2, nb_mask_attn=10, nb_mask_input=1)
 NCE_LAYERS = [0, 2, 4, 8]      # ids 4 and 8 are beyond the 3 blocks: they tap nothing (compute_feats :504-515)
 

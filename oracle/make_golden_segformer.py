@@ -17,7 +17,7 @@ import torch.nn.functional as F  # noqa: E402
 import jg_oracle as O  # noqa: E402
 from make_golden import checks  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("JG_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")   # JG_GOLDEN_OUT: tests/test_oracle_golden.py::test_fixtures_regenerate
 CFGS = {"s64": dict(S=64, B=2), "s128": dict(S=128, B=1)}
 
 

@@ -373,7 +373,12 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
     ls = model.loss_scale
     gen = cut_gen(c)
     skip = _zero_grad_bias(tr.G, gen)
+    # the rounding floor of THIS comparison, measured on CPU: the fp32 oracle against itself with 16-bit storage of every inter-layer
+    # activation and activation gradient (tests/test_oracle_golden.py::test_cut_rounding_yardstick -> profiles/r03_rounding_yardstick_cut.json)
+    import json
+    yard = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rounding_yardstick_cut.json")))[name]["fp16"]
     bad, errs, table = [], [], []
+    per_key = {"G": [], "F": []}
     for net, key in ((model.netG_A, "G"), (model.netF, "F")):
         for k, p in net.named_parameters():
             ref = tr.last_grads[key][k]
@@ -387,20 +392,24 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
             cos = float((mine.double().flatten() @ ref.double().flatten()) / (float(mine.double().norm()) * float(ref.double().norm()) + 1e-300))
             rel = err / (float(ref.norm()) + floor + 1e-30)
             errs.append(rel)
+            per_key[key].append(rel)
             table.append(f"{rel:10.3e} cos={cos:7.4f} ref={float(ref.norm()):10.3e} mine={float(mine.norm()):10.3e} floor={floor:9.2e} {key}.{k}")
-            # per tensor: direction first (a wrong kernel shows as a cosine well below 0.98; the 16-bit noise of this stack keeps every
-            # tensor at >= 0.989 over all builds of round 2), then the noise amplitude with head-room over the observed 0.12 - 0.15 band
-            if rel > 0.20 or (float(ref.norm()) > 10 * floor and float(ref.norm()) > 1e-6 and cos < 0.98):
-                bad.append((key, k, rel, cos, float(ref.norm()), floor))
+            # per tensor: direction first (a wrong kernel shows as a cosine well below the floor's own minimum), then the amplitude
+            # against TWICE the worst tensor of the measured rounding floor of the same network (round 2 used a fitted 0.20 for all)
+            if rel > 2.0 * yard[key]["grad_worst"] or (float(ref.norm()) > 10 * floor and float(ref.norm()) > 1e-6 and cos < yard[key]["cos_min"] - 0.02):
+                bad.append((key, k, rel, cos, float(ref.norm()), floor, yard[key]["grad_worst"]))
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/grad_table_cut_{name}.txt", "w") as f:
         f.write("\n".join(table))
-    # gradient direction under 16-bit activations: ~10 % on this stack
+    with open(f"gpurun_out/grad_table_cut_{name}.txt", "a") as f:
+        f.write("\n" + "\n".join(f"# {key}: median {sorted(v)[len(v) // 2]:.3e} worst {max(v):.3e} | rounding floor median {yard[key]['grad_median']:.3e} "
+                                  f"worst {yard[key]['grad_worst']:.3e}" for key, v in per_key.items()))
     assert not bad, bad[:8]
-    # the median is a NOISY statistic of this chaotic (ReLU-mask / 16-bit) comparison: over eight builds that differ only in kernel
-    # scheduling or in 1e-7-level arithmetic (tools bisect of round 2) it moved between 0.062 and 0.083 with every cosine >= 0.989;
-    # the bound sits above that band, the per-tensor bound above catches a wrong kernel
-    assert sorted(errs)[len(errs) // 2] < 0.10, sorted(errs)[len(errs) // 2]
+    # medians per network against 1.5x the floor's median (the floor itself: G 0.068 - 0.083, F 0.002 - 0.013 in fp16 -- the 2 - 9 % of
+    # round 2 ARE the 16-bit conditioning of this ReLU / InstanceNorm stack, measured, not a kernel defect)
+    for key, v in per_key.items():
+        med = sorted(v)[len(v) // 2]
+        assert med <= 1.5 * yard[key]["grad_median"] + 1e-4, (key, med, yard[key]["grad_median"])
 
 
 def test_cut_checkpoints_reference_layout(golden_dir, tmp_path):

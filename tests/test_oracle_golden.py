@@ -568,6 +568,110 @@ def test_rounding_yardstick():
                 assert abs(v - committed[shape][dt][k]) <= 0.25 * committed[shape][dt][k] + 1e-6, (shape, dt, k, v, committed[shape][dt][k])
 
 
+# ---- rounding yardstick of the CUT step: what a perfect 16-bit execution of G / F / D may differ by -----------
+YARD_CUT_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rounding_yardstick_cut.json")
+YARD_CUT_CASES = ["monce", "segformer", "mobile_attn"]
+
+
+def cut_zero_grad_bias(gen):
+    """parameters of the CUT generators whose gradient is analytically zero (a conv bias in front of an InstanceNorm, the key bias
+    of an attention layer): compared with an absolute floor taken from the same layer's weight gradient"""
+    def skip(k):
+        if gen == "segformer":
+            return k.endswith("in_proj_bias")
+        if "resnet_attn" in gen:
+            return k.endswith(".bias") and not k.startswith("deconv3_")
+        return k.endswith(".bias")
+    return skip
+
+
+def cut_first_step_oracle(g, dtype16, rounded):
+    """first G-group (and D-group) backward of the oracle CUT trainer on the step-0 inputs of a cutstep fixture, weights and inputs
+    made `dtype16`-representable exactly as tests/test_gpu_5_cutloss.py::test_cut_model_first_step_gradients_vs_oracle does;
+    `rounded`: with every inter-layer activation (and its gradient) of G and D stored in dtype16 (oracle `activation_rounding`) and the
+    HIP path's static fp16 loss scale of the CUT model (1024, models/cut_model.py)."""
+    import random
+
+    c = g["cfg"]
+    s = g["steps"][0]
+    tr, _ = cut_trainer_for(g)
+    isbuf = lambda k: "running_" in k or "num_batches_tracked" in k
+    r16 = lambda v: v.to(dtype16).float() if torch.is_floating_point(v) else v
+    sdG = {k: r16(v) for k, v in O.synth_state_dict({k: torch.empty(g["shapesG"][k]) for k in g["keysG"]}, 0).items()}
+    tr.G = {k: v.clone() for k, v in sdG.items() if not isbuf(k)}
+    tr.Gbuf = {k: v.clone() for k, v in sdG.items() if isbuf(k)}
+    tr.D = {k: r16(v) for k, v in tr.D.items()}
+    tr.pool.rng = tr.real_pools[0].rng = tr.real_pools[1].rng = random.Random(0)
+    nl = cut_ntaps(c)
+    ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
+    A, Bi = r16(s["A"]), r16(s["B"])
+    if rounded:
+        tr.grad_scale = 1024.0 if dtype16 == torch.float16 else 1.0
+        with O.activation_rounding(dtype16):
+            losses = tr.step(A, Bi, ids_ab, ids_idt, uniforms=s.get("uniforms") or None)
+    else:
+        losses = tr.step(A, Bi, ids_ab, ids_idt, uniforms=s.get("uniforms") or None)
+    return tr, losses
+
+
+def cut_rounding_yardstick(golden_dir, name):
+    g = load(golden_dir, f"cutstep_{name}.pt")
+    gen = cut_gen(g["cfg"])
+    skip = cut_zero_grad_bias(gen)
+    out = {}
+    for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        ref, lref = cut_first_step_oracle(g, dt, rounded=False)
+        rnd, lrnd = cut_first_step_oracle(g, dt, rounded=True)
+        res = {"loss_rel": {k: abs(lrnd[k] - lref[k]) / (abs(lref[k]) + 1e-12) for k in lref},
+               "fake_B_rel": float((rnd.fake_B - ref.fake_B).norm() / ref.fake_B.norm())}
+        # PatchGAN: the biases of the convolutions that feed an InstanceNorm (all but the first and the last one) have a zero gradient
+        dconv = sorted(int(k.split(".")[1]) for k in ref.last_grads["D"] if k.endswith(".bias"))
+        dzero = {f"model.{i}.bias" for i in dconv[1:-1]}
+        for key in ("G", "F", "D"):
+            errs, coss = [], []
+            for k, gr in ref.last_grads[key].items():
+                mine = rnd.last_grads[key][k]
+                floor = 0.0
+                if (key == "G" and skip(k)) or (key == "D" and k in dzero):
+                    wk = k.replace("in_proj_bias", "in_proj_weight") if k.endswith("in_proj_bias") else k[:-4] + "weight"
+                    floor = 2e-3 * float(ref.last_grads[key][wk].norm())
+                errs.append(float((mine.double() - gr.double()).norm()) / (float(gr.norm()) + floor + 1e-30))
+                if float(gr.norm()) > 10 * floor and float(gr.norm()) > 1e-6:
+                    coss.append(float((mine.double().flatten() @ gr.double().flatten()) / (float(mine.double().norm()) * float(gr.double().norm()) + 1e-300)))
+            errs.sort()
+            res[key] = dict(grad_median=errs[len(errs) // 2], grad_p90=errs[int(len(errs) * 0.9)], grad_worst=errs[-1], cos_min=min(coss))
+        out[tag] = res
+    return out
+
+
+@pytest.mark.parametrize("name", YARD_CUT_CASES)
+def test_cut_rounding_yardstick(golden_dir, name):
+    """Measured rounding floor of the first CUT step (G / F / D gradients, losses, fake_B) for the fixtures the GPU gradient tests use;
+    the committed numbers bound tests/test_gpu_5_cutloss.py::test_cut_model_first_step_gradients_vs_oracle.  JG_WRITE_YARDSTICK=1 rewrites
+    the file (one entry per case)."""
+    import json
+
+    res = cut_rounding_yardstick(golden_dir, name)
+    for key in ("G", "F", "D"):
+        assert res["fp16"][key]["grad_median"] <= res["bf16"][key]["grad_median"] * 1.05 + 1e-9
+        assert res["fp16"][key]["grad_worst"] > 0
+    committed = json.load(open(YARD_CUT_FILE)) if os.path.exists(YARD_CUT_FILE) else {}
+    if os.environ.get("JG_WRITE_YARDSTICK"):
+        committed[name] = res
+        committed["_meta"] = ("oracle/jg_oracle.py OracleCUTTrainer.step on cutstep_<case>.pt step 0 under activation_rounding(dtype): fp32 arithmetic, "
+                              "16-bit storage of every inter-layer activation and activation gradient of G and D; 16-bit-representable weights and inputs on both sides")
+        with open(YARD_CUT_FILE, "w") as f:
+            json.dump(committed, f, indent=1)
+    for dt in ("fp16", "bf16"):
+        for key in ("G", "F", "D"):
+            for k, v in res[dt][key].items():
+                c = committed[name][dt][key][k]
+                if k == "cos_min":
+                    assert v >= c - 0.05, (name, dt, key, k, v, c)
+                else:      # the comparison is chaotic (ReLU masks flip under rounding): the statistic itself moves with the torch build
+                    assert 0.5 * c - 1e-6 <= v <= 2.0 * c + 1e-6, (name, dt, key, k, v, c)
+
+
 # ---- class-conditioned palette_model (alg_diffusion_cond_embed = "class"): oracle/make_golden_cond.py fixture -------------------
 def cls_state(g, T_test=None):
     sched = {}
@@ -639,3 +743,50 @@ def test_palette_conditioning(golden_dir, tag):
         y, ret = O.ddpm_restoration(sd, sm["A"], sm["y_t0"], sm["B"], sm["mask"], sm["noises"], cfg, sample_num=2, cls=sm["cls"])
     torch.testing.assert_close(y, sm["y_out"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(ret, sm["ret"], rtol=1e-4, atol=1e-5)
+
+
+# ---- the committed fixtures regenerate from the committed recipes ------------------------------------------------
+RECIPES = ["make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
+           "make_golden_projd.py", "make_golden_resattn.py", "make_golden_sampling.py", "make_golden_segformer.py"]
+
+
+def _same(a, b, path):
+    """recursive equality of two loaded fixtures: tensors bit-exact, containers element-wise, floats exactly"""
+    if isinstance(a, torch.Tensor):
+        assert isinstance(b, torch.Tensor) and a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), path
+    elif isinstance(a, dict):
+        assert isinstance(b, dict) and list(a.keys()) == list(b.keys()), (path, list(a.keys()), list(b.keys()) if isinstance(b, dict) else b)
+        for k in a:
+            _same(a[k], b[k], f"{path}[{k!r}]")
+    elif isinstance(a, (list, tuple)):
+        assert type(a) is type(b) and len(a) == len(b), path
+        for i, (x, y) in enumerate(zip(a, b)):
+            _same(x, y, f"{path}[{i}]")
+    else:
+        assert a == b or (a != a and b != b), (path, a, b)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/models"), reason="the reference tree is only present in the build container")
+def test_fixtures_regenerate(golden_dir, tmp_path):
+    """Every file under tests/golden/ is an output of the UNMODIFIED reference: run every oracle/make_golden*.py (they import
+    /root/reference through oracle/ref_shim.py) into a scratch directory and require each regenerated fixture to equal the committed
+    one bit for bit -- a recipe that drifts away from the fixture it once wrote (as make_golden_cutstep.py did in round 2) fails here."""
+    import subprocess
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, JG_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+
+    def run(script):
+        r = subprocess.run([sys.executable, os.path.join(root, "oracle", script)], env=env, cwd="/tmp", capture_output=True, text=True)
+        return script, r.returncode, (r.stdout + r.stderr)[-1500:]
+
+    with ThreadPoolExecutor(max_workers=3) as ex:      # torch-CPU reductions are bit-reproducible only at the thread count the fixtures were written with (the default)
+        for script, rc, tail in ex.map(run, RECIPES):
+            assert rc == 0, (script, tail)
+    committed = sorted(f for f in os.listdir(golden_dir) if f.endswith(".pt"))
+    made = sorted(f for f in os.listdir(tmp_path) if f.endswith(".pt"))
+    assert made == committed, (set(committed) ^ set(made))
+    for f in committed:
+        _same(torch.load(os.path.join(golden_dir, f), weights_only=False), torch.load(os.path.join(tmp_path, f), weights_only=False), f)
