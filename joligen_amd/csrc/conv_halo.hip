@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
       const unsigned bbyte = (NABUF * HALO_CH + bslot * B_BUF) * 16;
       const unsigned b0 = lds0 + bbyte + bfrag[0], b1 = lds0 + bbyte + (bfrag[0] ^ 64);
       const unsigned a1 = lds0 + abyte + (afrag[s3] ^ 64), an = lds0 + nbyte + afrag[ns3];
-      if (!(p.dbg & 1024)) jg_rd4<0, 2048, 4096, 6144>(fb[0], fb[1], fb[2], fb[3], b0);   // dbg 1024: timing without the exposed post-barrier reads
+      jg_rd4<0, 2048, 4096, 6144>(fb[0], fb[1], fb[2], fb[3], b0);
       // weight tile of K-step k + NBBUF - 1 into the slot freed at the previous barrier; one halo round of the next chunk.
       // (measured, profiles/r03_halo_pipe_ablation.txt: spreading the pieces between the MFMA groups, staggering them between the two waves
       // of a SIMD, or leaving the halo piece in flight across the barrier are all slower than issuing them right here)
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, MINB) void conv3x3_halo_kernel(ConvP p) {
       } else {
         wait_vmcnt<0>();
       }
-      if (!(p.dbg & 512)) __builtin_amdgcn_s_barrier();      // dbg 512: timing without the per-step barrier (only meaningful with 128 + 4)
+      __builtin_amdgcn_s_barrier();
       if (++bslot == NBBUF) bslot = 0;
     };
     read_fa(0);
