@@ -293,6 +293,19 @@ int jg_reflect_pad2d_bwd(int dtype, const void* dy, void* dx, int B, int H, int 
  * at (top, left), zeros elsewhere): reflect-padded depth-wise conv of SeparableConv2d (mobile_modules.py:4-40) = pad -> dwconv -> crop */
 int jg_crop2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int top, int left, int Ho, int Wo, int adjoint, jg_stream_t s);
 int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s);
+
+/* Frozen tf_efficientnet_lite0 feature network of the projected discriminator (models/modules/projected_d/projector.py:51-59,251-255; timm
+ * MBConv blocks; the feature network stays in eval mode, discriminator.py:267-270, so BatchNorm is the per-channel affine scale / shift):
+ *   dwconv_affine_act : y = act(scale[c] * dwconv_kxk(x, w)[c] + shift[c]); k = 3 | 5, stride 1 | 2, explicit top / left zero padding
+ *                       (TF "SAME" is asymmetric at stride 2), w = fp32 [k*k][C], act 0 = none, 1 = ReLU6; _bwd = the INPUT gradient
+ *                       (weights are frozen) from dy and the forward output y (ReLU6 pass-through set = 0 < y < 6)
+ *   chan_affine_act   : y = act(scale[c] * x + shift[c]) over P pixels (BatchNorm + ReLU6 behind the 1x1 convolutions) and its gradient */
+int jg_dwconv_affine_act_fwd(int dtype, const void* x, const float* w, const float* scale, const float* shift, void* y, int B, int H, int W, int C,
+                             int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, jg_stream_t s);
+int jg_dwconv_affine_act_bwd(int dtype, const void* dy, const void* y, const float* w, const float* scale, void* dx, int B, int H, int W, int C,
+                             int k, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, jg_stream_t s);
+int jg_chan_affine_act_fwd(int dtype, const void* x, const float* scale, const float* shift, void* y, int64_t P, int C, int act, jg_stream_t s);
+int jg_chan_affine_act_bwd(int dtype, const void* dy, const void* y, const float* scale, void* dx, int64_t P, int C, int act, jg_stream_t s);
 int jg_subsample2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s);
 int jg_channel_sum(int dtype, const void* x, int64_t ldx, float* out, int64_t P, int C, float scale, jg_stream_t s);
 

@@ -10,7 +10,7 @@ Differences that are the point of this build:
   * the optimizer is the fused AdamW(+EMA+zero_grad) kernel; the EMA copy is a flat buffer and
     `net<name>_ema` is a light module view of it (same state_dict keys);
   * no GradScaler: bf16 activations need none, fp16 uses a static loss scale.
-Evaluation / visuals / metrics / export (reference :870-938, :1637-2287) are out of scope.
+Evaluation / metrics (reference :1637-2287) are out of scope; `export_networks` (:870-938) traces plain-torch mirrors (util/export.py).
 """
 from __future__ import annotations
 
@@ -397,13 +397,28 @@ class BaseModel:
             self._ckpt_threads = []
 
     def export_networks(self, epoch):
-        """:870-938.  The reference exports ONNX / TorchScript for GAN generators only (palette / cm are skipped there too), by
-        loading the saved `.pth` into its own CPU modules (util/export.py).  The checkpoints written here interchange with the
-        reference, so the same exporter runs on them unchanged; this build has no CPU module graph to trace."""
-        if self.opt.model_type in ("palette", "cm"):
-            return
-        raise NotImplementedError("ONNX / TorchScript export of GAN generators: run the reference's util/export.py on the "
-                                  "<epoch>_net_G_A.pth written by save_networks (same keys and layout)")
+        """:870-938.  For every network of `model_names_export` (the GAN generators; palette / cm are skipped by the reference too) the
+        `<epoch>_net_<name>.pth` written by save_networks is loaded into a CPU generator and traced to `<epoch>_net_<name>.onnx`
+        (always, except for the generators the reference excludes) and `<epoch>_net_<name>.pt` (TorchScript, `train_export_jit`).
+        util/export.py holds the plain-torch generators the tracing runs on (the HIP modules are not traceable); an export this
+        installation cannot produce (no `onnx` package, no mirror of the generator) is reported and skipped -- the training loop
+        (train.py:351-357 calls this after every save) goes on.  Returns the list of files written."""
+        if self.opt.model_type in ("palette", "cm", "cm_gan", "sc", "b2b"):
+            return []
+        from ..util.export import export
+
+        self.wait_checkpoints()          # an asynchronous save of this epoch must be on disk before it is read back
+        written = []
+        netG = self.opt.G_netG
+        for name in getattr(self, "model_names_export", ["G_A"]):
+            save_path = os.path.join(self.save_dir, "%s_net_%s.pth" % (epoch, name))
+            onnx_ok = (not getattr(self.opt, "train_feat_wavelet", False) and not any(t in netG for t in ("ittr", "hdit", "img2img_turbo"))
+                       and netG != "hat" and not (torch.__version__[0] == "2" and "segformer" in netG))
+            if onnx_ok:
+                written.append(export(self.opt, save_path, save_path.replace(".pth", ".onnx"), getattr(self, "onnx_opset_version", 12), "onnx"))
+            if getattr(self.opt, "train_export_jit", False) and not any(t in netG for t in ("uvit", "hdit", "img2img_turbo")):
+                written.append(export(self.opt, save_path, save_path.replace(".pth", ".pt"), getattr(self, "onnx_opset_version", 12), "jit"))
+        return [w for w in written if w]
 
     def load_networks(self, epoch, load_dir=None):
         self.wait_checkpoints()
@@ -415,7 +430,10 @@ class BaseModel:
                 del state_dict._metadata
             # :1098-1103: the reference passes `strict=self.opt.model_load_no_strictness` (non-strict unless the flag is set -- the
             # flag's name says the opposite, the call is what reference checkpoints rely on)
-            self._net(name).load_state_dict(state_dict, strict=bool(getattr(self.opt, "model_load_no_strictness", False)))
+            net = self._net(name)
+            res = net.load_state_dict(state_dict, strict=bool(getattr(self.opt, "model_load_no_strictness", False)))
+            if hasattr(net, "check_loaded_backbone"):      # projected discriminator: a checkpoint without the frozen backbone must not pass silently
+                net.check_loaded_backbone(res, path)
 
 
 class _EmaView:

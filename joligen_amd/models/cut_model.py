@@ -113,8 +113,11 @@ class CUTModel(BaseModel):
                 else:
                     from ..modules.projected_d import ProjectedDiscriminator
 
+                    # jg_projd_backbone: "lite0" (tf_efficientnet_lite0, the reference's feature network) | "standin" (tests);
+                    # jg_projd_pretrained: path of a timm tf_efficientnet_lite0 state_dict (the weights cannot be downloaded here)
                     net = ProjectedDiscriminator(getattr(opt, "D_proj_network_type", "efficientnet"), interp=getattr(opt, "D_proj_interp", -1),
-                                                 img_size=opt.data_crop_size)
+                                                 img_size=opt.data_crop_size, backbone=getattr(opt, "jg_projd_backbone", "lite0"),
+                                                 pretrained_path=getattr(opt, "jg_projd_pretrained", ""))
                 setattr(self, "netD_B_" + d, net)
                 self.discriminators_names.append("D_B_" + d)
             self.model_names += ["F"] + self.discriminators_names

@@ -4,11 +4,12 @@
 `FeatureFusionBlockMatrix` :248-287) for the convolutional ("efficientnet") variant, `proj_type` 2, `cout` 64, `expand` True.
 
 What is and is not here
-  * The frozen feature network's BACKBONE in the reference is a pretrained timm model (`tf_efficientnet_lite0`): neither timm nor its
-    weights are available offline, so the backbone is a STAND-IN with the same interface -- four stages at strides 4 / 8 / 16 / 32 with
-    tf_efficientnet_lite0's feature widths (24 / 40 / 112 / 320), built from `conv_stem`, `bn1`, `blocks[0:9]` exactly the way
-    `_make_efficientnet` slices a timm EfficientNet (`StandInEfficientNet` below; the same torch module, handed to the UNMODIFIED
-    reference through a stubbed `timm.create_model`, produced the fixtures).  Everything downstream of the backbone is the reference's
+  * The frozen feature network's BACKBONE in the reference is a pretrained timm model (`tf_efficientnet_lite0`).  Round 3: its
+    ARCHITECTURE is built (16 MBConv blocks, `make_efficientnet_lite0`, state_dict keys of timm re-homed by `_make_efficientnet`), on the
+    depth-wise / point-wise kernels of csrc/effnet.hip; timm and its weights are not available offline, so the weights are random until a
+    checkpoint is loaded (`jg_projd_pretrained`, or a reference D checkpoint) and a loud warning says so.  `backbone="standin"`
+    (opt-in, tests) keeps the round-2 STAND-IN -- four stages at strides 4 / 8 / 16 / 32 with the same feature widths (24 / 40 / 112 /
+    320) -- which, handed to the UNMODIFIED reference through a stubbed `timm.create_model`, produced tests/golden/projd.pt.  Everything downstream of the backbone is the reference's
     arithmetic: cross-channel mixing (1x1 convs), cross-scale mixing (add -> bilinear x2, align_corners -> 1x1 conv, top-down), the
     four spectral-norm / GroupNorm / LeakyReLU mini-discriminators, the concatenated logits, and the hinge objective.
   * state_dict() keys follow the reference (`freeze_feature_network.scratch.layer0_ccm.weight`,
@@ -303,6 +304,257 @@ def _hip_stage(cin, cout):
     return nn.Sequential(JGConv2d(cin, cout, 4, padding=1, stride=2), nn.LeakyReLU(0.2))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# tf_efficientnet_lite0 (timm `_gen_efficientnet_lite`, channel / depth multiplier 1.0): the architecture of the reference's frozen
+# feature network (projector.py:251-255 `timm.create_model("tf_efficientnet_lite0", pretrained=True)`), cut into stages the way
+# `_make_efficientnet` (projector.py:51-59) cuts it.  timm is not installed here and its weights cannot be downloaded: the ARCHITECTURE
+# below restates timm's published definition (efficientnet.py `_gen_efficientnet_lite`, _efficientnet_blocks.py `DepthwiseSeparableConv`
+# / `InvertedResidual`, TF "SAME" padding, BatchNorm eps 1e-3, ReLU6, no squeeze-excite) with timm's attribute names, so that a real
+# `tf_efficientnet_lite0` checkpoint (or a reference `<epoch>_net_D_B_projected_d.pth`) loads key for key; the WEIGHTS are random until one
+# is loaded ("backbone parity unpinned: timm absent").
+#   (block type, repeats, kernel, stride, expansion, output channels)
+# ---------------------------------------------------------------------------------------------------------------------
+LITE0_STEM = 32
+LITE0_ARCH = (("ds", 1, 3, 1, 1, 16), ("ir", 2, 3, 2, 6, 24), ("ir", 2, 5, 2, 6, 40), ("ir", 3, 3, 2, 6, 80), ("ir", 3, 5, 1, 6, 112),
+              ("ir", 4, 5, 2, 6, 192), ("ir", 1, 3, 1, 6, 320))
+LITE0_BN_EPS = 1e-3
+
+
+def tf_same_pad(size, k, stride):
+    """TF 'SAME' padding of timm's Conv2dSame: (low, high) zero padding of one axis"""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return total // 2, total - total // 2
+
+
+class _FrozenBN(nn.Module):
+    """BatchNorm2d of a frozen network in eval mode = per-channel affine (scale, shift); same state_dict entries as nn.BatchNorm2d"""
+
+    def __init__(self, c, eps=LITE0_BN_EPS):
+        super().__init__()
+        self.weight, self.bias = nn.Parameter(torch.ones(c)), nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps = eps
+        self._key, self._affine = None, None
+
+    def affine(self):
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version, self.weight.data_ptr())
+        if key != self._key:
+            with torch.no_grad():
+                sc = self.weight.detach().float() / torch.sqrt(self.running_var.float() + self.eps)
+                self._affine = (sc.contiguous(), (self.bias.detach().float() - self.running_mean.float() * sc).contiguous())
+            self._key = key
+        return self._affine
+
+
+class _PWConv(nn.Conv2d, JGConvNd):
+    """bias-free point-wise / stem convolution (timm creates every EfficientNet convolution without a bias) on the MFMA kernels"""
+
+    def __init__(self, cin, cout, k=1, stride=1):
+        nn.Conv2d.__init__(self, cin, cout, k, stride=stride, padding=0, bias=False)
+        self.needs_dgrad = True
+        self.jg_padding, self.jg_stride = 0, stride
+
+    def forward(self, x):
+        if self.meta is None:
+            raise RuntimeError("EfficientNet convolution used before ParamArena finalisation")
+        return ops.conv2d(x, self.meta, None, 1.0)
+
+
+class _DWWeight(nn.Module):
+    """`conv_dw.weight` [C, 1, k, k] of timm; the kernels read a cached fp32 [k*k][C] copy"""
+
+    def __init__(self, c, k, stride):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c, 1, k, k))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+        self.k, self.stride = k, stride
+        self._key, self._taps = None, None
+
+    def taps(self):
+        key = (self.weight._version, self.weight.data_ptr())
+        if key != self._key:
+            with torch.no_grad():
+                w = self.weight.detach().float()
+                self._taps = w.reshape(w.shape[0], -1).t().contiguous()
+            self._key = key
+        return self._taps
+
+
+class _DWAffineActFn(torch.autograd.Function):
+    """relu6(scale * dwconv_kxk(x) + shift), TF SAME padding; backward = input gradient only (frozen weights)"""
+
+    @staticmethod
+    def forward(ctx, x, taps, scale, shift, k, stride, act):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        (pt, _), (pl, _) = tf_same_pad(H, k, stride), tf_same_pad(W, k, stride)
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        y = torch.empty((B, Ho, Wo, C), device=x.device, dtype=x.dtype)
+        check(_lib.lib().jg_dwconv_affine_act_fwd(_dt(x), x.data_ptr(), taps.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), B, H, W, C,
+                                                  k, stride, pt, pl, Ho, Wo, act, _st()), "jg_dwconv_affine_act_fwd")
+        ctx.geo = (B, H, W, C, k, stride, pt, pl, Ho, Wo, act)
+        ctx.save_for_backward(y, taps, scale)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        y, taps, scale = ctx.saved_tensors
+        B, H, W, C, k, stride, pt, pl, Ho, Wo, act = ctx.geo
+        dy = dy.contiguous()
+        dx = torch.empty((B, H, W, C), device=dy.device, dtype=dy.dtype)
+        check(_lib.lib().jg_dwconv_affine_act_bwd(_dt(dy), dy.data_ptr(), y.data_ptr(), taps.data_ptr(), scale.data_ptr(), dx.data_ptr(), B, H, W, C,
+                                                  k, stride, pt, pl, Ho, Wo, act, _st()), "jg_dwconv_affine_act_bwd")
+        return dx, None, None, None, None, None, None
+
+
+class _ChanAffineActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, act):
+        x = x.contiguous()
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        check(_lib.lib().jg_chan_affine_act_fwd(_dt(x), x.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), x.numel() // C, C, act, _st()),
+              "jg_chan_affine_act_fwd")
+        ctx.act = act
+        ctx.save_for_backward(y, scale)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        y, scale = ctx.saved_tensors
+        dy = dy.contiguous()
+        C = y.shape[-1]
+        dx = torch.empty_like(y)
+        check(_lib.lib().jg_chan_affine_act_bwd(_dt(dy), dy.data_ptr(), y.data_ptr(), scale.data_ptr(), dx.data_ptr(), y.numel() // C, C, ctx.act, _st()),
+              "jg_chan_affine_act_bwd")
+        return dx, None, None, None
+
+
+def _bn_act(x, bn, relu6):
+    sc, sh = bn.affine()
+    return _ChanAffineActFn.apply(x, sc, sh, 1 if relu6 else 0)
+
+
+def _dw_bn_act(x, dw, bn):
+    sc, sh = bn.affine()
+    return _DWAffineActFn.apply(x, dw.taps(), sc, sh, dw.k, dw.stride, 1)
+
+
+class _ZeroPadFn(torch.autograd.Function):
+    """zero padding (top, left, bottom, right) of an NHWC map = the adjoint of a window crop (jg_crop2d)"""
+
+    @staticmethod
+    def forward(ctx, x, pt, pl, pb, pr):
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        y = torch.empty((B, H + pt + pb, W + pl + pr, C), device=x.device, dtype=x.dtype)
+        check(_lib.lib().jg_crop2d(_dt(x), x.data_ptr(), y.data_ptr(), B, H + pt + pb, W + pl + pr, C, pt, pl, H, W, 1, _st()), "jg_crop2d")
+        ctx.geo = (pt, pl, H, W)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        pt, pl, H, W = ctx.geo
+        dy = dy.contiguous()
+        B, Hp, Wp, C = dy.shape
+        dx = torch.empty((B, H, W, C), device=dy.device, dtype=dy.dtype)
+        check(_lib.lib().jg_crop2d(_dt(dy), dy.data_ptr(), dx.data_ptr(), B, Hp, Wp, C, pt, pl, H, W, 0, _st()), "jg_crop2d")
+        return dx, None, None, None, None
+
+
+class DepthwiseSeparableConv(nn.Module):
+    """timm _efficientnet_blocks.DepthwiseSeparableConv (no SE, pw_act False): dw kxk -> BN -> ReLU6 -> 1x1 -> BN (+ x)"""
+
+    def __init__(self, cin, cout, k, stride):
+        super().__init__()
+        self.conv_dw, self.bn1 = _DWWeight(cin, k, stride), _FrozenBN(cin)
+        self.conv_pw, self.bn2 = _PWConv(cin, cout), _FrozenBN(cout)
+        self.has_skip = stride == 1 and cin == cout
+
+    def forward(self, x):
+        h = _dw_bn_act(x, self.conv_dw, self.bn1)
+        h = _bn_act(self.conv_pw(h), self.bn2, False)
+        return _AddFn.apply(h, x) if self.has_skip else h
+
+
+class InvertedResidual(nn.Module):
+    """timm _efficientnet_blocks.InvertedResidual (no SE): 1x1 expand -> BN -> ReLU6 -> dw kxk -> BN -> ReLU6 -> 1x1 project -> BN (+ x)"""
+
+    def __init__(self, cin, cout, k, stride, exp):
+        super().__init__()
+        mid = cin * exp
+        self.conv_pw, self.bn1 = _PWConv(cin, mid), _FrozenBN(mid)
+        self.conv_dw, self.bn2 = _DWWeight(mid, k, stride), _FrozenBN(mid)
+        self.conv_pwl, self.bn3 = _PWConv(mid, cout), _FrozenBN(cout)
+        self.has_skip = stride == 1 and cin == cout
+
+    def forward(self, x):
+        h = _bn_act(self.conv_pw(x), self.bn1, True)
+        h = _dw_bn_act(h, self.conv_dw, self.bn2)
+        h = _bn_act(self.conv_pwl(h), self.bn3, False)
+        return _AddFn.apply(h, x) if self.has_skip else h
+
+
+def lite0_blocks():
+    """the seven `blocks[i]` Sequentials of tf_efficientnet_lite0"""
+    blocks, cin = [], LITE0_STEM
+    for kind, rep, k, stride, exp, cout in LITE0_ARCH:
+        stage = []
+        for r in range(rep):
+            s = stride if r == 0 else 1
+            stage.append(DepthwiseSeparableConv(cin, cout, k, s) if kind == "ds" else InvertedResidual(cin, cout, k, s, exp))
+            cin = cout
+        blocks.append(nn.Sequential(*stage))
+    return blocks
+
+
+def _run_lite0(mod, x):
+    if isinstance(mod, _PWConv) and mod.kernel_size[0] == 3:       # conv_stem: TF SAME padding made explicit
+        (pt, pb), (pl, pr) = tf_same_pad(x.shape[1], 3, 2), tf_same_pad(x.shape[2], 3, 2)
+        return mod(_ZeroPadFn.apply(x, pt, pl, pb, pr))
+    if isinstance(mod, _FrozenBN):                                  # bn1 of the stem: BatchNormAct2d (BN + ReLU6)
+        return _bn_act(x, mod, True)
+    if isinstance(mod, (DepthwiseSeparableConv, InvertedResidual)):
+        return mod(x)
+    if isinstance(mod, (nn.Sequential, _Stage)):
+        for sub in mod.children():
+            x = _run_lite0(sub, x)
+        return x
+    raise NotImplementedError(type(mod))
+
+
+class _Lite0Stage(nn.Module):
+    """one `pretrained.layer<i>` of _make_efficientnet over the real architecture (same child indices as the reference's Sequentials)"""
+
+    def __init__(self, items):
+        super().__init__()
+        for i, it in enumerate(items):
+            self.add_module(str(i), it)
+
+    def forward(self, x):
+        for mod in self.children():
+            x = _run_lite0(mod, x)
+        return x
+
+
+def make_efficientnet_lite0():
+    """`_make_efficientnet(timm tf_efficientnet_lite0)` (projector.py:51-59): layer0 = conv_stem, bn1, blocks[0:2]; layer1 = blocks[2:3];
+    layer2 = blocks[3:5]; layer3 = blocks[5:9]"""
+    b = lite0_blocks()
+    pre = nn.Module()
+    pre.layer0 = _Lite0Stage([_PWConv(3, LITE0_STEM, 3, stride=2), _FrozenBN(LITE0_STEM), b[0], b[1]])
+    pre.layer1 = _Lite0Stage([b[2]])
+    pre.layer2 = _Lite0Stage([b[3], b[4]])
+    pre.layer3 = _Lite0Stage([b[5], b[6]])
+    return pre
+
+
 class FeatureFusionBlockMatrix(nn.Module):
     """blocks.py:248-287: (x0 [+ x1]) -> bilinear x2 (align_corners=True) -> 1x1 conv to features // 2 when `expand`."""
 
@@ -319,14 +571,19 @@ class FeatureFusionBlockMatrix(nn.Module):
 class Proj(nn.Module):
     """projector.py:490-589 with proj_type 2: frozen backbone -> CCM (1x1 convs to cout * (1, 2, 4, 8)) -> CSM (top-down fusion)."""
 
-    def __init__(self, cout=64, expand=True, interp=256):
+    def __init__(self, cout=64, expand=True, interp=256, backbone="lite0"):
         super().__init__()
         w = TF_EFFICIENTNET_LITE0_WIDTHS
-        pre = nn.Module()
-        pre.layer0 = _Stage([JGConv2d(3, 16, 4, padding=1, stride=2), nn.LeakyReLU(0.2), nn.Identity(), _hip_stage(16, w[0])])
-        pre.layer1 = _Stage([_hip_stage(w[0], w[1])])
-        pre.layer2 = _Stage([nn.Identity(), _hip_stage(w[1], w[2])])
-        pre.layer3 = _Stage([nn.Identity(), nn.Identity(), nn.Identity(), _hip_stage(w[2], w[3])])
+        if backbone == "lite0":        # the reference's architecture (timm tf_efficientnet_lite0), weights to be loaded
+            pre = make_efficientnet_lite0()
+        elif backbone == "standin":    # the 5-convolution stand-in that drives the reference fixture tests/golden/projd.pt
+            pre = nn.Module()
+            pre.layer0 = _Stage([JGConv2d(3, 16, 4, padding=1, stride=2), nn.LeakyReLU(0.2), nn.Identity(), _hip_stage(16, w[0])])
+            pre.layer1 = _Stage([_hip_stage(w[0], w[1])])
+            pre.layer2 = _Stage([nn.Identity(), _hip_stage(w[1], w[2])])
+            pre.layer3 = _Stage([nn.Identity(), nn.Identity(), nn.Identity(), _hip_stage(w[2], w[3])])
+        else:
+            raise ValueError(f"projected-discriminator backbone {backbone!r}")
         self.pretrained = pre
         ccm = [cout, cout * 2, cout * 4, cout * 8] if expand else [cout] * 4
         sc = nn.Module()
@@ -357,17 +614,64 @@ class Proj(nn.Module):
 class ProjectedDiscriminator(nn.Module):
     """discriminator.py:233-286.  forward(x: [B, S, S, 8] 16-bit NHWC image, 3 valid channels) -> logits [B, N]."""
 
-    def __init__(self, projector_model="efficientnet", interp=-1, img_size=256, cout=64, expand=True):
+    def __init__(self, projector_model="efficientnet", interp=-1, img_size=256, cout=64, expand=True, backbone="lite0", pretrained_path=""):
         super().__init__()
         if projector_model != "efficientnet":
             raise NotImplementedError(f"D_proj_network_type={projector_model!r}: the convolutional ('efficientnet') projector is built; the "
                                       "ViT / CLIP / DINOv2 / SegFormer feature networks need pretrained weights that are not available offline")
         self.interp = interp
         size = interp if interp > 0 else img_size
-        self.freeze_feature_network = Proj(cout=cout, expand=expand, interp=size)
+        self.backbone = backbone
+        self.freeze_feature_network = Proj(cout=cout, expand=expand, interp=size, backbone=backbone)
         self.freeze_feature_network.requires_grad_(False)
+        self.backbone_pretrained = False
+        if pretrained_path:
+            self.load_pretrained_backbone(pretrained_path)
+        elif backbone == "standin":
+            import warnings
+
+            warnings.warn("ProjectedDiscriminator: backbone='standin' is the 5-convolution fixture driver, NOT the reference's "
+                          "tf_efficientnet_lite0 -- tests only (opt-in through jg_projd_backbone='standin')", stacklevel=2)
+        else:
+            import warnings
+
+            warnings.warn("ProjectedDiscriminator: tf_efficientnet_lite0 is built with RANDOM frozen weights -- timm's pretrained checkpoint "
+                          "cannot be downloaded here.  A projected GAN on random features is not the reference's discriminator: pass "
+                          "jg_projd_pretrained=<tf_efficientnet_lite0 state_dict .pth> or load a reference D checkpoint.", stacklevel=2)
         self.discriminator = MultiScaleD(self.freeze_feature_network.CHANNELS, self.freeze_feature_network.RESOLUTIONS)
         self.arena = None
+
+    def load_pretrained_backbone(self, path):
+        """load a timm `tf_efficientnet_lite0` state_dict (keys `conv_stem.weight`, `bn1.*`, `blocks.<i>.<j>.*`) into the stages the way
+        `_make_efficientnet` re-homes the modules; every backbone entry must be present"""
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        remap = {}
+        for k, v in sd.items():
+            if k.startswith("conv_stem."):
+                remap["layer0.0." + k[len("conv_stem."):]] = v
+            elif k.startswith("bn1."):
+                remap["layer0.1." + k[len("bn1."):]] = v
+            elif k.startswith("blocks."):
+                i, rest = k[len("blocks."):].split(".", 1)
+                i = int(i)
+                stage, idx = (("layer0", i + 2) if i < 2 else ("layer1", 0) if i == 2 else ("layer2", i - 3) if i < 5 else ("layer3", i - 5))
+                remap[f"{stage}.{idx}.{rest}"] = v
+        res = self.freeze_feature_network.pretrained.load_state_dict(remap, strict=True)
+        self.backbone_pretrained = True
+        return res
+
+    def check_loaded_backbone(self, incompatible, source=""):
+        """after a non-strict load_state_dict of a discriminator checkpoint: a checkpoint that does not carry the frozen backbone
+        (missing / unexpected `freeze_feature_network.pretrained.*` keys) must not pass silently -- the backbone would stay random"""
+        pre = "freeze_feature_network.pretrained."
+        missing = [k for k in incompatible.missing_keys if k.startswith(pre)]
+        unexpected = [k for k in incompatible.unexpected_keys if k.startswith(pre)]
+        if missing or unexpected:
+            raise RuntimeError(f"projected discriminator checkpoint {source}: backbone keys do not match the {self.backbone} feature network "
+                               f"(missing {missing[:3]}{'...' if len(missing) > 3 else ''}, unexpected {unexpected[:3]}"
+                               f"{'...' if len(unexpected) > 3 else ''}): the frozen features would stay randomly initialised")
+        self.backbone_pretrained = True
 
     def train(self, mode=True):
         self.freeze_feature_network.train(False)

@@ -1,4 +1,4 @@
-"""Generate tests/golden/projd.pt by running the UNMODIFIED reference ProjectedDiscriminator (/root/reference) on CPU.
+"""Generate tests/golden/projd.pt and projd_lite0.pt by running the UNMODIFIED reference ProjectedDiscriminator (/root/reference) on CPU.
 
 TEST INFRASTRUCTURE ONLY.  Run in the build container:   PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_projd.py
 
@@ -6,6 +6,10 @@ timm (and the pretrained tf_efficientnet_lite0 weights) are not available offlin
 stand-in backbone `joligen_amd.modules.projected_d.StandInEfficientNet` (a plain torch module with the attributes the reference's
 `_make_efficientnet` slices).  Everything else -- Proj's CCM / CSM, MultiScaleD, SingleDisc, DownBlock, spectral norm, the hinge
 objective of GANLoss("projected") and DiscriminatorGANLoss.compute_loss_D / compute_loss_G -- is the reference's own code.
+
+projd_lite0.pt (round 3): the same run with `timm.create_model` returning oracle/efficientnet_lite0_torch.py::TfEfficientNetLite0 -- the
+REAL architecture of tf_efficientnet_lite0 (16 MBConv blocks, TF SAME padding, BatchNorm eps 1e-3 in eval mode, ReLU6), restated from
+timm's published definition because timm is an absent dependency; its weights are synthetic (seeded), "backbone parity unpinned".
 
 Pinned: logits of D(real) and D(fake) (two training forwards = two power iterations), the discriminator loss and the gradient of
 every trainable parameter, the generator-side loss and its gradient with respect to the fake image (third forward), and the
@@ -30,12 +34,17 @@ from make_golden import checks  # noqa: E402
 OUT = os.environ.get("JG_GOLDEN_OUT") or os.path.join(ROOT, "tests", "golden")   # JG_GOLDEN_OUT: tests/test_oracle_golden.py::test_fixtures_regenerate
 
 
-def main():
+def main(backbone="standin", out_name="projd.pt"):
     import timm
 
-    from joligen_amd.modules.projected_d import StandInEfficientNet
+    if backbone == "standin":
+        from joligen_amd.modules.projected_d import StandInEfficientNet
 
-    timm.create_model = lambda *a, **k: StandInEfficientNet()
+        timm.create_model = lambda *a, **k: StandInEfficientNet()
+    else:       # the real architecture (oracle/efficientnet_lite0_torch.py: timm's tf_efficientnet_lite0 restated; weights synthetic)
+        from efficientnet_lite0_torch import TfEfficientNetLite0
+
+        timm.create_model = lambda *a, **k: TfEfficientNetLite0()
     from models.modules.loss import DiscriminatorGANLoss
     from models.modules.projected_d.discriminator import ProjectedDiscriminator
 
@@ -68,9 +77,10 @@ def main():
                     real=real, fake=fake, pred_real=pred_real, loss_D=loss_D.detach(), grad_checks=checks(grads),
                     grad_sample={k: grads[k].flatten()[:6].clone() for k in list(grads)[:6]},
                     uv_mid=checks(sd_mid), loss_G=loss_G.detach(), dfake=fk.grad.detach().clone(), uv_after=checks(sd_after)),
-               os.path.join(OUT, "projd.pt"))
-    print("projd: keys", len(ref_sd), "trainable", len(grads), "loss_D", float(loss_D), "loss_G", float(loss_G), "logits", tuple(pred_real.shape))
+               os.path.join(OUT, out_name))
+    print(out_name, "keys", len(ref_sd), "trainable", len(grads), "loss_D", float(loss_D), "loss_G", float(loss_G), "logits", tuple(pred_real.shape))
 
 
 if __name__ == "__main__":
     main()
+    main("lite0", "projd_lite0.pt")

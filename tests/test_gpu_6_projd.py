@@ -119,11 +119,31 @@ def test_spectral_conv_vs_torch(cin, cout, k, stride, pad, bias, dtype):
     assert relerr(m.c.weight_u, ref.weight_u) < 1e-5 and relerr(m.c.weight_v, ref.weight_v) < 1e-5
 
 
+FIXTURES = ["projd.pt", "projd_lite0.pt"]     # stand-in backbone (round 2) | tf_efficientnet_lite0 architecture (round 3)
+
+
+def _yard(fixture, dtype):
+    """measured rounding floor of this fixture's gradients (tests/test_oracle_golden.py::test_projd_rounding_yardstick)"""
+    import json
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rounding_yardstick_projd.json")
+    return json.load(open(path))[fixture]["fp16" if dtype == torch.float16 else "bf16"]
+
+
+def _backbone_of(g):
+    """which backbone drove the reference when the fixture was written: timm's key names (conv_dw / conv_pwl) = tf_efficientnet_lite0"""
+    return "lite0" if any("conv_dw" in k for k in g["keys"]) else "standin"
+
+
 def build_projd(g, dtype, seed=5):
+    import warnings
+
     from joligen_amd.modules.projected_d import ProjectedDiscriminator
 
     c = g["cfg"]
-    net = ProjectedDiscriminator("efficientnet", interp=c["interp"], img_size=c["S"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")       # "random frozen weights" / "stand-in": the fixture's synthetic weights are loaded right below
+        net = ProjectedDiscriminator("efficientnet", interp=c["interp"], img_size=c["S"], backbone=_backbone_of(g))
     assert list(net.state_dict().keys()) == g["keys"]
     for k, v in net.state_dict().items():
         assert tuple(v.shape) == tuple(g["shapes"][k]), k
@@ -133,15 +153,18 @@ def build_projd(g, dtype, seed=5):
     return net
 
 
+@pytest.mark.parametrize("fixture", FIXTURES)
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_projected_discriminator_vs_reference_golden(golden_dir, dtype):
+def test_projected_discriminator_vs_reference_golden(golden_dir, dtype, fixture):
     """The fixture's sequence on HIP: D(real), D(fake) (training forwards: spectral-norm power iterations), the hinge discriminator
     loss and the gradient of all 44 trainable tensors, then the generator-side loss and its gradient w.r.t. the fake image through the
-    frozen feature network (stand-in backbone, CCM, CSM).  state_dict keys / shapes are the reference's."""
+    frozen feature network (backbone, CCM, CSM).  state_dict keys / shapes are the reference's.  projd_lite0.pt: the reference ran over
+    the tf_efficientnet_lite0 ARCHITECTURE (16 MBConv blocks, TF SAME padding, eval-mode BatchNorm, ReLU6; synthetic weights -- parity of
+    the backbone against timm itself is unpinned, timm is absent), the HIP side runs csrc/effnet.hip + the MFMA 1x1 convolutions."""
     from joligen_amd import ops
     from joligen_amd.modules.projected_d import hinge_loss
 
-    g = load(golden_dir, "projd.pt")
+    g = load(golden_dir, fixture)
     net = build_projd(g, dtype)
     for n, p in net.named_parameters():
         p.requires_grad_(not n.startswith("freeze"))
@@ -164,7 +187,7 @@ def test_projected_discriminator_vs_reference_golden(golden_dir, dtype):
         mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
         # GroupNorm over groups of TWO channels + LeakyReLU + a hinge (sign-like) loss: the first blocks' gradients carry 4 - 6 % of
         # 16-bit rounding noise against the fp32 reference (per-parameter table of the oracle test below), the last ones 0.1 %
-        t = max(4 * tol, 0.08) * float(ref[0]) + 1e-7
+        t = max(4 * tol, 0.08, 2.0 * _yard(fixture, dtype)["grad_worst"]) * float(ref[0]) + 1e-7      # >= twice the measured rounding floor
         if abs(float(mine[0] - ref[0])) > t or abs(float(mine[1] - ref[1])) > 2 * t * max(1.0, v.numel() ** 0.5 / 4):
             bad.append((k, mine.tolist(), ref.tolist()))
     assert not bad, bad[:6]
@@ -176,26 +199,37 @@ def test_projected_discriminator_vs_reference_golden(golden_dir, dtype):
     fk = ops.to_nhwc(g["fake"].to(D0), dtype, 8).requires_grad_(True)
     loss_G = hinge_loss(net(fk), True, relu=False)
     assert abs(float(loss_G) - float(g["loss_G"])) < tol * abs(float(g["loss_G"])) + 2e-3
-    loss_G.backward()
-    dfk = fk.grad.permute(0, 3, 1, 2)[:, :3].float()
-    assert relerr(dfk, g["dfake"]) < (0.05 if dtype == torch.float16 else 0.2), relerr(dfk, g["dfake"])
+    # fp16: the image gradient of this loss is ~1e-6 per pixel -- below fp16's normal range after 16 frozen blocks; the model applies its
+    # static loss scale to exactly this backward (models/cut_model.py: 1024 for fp16)
+    ls = 1024.0 if dtype == torch.float16 else 1.0
+    (loss_G * ls).backward()
+    dfk = fk.grad.permute(0, 3, 1, 2)[:, :3].float() / ls
+    # ReLU6 / LeakyReLU masks flip under 16-bit rounding: the image gradient through the frozen network is bounded by twice its
+    # measured rounding floor (0.03 / 0.10 stand-in, 0.076 / 0.26 tf_efficientnet_lite0 for fp16 / bf16)
+    assert relerr(dfk, g["dfake"]) < 2.0 * _yard(fixture, dtype)["dfake_rel"], (relerr(dfk, g["dfake"]), _yard(fixture, dtype)["dfake_rel"])
     for n, p in net.named_parameters():
         if n.startswith("freeze"):
             assert not p.requires_grad
 
 
-def test_projected_discriminator_first_step_vs_oracle(golden_dir):
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_projected_discriminator_first_step_vs_oracle(golden_dir, fixture):
     """per-parameter gradients (not just checksums) of the discriminator loss against the CPU oracle on fp16-representable weights"""
     from joligen_amd import ops
     from joligen_amd.modules.projected_d import hinge_loss
 
     dtype = torch.float16
-    g = load(golden_dir, "projd.pt")
+    g = load(golden_dir, fixture)
     g = dict(g, real=g["real"].half().float(), fake=g["fake"].half().float())
     P0 = {k: (v.half().float() if (torch.is_floating_point(v) and not k.endswith(("weight_u", "weight_v"))) else v) for k, v in projd_state(g).items()}
+    import warnings
+
     from joligen_amd.modules.projected_d import ProjectedDiscriminator
 
-    net = ProjectedDiscriminator("efficientnet", interp=g["cfg"]["interp"], img_size=g["cfg"]["S"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        net = ProjectedDiscriminator("efficientnet", interp=g["cfg"]["interp"], img_size=g["cfg"]["S"],
+                                     backbone=_backbone_of(g))
     net.load_state_dict(P0)
     net.jg_finalize(torch.device(D0), dtype)
     net.train()
@@ -214,10 +248,11 @@ def test_projected_discriminator_first_step_vs_oracle(golden_dir):
             errs.append((relerr(p.grad, r["grads"][k]), k))
     errs.sort(reverse=True)
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/grad_table_projd.txt", "w") as f:
+    with open(f"gpurun_out/grad_table_{fixture[:-3]}.txt", "w") as f:
         f.write("\n".join(f"{e:10.3e} {k}" for e, k in errs))
-    assert errs[0][0] < 0.1, errs[:6]
-    assert errs[len(errs) // 2][0] < 0.03, errs[len(errs) // 2]
+    y = _yard(fixture, dtype)
+    assert errs[0][0] < max(0.1, 2.0 * y["grad_worst"]), (errs[:6], y)
+    assert errs[len(errs) // 2][0] < max(0.03, 1.5 * y["grad_median"]), (errs[len(errs) // 2], y)
 
 
 def test_cut_model_with_projected_and_basic_discriminators():

@@ -1,0 +1,110 @@
+"""GPU: the reference's training loop (train.py:195-301, 351-357) replayed against joligen_amd with the SHIPPED example configurations
+(tests/examples/*.json are verbatim copies of /root/reference/examples/example_ddpm_noglasses2glasses.json and
+example_gan_horse2zebra.json) plus the measurement overrides of SURVEY.md Appendix C:
+
+    opt = parse(example JSON + overrides) -> create_model -> data_dependent_initialize -> setup -> single_gpu
+    N x (set_input, optimize_parameters, get_current_losses) -> save_networks("latest") -> export_networks("latest")
+    -> update_learning_rate -> a second process-like model continues from the checkpoint (train_continue)
+
+What it pins: the drop-in boundary b1 -- the example JSONs load unchanged, the model API is the one
+train.py drives, the checkpoints carry reference-layout keys, and `export_networks` no longer ends the loop for `cut`."""
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+EX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples")
+
+
+def _loop(opt, data, n_steps):
+    """train.py:194-357 without the dataloader / visualizer / metrics"""
+    from joligen_amd.models import create_model
+
+    model = create_model(opt, 0)
+    if hasattr(model, "data_dependent_initialize"):
+        model.data_dependent_initialize(data)
+    model.setup(opt)
+    model.single_gpu()
+    losses = []
+    for _ in range(n_steps):
+        model.set_input(data)
+        model.optimize_parameters()
+        losses.append({k: float(v) for k, v in model.get_current_losses().items()})       # output_print_freq path (:288-303)
+    return model, losses
+
+
+def _appendix_c(tmp_path, **kw):
+    ov = dict(train_iter_size=1, output_display_type=["none"], output_print_freq=10 ** 9, checkpoints_dir=str(tmp_path), gpu_ids="0",
+              train_metrics_list=[], jg_act_dtype="bf16")
+    ov.update(kw)
+    return ov
+
+
+def test_example_ddpm_json_through_the_train_loop(tmp_path):
+    from joligen_amd.options import opt_from_json
+    from bench import synth_batch
+
+    ov = _appendix_c(tmp_path, name="ddpm_e2e", data_crop_size=128, data_load_size=128, train_batch_size=4)
+    opt = opt_from_json(os.path.join(EX, "example_ddpm_noglasses2glasses.json"), ov)
+    assert opt.model_type == "palette" and opt.G_netG == "unet_mha" and opt.train_G_ema and opt.train_optim == "adamw"
+    data = synth_batch(4, 128, 3, torch.device("cuda:0"))
+    torch.manual_seed(0)
+    model, losses = _loop(opt, data, 4)
+    assert all(math.isfinite(v) for l in losses for v in l.values()) and "G_tot" in losses[0]
+    assert losses[-1]["G_tot"] < losses[0]["G_tot"] * 1.5
+    model.save_networks("latest")
+    assert model.export_networks("latest") == []            # the reference skips palette / cm as well (base_model.py:885-891)
+    lr0 = model.optimizers[0].param_groups[0]["lr"]
+    model.update_learning_rate()
+    assert model.optimizers[0].param_groups[0]["lr"] <= lr0
+    sd = torch.load(os.path.join(str(tmp_path), "ddpm_e2e", "latest_net_G_A.pth"), map_location="cpu")
+    assert "denoise_fn.model.input_blocks.0.0.weight" in sd and sd["denoise_fn.model.input_blocks.0.0.weight"].shape == (64, 6, 3, 3)
+    assert os.path.exists(os.path.join(str(tmp_path), "ddpm_e2e", "latest_net_G_A_ema.pth"))
+    # continue from the checkpoint: the reloaded parameters are the saved ones
+    opt2 = opt_from_json(os.path.join(EX, "example_ddpm_noglasses2glasses.json"), dict(ov, train_continue=True))
+    from joligen_amd.models import create_model
+
+    m2 = create_model(opt2, 0)
+    m2.setup(opt2)
+    sd2 = m2._net("G_A").state_dict()
+    for k, v in sd.items():
+        assert torch.equal(sd2[k].cpu(), v), k
+
+
+def test_example_gan_horse2zebra_json_through_the_train_loop(tmp_path):
+    """mobile_resnet_attn generator + [projected_d, basic] discriminators, MoNCE, 256x256, batch 4 -- the JSON as shipped"""
+    from joligen_amd.options import opt_from_json
+
+    ov = _appendix_c(tmp_path, name="h2z_e2e", train_export_jit=True)
+    opt = opt_from_json(os.path.join(EX, "example_gan_horse2zebra.json"), ov)
+    assert opt.model_type == "cut" and opt.G_netG == "mobile_resnet_attn" and opt.D_netDs == ["projected_d", "basic"] and opt.train_batch_size == 4
+    g = torch.Generator().manual_seed(5)
+    data = {"A": torch.rand(4, 3, 256, 256, generator=g) * 2 - 1, "B": torch.rand(4, 3, 256, 256, generator=g) * 2 - 1,
+            "A_img_paths": ["synthetic"] * 4, "B_img_paths": ["synthetic"] * 4}
+    torch.manual_seed(0)
+    model, losses = _loop(opt, data, 3)
+    assert set(losses[0]) >= {"G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_projected_d", "G_GAN_D_B_basic", "D_tot"}
+    assert all(math.isfinite(v) for l in losses for v in l.values()), losses
+    model.save_networks("latest")
+    written = model.export_networks("latest")          # train.py:352,357: called after EVERY save
+    d = os.path.join(str(tmp_path), "h2z_e2e")
+    assert os.path.join(d, "latest_net_G_A.pt") in written          # TorchScript (train_export_jit); ONNX needs the `onnx` package
+    model.update_learning_rate()
+    # the exported graph reproduces the HIP generator on the same input (fp32 CPU trace of the same weights vs bf16 kernels)
+    jit = torch.jit.load(os.path.join(d, "latest_net_G_A.pt"))
+    x = data["A"][:1]
+    with torch.no_grad():
+        ref = jit(x)
+    model.netG_A.eval()
+    from joligen_amd import ops
+
+    with torch.no_grad():
+        y = model.netG_A(ops.to_nhwc(x.to("cuda:0"), torch.bfloat16, 8))
+    y = y.permute(0, 3, 1, 2)[:, :3].float().cpu()
+    assert float((y - ref).norm() / ref.norm()) < 5e-2
+    for name in ("G_A", "F", "D_B_projected_d", "D_B_basic"):
+        assert os.path.exists(os.path.join(d, f"latest_net_{name}.pth")), name
+    sd = torch.load(os.path.join(d, "latest_net_G_A.pth"), map_location="cpu")
+    assert "resnet_blocks.0.conv1.conv.0.weight" in sd and "deconv3_attention.weight" in sd

@@ -474,10 +474,12 @@ def projd_run_oracle(P, g):
                 uv_after=uv_after)
 
 
-def test_projected_discriminator(golden_dir):
+@pytest.mark.parametrize("fixture", ["projd.pt", "projd_lite0.pt"])
+def test_projected_discriminator(golden_dir, fixture):
     """the CPU restatement of Proj (CCM / CSM), MultiScaleD / SingleDisc / DownBlock with spectral norm, and the hinge losses against
-    the unmodified reference run over the stand-in backbone"""
-    g = load(golden_dir, "projd.pt")
+    the unmodified reference run over the stand-in backbone (projd.pt) and over the tf_efficientnet_lite0 architecture (projd_lite0.pt:
+    the reference's own `_make_efficientnet` slicing of oracle/efficientnet_lite0_torch.py, eval-mode BatchNorm, TF SAME padding)"""
+    g = load(golden_dir, fixture)
     r = projd_run_oracle(projd_state(g), g)
     torch.testing.assert_close(r["pred_real"], g["pred_real"], rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(r["loss_D"], g["loss_D"], rtol=1e-5, atol=1e-6)
@@ -670,6 +672,49 @@ def test_cut_rounding_yardstick(golden_dir, name):
                     assert v >= c - 0.05, (name, dt, key, k, v, c)
                 else:      # the comparison is chaotic (ReLU masks flip under rounding): the statistic itself moves with the torch build
                     assert 0.5 * c - 1e-6 <= v <= 2.0 * c + 1e-6, (name, dt, key, k, v, c)
+
+
+# ---- rounding yardstick of the projected discriminator (both backbones) ---------------------------------------------------------------
+YARD_PROJD_FILE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rounding_yardstick_projd.json")
+
+
+def projd_rounding_yardstick(golden_dir, fixture):
+    """the fixture's D step + G-side image gradient in the fp32 oracle against the same oracle with 16-bit storage of every inter-layer
+    activation / activation gradient (`activation_rounding`), weights and inputs 16-bit-representable on both sides: ReLU6 / LeakyReLU
+    masks that flip under rounding make the image gradient through the 16 frozen MBConv blocks (and the small second mini-discriminator's
+    gradients) far noisier than the forward -- this measures by how much"""
+    g = load(golden_dir, fixture)
+    out = {}
+    for tag, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        r16 = lambda v: v.to(dt).float()
+        gg = dict(g, real=r16(g["real"]), fake=r16(g["fake"]))
+        P0 = {k: (r16(v) if (torch.is_floating_point(v) and not k.endswith(("weight_u", "weight_v"))) else v) for k, v in projd_state(g).items()}
+        ref = projd_run_oracle({k: v.clone() for k, v in P0.items()}, gg)
+        with O.activation_rounding(dt):
+            rnd = projd_run_oracle({k: v.clone() for k, v in P0.items()}, gg)
+        errs = sorted(float((rnd["grads"][k] - ref["grads"][k]).norm() / (ref["grads"][k].norm() + 1e-30)) for k in ref["grads"])
+        out[tag] = dict(pred_real_rel=float((rnd["pred_real"] - ref["pred_real"]).norm() / ref["pred_real"].norm()),
+                        dfake_rel=float((rnd["dfake"] - ref["dfake"]).norm() / ref["dfake"].norm()),
+                        grad_median=errs[len(errs) // 2], grad_worst=errs[-1])
+    return out
+
+
+@pytest.mark.parametrize("fixture", ["projd.pt", "projd_lite0.pt"])
+def test_projd_rounding_yardstick(golden_dir, fixture):
+    """committed floor of tests/test_gpu_6_projd.py's gradient tolerances (JG_WRITE_YARDSTICK=1 rewrites the entry)"""
+    import json
+
+    res = projd_rounding_yardstick(golden_dir, fixture)
+    committed = json.load(open(YARD_PROJD_FILE)) if os.path.exists(YARD_PROJD_FILE) else {}
+    if os.environ.get("JG_WRITE_YARDSTICK"):
+        committed[fixture] = res
+        committed["_meta"] = "oracle projd_run_oracle under activation_rounding(dtype) vs plain fp32, 16-bit-representable weights / inputs on both sides"
+        with open(YARD_PROJD_FILE, "w") as f:
+            json.dump(committed, f, indent=1)
+    for dt in ("fp16", "bf16"):
+        for k, v in res[dt].items():
+            c = committed[fixture][dt][k]
+            assert 0.5 * c - 1e-6 <= v <= 2.0 * c + 1e-6, (fixture, dt, k, v, c)
 
 
 # ---- class-conditioned palette_model (alg_diffusion_cond_embed = "class"): oracle/make_golden_cond.py fixture -------------------
