@@ -13,6 +13,11 @@ Appendix C (data_crop_size 256, train_batch_size 32, train_iter_size 1,
 G_unet_mha_vit_efficient true).  A step = set_input(device-resident batch) + optimize_parameters()
 (forward, backward, gradient all-reduce, fused AdamW + EMA, refresh of the bf16 weights).
 
+Default run: 50 timed steps; `ms_per_step` / `value` follow the contract (K steps / total time, max over ranks),
+`ms_per_step_median` is the median of the per-step HIP-event times of the same region.  With the default flags (N = 1, palette) the
+line also carries a `cut` object: the CUT G+D step of BASELINE configs[2] (SegFormer-attn G + [projected_d, basic] D + MoNCE,
+256x256, batch 16) measured in the same process right after the palette leg, with its own roofline and CPU baseline.
+
 Extra objects on the JSON line:
   roofline     -- dominant kernel = the one with the largest summed time (conv3x3_halo_kernel: halo-resident
                   implicit-GEMM 3x3 convolution, forward + input-gradient):
@@ -135,7 +140,7 @@ def cpu_baseline_subprocess(args, timeout_s=240):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
-           "--efficient", str(args.efficient), "--model", args.model, "--netG", args.netG]
+           "--efficient", str(args.efficient), "--model", args.model, "--netG", args.netG, "--netDs", args.netDs]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in out.stdout.splitlines():
@@ -187,8 +192,17 @@ def cpu_baseline(args):
         sdG = {k: v.detach() for k, v in netG.state_dict().items()}
         sdF = {k: v.detach().float() for k, v in netF.state_dict().items()}
         sdD = {k: v.detach().float() for k, v in NLayerDiscriminator(3, 64).state_dict().items()}
+        sdPD = None
+        if "projected_d" in args.netDs.split(","):
+            import warnings
+
+            from joligen_amd.modules.projected_d import ProjectedDiscriminator
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                sdPD = {k: v.detach() for k, v in ProjectedDiscriminator(img_size=S).state_dict().items()}
         tr = O.OracleCUTTrainer(sdG, sdF, sdD, 9, layers, num_patches=256, T=T, monce=True, pool_size=50, pool_rng=random.Random(0),
-                                ema_beta=0.999, gen="segformer" if seg else (args.netG if "resnet_attn" in args.netG else "resnet"))
+                                ema_beta=0.999, gen="segformer" if seg else (args.netG if "resnet_attn" in args.netG else "resnet"),
+                                sdPD=sdPD, proj_interp=-1)
         A, Bm = batch["A"], batch["B"]
         with torch.no_grad():
             hw = [f.shape[2] * f.shape[3] for f in (O.segformer_backbone(sdG, A) if seg else tr._feats(sdG, A))]
@@ -206,8 +220,8 @@ def cpu_baseline(args):
                 break
         per_step = sum(times[1:]) / len(times[1:])
         return {"value": round(Bc / per_step, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-                "sample": f"oracle/jg_oracle.py OracleCUTTrainer ({args.netG} G + basic D + F, MoNCE), {len(times) - 1} timed full iterations "
-                          f"(G/F group + D group, 3 Adam steps, EMA) of batch {Bc} at {S}x{S} fp32 after 1 warm-up, {cores} torch threads"}
+                "sample": f"oracle/jg_oracle.py OracleCUTTrainer ({args.netG} G + D_netDs [{args.netDs}] + F, MoNCE), {len(times) - 1} timed full iterations "
+                          f"(G/F group + D group, {3 + (sdPD is not None)} Adam steps, EMA) of batch {Bc} at {S}x{S} fp32 after 1 warm-up, {cores} torch threads"}
     if args.model == "cm":
         from joligen_amd.models.cm_model import define_G_cm
 
@@ -246,10 +260,110 @@ def cpu_baseline(args):
                       f"of batch {Bc} at {S}x{S} fp32 after 1 warm-up, {cores} torch threads"}
 
 
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+RIDGE_FLOP_PER_BYTE = PEAK_BF16_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+
+def csrc_sha():
+    """sha1 of the kernel sources (the same digest tools/collect_evidence.sh stamps into the committed profiles)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "joligen_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip"))) + sorted(glob.glob(os.path.join(d, "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
+def timed_region(step, steps, warmup, fence):
+    """W untimed steps, then exactly K steps between two fences; returns (seconds of the K steps, per-step milliseconds from HIP events
+    recorded on the compute stream after every step -- two event records per step, no synchronisation inside the region)"""
+    for _ in range(warmup):
+        step()
+    fence()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(steps):
+        step()
+        evs[i + 1].record()
+    fence()
+    dt = time.perf_counter() - t0
+    return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+
+
+def kernel_table(recs, nsteps):
+    """per kernel INSTANCE (the name the dispatch recorded, jg_last_kernel): launches, time, algorithmic FLOPs and HBM bytes; each row
+    is priced against the roof its arithmetic intensity puts it under (ridge = 2500 TFLOP/s / 8 TB/s = 312 FLOP/B)"""
+    per = {}
+    for name, e0, e1, fl, _geo, by in recs:
+        d = per.setdefault(name, [0, 0.0, 0.0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += fl
+        d[3] += by
+    out = {}
+    for k, (n, t, f, b) in per.items():
+        tf, gbs = f / t / 1e12, b / t / 1e9
+        mfma = f / max(b, 1.0) >= RIDGE_FLOP_PER_BYTE
+        out[k] = {"bound": "mfma" if mfma else "hbm", "achieved": round(tf if mfma else gbs, 2), "peak": PEAK_BF16_TFLOPS if mfma else HBM_PEAK_GBS,
+                  "unit": "TFLOP/s" if mfma else "GB/s", "frac": round((tf / PEAK_BF16_TFLOPS) if mfma else (gbs / HBM_PEAK_GBS), 4),
+                  "tflops": round(tf, 2), "algorithmic_gbs": round(gbs, 1), "launches_per_step": n // nsteps, "avg_launch_us": round(t / n * 1e6, 2),
+                  "avg_flops_per_launch": round(f / n, 1), "avg_bytes_per_launch": round(b / n, 1), "time_per_step_ms": round(t / nsteps * 1e3, 3)}
+    return out
+
+
+def cut_leg(local_rank, no_cpu):
+    """BASELINE configs[2] on one GPU: cut_model, SegFormer-attn G + [projected_d (tf_efficientnet_lite0 architecture, random frozen
+    weights), basic] D + mlp_sample F + MoNCE, 256x256, batch 16, bf16.  Returns the `cut` object of the JSON line."""
+    import warnings
+
+    from joligen_amd import ops
+
+    ns = argparse.Namespace(model="cut", netG="segformer_attn_conv", netDs="projected_d,basic", batch=16, size=256, dtype="bf16", efficient=1,
+                            force_exchange=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model, _ = build_model(ns, 0, local_rank, 1)
+    dev = torch.device("cuda", local_rank)
+    g = torch.Generator().manual_seed(77)
+    batch = {"A": (torch.rand(ns.batch, 3, ns.size, ns.size, generator=g) * 2 - 1).to(dev), "B": (torch.rand(ns.batch, 3, ns.size, ns.size, generator=g) * 2 - 1).to(dev)}
+
+    def step():
+        model.set_input(batch)
+        model.optimize_parameters()
+
+    steps, warmup = 20, 5
+    dt, per_step = timed_region(step, steps, warmup, torch.cuda.synchronize)
+    ops.KERNEL_TIMING = []
+    step()
+    torch.cuda.synchronize()
+    recs, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
+    table = kernel_table(recs, 1)
+    dom = max(table, key=lambda k: table[k]["time_per_step_ms"])
+    roof = dict(table[dom], kernel=dom, traffic=None,
+                measured="HIP events around every convolution-family launch of one instrumented step (the SegFormer step is ~2500 launches of "
+                         "10 - 30 us: dispatch-bound next to its HBM-bound streaming kernels, DESIGN.md 11); achieved = algorithmic bytes (or FLOPs) "
+                         "of the dominant instance / its summed launch time",
+                conv_family_ms_per_step=round(sum(r["time_per_step_ms"] for r in table.values()), 3),
+                other_kernels={k: v for k, v in table.items() if k != dom})
+    cpu = None if no_cpu else cpu_baseline_subprocess(ns, timeout_s=180)
+    loss = float(model.get_current_losses()["G_tot"])
+    return {"metric": "train images/sec at 256x256 (CUT G+D step)", "value": round(ns.batch * steps / dt, 3), "unit": "images/sec",
+            "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2], 3), "steps": steps, "warmup": warmup,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "cut_model, segformer_attn_conv G (MiT-b0 + heads + ResnetDecoder tail) + D_netDs [projected_d (tf_efficientnet_lite0 "
+                                   "architecture, random frozen weights: timm checkpoint unavailable), basic] + mlp_sample F, MoNCE, nce_idt, hinge / lsgan, "
+                                   "256x256, batch 16/GPU, Adam x4 + EMA, iter_size 1 (BASELINE configs[2] shape; example_gan_mario2sonic.json without "
+                                   "vision_aided / semantic mask)", "global_batch": ns.batch, "final_loss": round(loss, 5)},
+            "roofline": roof, "cpu_baseline": cpu}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch (BASELINE configs[1]: 32)")
     ap.add_argument("--size", type=int, default=256)
@@ -261,6 +375,7 @@ def main():
     ap.add_argument("--model", default="palette", choices=["palette", "cm", "cut"],
                     help="palette = BASELINE configs[1] (the bench line); cm = the consistency-model step of configs[4] (same UNet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cut-leg", action="store_true", help="skip the CUT (BASELINE configs[2]) leg of the default line")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="dev: run the multi-GPU gradient exchange path on one GPU (1-rank RCCL group)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -311,22 +426,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    from joligen_amd import parallel as jg_parallel
+
+    if world > 1 or args.force_exchange:
+        jg_parallel.TIMING = []
+    for _ in range(args.warmup):          # warm-up outside timed_region(): the exchange diagnostics start with the timed steps
         step()
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    dt = time.perf_counter() - t0
+    if jg_parallel.TIMING is not None:
+        jg_parallel.TIMING.clear()
+    dt, per_step_ms = timed_region(step, args.steps, 0, fence)
+    dt_local = dt
+    exch = None
+    if jg_parallel.TIMING:
+        ex_ms = sorted(a.elapsed_time(b) for a, b in jg_parallel.TIMING)
+        exch = {"wait_plus_optimizer_ms_median": round(ex_ms[len(ex_ms) // 2], 3), "wait_plus_optimizer_ms_max": round(ex_ms[-1], 3),
+                "note": "compute-stream time between the first chunk wait and the last optimizer chunk of allreduce_and_step (exposed part of the "
+                        "gradient exchange + the chunked fused optimizer; the optimizer alone is ~0.4 ms at this size)", "wire": jg_parallel.GRAD_WIRE}
+    jg_parallel.TIMING = None
     # logging path of the reference (train.py:293-301): the printed loss is the mean over the ranks
     loss = float(model.get_current_losses_reduced()["G_tot"].detach())
     n_ranks_seen = dist.get_world_size() if dist.is_initialized() else 1
+    per_rank = None
     if world > 1:
+        # diagnostics of a scaling run: every rank's own wall time for the K steps and its own median step / exchange time
+        mine = torch.tensor([dt_local / args.steps * 1e3, sorted(per_step_ms)[len(per_step_ms) // 2],
+                             exch["wait_plus_optimizer_ms_median"] if exch else 0.0], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(float(t[0]), 3) for t in allr], "ms_per_step_median": [round(float(t[1]), 3) for t in allr],
+                    "exchange_wait_plus_optimizer_ms_median": [round(float(t[2]), 3) for t in allr]}
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     ms_per_step = dt / args.steps * 1e3
+    ms_median = sorted(per_step_ms)[len(per_step_ms) // 2]
     value = args.batch * world * args.steps / dt
 
     # ---- dominant-kernel roofline: instrumented pass, HIP events around every conv launch ----
@@ -352,53 +486,50 @@ def main():
         side_was, unet_exec.WGRAD_STREAM = unet_exec.WGRAD_STREAM, False
         recs = instrumented()
         unet_exec.WGRAD_STREAM = side_was
-        per = {}
         if args.dump_kernel_timing:
             agg = {}
-            for name, e0, e1, fl, geo in recs:
+            for name, e0, e1, fl, geo, _by in recs:
                 a = agg.setdefault((name, geo), [0, 0.0, fl])
                 a[0] += 1
                 a[1] += e0.elapsed_time(e1)
             with open(args.dump_kernel_timing, "w") as f:
                 for (name, geo), (n_, t_, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                    f.write(f"{name:9s} {str(geo):48s} calls/step {n_ / 2:5.1f} ms/step {t_ / 2:8.3f} avg_us {t_ / n_ * 1e3:9.1f} TF {fl / (t_ / n_ * 1e-3) / 1e12:7.1f}\n")
-        for name, e0, e1, fl, _geo in recs:
-            d = per.setdefault(name, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += e0.elapsed_time(e1) * 1e-3
-            d[2] += fl
-        dom = max(per, key=lambda k: per[k][1])
-        n, tsum, fsum = per[dom]
-        achieved = fsum / tsum / 1e12
+                    f.write(f"{name:40s} {str(geo):48s} calls/step {n_ / 2:5.1f} ms/step {t_ / 2:8.3f} avg_us {t_ / n_ * 1e3:9.1f} TF {fl / (t_ / n_ * 1e-3) / 1e12:7.1f}\n")
+        table = kernel_table(recs, 2)
+        # the dominant kernel is ONE instance (the dispatch's own name: the persistent Cin = 64 kernel is not a halo-kernel row)
+        dom = max(table, key=lambda k: table[k]["time_per_step_ms"])
         # HBM traffic per launch of the dominant kernel: rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md "HBM") of
-        # this same command on the build named in profiles/r02_pmc_hbm_traffic.md, committed as profiles/r02_pmc.json.  PMC counters
-        # cannot be read from inside the timed process: this is the committed measurement of the same kernel, not of this run.
-        traffic, traffic_src = None, None
-        try:
-            if args.model != "palette":
-                raise KeyError("the committed PMC passes were taken on the palette_model command")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc.json")))
-            traffic = round(pmc[dom.split("<")[0]]["bytes_per_launch"], 1)
-            traffic_src = pmc.get("_meta", {}).get("build", "profiles/r02_pmc.json")
-        except Exception:
-            pass
-        roofline = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE; committed PMC passes of " + str(traffic_src)
-                                    + ", profiles/r02_pmc_hbm_traffic.md; MFMA-busy counters of the same build: profiles/r02_mfma_busy.md)",
-                    "launches_per_step": n // 2, "avg_launch_us": round(tsum / n * 1e6, 2),
-                    "avg_flops_per_launch": round(fsum / n, 1), "time_per_step_ms": round(tsum / 2 * 1e3, 3),
-                    "measured": "HIP events around every launch of an instrumented step with the weight-gradient side stream OFF "
-                                "(one kernel on the GPU at a time); the timed region runs with it on",
-                    "other_kernels": {}}
+        # this same command, committed under profiles/ with the sha of the kernel sources they were taken on.  PMC counters cannot be
+        # read from inside the timed process: `traffic` is that committed measurement, `traffic_build` says which build it is from and
+        # `running_build` which one produced every other number of this line.
+        traffic, traffic_build, traffic_file = None, None, None
+        for cand in ("r03_pmc.json", "r02_pmc.json"):
+            try:
+                if args.model != "palette":
+                    break
+                pmc = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                row = pmc.get(dom) or pmc.get(dom.split("<")[0])
+                if row:
+                    traffic, traffic_build, traffic_file = round(row["bytes_per_launch"], 1), pmc.get("_meta", {}).get("build"), "profiles/" + cand
+                    break
+            except Exception:
+                pass
+        roofline = dict(table[dom], kernel=dom, traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                        traffic_source=traffic_file, traffic_build=traffic_build, running_build="csrc sha1 " + csrc_sha(),
+                        measured="HIP events around every launch of an instrumented pass of 2 steps with the weight-gradient side stream OFF "
+                                 "(one kernel on the GPU at a time); the timed region runs with it on",
+                        other_kernels={k: v for k, v in table.items() if k != dom})
+        # all instances of the halo-resident 3x3 forward / input-gradient family together (what rounds 1-2 reported as one row)
+        fam = [v for k, v in table.items() if k.startswith("conv3x3_halo_kernel") or k.startswith("conv3x3_p64_kernel")]
+        if fam:
+            ft = sum(v["time_per_step_ms"] for v in fam) * 1e-3
+            ff = sum(v["avg_flops_per_launch"] * v["launches_per_step"] for v in fam)
+            roofline["conv3x3_family"] = {"instances": len(fam), "launches_per_step": sum(v["launches_per_step"] for v in fam),
+                                          "time_per_step_ms": round(ft * 1e3, 3), "achieved_tflops": round(ff / ft / 1e12, 2),
+                                          "frac_of_mfma_peak": round(ff / ft / 1e12 / PEAK_BF16_TFLOPS, 4)}
         if recs_overlapped:
-            ov = [e0.elapsed_time(e1) for name, e0, e1, fl, _g in recs_overlapped if name == dom]
+            ov = [e0.elapsed_time(e1) for name, e0, e1, fl, _g, _b in recs_overlapped if name == dom]
             roofline["avg_launch_us_overlapped"] = round(sum(ov) / max(len(ov), 1) * 1e3, 2)
-        for k, (n2, t2, f2) in per.items():
-            if k != dom:
-                roofline["other_kernels"][k] = {"achieved": round(f2 / t2 / 1e12, 2), "frac": round(f2 / t2 / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                                "launches_per_step": n2 // 2, "avg_launch_us": round(t2 / n2 * 1e6, 2),
-                                                "time_per_step_ms": round(t2 / 2 * 1e3, 3)}
         gf = FWD_GFLOP_PER_IMG.get((args.size, bool(args.efficient)))
         if gf and args.model != "cut":
             # palette: forward + backward (2x) = 3x; cm: student forward + teacher forward + backward = 4x
@@ -409,14 +540,20 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_subprocess(args)
+    cut = None
+    if rank == 0 and world == 1 and args.model == "palette" and not args.no_cut_leg and not args.force_exchange:
+        try:       # the CUT half of BASELINE's metric ("DDPM UNet & CUT G+D step") on the same line; never at the palette line's expense
+            cut = cut_leg(local_rank, args.no_cpu_baseline)
+        except Exception as e:
+            cut = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         line = {
             "metric": f"train images/sec at {args.size}x{args.size} ({'DDPM UNet' if args.model == 'palette' else 'CM UNet' if args.model == 'cm' else 'CUT'} step)",
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(ms_median, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"cut_model, {args.netG} G (ngf 64, 9 blocks) + D_netDs [{args.netDs}] (projected_d: stand-in backbone, DESIGN.md 14) + mlp_sample F, MoNCE, nce_idt, lsgan / hinge, "
+            "config": {"workload": (f"cut_model, {args.netG} G (ngf 64, 9 blocks) + D_netDs [{args.netDs}] (projected_d: tf_efficientnet_lite0 architecture, random frozen weights, DESIGN.md 14) + mlp_sample F, MoNCE, nce_idt, lsgan / hinge, "
                                     f"{args.size}x{args.size}, batch {args.batch}/GPU, Adam x3 + EMA, iter_size 1") if args.model == "cut" else
                                    f"{'palette_model DDPM' if args.model == 'palette' else 'cm_model consistency'}, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
                                    f"res_blocks[2,2,2,2] mid-attn 16x32, {args.size}x{args.size}, batch {args.batch}/GPU, "
@@ -425,8 +562,12 @@ def main():
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image_size": args.size,
                        "efficient": bool(args.efficient), "parallelism": f"dp{world}", "final_loss": round(loss, 6),
                        "n_ranks_seen": n_ranks_seen},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "cut": cut,
         }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+        if exch is not None:
+            line["exchange"] = exch
     # RCCL prints its banner through C stdio (block-buffered when stdout is a pipe, i.e. written at exit): every rank flushes it
     # now, so that rank 0's JSON line is the LAST line of the job's stdout
     import ctypes

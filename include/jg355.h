@@ -40,6 +40,9 @@ const char* jg_strerror(int code);
  * Returns JG_OK / JG_ERR_BAD_ARG (unknown name); jg_get_tuning returns the current value or -1. */
 int jg_set_tuning(const char* name, int value);
 int jg_get_tuning(const char* name);
+/* name of the kernel instance the calling thread's last jg_conv2d_nt / jg_conv2d_wgrad_tn launch was dispatched to ("" when the dispatch
+ * site does not record one): profiling tools label their rows with what ran */
+const char* jg_last_kernel(void);
 
 /* Implicit-GEMM convolution / batched GEMM "NT" on MFMA (v_mfma_f32_16x16x32_{f16,bf16}).
  *   y[z][m][n] = alpha * sum_k A[z][m][k] * w[z][n][k] + bias[n] + res_scale * res[z][m][n]

@@ -52,6 +52,7 @@ SIGNATURES = {
     "jg_strerror": [c_i32],
     "jg_set_tuning": [C.c_char_p, c_i32],
     "jg_get_tuning": [C.c_char_p],
+    "jg_last_kernel": [],
     "jg_conv2d_nt": [c_i32, C.POINTER(ConvArgs), c_p],
     "jg_conv2d_wgrad_tn": [c_i32, C.POINTER(WgradArgs), c_p],
     "jg_gn_stats": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_p],
@@ -221,7 +222,7 @@ def lib():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is absent
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name == "jg_strerror" else c_i32
+        fn.restype = C.c_char_p if name in ("jg_strerror", "jg_last_kernel") else c_i32
     _lib = L
     return L
 

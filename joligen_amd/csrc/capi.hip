@@ -34,6 +34,12 @@ void tune_init() {
 }
 }  // namespace
 
+namespace {
+thread_local const char* g_last_kernel = "";
+}
+void jg_note_kernel(const char* name) { g_last_kernel = name ? name : ""; }
+extern "C" const char* jg_last_kernel(void) { return g_last_kernel; }
+
 int jg_tune(int which) {
   std::call_once(g_tune_once, tune_init);
   return g_tune[which].load(std::memory_order_relaxed);

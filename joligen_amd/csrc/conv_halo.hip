@@ -430,14 +430,16 @@ void dispatch_halo(const ConvP& p, hipStream_t st) {
   // compiler-scheduled loop (A/B, tools/halo_pipe_ab.py)
   const int pipe = jg_tune(JG_TUNE_HALO_PIPE);
   if ((fill256 && cfg == 0) || (cfg == 3 && p.N % 256 == 0)) {
+    jg_note_kernel("conv3x3_halo_kernel<256-wide,8 waves>");
     if (pipe) launch_halo<T, 256, 512, 2, 4, 2, 2, 1, 1>(p, st); else launch_halo<T, 256, 512, 2, 4, 2, 2, 1>(p, st);
   }
-  else if (p.N % 128 == 0 && cfg == 2) launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st);
+  else if (p.N % 128 == 0 && cfg == 2) { jg_note_kernel("conv3x3_halo_kernel<128-wide,8 waves>"); launch_halo<T, 128, 512, 4, 2, 2, 3, 1>(p, st); }
   else if (p.N % 128 == 0) {   // 4 waves x (128 px x 64 ch), 2 workgroups / CU
+    jg_note_kernel("conv3x3_halo_kernel<128-wide,4 waves>");
     if (pipe) launch_halo<T, 128, 256, 2, 2, 1, 2, 2, 1>(p, st); else launch_halo<T, 128, 256, 2, 2, 1, 2, 2>(p, st);
   }
-  else if (cfg == 4) launch_halo<T, 64, 256, 4, 1, 1, 4, 2>(p, st);
-  else launch_halo<T, 64, 256, 4, 1, 1, 3, 2>(p, st);
+  else if (cfg == 4) { jg_note_kernel("conv3x3_halo_kernel<64-wide>"); launch_halo<T, 64, 256, 4, 1, 1, 4, 2>(p, st); }
+  else { jg_note_kernel("conv3x3_halo_kernel<64-wide>"); launch_halo<T, 64, 256, 4, 1, 1, 3, 2>(p, st); }
 }
 
 }  // namespace
@@ -487,6 +489,7 @@ bool jg_conv_halo_try(int dtype, const ConvP& p0, int nbatch, hipStream_t st) {
     if (p.stats && p.stats_mode != 0) return false;
     p.H >>= 1; p.W >>= 1; p.x_up = 0;
     if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31)) return false;
+    jg_note_kernel("conv3x3_halo_kernel<subpixel>");
     if (dtype == JG_F16) {
       if (p.N % 128 == 0) launch_halo_phase<f16_t, 128, 256, 2, 2, 1, 2, 2>(p, st); else launch_halo_phase<f16_t, 64, 256, 4, 1, 1, 3, 2>(p, st);
     } else if (dtype == JG_BF16) {

@@ -298,6 +298,7 @@ bool jg_conv_p64_try(int dtype, const ConvP& p0, int nbatch, hipStream_t st) {
   if (mode >= 2 && Gs > mode) Gs = mode;
   if (Gs > nsp) Gs = nsp;
   const int grid = Gs * tilesN;
+  jg_note_kernel("conv3x3_p64_kernel");
   if (dtype == JG_F16) hipLaunchKernelGGL((conv3x3_p64_kernel<f16_t>), dim3(grid), dim3(512), 0, st, p, nsp, Gs, tilesN);
   else if (dtype == JG_BF16) hipLaunchKernelGGL((conv3x3_p64_kernel<bf16_t>), dim3(grid), dim3(512), 0, st, p, nsp, Gs, tilesN);
   else return false;

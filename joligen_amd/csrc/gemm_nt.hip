@@ -441,6 +441,7 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
 }  // namespace
 
 extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream) {
+  jg_note_kernel("");      // the dispatch sites that record their instance overwrite it (jg_last_kernel)
   if (!a || !a->x || !a->w || !a->y) return JG_ERR_BAD_ARG;
   if (a->Cin % 8 || a->Cout % 4 || a->ldx % 8 || a->ldw % 8 || a->ldy % 4) return JG_ERR_BAD_ARG;
   if (a->res && (a->ldres % 4)) return JG_ERR_BAD_ARG;

@@ -433,6 +433,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
 }  // namespace
 
 extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream) {
+  jg_note_kernel("");
   if (!a || !a->dy || !a->x || !a->dw) return JG_ERR_BAD_ARG;
   if (a->Cin % 8 || a->Cout % 8 || a->ldx % 8 || a->lddy % 8) return JG_ERR_BAD_ARG;
   if (a->nbatch < 1 || a->nh < 1 || a->splitk < 1) return JG_ERR_BAD_ARG;

@@ -367,6 +367,8 @@ void dispatch_wg(const WgP& p, hipStream_t st) {
   const bool big = cfg == 2 || (cfg == 0 && per1 >= 64);
   // mirrored borders (pad_mode 1) are compiled only into the 16x16 / 64-co configuration: the extra address arithmetic would push
   // the register-tight 8-row configurations into spilling
+  jg_note_kernel(p.reflect || !(big && p.Cout % 128 == 0) ? (cfg == 3 && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,64 co,4 waves>" : "wgrad3x3_halo_kernel<16 rows,64 co>")
+                                                          : "wgrad3x3_halo_kernel<8 rows,128 co>");
   if (p.reflect) launch_wg<T, 16, 2, 2, 1>(p, st);
   else if (p.x_up && big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2, 2>(p, st);   // upsample-on-read: the two shapes the UNet up-blocks use
   else if (p.x_up) launch_wg<T, 16, 2, 2, 2>(p, st);

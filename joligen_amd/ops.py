@@ -115,11 +115,15 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
     if KERNEL_TIMING is not None:
         ev1.record()
+        ran = _lib.lib().jg_last_kernel().decode()      # the instance the dispatch picked ("" where the site records none)
         if x_mode == 2:    # sub-pixel form: 4 of the 9 tap-MACs per output pixel are executed -- count the MFMA work actually done
-            KERNEL_TIMING.append(("conv3x3_halo_kernel<subpixel>", ev0, ev1, 2.0 * B * Ho * Wo * Cout * 4 * Cin, (nbatch, B, Ho, Wo, Cin, Cout, 2)))
+            KERNEL_TIMING.append((ran or "conv3x3_halo_kernel<subpixel>", ev0, ev1, 2.0 * B * Ho * Wo * Cout * 4 * Cin, (nbatch, B, Ho, Wo, Cin, Cout, 2),
+                                  2.0 * nbatch * (B * (Ho // 2) * (Wo // 2) * Cin + B * Ho * Wo * Cout) + 2.0 * 16 * Cin * Cout))
         else:
-            KERNEL_TIMING.append((_conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, B * Ho * Wo if (stats is None or (R == 3 and Cin == 8 and gn_reduce is None)) else 0), ev0, ev1,
-                                  2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R)))
+            KERNEL_TIMING.append((ran or _conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, B * Ho * Wo if (stats is None or (R == 3 and Cin == 8 and gn_reduce is None)) else 0), ev0, ev1,
+                                  2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R),
+                                  # algorithmic HBM bytes: every input / output / residual element once (16-bit), the weights once
+                                  2.0 * nbatch * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if res is not None else 1)) + 2.0 * R * S * Cin * Cout))
 
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
@@ -146,8 +150,9 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     check(_lib.lib().jg_conv2d_wgrad_tn(_dt(dy), C.byref(a), _st()), "jg_conv2d_wgrad_tn")
     if KERNEL_TIMING is not None:
         ev1.record()
-        KERNEL_TIMING.append((_wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode), ev0, ev1,
-                              2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk)))
+        KERNEL_TIMING.append((_lib.lib().jg_last_kernel().decode() or _wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode), ev0, ev1,
+                              2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk),
+                              2.0 * nbatch * (B * H * W * Cin + B * Ho * Wo * Cout) + 4.0 * R * S * Cin * Cout))
 
 
 def axpby(a, alpha=1.0, b=None, beta=0.0, alpha_dev=None, out=None):

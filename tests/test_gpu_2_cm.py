@@ -175,3 +175,50 @@ def test_cm_restoration_vs_reference_golden(golden_dir, name, dtype_name):
     assert tuple(vis[0]["mask_0"].shape) == tuple(g["mask"].shape[1:])
     test_vis = model.get_current_visuals(B, phase="test", test_name="t")
     assert all(not k for v in test_vis for k in v if "noisy" in k)
+
+
+def test_cm_c5_shape_first_step_gradients_vs_oracle():
+    """BASELINE configs[4] shape (cm_model, the C2 UNet: ngf 64, mults [1,2,4,8], 2 res-blocks / level, mid-block attention, in-ch 3,
+    cond_embed_dim 256; 256x256) at batch 1 against the CPU oracle: loss of the consistency step and every weight gradient, bounded by
+    the rounding floor MEASURED on the same inputs (the oracle with 16-bit storage between layers, `activation_rounding`)."""
+    c = dict(ngf=64, mults=[1, 2, 4, 8], res_blocks=[2, 2, 2, 2], attn_res=[16], efficient=True, S=256, B=1)
+    model = make_model(c, "fp16")
+    net = model.netG_A
+    sd = {k: (v.float().cpu().half().float() if (torch.is_floating_point(v) and v.dim() >= 3) else v.float().cpu()) for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)
+    cfg = O.UNetCfg(in_channel=3, inner_channel=64, out_channel=3, res_blocks=c["res_blocks"], attn_res=c["attn_res"], channel_mults=c["mults"],
+                    efficient=True, cond_embed_dim=256)
+    g = torch.Generator().manual_seed(19)
+    Bimg = (torch.rand(1, 3, 256, 256, generator=g) * 2 - 1).half().float()
+    mask = torch.zeros(1, 1, 256, 256, dtype=torch.int64)
+    mask[:, :, 40:170, 60:210] = 1
+    A = Bimg * (1 - mask) + torch.randn(Bimg.shape, generator=g).half().float() * mask
+    tr = O.OracleCMTrainer(sd, cfg, model.total_t)
+    noise, ts = O.cm_draw_step_randomness(torch.Generator().manual_seed(3), Bimg, tr.sigmas())
+    loss_ref, grads, _ = tr.loss_and_grads(Bimg, mask, noise, ts)
+    tr16 = O.OracleCMTrainer(sd, cfg, model.total_t)
+    tr16.grad_scale = model.loss_scale          # the HIP path's static fp16 loss scale
+    with O.activation_rounding(torch.float16):
+        loss_16, grads16, _ = tr16.loss_and_grads(Bimg, mask, noise, ts)
+    net.current_t = 0
+    model.rng_injection = lambda b: (noise, ts)
+    model.set_input({"A": A, "B": Bimg, "B_label_mask": mask})
+    net.arena.g.zero_()
+    model.compute_cm_loss()
+    model.loss_G_tot.backward()
+    torch.cuda.synchronize()
+    assert abs(float(model.loss_G_tot) - float(loss_ref)) < 2e-2 * abs(float(loss_ref)), (float(model.loss_G_tot), float(loss_ref))
+    scale = model.loss_scale
+    mine_e, floor_e = [], []
+    for k, p in net.named_parameters():
+        if (k.endswith(".weight") and p.dim() >= 2) and float(grads[k].norm()) > 1e-12:
+            mine_e.append((relerr(p.grad.detach().float().cpu() / scale, grads[k]), k))
+            floor_e.append(relerr(grads16[k], grads[k]))
+    mine_e.sort(reverse=True)
+    floor_e.sort(reverse=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_table_c5_cm_fp16.txt", "w") as f:
+        f.write(f"# rounding floor (oracle, 16-bit storage): worst {floor_e[0]:.3e} median {floor_e[len(floor_e) // 2]:.3e}\n")
+        f.write("\n".join(f"{e:10.3e} {k}" for e, k in mine_e))
+    assert mine_e[0][0] <= max(2.0 * floor_e[0], 2e-2), (mine_e[:5], floor_e[:3])
+    assert mine_e[len(mine_e) // 2][0] <= max(1.5 * floor_e[len(floor_e) // 2], 5e-3), (mine_e[len(mine_e) // 2], floor_e[len(floor_e) // 2])

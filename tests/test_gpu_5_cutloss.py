@@ -506,3 +506,95 @@ def test_cut_full_size_properties(netG):
     k0 = next(iter(before["G_A"]))
     cur = dict(model.netG_A.named_parameters())[k0].detach()
     assert float((ema[k0] - cur).abs().max()) > 0 and float((ema[k0] - cur).abs().max()) <= 1.02 * n_steps * lrs["G_A"]
+
+
+def test_cut_c3_shape_first_step_gradients_vs_oracle():
+    """BASELINE configs[2] at its own shape: cut_model, SegFormer-attn generator (MiT-b0 + two heads + BatchNorm
+    decoder tail) + [projected_d (tf_efficientnet_lite0 architecture), basic] discriminators + MoNCE, 256x256, batch 1, fp16.  First
+    G-group backward on identical 16-bit-representable weights and inputs against the CPU oracle (oracle/jg_oracle.py OracleCUTTrainer with
+    its projected-discriminator term), with injected DropPath / Dropout2d uniforms and patch ids.  Bounds: the losses to the forward
+    tolerance; every G / F gradient tensor against TWICE the rounding floor measured here on the same inputs (the oracle with 16-bit
+    storage between layers)."""
+    import random
+    import warnings
+
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    S, Bn, dtype = 256, 1, torch.float16
+    cfg = {"model_type": "cut", "G": {"netG": "segformer_attn_conv", "ngf": 64, "nblocks": 9},
+           "D": {"netDs": ["projected_d", "basic"], "ndf": 64, "proj_interp": -1}, "alg": {"cut": {"nce_loss": "monce", "num_patches": 256}},
+           "data": {"crop_size": S, "load_size": S}, "train": {"batch_size": Bn, "pool_size": 50, "G_ema": True}}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = create_model(opt_from_json(cfg, overrides={"jg_act_dtype": "fp16", "gpu_ids": "0"}), 0)
+    g = torch.Generator().manual_seed(31)
+    A = (torch.rand(Bn, 3, S, S, generator=g) * 2 - 1).half().float()
+    Bi = (torch.rand(Bn, 3, S, S, generator=g) * 2 - 1).half().float()
+    model.data_dependent_initialize({"A": A, "B": Bi})
+    r16 = lambda v: v.half().float() if torch.is_floating_point(v) else v
+    sdG = {k: r16(v) for k, v in O.synth_state_dict(model.netG_A.state_dict(), seed=0).items()}
+    sdD = {k: r16(v) for k, v in O.synth_state_dict(model.netD_B_basic.state_dict(), seed=1).items()}
+    sdF = O.synth_state_dict(model.netF.state_dict(), seed=3)
+    sdPD = {k: (v if k.endswith(("weight_u", "weight_v")) else r16(v)) for k, v in O.synth_state_dict(model.netD_B_projected_d.state_dict(), seed=5).items()}
+    model.netG_A.load_state_dict(sdG)
+    model.netD_B_basic.load_state_dict(sdD)
+    model.netF.load_state_dict(sdF)
+    model.netD_B_projected_d.load_state_dict(sdPD)
+    hw = [(S // s) ** 2 for s in (4, 8, 16, 32)]
+    ids = [[torch.randperm(n, generator=g)[:min(256, n)] for n in hw] for _ in range(2)]
+    # generator forward on cat(A, B): 14 DropPath draws [2 B] + 2 Dropout2d draws [2 B, 256]; then 4 encoder passes of 14 DropPath draws [B]
+    uni = [torch.rand(2 * Bn, generator=g) for _ in range(14)] + [torch.rand(2 * Bn, 256, generator=g) for _ in range(2)] \
+        + [torch.rand(Bn, generator=g) for _ in range(56)]
+    model.patch_ids_injection = lambda call, shapes: [i.to(D0) for i in ids[0 if call == 0 else 1]]
+    uit = iter(uni)
+    model.netG_A.rand.source = lambda shape, uit=uit: next(uit)
+    model.set_input({"A": A, "B": Bi})
+    for net in ("G_A", "F", "D_B_basic", "D_B_projected_d"):
+        model.set_requires_grad(getattr(model, "net" + net), net in ("G_A", "F"))
+    model.forward()
+    model.compute_G_loss()
+    model.loss_G_tot.backward()
+    torch.cuda.synchronize()
+    assert next(uit, None) is None, "not all uniforms were consumed: the draw count of the SegFormer generator changed"
+
+    def oracle(rounded):
+        tr = O.OracleCUTTrainer(sdG, sdF, sdD, 9, [0, 1, 2, 3], num_patches=256, T=0.2, monce=True, pool_size=50, pool_rng=random.Random(0),
+                                ema_beta=0.999, gen="segformer", sdPD=sdPD, proj_interp=-1)
+        if rounded:
+            tr.grad_scale = model.loss_scale
+            with O.activation_rounding(torch.float16):
+                lo = tr.step(A, Bi, ids[0], ids[1], uniforms=uni)
+        else:
+            lo = tr.step(A, Bi, ids[0], ids[1], uniforms=uni)
+        return tr, lo
+
+    ref, lo = oracle(False)
+    rnd, _ = oracle(True)
+    losses = {k: float(v) for k, v in model.get_current_losses().items()}
+    for ok, rk in (("G_GAN", "G_GAN_D_B_basic"), ("G_GAN_PD", "G_GAN_D_B_projected_d"), ("G_NCE", "G_NCE"), ("G_NCE_Y", "G_NCE_Y")):
+        assert abs(losses[rk] - lo[ok]) <= 6e-3 * abs(lo[ok]) + 2e-3, (rk, losses[rk], lo[ok])
+    ls = model.loss_scale
+    skip = _zero_grad_bias(ref.G, "segformer")
+    table, bad = [], []
+    per = {"G": ([], []), "F": ([], [])}
+    for net, key in ((model.netG_A, "G"), (model.netF, "F")):
+        for k, p in net.named_parameters():
+            r = ref.last_grads[key][k]
+            floor = 0.0
+            if key == "G" and skip(k):
+                floor = 2e-3 * float(ref.last_grads[key][k.replace("in_proj_bias", "in_proj_weight")].norm())
+            den = float(r.norm()) + floor + 1e-30
+            mine = float((p.grad.detach().float().cpu() / ls - r).norm()) / den
+            fl = float((rnd.last_grads[key][k] - r).norm()) / den
+            per[key][0].append(mine)
+            per[key][1].append(fl)
+            table.append(f"{mine:10.3e} floor={fl:10.3e} {key}.{k}")
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/grad_table_cut_c3_shape.txt", "w") as f:
+        f.write("\n".join(table))
+        for key, (m_, f_) in per.items():
+            f.write(f"\n# {key}: median {sorted(m_)[len(m_) // 2]:.3e} worst {max(m_):.3e} | rounding floor median {sorted(f_)[len(f_) // 2]:.3e} worst {max(f_):.3e}")
+    for key, (m_, f_) in per.items():
+        assert max(m_) <= 2.0 * max(f_) + 1e-3, (key, max(m_), max(f_))
+        assert sorted(m_)[len(m_) // 2] <= 1.5 * sorted(f_)[len(f_) // 2] + 1e-4, (key, sorted(m_)[len(m_) // 2], sorted(f_)[len(f_) // 2])

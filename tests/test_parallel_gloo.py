@@ -261,3 +261,134 @@ def test_logging_loss_allreduce(tmp_path):
     assert abs(r0["G_tot"] - 1.5) < 1e-6 and abs(r0["G_NCE"] - 0.75) < 1e-6 and abs(r0["D_tot"] - 2.0) < 1e-6
     single = OrderedDict(a=torch.tensor(2.0))
     assert parallel.reduce_losses(single) is single
+
+
+# ---- model level: the palette step at 2 x B/2 through the exchange == the single-process step at B ----------------
+MODEL_CFG = dict(ngf=32, mults=[1, 2], res_blocks=[1, 1], attn_res=[16], efficient=True, S=32, B=4)
+
+
+def _model_inputs():
+    c = MODEL_CFG
+    cfg = O.UNetCfg(in_channel=6, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"], attn_res=c["attn_res"],
+                    channel_mults=c["mults"], efficient=c["efficient"])
+    from joligen_amd.models.palette_model import define_G
+    from joligen_amd.options import opt_from_json
+
+    ov = dict(G_ngf=c["ngf"], G_unet_mha_channel_mults=c["mults"], G_unet_mha_res_blocks=c["res_blocks"], G_unet_mha_attn_res=c["attn_res"],
+              G_unet_mha_vit_efficient=c["efficient"], data_crop_size=c["S"], train_batch_size=c["B"])
+    sd = O.synth_state_dict(define_G(**vars(opt_from_json({}, ov))).state_dict(), seed=0)
+    g = torch.Generator().manual_seed(21)
+    B, S = c["B"], c["S"]
+    steps = []
+    for _ in range(2):
+        Bimg = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+        mask = torch.zeros(B, 1, S, S, dtype=torch.int64)
+        mask[:, :, 6:20, 8:26] = 1
+        A = Bimg * (1 - mask) + torch.randn(B, 3, S, S, generator=g) * mask
+        t, u, noise = O.draw_step_randomness(g, Bimg, 2000)
+        steps.append((Bimg, A, mask, noise, t, u))
+    return cfg, sd, steps
+
+
+class _OracleArena(FakeArena):
+    """flat view of an OraclePaletteTrainer's parameters: the arena surface parallel.allreduce_and_step drives"""
+
+    def __init__(self, tr):
+        self.names = tr.param_names
+        self.shapes = [tr.P[k].shape for k in self.names]
+        self.numel = sum(int(torch.tensor(s).prod()) if len(s) else 1 for s in self.shapes)
+        self.p = torch.cat([tr.P[k].reshape(-1) for k in self.names])
+        self.g, self.m, self.v = torch.zeros(self.numel), torch.zeros(self.numel), torch.zeros(self.numel)
+        self.ema, self.step, self.dirty, self.calls = None, 0, False, []
+
+    def load_grads(self, grads):
+        self.g += torch.cat([grads[k].reshape(-1) for k in self.names])
+
+    def store_params(self, tr):
+        off = 0
+        for k, s in zip(self.names, self.shapes):
+            n = tr.P[k].numel()
+            tr.P[k] = self.p[off:off + n].reshape(s).clone()
+            off += n
+
+
+def _worker_model(rank, world, port, out, wire):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from joligen_amd import parallel
+
+    parallel.GRAD_WIRE = wire
+    cfg, sd, steps = _model_inputs()
+    if rank == 1:      # ranks start from different weights; the constructor broadcast makes them rank 0's
+        sd = {k: (v + 0.01 if torch.is_floating_point(v) and not O._is_buffer(k) else v) for k, v in sd.items()}
+    tr = O.OraclePaletteTrainer(sd, cfg, ema_beta=None)
+    arena = _OracleArena(tr)
+    parallel.broadcast_params(arena, 0)
+    arena.store_params(tr)
+    hp = dict(lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=True, ema_beta=None, zero_grad=True)
+    half = MODEL_CFG["B"] // world
+    sl = slice(rank * half, (rank + 1) * half)
+    losses = []
+    for Bimg, A, mask, noise, t, u in steps:           # each rank: its half of the batch (DistributedSampler semantics)
+        loss, grads, _ = tr.loss_and_grads(Bimg[sl], A[sl], mask[sl], noise[sl], t[sl], u[sl])
+        arena.load_grads(grads)
+        arena.step += 1
+        parallel.allreduce_and_step(arena, hp, grad_scale=1.0, n_chunks=4)
+        arena.store_params(tr)
+        losses.append(float(parallel.reduce_losses({"G_tot": loss})["G_tot"]))
+    torch.save(dict(p=arena.p, losses=losses), out % rank)
+    dist.destroy_process_group()
+
+
+def _single_process_reference():
+    cfg, sd, steps = _model_inputs()
+    tr = O.OraclePaletteTrainer(sd, cfg, ema_beta=None)
+    losses = []
+    for Bimg, A, mask, noise, t, u in steps:
+        losses.append(float(tr.optimize_parameters(Bimg, A, mask, noise, t, u)))
+    return torch.cat([tr.P[k].reshape(-1) for k in tr.param_names]), losses
+
+
+def test_palette_step_two_ranks_equals_single_process_batch(tmp_path):
+    """the FULL palette optimisation step (DDPM loss, UNet backward, AdamW) of a batch of 4 split over two ranks -- every rank computes
+    its half with the CPU oracle (the HIP model needs a GPU), the gradients travel through parallel.allreduce_and_step in 4 chunks with
+    DDP mean semantics -- reproduces the single-process step on the whole batch: the MSE loss is a mean over B*C*H*W, so the mean of
+    the two half-batch gradients IS the full-batch gradient (models/base_model.py:725-737 of the reference: DDP averages)."""
+    world = 2
+    out = str(tmp_path / "pm%d.pt")
+    mp.spawn(_worker_model, args=(world, _free_port(), out, "fp32"), nprocs=world, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert torch.equal(r0["p"], r1["p"])
+    ref_p, ref_losses = _single_process_reference()
+    # Adam's first steps are sign-like: on the few hundred elements whose gradient is analytically zero (biases in front of a
+    # GroupNorm: pure fp32 summation noise, other in the two-halves order than in the full batch) the update differs by up to lr per
+    # step; everywhere else the two trajectories agree to rounding
+    d = (r0["p"] - ref_p).abs()
+    assert float((d > 2e-7 + 2e-5 * ref_p.abs()).float().mean()) < 1e-3, float((d > 2e-7 + 2e-5 * ref_p.abs()).float().mean())
+    assert float(d.max()) <= 2.1 * 2 * 2e-4, float(d.max())
+    assert float((r0["p"] - ref_p).norm() / ref_p.norm()) < 1e-5
+    for a, b in zip(r0["losses"], ref_losses):          # the logged loss = mean over the ranks of the half-batch means
+        assert abs(a - b) < 1e-5 * abs(b)
+
+
+def test_bf16_gradient_wire_format(tmp_path):
+    """JG_GRAD_WIRE=bf16 (parallel.GRAD_WIRE): the chunks travel as bf16 and are widened back into the fp32 arena before the optimizer;
+    replicas stay bit-identical, and the step differs from the fp32 wire only by one bf16 rounding of the summed gradient (Adam turns a
+    2^-9 relative gradient error into at most an lr-sized change of an element whose moment ratio sits at a rounding boundary)"""
+    world = 2
+    out = str(tmp_path / "bw%d.pt")
+    try:
+        mp.spawn(_worker_model, args=(world, _free_port(), out, "bf16"), nprocs=world, join=True)
+    except Exception as e:       # a gloo build without bf16 all-reduce: the wire format is an RCCL-side option
+        if "bfloat16" in str(e).lower() or "BFloat16" in str(e):
+            import pytest
+            pytest.skip("gloo in this torch build cannot all-reduce bf16")
+        raise
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    assert torch.equal(r0["p"], r1["p"])
+    ref_p, _ = _single_process_reference()
+    d = (r0["p"] - ref_p).abs()
+    assert float(d.max()) <= 2.1 * 2 * 2e-4                   # two steps of at most lr each way
+    assert float((d > 1e-6).float().mean()) < 0.5             # most elements agree to rounding
+    assert float(((r0["p"] - ref_p).norm()) / (ref_p.norm())) < 1e-4
