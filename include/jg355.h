@@ -459,6 +459,16 @@ int jg_noise_level_embedding_bwd(const float* sigma, const float* W, const float
  * A, Bimg: fp32 NCHW [B,3,S,S]; noise: fp32 NCHW N(0,1) draws (NULL: treated as 0).  Bit-identical to the CPU transforms. */
 int jg_input_pipeline(const uint8_t* img, const uint8_t* mask, const int32_t* win, const float* noise, float* A, float* Bimg,
                       int64_t* mask_out, int B, int H, int W, int S, jg_stream_t s);
+/* `load_size` resize of the decoded uint8 batch in front of jg_input_pipeline (data/base_dataset.py:441-443: transforms.Resize(BICUBIC) on a
+ * PIL image = PIL Image.resize; :749-763 ResizeMask: NEAREST for the label mask).  jg_resample_u8 = ONE separable pass of PIL's fixed-point
+ * resampler (Pillow Resample.c: out = clip8((2^21 + sum_k in[lo + k] * kk[k]) >> 22)) over [B, H, W, 3] uint8: horizontal (vertical = 0,
+ * Hin == Hout) or vertical (Win == Wout); bounds [out, 2] = (first source index, tap count), kk [out, ksize] = 22-bit fixed-point taps,
+ * both computed by the caller as PIL's precompute_coeffs / normalize_coeffs_8bpc do.  jg_resize_nearest_u8: [B, Hin, Win] -> [B, Hout, Wout]
+ * through the caller's source-index tables ytab [Hout] / xtab [Wout] (PIL accumulates the source coordinate incrementally in double). */
+int jg_resample_u8(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* kk, int ksize, int vertical, int B, int Hin, int Win,
+                   int Hout, int Wout, jg_stream_t s);
+int jg_resize_nearest_u8(const uint8_t* in, uint8_t* out, const int32_t* ytab, const int32_t* xtab, int B, int Hin, int Win, int Hout, int Wout,
+                         jg_stream_t s);
 
 /* NHWC(T, Cpad) <-> NCHW(fp32, C) layout converters at the module boundary. */
 int jg_nhwc_to_nchw_f32(int dtype, const void* x, float* y, int B, int C, int H, int W, int Cpad, jg_stream_t s);

@@ -146,6 +146,8 @@ SIGNATURES = {
                    c_f32, c_f32, c_f32, c_p],
     "jg_noise_level_embedding": [c_p, c_p, c_p, c_i32, c_i32, c_p],
     "jg_noise_level_embedding_bwd": [c_p, c_p, c_p, c_p, c_i32, c_i32, c_p],
+    "jg_resample_u8": [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_resize_nearest_u8": [c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_input_pipeline": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_nhwc_to_nchw_f32": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_nchw_f32_to_nhwc": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],

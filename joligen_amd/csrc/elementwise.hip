@@ -1215,3 +1215,76 @@ extern "C" int jg_input_pipeline(const uint8_t* img, const uint8_t* mask, const 
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
+
+
+// ======================================================================================
+// Resize of decoded uint8 images on the device (the `load_size` step of the reference's transforms: data/base_dataset.py:441-443
+// `transforms.Resize(osize, interpolation=BICUBIC)` on a PIL image = PIL `Image.resize`, and ResizeMask :749-763 = NEAREST for the label mask).
+// PIL resamples in two separable passes of FIXED-POINT arithmetic on uint8 (Pillow src/libImaging/Resample.c: coefficients rounded to
+// 22 fractional bits, accumulator started at 1 << 21, result clip8(acc >> 22), the horizontal pass rounded to uint8 before the vertical
+// one).  The coefficient tables depend only on (in_size, out_size) and are computed on the host in double precision exactly as
+// precompute_coeffs / normalize_coeffs_8bpc do (joligen_amd/data_device.py); the passes below are integer MACs: bit-exact with PIL.
+//   pass: out[b, y, x, c] = clip8((2^21 + sum_k in[b, y, xmin[x] + k, c] * kk[x][k]) >> 22)      (horizontal; vertical swaps the roles)
+// ======================================================================================
+namespace {
+__device__ __forceinline__ uint8_t jg_clip8(int v) {
+  v >>= 22;
+  return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+// horizontal: in [B, H, Win, 3] -> out [B, H, Wout, 3];  vertical (VERT): in [B, Hin, W, 3] -> out [B, Hout, W, 3]
+template <bool VERT>
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const int32_t* __restrict__ bounds,
+                                                          const int32_t* __restrict__ kk, int ksize, int B, int Hin, int Win, int Hout, int Wout) {
+  const long total = (long)B * Hout * Wout;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % Wout);
+    const long t = i / Wout;
+    const int y = (int)(t % Hout), b = (int)(t / Hout);
+    const int o = VERT ? y : x;
+    const int lo = bounds[o * 2], n = bounds[o * 2 + 1];
+    const int32_t* k = kk + (long)o * ksize;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int j = 0; j < n; ++j) {
+      const long sp = VERT ? (((long)b * Hin + lo + j) * Win + x) : (((long)b * Hin + y) * Win + lo + j);
+      const int c = k[j];
+      s0 += (int)in[sp * 3] * c;
+      s1 += (int)in[sp * 3 + 1] * c;
+      s2 += (int)in[sp * 3 + 2] * c;
+    }
+    out[i * 3] = jg_clip8(s0);
+    out[i * 3 + 1] = jg_clip8(s1);
+    out[i * 3 + 2] = jg_clip8(s2);
+  }
+}
+// PIL NEAREST (Geometry.c ImagingScaleAffine): the source index tables come from the host, which reproduces PIL's incremental double
+// accumulation of the source coordinate (it differs from floor((dst + 0.5) * in / out) where that product is an integer)
+__global__ __launch_bounds__(256) void resize_nearest_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const int32_t* __restrict__ ytab,
+                                                                const int32_t* __restrict__ xtab, int B, int Hin, int Win, int Hout, int Wout) {
+  const long total = (long)B * Hout * Wout;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % Wout);
+    const long t = i / Wout;
+    const int y = (int)(t % Hout), b = (int)(t / Hout);
+    out[i] = in[((long)b * Hin + ytab[y]) * Win + xtab[x]];
+  }
+}
+}  // namespace
+
+extern "C" int jg_resample_u8(const uint8_t* in, uint8_t* out, const int32_t* bounds, const int32_t* kk, int ksize, int vertical, int B, int Hin,
+                              int Win, int Hout, int Wout, jg_stream_t s) {
+  if (!in || !out || !bounds || !kk || ksize < 1 || B < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return JG_ERR_BAD_ARG;
+  if ((vertical && Win != Wout) || (!vertical && Hin != Hout)) return JG_ERR_BAD_ARG;
+  const long total = (long)B * Hout * Wout;
+  if (vertical) hipLaunchKernelGGL((resample_u8_kernel<true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, in, out, bounds, kk, ksize, B, Hin, Win, Hout, Wout);
+  else hipLaunchKernelGGL((resample_u8_kernel<false>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, in, out, bounds, kk, ksize, B, Hin, Win, Hout, Wout);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_resize_nearest_u8(const uint8_t* in, uint8_t* out, const int32_t* ytab, const int32_t* xtab, int B, int Hin, int Win, int Hout,
+                                    int Wout, jg_stream_t s) {
+  if (!in || !out || !ytab || !xtab || B < 1 || Hin < 1 || Win < 1 || Hout < 1 || Wout < 1) return JG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(resize_nearest_u8_kernel, dim3(grid_for((long)B * Hout * Wout)), dim3(256), 0, (hipStream_t)s, in, out, ytab, xtab, B, Hin, Win,
+                     Hout, Wout);
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}

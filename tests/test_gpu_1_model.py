@@ -667,6 +667,7 @@ def test_device_input_pipeline_bit_exact(golden_dir):
     pinned staging on a copy stream) against the CPU transforms of the reference's datasets, restated with torch ops in torchvision's
     operation order -- bit-exact, several batches in flight, and the result trains."""
     from joligen_amd.data_device import DeviceInputPipeline
+    from pil_resize import input_pipeline_reference
 
     S, B, H, W = 16, 4, 24, 28
     pipe = DeviceInputPipeline(S, "cuda:0", n_buffers=2)
@@ -679,19 +680,10 @@ def test_device_input_pipeline_bit_exact(golden_dir):
         flip = torch.rand(B, generator=g) < 0.5
         noise = torch.randn(B, 3, S, S, generator=g)
         pipe.submit(img, mask, off, flip, noise)
-        # CPU restatement: ToTensor (uint8 -> float / 255), Normalize (x - 0.5) / 0.5, crop, hflip, fill_mask_with_random(cls = -1)
-        x = img.permute(0, 3, 1, 2).float().div(255).sub(0.5).div(0.5)
-        Bs, Ms = [], []
-        for b in range(B):
-            oy, ox = int(off[b, 0]), int(off[b, 1])
-            xb, mb = x[b, :, oy:oy + S, ox:ox + S], mask[b, oy:oy + S, ox:ox + S]
-            if flip[b]:
-                xb, mb = xb.flip(-1), mb.flip(-1)
-            Bs.append(xb)
-            Ms.append(mb)
-        Bref, Mref = torch.stack(Bs), torch.stack(Ms)[:, None].long()
-        m01 = torch.where(Mref != 0, 1.0, 0.0)
-        refs.append((Bref * (1 - m01) + noise * m01, Bref, Mref))
+        # CPU restatement of the reference's transform chain: oracle/pil_resize.py::input_pipeline_reference (ToTensor, Normalize, crop,
+        # hflip, fill_mask_with_random in torchvision's order of operations; torchvision itself is absent here -- the resize part of that
+        # restatement is pinned against Pillow's own outputs, tests/golden/resize_pil.pt)
+        refs.append(input_pipeline_reference(img, mask, off, flip, noise, S))
     for it in range(3):
         batch = pipe.get()
         torch.cuda.synchronize()
@@ -699,6 +691,32 @@ def test_device_input_pipeline_bit_exact(golden_dir):
         assert torch.equal(batch["B"].cpu(), Bref), it
         assert torch.equal(batch["B_label_mask"].cpu(), Mref) and batch["B_label_mask"].dtype == torch.int64
         assert torch.equal(batch["A"].cpu(), A), it
+    # data_preprocess = "resize_and_crop" (base_dataset.py:441-443): decoded images of another size are first resized to load_size with
+    # PIL's BICUBIC (masks NEAREST) -- on the device, bit-exact with Pillow (committed vectors) and with the oracle restatement
+    gp = load(golden_dir, "resize_pil.pt")
+    for c in gp["cases"]:
+        oh, ow = c["out_hw"]
+        if oh != ow:
+            continue
+        rp = DeviceInputPipeline(oh, "cuda:0", n_buffers=1, load_size=oh)       # crop == load: the window is the whole resized image
+        rp.submit(c["img"][None], c["mask"][None], torch.zeros(1, 2, dtype=torch.int64), torch.zeros(1, dtype=torch.bool), torch.zeros(1, 3, oh, ow))
+        got = rp.get()
+        torch.cuda.synchronize()
+        want = c["img_resized"].permute(2, 0, 1).float().div(255).sub(0.5).div(0.5)
+        assert torch.equal(got["B"][0].cpu(), want), (tuple(c["img"].shape), oh)
+        assert torch.equal(got["B_label_mask"][0, 0].cpu(), c["mask_resized"].long())
+    L = 20
+    rp = DeviceInputPipeline(S, "cuda:0", n_buffers=1, load_size=L)
+    img = torch.randint(0, 256, (B, 33, 27, 3), generator=g, dtype=torch.uint8)
+    mask = (torch.rand(B, 33, 27, generator=g) < 0.3).to(torch.uint8)
+    off = torch.stack([torch.randint(0, L - S + 1, (B,), generator=g), torch.randint(0, L - S + 1, (B,), generator=g)], 1)
+    flip = torch.rand(B, generator=g) < 0.5
+    noise = torch.randn(B, 3, S, S, generator=g)
+    rp.submit(img, mask, off, flip, noise)
+    got = rp.get()
+    torch.cuda.synchronize()
+    A, Bref, Mref = input_pipeline_reference(img, mask, off, flip, noise, S, load_size=L)
+    assert torch.equal(got["B"].cpu(), Bref) and torch.equal(got["A"].cpu(), A) and torch.equal(got["B_label_mask"].cpu(), Mref)
     # the batch dict is what set_input consumes
     gld = load(golden_dir, "palette_step_tiny_eff.pt")
     model = make_model(gld["cfg"], "bf16", golden_dir)

@@ -790,8 +790,30 @@ def test_palette_conditioning(golden_dir, tag):
     torch.testing.assert_close(ret, sm["ret"], rtol=1e-4, atol=1e-5)
 
 
+# ---- input transforms (f3): the resize restatement against Pillow's own outputs -------------------------------------------------------
+def test_pil_resize_restatement(golden_dir):
+    """oracle/pil_resize.py (Pillow's fixed-point BICUBIC resampler and its incrementally-accumulated NEAREST, restated) against
+    `Image.resize` outputs committed by oracle/make_golden_resize.py: bit-exact, down- / up-sampling, non-square"""
+    import pil_resize as R
+
+    g = load(golden_dir, "resize_pil.pt")
+    assert len(g["cases"]) >= 5
+    for c in g["cases"]:
+        oh, ow = c["out_hw"]
+        assert torch.equal(torch.from_numpy(R.resize_bicubic_u8(c["img"].numpy(), oh, ow)), c["img_resized"]), (tuple(c["img"].shape), oh, ow)
+        assert torch.equal(torch.from_numpy(R.resize_nearest_u8(c["mask"].numpy(), oh, ow)), c["mask_resized"]), (tuple(c["mask"].shape), oh, ow)
+    # the product's host-side tables are the same numbers
+    from joligen_amd.data_device import pil_bicubic_tables, pil_nearest_table
+
+    for a, b in ((56, 32), (29, 48), (64, 24), (96, 71)):
+        bo, kk = R.precompute_coeffs(a, b)
+        pb, pk = pil_bicubic_tables(a, b)
+        assert torch.equal(pb, torch.from_numpy(bo)) and torch.equal(pk, torch.from_numpy(kk))
+        assert torch.equal(pil_nearest_table(a, b).long(), torch.from_numpy(R.nearest_index_table(a, b)))
+
+
 # ---- the committed fixtures regenerate from the committed recipes (VERDICT r2 weak #2) ------------------------------------------------
-RECIPES = ["make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
+RECIPES = ["make_golden_resize.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
            "make_golden_projd.py", "make_golden_resattn.py", "make_golden_sampling.py", "make_golden_segformer.py"]
 
 
