@@ -78,7 +78,7 @@ def check_update(tag, before, after, ref_before, ref_after, cos_min, skip=lambda
     for c, r, n, k in table:
         if n >= 512:
             assert r > 0.5, (tag, "tensor did not move", k, r)
-            assert c > 0.0, (tag, "tensor moved against the oracle's update", k, c)
+            assert c > 0.5, (tag, "tensor moved across / against the oracle's update", k, c)      # observed >= 0.77 (CUT), >= 0.9 (palette / cm)
     return cos, ratio
 
 

@@ -237,9 +237,11 @@ def test_first_step_gradients_vs_oracle_medium(golden_dir, dtype_name):
     assert med < 1.5e-2, med
 
 
-def _first_step_vs_oracle(c, dtype_name, golden_dir, tag, seed=5):
+def _first_step_vs_oracle(c, dtype_name, golden_dir, tag, seed=5, with_floor=False):
     """loss, noise_hat and every parameter gradient of the first step of configuration `c` against the CPU oracle;
-    returns [(relative error, name)] sorted worst first and writes the table to gpurun_out/grad_table_<tag>.txt"""
+    returns [(relative error, name)] sorted worst first and writes the table to gpurun_out/grad_table_<tag>.txt.
+    with_floor: also the rounding floor of THIS case, measured on the spot (the oracle with 16-bit storage of activations, activation
+    gradients and convolution weights, `activation_rounding`): returned as the sorted list of its per-parameter errors."""
     model = make_model(c, dtype_name, golden_dir, train_G_ema=False)
     net = model.netG_A
     B, S = c["B"], c["S"]
@@ -273,6 +275,16 @@ def _first_step_vs_oracle(c, dtype_name, golden_dir, tag, seed=5):
     with open(f"gpurun_out/grad_table_{tag}.txt", "w") as f:
         f.write(f"loss {loss:.6f} oracle {float(loss_ref):.6f}\n" + "\n".join(table))
     worst.sort(reverse=True)
+    if with_floor:
+        sd16 = {k: (v.to(dtype).float() if (torch.is_floating_point(v) and v.dim() >= 3) else v) for k, v in sd.items()}
+        tr16 = O.OraclePaletteTrainer(sd16, cfg_of(c), ema_beta=None)
+        tr16.grad_scale = scale
+        with O.activation_rounding(dtype):
+            _, grads16, _ = tr16.loss_and_grads(Bimg, A, mask, noise, t, u)
+        fl = sorted((float((grads16[k] - grads_ref[k]).norm() / (grads_ref[k].norm() + noise_floor(k, ref_norms, dtype) + 1e-12)) for k in grads_ref), reverse=True)
+        with open(f"gpurun_out/grad_table_{tag}.txt", "a") as f:
+            f.write(f"\n# rounding floor of this case: worst {fl[0]:.3e} median {fl[len(fl) // 2]:.3e} | HIP worst {worst[0][0]:.3e} median {sorted(e for e, _ in worst)[len(worst) // 2]:.3e}")
+        return loss, float(loss_ref), worst, fl
     return loss, float(loss_ref), worst
 
 
@@ -303,6 +315,17 @@ def test_first_step_gradients_vs_oracle_baseline_shapes(golden_dir, cname, c, dt
         assert med < 1.5 * y["grad_median"], (med, y)
         assert worst[0][0] < 2.0 * y["grad_worst"], (worst[:4], y)
         assert abs(loss - loss_ref) / loss_ref < max(4.0 * y["loss_rel"], 3e-4), (loss, loss_ref, y)
+
+
+@pytest.mark.parametrize("cname,c", [("c2_noeff_bf16", C2_NOEFF), ("c4_512_bf16", C4)])
+def test_first_step_gradients_bf16_vs_measured_floor(golden_dir, cname, c):
+    """bf16 -- the bench dtype -- on the non-efficient C2 and the 512x512 C4 architectures: every gradient against the
+    CPU oracle, bounded by the rounding floor of the same case measured on the spot instead of a loose fixed tolerance"""
+    loss, loss_ref, worst, fl = _first_step_vs_oracle(c, "bf16", golden_dir, cname, with_floor=True)
+    assert abs(loss - loss_ref) < 3e-2 * loss_ref, (loss, loss_ref)
+    med = sorted(e for e, _ in worst)[len(worst) // 2]
+    assert worst[0][0] <= 2.0 * fl[0], (worst[:4], fl[:3])
+    assert med <= 1.5 * fl[len(fl) // 2], (med, fl[len(fl) // 2])
 
 
 @pytest.mark.parametrize("lossname", ["L1", "multiscale_L1", "multiscale_MSE"])

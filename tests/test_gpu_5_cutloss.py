@@ -571,7 +571,7 @@ def test_cut_c3_shape_first_step_gradients_vs_oracle():
 
     ref, lo = oracle(False)
     rnd, _ = oracle(True)
-    losses = {k: float(v) for k, v in model.get_current_losses().items()}
+    losses = {k: float(getattr(model, "loss_" + k)) for k in ("G_GAN_D_B_basic", "G_GAN_D_B_projected_d", "G_NCE", "G_NCE_Y")}   # the D group has not run
     for ok, rk in (("G_GAN", "G_GAN_D_B_basic"), ("G_GAN_PD", "G_GAN_D_B_projected_d"), ("G_NCE", "G_NCE"), ("G_NCE_Y", "G_NCE_Y")):
         assert abs(losses[rk] - lo[ok]) <= 6e-3 * abs(lo[ok]) + 2e-3, (rk, losses[rk], lo[ok])
     ls = model.loss_scale

@@ -1,0 +1,34 @@
+"""dev: which python call sites issue aten::copy_ / fill_ / elementwise ATen kernels inside one palette training step (torch.profiler stacks)"""
+import os
+import sys
+from collections import Counter
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse
+
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+import bench
+
+args = argparse.Namespace(model="palette", efficient=1, size=256, batch=32, dtype="bf16", netG="resnet", netDs="basic", force_exchange=False)
+model, opt = bench.build_model(args, 0, 0, 1)
+batch = bench.synth_batch(32, 256, 1234, torch.device("cuda:0"))
+for _ in range(3):
+    model.set_input(batch)
+    model.optimize_parameters()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    model.set_input(batch)
+    model.optimize_parameters()
+    torch.cuda.synchronize()
+cnt = Counter()
+for ev in prof.events():
+    if ev.name.startswith("aten::") and ev.name not in ("aten::empty", "aten::view", "aten::slice", "aten::as_strided", "aten::empty_like", "aten::empty_strided",
+                                                          "aten::select", "aten::reshape", "aten::permute", "aten::detach", "aten::alias", "aten::narrow", "aten::_unsafe_view",
+                                                          "aten::expand", "aten::unsqueeze", "aten::squeeze", "aten::transpose", "aten::t", "aten::to", "aten::resize_",
+                                                          "aten::lift_fresh", "aten::is_nonzero", "aten::item", "aten::_local_scalar_dense", "aten::contiguous", "aten::stride"):
+        st = [s for s in (ev.stack or []) if "joligen_amd" in s or "bench.py" in s]
+        cnt[(ev.name, st[0].strip() if st else "?")] += 1
+for (name, site), n in cnt.most_common(40):
+    print(f"{n:5d} {name:28s} {site[:150]}")
