@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
     } else {
       wait_vmcnt<0>();
     }
-    __builtin_amdgcn_s_barrier();
+    if (!(dbg & 8)) __builtin_amdgcn_s_barrier();              // JG_HALO_DBG 8 (with 4): timing without the per-tile barriers
     const int boff = buf * (BUF_CH * 16);
     if (dbg & 2) {                                            // JG_HALO_DBG 2: timing without the MFMAs and fragment reads
       __builtin_amdgcn_s_barrier();
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
         for (int i = 0; i < CPW; ++i) acc[t9][i] = Mfma<T>::run(fa[i], fb, acc[t9][i]);
       }
     }
-    __builtin_amdgcn_s_barrier();
+    if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
   }
 
   // ---- epilogue: D row = co = g*4 + q, col = ci = i16 ----------------------------------------------------
