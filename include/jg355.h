@@ -101,6 +101,12 @@ typedef struct {
    * input gradient of `conv(Upsample(h))` w.r.t. h, without the full-resolution gradient in between.  No bias / res / stats;
    * halo-resident 3x3 kernel only, else JG_ERR_UNSUPPORTED. */
   int32_t y_mode;
+  /* optional fp32 scratch for the split-K form of the generic kernel (16-byte aligned, ws_bytes long, contents irrelevant on entry and
+   * on return).  Layers with few output tiles and a long reduction -- the discriminators' 4x4 stride-2 convolutions at 16x16 .. 4x4
+   * (projected_d/discriminator.py DownBlock / SingleDisc, NLayerDiscriminator's last layers) -- leave most of the 256 CUs idle with one
+   * workgroup per output tile; with a workspace the launch is cut into K slices whose partial tiles are summed in slice order by a
+   * second, element-wise launch: same result on every run.  NULL = never split.  Not combined with stats / res_mode 1. */
+  void* ws; int64_t ws_bytes;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
 /* Folded weights of x_mode 2 from the fp32 master weights w32 [Cout][3][3][Cin]: out[py*2+px][co][a][b][ci] (dtype) = sum of the

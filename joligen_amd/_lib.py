@@ -30,7 +30,7 @@ class ConvArgs(C.Structure):
         + [(n, c_i64) for n in ("ldx", "ldw", "ldy", "ldres")]
         + [(n, c_i32) for n in ("nbatch", "nh")]
         + [(n, c_i64) for n in ("sxb", "sxh", "swb", "swh", "syb", "syh", "srb", "srh")]
-        + [("alpha", c_f32), ("res_scale", c_f32), ("out_f32", c_i32), ("stats", c_p), ("ldstats", c_i64), ("stats_slots", c_i32), ("stats_mode", c_i32), ("gn_x", c_p), ("gn_ldx", c_i64), ("gn_ab", c_p), ("gn_act", c_i32), ("pad_mode", c_i32), ("res_mode", c_i32), ("x_mode", c_i32), ("y_mode", c_i32)]
+        + [("alpha", c_f32), ("res_scale", c_f32), ("out_f32", c_i32), ("stats", c_p), ("ldstats", c_i64), ("stats_slots", c_i32), ("stats_mode", c_i32), ("gn_x", c_p), ("gn_ldx", c_i64), ("gn_ab", c_p), ("gn_act", c_i32), ("pad_mode", c_i32), ("res_mode", c_i32), ("x_mode", c_i32), ("y_mode", c_i32), ("ws", c_p), ("ws_bytes", c_i64)]
     )
 
 

@@ -28,6 +28,9 @@ struct ConvP {
                   // 2: the same convolution in its sub-pixel form (four 2x2-tap phases, folded weights)
   int res_up;     // 1: res is [B, Ho/2, Wo/2, N] and is read through the nearest-upsample index map (UNet up-block skip path)
   int reflect;    // 1: out-of-image halo pixels mirror the interior (nn.ReflectionPad2d(1) in front of a pad-0 3x3 conv)
+  // split-K of the generic LDS-DMA kernel (gemm_nt.hip): splitk > 1 = blockIdx.y owns a slice of the K loop and stores its raw fp32
+  // partial tile to ws[((split * nbatch + z) * M + m) * N + n]; jg_splitk_finalize sums the slices in a fixed order (deterministic)
+  float* ws; int splitk;
 };
 
 // output pixel row m = (b * Ho + oh) * Wo + ow  ->  row of the half-resolution residual

@@ -243,10 +243,15 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
     iw0[i] = ow * p.stride - p.pad;
     pb[i] = b * p.H;
   }
-  int c = (kc * 8) % p.Cin;
-  int rs0 = (kc * 8) / p.Cin;
+  // split-K: blockIdx.y owns K-steps [ks0, ks1)
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int kper = (nk_all + p.splitk - 1) / p.splitk;
+  const int ks0 = blockIdx.y * kper;
+  const int nk = min(nk_all, ks0 + kper) - ks0;       // <= 0: this slice stores zeros
+  long kg = (long)ks0 * BK + kc * 8;
+  int c = (int)(kg % p.Cin);
+  int rs0 = (int)(kg / p.Cin);
   int r = rs0 / p.S, s = rs0 % p.S;
-  long kg = kc * 8;
   const T* zp = reinterpret_cast<const T*>(&jg_zero_page);
 
   typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -306,8 +311,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  issue_loads(0);
+  if (nk > 0) issue_loads(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int ks = 0; ks < nk; ++ks) {
@@ -321,6 +325,20 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
     __syncthreads();
   }
 
+  if (p.splitk > 1) {     // raw fp32 partial sums of this K slice; alpha / bias / residual / rounding happen in jg_splitk_finalize
+    float* wsb = p.ws + ((long)blockIdx.y * gridDim.z + z) * p.M * p.N;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WM + i * 16 + (lane & 15);
+        if (m < p.M) *reinterpret_cast<float4*>(wsb + (long)m * p.N + n) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+      }
+    }
+    return;
+  }
   if constexpr (sizeof(sm) >= 4 * 16384 && TN == 4 && TM == 4) {
     if (!p.out_f32 && (p.N & 7) == 0) {
       // LDS-transposed epilogue with full-line residual reads / stores (conv_epilogue.h); all waves are past the
@@ -388,14 +406,69 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
   }
 }
 
+// y = alpha * sum over the K slices (in slice order) + bias + res_scale * res, one thread per 4 output channels
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(ConvP p, int nbatch) {
+  const long n4 = p.N >> 2;
+  const long total = (long)nbatch * p.M * n4;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n = (int)(idx % n4) * 4;
+  const long zm = idx / n4;
+  const long m = zm % p.M;
+  const int z = (int)(zm / p.M);
+  const int zb = z / p.nh, zh = z % p.nh;
+  const long slice = (long)nbatch * p.M * p.N;
+  const float* src = p.ws + (long)z * p.M * p.N + m * p.N + n;
+  float4 a = *reinterpret_cast<const float4*>(src);
+  for (int sp = 1; sp < p.splitk; ++sp) {
+    const float4 b = *reinterpret_cast<const float4*>(src + sp * slice);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float v[4] = {p.alpha * a.x, p.alpha * a.y, p.alpha * a.z, p.alpha * a.w};
+  if (p.bias) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += p.bias[n + q];
+  }
+  if (p.res) {
+    const T* resb = (const T*)p.res + zb * p.srb + zh * p.srh;
+    float rf[4];
+    unpack4<T>(*reinterpret_cast<const uint2*>(resb + m * p.ldres + n), rf);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] += p.res_scale * rf[q];
+  }
+  char* yb = p.y + (zb * p.syb + zh * p.syh) * (p.out_f32 ? 4 : 2);
+  if (p.out_f32) *reinterpret_cast<float4*>((float*)yb + m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+  else *reinterpret_cast<uint2*>((T*)yb + m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+}
+
+// K slices for a launch of `blocks` workgroups over `nk` K-steps: fill ~256 CUs, keep >= 4 K-steps per slice
+static int pick_conv_splitk(long blocks, int nk, long out_elems, long ws_bytes) {
+  if (blocks >= 128 || nk < 16) return 1;
+  int sk = (int)((256 + blocks - 1) / blocks);
+  if (sk > nk / 4) sk = nk / 4;
+  if (sk > 32) sk = 32;
+  while (sk > 1 && (long)sk * out_elems * 4 > ws_bytes) --sk;
+  return sk < 2 ? 1 : sk;
+}
+
 template <typename T, int BM, int BN, int BK, int WMv, int WNv>
-void launch_glds(const ConvP& p, int nbatch, hipStream_t st) {
-  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, nbatch);
+void launch_glds(ConvP p, int nbatch, hipStream_t st, long ws_bytes = 0) {
+  const long blocks = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * nbatch;
+  p.splitk = 1;
+  if (p.ws && !p.stats && !p.res_up && (p.N & 3) == 0 && jg_tune(JG_TUNE_CONV_SPLITK))
+    p.splitk = pick_conv_splitk(blocks, (p.K + BK - 1) / BK, (long)nbatch * p.M * p.N, ws_bytes);
+  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.splitk, nbatch);
   hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, st, p);
+  if (p.splitk > 1) {
+    jg_note_kernel(BN == 64 ? "conv_nt_glds_kernel<256,64,64,4,1>+splitK" : "conv_nt_glds_kernel<128,128,64,2,2>+splitK");
+    const long total = (long)nbatch * p.M * (p.N >> 2);
+    hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, nbatch);
+  }
 }
 
 template <typename T>
-int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
+int launch_conv(const ConvP& p, int nbatch, hipStream_t st, long ws_bytes) {
   const int variant = jg_tune(JG_TUNE_CONV_VARIANT);  // 1: register-staged 32-deep; 2..5: LDS-DMA staged (128x128x64 = 3); 6: + halo-resident 3x3
   if (p.stats && variant < 2) return JG_ERR_UNSUPPORTED;
   // streaming (LDS-free) kernels for the HBM-bound shapes first: 1x1 at >= 64k pixels, the 8-channel 3x3 stem, 64 -> 64 3x3 at >= 1M pixels
@@ -414,11 +487,11 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st) {
   if (p.reflect || p.x_up || p.y_pool) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read / pooled stores exist only in the halo-resident kernel
   if (variant >= 2) {
     if (p.N <= 64) {
-      if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st);
+      if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st, ws_bytes);
       else launch_glds<T, 256, 64, 32, 4, 1>(p, nbatch, st);
     } else {
       if (variant == 2) launch_glds<T, 128, 128, 32, 2, 2>(p, nbatch, st);
-      else if (variant == 3 || variant >= 6) launch_glds<T, 128, 128, 64, 2, 2>(p, nbatch, st);
+      else if (variant == 3 || variant >= 6) launch_glds<T, 128, 128, 64, 2, 2>(p, nbatch, st, ws_bytes);
       else if (variant == 4) launch_glds<T, 256, 128, 32, 2, 2>(p, nbatch, st);
       else launch_glds<T, 256, 128, 64, 2, 2>(p, nbatch, st);
     }
@@ -479,5 +552,7 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
     const long hw = (long)a->Ho * a->Wo;
     if (a->nbatch != 1 || a->out_f32 || hw % 256 || a->Cout % 64) return JG_ERR_UNSUPPORTED;
   }
-  JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream););
+  p.ws = (float*)a->ws; p.splitk = 1;
+  if (a->ws && (a->ws_bytes < 0 || ((uintptr_t)a->ws & 15))) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream, a->ws ? (long)a->ws_bytes : 0););
 }

@@ -35,8 +35,13 @@ def _dt(t: torch.Tensor) -> int:
         raise TypeError(f"joligen_amd activations must be float16/bfloat16, got {t.dtype}") from None
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream     # torch.cuda.current_stream() builds a Stream object per call (~8 us): too slow for a per-launch lookup
+_cur_device = torch.cuda.current_device
+
+
 def _st() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """raw hipStream_t of torch's current stream on the current device"""
+    return _raw_stream(_cur_device())
 
 
 def _p(t):
@@ -82,6 +87,18 @@ def _wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode):
     return "wgrad_tn_tr_kernel<1>" if Cout <= 64 else "wgrad_tn_tr_kernel<2>"
 
 
+_CONV_WS = {}               # (device index, stream) -> fp32 scratch of the split-K form of the generic conv kernel (jg_conv_args.ws)
+CONV_WS_BYTES = 32 << 20
+
+
+def _conv_ws(dev):
+    key = (dev.index, _raw_stream(dev.index))
+    ws = _CONV_WS.get(key)
+    if ws is None:
+        ws = _CONV_WS[key] = torch.empty(CONV_WS_BYTES // 4, device=dev, dtype=torch.float32)
+    return ws
+
+
 def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
             ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
             sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0, x_mode=0, y_mode=0):
@@ -106,6 +123,9 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     a.res_mode = res_mode
     a.x_mode = x_mode
     a.y_mode = y_mode
+    if B * Ho * Wo <= 16384 and R * S * Cin >= 1024:      # few output tiles, long reduction: let the library cut the K loop (needs scratch)
+        ws = _conv_ws(x.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), CONV_WS_BYTES
     if gn_reduce is not None:   # (norm input x, pixel stride, ab coefficients, act): GroupNorm-backward reductions in the epilogue
         gx, gldx, gab, gact = gn_reduce
         a.stats_mode, a.gn_x, a.gn_ldx, a.gn_ab, a.gn_act = 1, gx.data_ptr(), gldx, gab.data_ptr(), gact

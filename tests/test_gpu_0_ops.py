@@ -85,6 +85,47 @@ def test_conv_forward(case, dtype):
     assert e2 < TOL[dtype], (case, dtype, e2)
 
 
+SPLITK_CASES = [
+    # B, H, W, Cin, Cout, k, pad, stride, kernel instance the dispatch must report        (discriminator shapes: few output tiles, long reduction)
+    (4, 7, 7, 512, 8, 4, 1, 1, "conv_nt_glds_kernel<256,64,64,4,1>+splitK"),       # SingleDisc / NLayerD final conv: one output channel (padded to 8)
+    (2, 16, 16, 256, 256, 4, 1, 2, "conv_nt_glds_kernel<128,128,64,2,2>+splitK"),  # DownBlock 4x4 stride 2
+    (3, 8, 8, 512, 192, 4, 1, 2, "conv_nt_glds_kernel<128,128,64,2,2>+splitK"),    # ragged N tile (192 of 256), 48 output pixels
+    (1, 4, 4, 1024, 64, 1, 0, 1, "conv_nt_glds_kernel<256,64,64,4,1>+splitK"),     # 1x1, K = 1024: exactly 16 K-steps
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", SPLITK_CASES)
+def test_conv_splitk_small_output(case, dtype):
+    """jg_conv_args.ws: the split-K form of the generic kernel (K slices -> fp32 partial tiles -> ordered sum + bias + residual) against the
+    fp32 reference, against the unsplit launch (JG_CONV_SPLITK 0), and run twice (the slice sum has a fixed order: bit-identical)."""
+    from joligen_amd import _lib, ops
+
+    B, H, W, Cin, Cout, k, pad, stride, inst = case
+    x = rnd((B, Cin, H, W), dtype, 11)
+    w = rnd((Cout, Cin, k, k), dtype, 12, 1.0 / math.sqrt(Cin * k * k))
+    bias = rnd((Cout,), torch.float32, 13)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = rnd((B, Cout, Ho, Wo), dtype, 14)
+    ref = 0.5 * F.conv2d(x.float(), w.float(), None, stride, pad) + bias.view(1, -1, 1, 1) + 0.7 * res.float()
+    d = dev()
+    args = (nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d), bias.to(d), nhwc(res).to(d), pad, stride, 0.5, 0.7)
+    y = torch.ops.jg355.conv2d_nt(*args)
+    assert _lib.lib().jg_last_kernel().decode() == inst
+    y_again = torch.ops.jg355.conv2d_nt(*args)
+    _lib.set_tuning("JG_CONV_SPLITK", 0)
+    try:
+        y_one = torch.ops.jg355.conv2d_nt(*args)
+        assert "splitK" not in _lib.lib().jg_last_kernel().decode()
+    finally:
+        _lib.set_tuning("JG_CONV_SPLITK", 1)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y_again)
+    e = relerr(nchw(y), ref)
+    assert e < TOL[dtype], (case, dtype, e)
+    assert relerr(y, y_one) < TOL[dtype]       # same products, another summation order ahead of the one 16-bit rounding
+
+
 def _make_conv_module(Cin, Cout, k, pad, dtype, real_cin=None, real_cout=None, needs_dgrad=True):
     """A JGConv2d inside a tiny module finalised by a ParamArena (exercises padding + refresh)."""
     import torch.nn as nn
