@@ -461,7 +461,8 @@ void launch_glds(ConvP p, int nbatch, hipStream_t st, long ws_bytes = 0) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.splitk, nbatch);
   hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, st, p);
   if (p.splitk > 1) {
-    jg_note_kernel(BN == 64 ? "conv_nt_glds_kernel<256,64,64,4,1>+splitK" : "conv_nt_glds_kernel<128,128,64,2,2>+splitK");
+    jg_note_kernel(BM == 64 ? "conv_nt_glds_kernel<64,64,64,2,2>+splitK" : BN == 32 ? "conv_nt_glds_kernel<256,32,64,4,1>+splitK"
+                   : BN == 64 ? "conv_nt_glds_kernel<256,64,64,4,1>+splitK" : "conv_nt_glds_kernel<128,128,64,2,2>+splitK");
     const long total = (long)nbatch * p.M * (p.N >> 2);
     hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p, nbatch);
   }
@@ -486,7 +487,21 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st, long ws_bytes) {
   }
   if (p.reflect || p.x_up || p.y_pool) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read / pooled stores exist only in the halo-resident kernel
   if (variant >= 2) {
-    if (p.N <= 64) {
+    // small launches (SegFormer / EfficientNet linear layers, discriminator tails): the default tiles leave most CUs without a workgroup
+    // -- 64 x 64 tiles quadruple the block count (their lower MFMA efficiency does not matter at these sizes); the K loop is cut on top
+    // of that when a workspace came along
+    const long b128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nbatch;
+    const long b256 = (long)((p.M + 255) / 256) * ((p.N + 63) / 64) * nbatch;
+    // (a long K loop is better served by the default tile cut into K slices: 55 vs 113 us on 512 -> 256, 4x4, 16x16 x 16 images)
+    const bool can_split = p.ws && !p.stats && !p.res_up && (p.K + 63) / 64 >= 16 && jg_tune(JG_TUNE_CONV_SPLITK);
+    const bool small = (variant == 3 || variant >= 6) && jg_tune(JG_TUNE_CONV_SMALL_TILE) && (p.N <= 64 ? b256 : b128) < 160 && !can_split;
+    if (small) {
+      jg_note_kernel("conv_nt_glds_kernel<64,64,64,2,2>");
+      launch_glds<T, 64, 64, 64, 2, 2>(p, nbatch, st, ws_bytes);
+    } else if (p.N <= 32 && (variant == 3 || variant >= 6) && jg_tune(JG_TUNE_CONV_SMALL_TILE)) {
+      jg_note_kernel("conv_nt_glds_kernel<256,32,64,4,1>");      // <= 32 output channels (7x7 content / output heads): no half-empty 64-wide tile
+      launch_glds<T, 256, 32, 64, 4, 1>(p, nbatch, st, ws_bytes);
+    } else if (p.N <= 64) {
       if (variant == 3 || variant >= 6) launch_glds<T, 256, 64, 64, 4, 1>(p, nbatch, st, ws_bytes);
       else launch_glds<T, 256, 64, 32, 4, 1>(p, nbatch, st);
     } else {

@@ -87,7 +87,7 @@ def test_conv_forward(case, dtype):
 
 SPLITK_CASES = [
     # B, H, W, Cin, Cout, k, pad, stride, kernel instance the dispatch must report        (discriminator shapes: few output tiles, long reduction)
-    (4, 7, 7, 512, 8, 4, 1, 1, "conv_nt_glds_kernel<256,64,64,4,1>+splitK"),       # SingleDisc / NLayerD final conv: one output channel (padded to 8)
+    (4, 7, 7, 512, 8, 4, 1, 1, "conv_nt_glds_kernel<256,32,64,4,1>+splitK"),       # SingleDisc / NLayerD final conv: one output channel (padded to 8)
     (2, 16, 16, 256, 256, 4, 1, 2, "conv_nt_glds_kernel<128,128,64,2,2>+splitK"),  # DownBlock 4x4 stride 2
     (3, 8, 8, 512, 192, 4, 1, 2, "conv_nt_glds_kernel<128,128,64,2,2>+splitK"),    # ragged N tile (192 of 256), 48 output pixels
     (1, 4, 4, 1024, 64, 1, 0, 1, "conv_nt_glds_kernel<256,64,64,4,1>+splitK"),     # 1x1, K = 1024: exactly 16 K-steps
@@ -124,6 +124,41 @@ def test_conv_splitk_small_output(case, dtype):
     e = relerr(nchw(y), ref)
     assert e < TOL[dtype], (case, dtype, e)
     assert relerr(y, y_one) < TOL[dtype]       # same products, another summation order ahead of the one 16-bit rounding
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    (2, 1, 256, 160, 160, 1, 0, 1, "conv_nt_glds_kernel<64,64,64,2,2>"),      # SegFormer linear layer: 8 tiles of 128 x 128 -> 24 of 64 x 64, ragged N
+    (1, 8, 8, 64, 72, 3, 1, 1, "conv_nt_glds_kernel<64,64,64,2,2>"),          # short K loop (9 steps: no split), N = 72: second column tile 8 wide
+    (4, 112, 112, 64, 32, 7, 3, 1, "conv_nt_glds_kernel<256,32,64,4,1>"),     # 7x7 content head: 32-wide tile, 196 tiles
+    (4, 112, 112, 32, 8, 7, 3, 1, "conv_nt_glds_kernel<256,32,64,4,1>"),      # 8 of the 32 columns live
+], ids=["linear160", "n72", "head7x7", "out7x7"])
+def test_conv_generic_small_and_narrow_tiles(case, dtype):
+    """dispatch of the generic LDS-DMA kernel below the halo / streaming kernels' shape limits: 64 x 64 tiles when the default tile would leave
+    most CUs idle, a 32-wide tile for <= 32 output channels; both against the fp32 reference and against the default tiles
+    (JG_CONV_SMALL_TILE 0: same products, same K order per output element -> bit-identical)."""
+    from joligen_amd import _lib
+
+    B, H, W, Cin, Cout, k, pad, stride, inst = case
+    x = rnd((B, Cin, H, W), dtype, 21)
+    w = rnd((Cout, Cin, k, k), dtype, 22, 1.0 / math.sqrt(Cin * k * k))
+    bias = rnd((Cout,), torch.float32, 23)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = rnd((B, Cout, Ho, Wo), dtype, 24)
+    ref = 0.5 * F.conv2d(x.float(), w.float(), None, stride, pad) + bias.view(1, -1, 1, 1) + 0.7 * res.float()
+    d = dev()
+    args = (nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d), bias.to(d), nhwc(res).to(d), pad, stride, 0.5, 0.7)
+    y = torch.ops.jg355.conv2d_nt(*args)
+    assert _lib.lib().jg_last_kernel().decode() == inst
+    _lib.set_tuning("JG_CONV_SMALL_TILE", 0)
+    try:
+        y_def = torch.ops.jg355.conv2d_nt(*args)
+        assert _lib.lib().jg_last_kernel().decode() != inst
+    finally:
+        _lib.set_tuning("JG_CONV_SMALL_TILE", 1)
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), ref) < TOL[dtype], (case, dtype)
+    assert torch.equal(y, y_def)
 
 
 def _make_conv_module(Cin, Cout, k, pad, dtype, real_cin=None, real_cout=None, needs_dgrad=True):
