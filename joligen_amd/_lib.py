@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libjg355.so")
-SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "conv_p64.hip", "conv1x1.hip", "gemm_tn.hip", "wgrad_halo.hip", "nce.hip", "segformer.hip", "projected_d.hip", "effnet.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
+SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "conv_p64.hip", "conv1x1.hip", "gemm_tn.hip", "wgrad_halo.hip", "wgrad_kxk.hip", "nce.hip", "segformer.hip", "projected_d.hip", "effnet.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
 
 JG_F16, JG_BF16 = 0, 1

@@ -460,7 +460,7 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   p.x_up = a->x_mode == 1;
   if (p.x_up && (p.reflect || (a->H & 1) || (a->W & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;
   const int variant = jg_tune(JG_TUNE_WGRAD_VARIANT);  // 1: register transpose; 2: transposing LDS reads; 3: 2 with 128-row tiles only; 4: + halo-resident 3x3
-  if (variant >= 4 && jg_wgrad_halo_try(dtype, p, a->nbatch, (hipStream_t)stream)) {
+  if (variant >= 4 && (jg_wgrad_halo_try(dtype, p, a->nbatch, (hipStream_t)stream) || jg_wgrad_kxk_try(dtype, p, a->nbatch, (hipStream_t)stream))) {
     JG_CHECK_LAUNCH();
     return JG_OK;
   }

@@ -20,3 +20,5 @@ struct WgP {
 
 // wgrad_halo.hip: returns true when the shape was handled by the halo-resident 3x3 kernel.
 bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st);
+// wgrad_kxk.hip: returns true when the shape was handled by the halo-resident large-kernel (7x7) weight-gradient kernel.
+bool jg_wgrad_kxk_try(int dtype, const WgP& p, int nbatch, hipStream_t st);

@@ -195,13 +195,14 @@ class ConvMeta:
         return ((H + 2 * self.pad - self.R) // self.stride + 1, (W + 2 * self.pad - self.S) // self.stride + 1)
 
 
-WGRAD_TARGET_BLOCKS = 1536
+WGRAD_TARGET_BLOCKS = int(os.environ.get("JG_WGRAD_TARGET_BLOCKS", "1536"))
 WGRAD_MAX_SPLITK = 512  # deeper splits only add atomic traffic on a tiny output
+WGRAD_SPLIT_PIX = int(os.environ.get("JG_WGRAD_SPLIT_PIX", "256"))     # fewest pixels a K slice of the weight gradient is worth
 
 
 def _wgrad_splitk(tiles, mpix, nbatch=1):
     want = max(1, (WGRAD_TARGET_BLOCKS + tiles - 1) // tiles)
-    cap = max(1, mpix // 256)
+    cap = max(1, mpix // WGRAD_SPLIT_PIX)
     return max(1, min(want, cap, WGRAD_MAX_SPLITK, 65535 // max(1, nbatch)))
 
 

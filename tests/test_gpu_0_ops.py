@@ -137,7 +137,7 @@ def test_conv_generic_small_and_narrow_tiles(case, dtype):
     """dispatch of the generic LDS-DMA kernel below the halo / streaming kernels' shape limits: 64 x 64 tiles when the default tile would leave
     most CUs idle, a 32-wide tile for <= 32 output channels; both against the fp32 reference and against the default tiles
     (JG_CONV_SMALL_TILE 0: same products, same K order per output element -> bit-identical)."""
-    from joligen_amd import _lib
+    from joligen_amd import _lib, ops  # noqa: F401  (ops registers torch.ops.jg355)
 
     B, H, W, Cin, Cout, k, pad, stride, inst = case
     x = rnd((B, Cin, H, W), dtype, 21)
@@ -385,6 +385,50 @@ def test_wgrad_halo_forced_configs(cfg, inst, shape, dtype):
         _lib.set_tuning("JG_WGRAD_HALO_CFG", prev)
     assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype], (inst, relerr(m.c.weight.grad, wr.grad))
     assert relerr(m.c.bias.grad, br.grad) < TOL[dtype], (inst, relerr(m.c.bias.grad, br.grad))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,real_cout,pad", [(4, 134, 134, 64, 32, 27, 0),      # content head behind ReflectionPad2d(3): pad 0, 134 -> 128
+                                                       (2, 128, 256, 128, 32, 32, 3),     # zero padding inside the kernel, two input chunks, W != H
+                                                       (4, 128, 128, 64, 8, 3, 3)])       # output head: 3 (8) output channels of the 32-wide tile
+def test_wgrad_7x7_halo_kernel(B, H, W, Cin, Cout, real_cout, pad, dtype):
+    """wgrad_kxk.hip (7x7 weight gradient, halo-resident, groups of two tap rows) against autograd of F.conv2d in fp32, and against the
+    im2col kernel it replaces (JG_WGRAD_VARIANT 3: same products, another summation order).  Called on this thread (jg_last_kernel is
+    per thread; a backward() would launch from autograd's worker)."""
+    from joligen_amd import _lib, ops
+
+    Ho, Wo = H + 2 * pad - 6, W + 2 * pad - 6
+    x = rnd((B, Cin, H, W), dtype, 31)
+    gy = rnd((B, real_cout, Ho, Wo), dtype, 32)
+    wr = (rnd((real_cout, Cin, 7, 7), dtype, 33, 1.0 / math.sqrt(Cin * 49))).float().requires_grad_(True)
+    br = torch.zeros(real_cout, requires_grad=True)
+    F.conv2d(x.float(), wr, br, 1, pad).backward(gy.float())
+    d = dev()
+    gyd = torch.zeros(B, Ho, Wo, Cout, dtype=dtype)          # channels real_cout .. Cout-1: the zero padding of the activation layout
+    gyd[..., :real_cout] = nhwc(gy)
+    gyd, xd = gyd.to(d), nhwc(x).to(d)
+
+    def run():
+        dw = torch.zeros(real_cout, 7, 7, Cin, device=d)
+        db = torch.zeros(real_cout, device=d)
+        ops.wgrad_tn(gyd, xd, dw, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=7, S=7, pad=pad, stride=1, Ho=Ho, Wo=Wo, lddy=Cout, ldx=Cin, lddw=49 * Cin,
+                     dbias=db, Cin_out=Cin, Cout_out=real_cout, splitk=ops._wgrad_splitk(((Cout + 127) // 128) * ((49 * Cin + 127) // 128), B * Ho * Wo),
+                     dbias_scale=1.0)
+        return dw, db, _lib.lib().jg_last_kernel().decode()
+
+    gw, gb, name = run()
+    assert name == "wgrad_kxk_halo_kernel<7x7,2 tap rows>"
+    prev = _lib.set_tuning("JG_WGRAD_VARIANT", 3)
+    try:
+        gw3, gb3, name3 = run()
+    finally:
+        _lib.set_tuning("JG_WGRAD_VARIANT", prev)
+    torch.cuda.synchronize()
+    assert "kxk" not in name3
+    ref_w = wr.grad.permute(0, 2, 3, 1)
+    assert relerr(gw, ref_w) < TOL[dtype], relerr(gw, ref_w)
+    assert relerr(gb, br.grad) < TOL[dtype], relerr(gb, br.grad)
+    assert relerr(gw, gw3) < 1e-4 and relerr(gb, gb3) < 1e-4
 
 
 def test_wgrad_halo_bench_splitk():
