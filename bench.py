@@ -342,10 +342,20 @@ def cut_leg(local_rank, no_cpu):
     recs, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     table = kernel_table(recs, 1)
     dom = max(table, key=lambda k: table[k]["time_per_step_ms"])
-    roof = dict(table[dom], kernel=dom, traffic=None,
-                measured="HIP events around every convolution-family launch of one instrumented step (the SegFormer step is ~2500 launches of "
-                         "10 - 30 us: dispatch-bound next to its HBM-bound streaming kernels, DESIGN.md 11); achieved = algorithmic bytes (or FLOPs) "
-                         "of the dominant instance / its summed launch time",
+    # HBM traffic of the dominant instance: the committed rocprofv3 PMC passes of this step (profiles/r03_cut_pmc.json, tools/collect_evidence.sh)
+    traffic, traffic_build, traffic_file = None, None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_cut_pmc.json")))
+        row = pmc.get(dom) or pmc.get(dom.split("<")[0])
+        if row:
+            traffic, traffic_build, traffic_file = round(row["bytes_per_launch"], 1), pmc.get("_meta", {}).get("build"), "profiles/r03_cut_pmc.json"
+    except Exception:
+        pass
+    roof = dict(table[dom], kernel=dom, traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
+                traffic_source=traffic_file, traffic_build=traffic_build, running_build="csrc sha1 " + csrc_sha(),
+                measured="HIP events around every convolution-family launch of one instrumented step (the step is ~4000 launches of 5 - 30 us: "
+                         "small-problem latency next to a few HBM-bound streaming kernels, DESIGN.md 11); achieved = algorithmic bytes (or FLOPs) "
+                         "of the dominant instance / its summed launch time (events around a 10 us launch include ~5 us of dispatch)",
                 conv_family_ms_per_step=round(sum(r["time_per_step_ms"] for r in table.values()), 3),
                 other_kernels={k: v for k, v in table.items() if k != dom})
     cpu = None if no_cpu else cpu_baseline_subprocess(ns, timeout_s=180)
