@@ -359,7 +359,7 @@ def cut_leg(local_rank, no_cpu):
                 conv_family_ms_per_step=round(sum(r["time_per_step_ms"] for r in table.values()), 3),
                 other_kernels={k: v for k, v in table.items() if k != dom})
     cpu = None if no_cpu else cpu_baseline_subprocess(ns, timeout_s=180)
-    loss = float(model.get_current_losses()["G_tot"])
+    loss = float(model.get_current_losses()["G_tot"].detach())
     return {"metric": "train images/sec at 256x256 (CUT G+D step)", "value": round(ns.batch * steps / dt, 3), "unit": "images/sec",
             "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2], 3), "steps": steps, "warmup": warmup,
             "dtype": "bf16", "data": "synthetic",

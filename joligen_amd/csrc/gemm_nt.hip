@@ -494,11 +494,14 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st, long ws_bytes) {
     const long b256 = (long)((p.M + 255) / 256) * ((p.N + 63) / 64) * nbatch;
     // (a long K loop is better served by the default tile cut into K slices: 55 vs 113 us on 512 -> 256, 4x4, 16x16 x 16 images)
     const bool can_split = p.ws && !p.stats && !p.res_up && (p.K + 63) / 64 >= 16 && jg_tune(JG_TUNE_CONV_SPLITK);
-    const bool small = (variant == 3 || variant >= 6) && jg_tune(JG_TUNE_CONV_SMALL_TILE) && (p.N <= 64 ? b256 : b128) < 160 && !can_split;
+    // stats_mode 1 (GroupNorm-backward reductions in the epilogue) exists only in the LDS-transposed epilogue of the 4 x 4-fragment wave
+    // tiles: those launches keep the default tiles
+    const bool alt_ok = (variant == 3 || variant >= 6) && jg_tune(JG_TUNE_CONV_SMALL_TILE) && !(p.stats && p.stats_mode == 1);
+    const bool small = alt_ok && (p.N <= 64 ? b256 : b128) < 160 && !can_split;
     if (small) {
       jg_note_kernel("conv_nt_glds_kernel<64,64,64,2,2>");
       launch_glds<T, 64, 64, 64, 2, 2>(p, nbatch, st, ws_bytes);
-    } else if (p.N <= 32 && (variant == 3 || variant >= 6) && jg_tune(JG_TUNE_CONV_SMALL_TILE)) {
+    } else if (p.N <= 32 && alt_ok) {
       jg_note_kernel("conv_nt_glds_kernel<256,32,64,4,1>");      // <= 32 output channels (7x7 content / output heads): no half-empty 64-wide tile
       launch_glds<T, 256, 32, 64, 4, 1>(p, nbatch, st, ws_bytes);
     } else if (p.N <= 64) {

@@ -447,17 +447,20 @@ def test_fused_schedule_matches_module_graph(golden_dir, efficient, dtype):
     from joligen_amd.modules import unet_exec
 
     res = {}
-    for fused in (False, True, "no_reduce_fusion"):
-        unet.jg_fused = bool(fused)
-        unet_exec.FUSE_GN_REDUCE = fused is True
-        net.arena.g.zero_()
-        x = x0.clone().requires_grad_(True)
-        emb = emb0.clone().requires_grad_(True)
-        out = unet(x, emb)
-        out.backward(R)
-        torch.cuda.synchronize()
-        res[fused] = (out.detach().float(), x.grad.float(), emb.grad.clone(), net.arena.g.clone())
-    unet_exec.FUSE_GN_REDUCE = True
+    keep = unet_exec.FUSE_GN_REDUCE          # (off by default, DESIGN.md 13: the flag must not leak into the tests that follow)
+    try:
+        for fused in (False, True, "no_reduce_fusion"):
+            unet.jg_fused = bool(fused)
+            unet_exec.FUSE_GN_REDUCE = fused is True
+            net.arena.g.zero_()
+            x = x0.clone().requires_grad_(True)
+            emb = emb0.clone().requires_grad_(True)
+            out = unet(x, emb)
+            out.backward(R)
+            torch.cuda.synchronize()
+            res[fused] = (out.detach().float(), x.grad.float(), emb.grad.clone(), net.arena.g.clone())
+    finally:
+        unet_exec.FUSE_GN_REDUCE = keep
     # GroupNorm-backward reductions in the dgrad epilogue vs the separate reduction pass: same sums
     assert relerr(res[True][3], res["no_reduce_fusion"][3]) < TOL_OUT[dtype], relerr(res[True][3], res["no_reduce_fusion"][3])
     tol = 4 * TOL_OUT[dtype]
