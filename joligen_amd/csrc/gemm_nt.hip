@@ -201,7 +201,7 @@ __device__ uint4 jg_zero_page = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ int swz128r(int row) { return (row >> 1) & 7; }
 
-template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
   }
   // split-K: blockIdx.y owns K-steps [ks0, ks1)
   const int nk_all = (p.K + BK - 1) / BK;
-  const int kper = (nk_all + p.splitk - 1) / p.splitk;
-  const int ks0 = blockIdx.y * kper;
+  const int kper = SPLIT ? (nk_all + p.splitk - 1) / p.splitk : nk_all;
+  const int ks0 = SPLIT ? blockIdx.y * kper : 0;
   const int nk = min(nk_all, ks0 + kper) - ks0;       // <= 0: this slice stores zeros
   long kg = (long)ks0 * BK + kc * 8;
   int c = (int)(kg % p.Cin);
@@ -325,22 +325,13 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
     __syncthreads();
   }
 
-  if (p.splitk > 1) {     // raw fp32 partial sums of this K slice; alpha / bias / residual / rounding happen in jg_splitk_finalize
-    float* wsb = p.ws + ((long)blockIdx.y * gridDim.z + z) * p.M * p.N;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
-      if (n >= p.N) continue;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int m = m0 + wm * WM + i * 16 + (lane & 15);
-        if (m < p.M) *reinterpret_cast<float4*>(wsb + (long)m * p.N + n) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-      }
-    }
-    return;
-  }
+  // split-K: this K slice's raw fp32 partial tile goes to the workspace through the plain fp32 store path below (no alpha / bias /
+  // residual / statistics: jg_splitk_finalize applies them once to the ordered sum).  SPLIT is a template flag: as a run-time condition
+  // (even a wave-uniform one) it cost the unsplit kernel 64 more VGPRs (264: one wave per SIMD instead of two) and 60 % of its speed.
+  constexpr bool split = SPLIT;
+  const bool of32 = p.out_f32 || split;
   if constexpr (sizeof(sm) >= 4 * 16384 && TN == 4 && TM == 4) {
-    if (!p.out_f32 && (p.N & 7) == 0) {
+    if (!of32 && (p.N & 7) == 0) {
       // LDS-transposed epilogue with full-line residual reads / stores (conv_epilogue.h); all waves are past the
       // last barrier of the K loop, each uses a private 16 KB scratch
       ConvP q = p;
@@ -363,16 +354,20 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
       return;
     }
   }
-  char* yb = p.y + (zb * p.syb + zh * p.syh) * (p.out_f32 ? 4 : 2);
-  const T* resb = p.res ? (const T*)p.res + zb * p.srb + zh * p.srh : nullptr;
+  char* yb = split ? (char*)(p.ws + ((long)blockIdx.y * gridDim.z + z) * p.M * p.N) : p.y + (zb * p.syb + zh * p.syh) * (p.out_f32 ? 4 : 2);
+  const long ldy = split ? (long)p.N : p.ldy;
+  const float alpha = split ? 1.f : p.alpha;
+  const float* bias = split ? nullptr : p.bias;
+  float* stats = split ? nullptr : p.stats;
+  const T* resb = (p.res && !split) ? (const T*)p.res + zb * p.srb + zh * p.srh : nullptr;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + wn * WN + j * 16 + (lane >> 4) * 4;
     if (n >= p.N) continue;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) {
+    if (bias) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bv[q] = p.bias[n + q];
+      for (int q = 0; q < 4; ++q) bv[q] = bias[n + q];
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -381,7 +376,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
       if (m >= p.M) continue;
       float v[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = p.alpha * acc[j][i][q] + bv[q];
+      for (int q = 0; q < 4; ++q) v[q] = alpha * acc[j][i][q] + bv[q];
       if (resb) {
         const long mr = p.res_up ? jg_res_up_row(p, m) : (long)m;
         const uint2 rv = *reinterpret_cast<const uint2*>(resb + mr * p.ldres + n);
@@ -390,10 +385,10 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] += p.res_scale * rf[q];
       }
-      if (p.out_f32) {
-        *reinterpret_cast<float4*>((float*)yb + (long)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+      if (of32) {
+        *reinterpret_cast<float4*>((float*)yb + (long)m * ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
-        *reinterpret_cast<uint2*>((T*)yb + (long)m * p.ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<uint2*>((T*)yb + (long)m * ldy + n) = pack4<T>(v[0], v[1], v[2], v[3]);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -402,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
       }
     }
     // host guarantees (Ho*Wo) % BM == 0 when stats != nullptr: the whole tile belongs to one image
-    if (p.stats) jg_stats_flush(p.stats, ((long)(m0 / (p.Ho * p.Wo)) * p.nslots + (m0 / BM) % p.nslots) * p.ldstats, n, s1, s2, lane);
+    if (stats) jg_stats_flush(stats, ((long)(m0 / (p.Ho * p.Wo)) * p.nslots + (m0 / BM) % p.nslots) * p.ldstats, n, s1, s2, lane);
   }
 }
 
@@ -459,7 +454,8 @@ void launch_glds(ConvP p, int nbatch, hipStream_t st, long ws_bytes = 0) {
   if (p.ws && !p.stats && !p.res_up && (p.N & 3) == 0 && jg_tune(JG_TUNE_CONV_SPLITK))
     p.splitk = pick_conv_splitk(blocks, (p.K + BK - 1) / BK, (long)nbatch * p.M * p.N, ws_bytes);
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.splitk, nbatch);
-  hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, st, p);
+  if (p.splitk > 1) hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv, true>), grid, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv, false>), grid, dim3(256), 0, st, p);
   if (p.splitk > 1) {
     jg_note_kernel(BM == 64 ? "conv_nt_glds_kernel<64,64,64,2,2>+splitK" : BN == 32 ? "conv_nt_glds_kernel<256,32,64,4,1>+splitK"
                    : BN == 64 ? "conv_nt_glds_kernel<256,64,64,4,1>+splitK" : "conv_nt_glds_kernel<128,128,64,2,2>+splitK");
