@@ -34,7 +34,8 @@ const char* jg_strerror(int code);
 
 /* Dispatch switches.  Each switch is read once from the environment variable of the same name
  * ("JG_HALO_CFG", "JG_WGRAD_HALO_CFG", "JG_CONV_VARIANT", "JG_WGRAD_VARIANT", "JG_SINKHORN_GENERIC", "JG_CONV1X1",
- * "JG_GN_REVERSE", "JG_HALO_DBG", "JG_PERSIST64"); jg_set_tuning overrides it for the rest of the process (parity tests use
+ * "JG_GN_REVERSE", "JG_HALO_DBG", "JG_PERSIST64", "JG_HALO_PIPE", "JG_WGRAD_PIPE", "JG_CONV_SPLITK", "JG_CONV_SMALL_TILE");
+ * jg_set_tuning overrides it for the rest of the process (parity tests use
  * it to force a tile configuration that the automatic choice only takes at bench-sized grids).  No reference counterpart:
  * the reference delegates kernel choice to cuDNN's heuristics (torch.backends.cudnn.benchmark, train.py:38-48).
  * Returns JG_OK / JG_ERR_BAD_ARG (unknown name); jg_get_tuning returns the current value or -1. */
