@@ -12,7 +12,7 @@ shapes -- checkpoints interchange both ways.  What differs is the execution:
   * mid-block attention = InstanceNorm1d -> 1x1 conv -> MFMA QK^T -> fp32 softmax -> MFMA PV.
 
 Not implemented (not on the SURVEY.md 8 path, raise at construction): wavelet `freq_space`,
-`use_new_attention_order`, `use_checkpoint`, non-groupnorm norms, dropout p > 0 in training.
+`use_new_attention_order`, `use_checkpoint`, non-groupnorm norms.
 """
 from __future__ import annotations
 
@@ -81,8 +81,6 @@ class ResBlock(EmbedBlock):
         else:
             lin = self.emb_layers[1]
             emb_out = ops.linear(emb, lin.weight, lin.bias, JG_ACT_SILU)
-        if self.dropout and self.training:
-            raise NotImplementedError("dropout > 0 inside ResBlock is not implemented")
         conv1 = self.in_layers[2]
         h = self.in_layers[0](x, act=JG_ACT_SILU)
         if self.updown:
@@ -97,6 +95,15 @@ class ResBlock(EmbedBlock):
         else:
             h = conv1(h)
         h = self.out_layers[0](h, film=emb_out, act=JG_ACT_SILU)  # GN * (1+scale) + shift, SiLU
+        if self.dropout and self.training:
+            # nn.Dropout(p) of out_layers (unet_generator_attn.py:207-215 of the reference): element-wise Bernoulli(1 - p) mask scaled by
+            # 1 / (1 - p), between the activation and the second convolution.  No BASELINE config sets G_dropout / a UNet dropout > 0:
+            # the mask is a torch device op on the module-by-module graph (the fused schedule hands such networks over to it);
+            # `dropout_rand` (callable(shape, device) -> uniforms) injects the draws for parity runs.
+            src = getattr(self, "dropout_rand", None)
+            u = src(h.shape, h.device) if src is not None else torch.rand(h.shape, device=h.device)
+            keep = 1.0 - float(self.dropout)
+            h = h * ((u < keep).to(h.dtype) * (1.0 / keep if keep > 0.0 else 0.0))
         skipw = 1.0 / math.sqrt(2) if self.efficient else 1.0
         if isinstance(self.skip_connection, nn.Identity):
             skip = x
@@ -238,7 +245,8 @@ class UNet(nn.Module):
         With a finalised arena the whole network runs as ONE autograd node on the fused schedule of
         unet_exec.py (same kernels, no concat / statistics / gradient-add passes); `jg_fused = False`
         selects the module-by-module graph below (what the parity tests compare it against)."""
-        if getattr(self, "jg_fused", True) and getattr(self, "_jg_arena_ref", None) is not None and input.is_cuda:
+        drop = bool(self.dropout) and self.training        # dropout > 0 in training: the module-by-module graph (ResBlock.forward) has the mask
+        if getattr(self, "jg_fused", True) and getattr(self, "_jg_arena_ref", None) is not None and input.is_cuda and not drop:
             from .unet_exec import fused_unet
 
             if embed_gammas is None:

@@ -427,6 +427,87 @@ def test_full_size_properties():
         assert relerr(y.float(), ref) < 8e-3, (B, S, Cin, Cout)
 
 
+def test_resblock_dropout_in_training(golden_dir):
+    """`nn.Dropout(p)` of ResBlock.out_layers (reference unet_generator_attn.py:207-215, 262): between SiLU and the second convolution,
+    Bernoulli(1 - p) mask scaled by 1 / (1 - p), training mode only.  Checked against the same network with dropout 0 and the mask applied
+    from outside (a forward pre-hook on the second convolution drawing the SAME uniforms): same output and input gradient;
+    eval mode ignores it; the default source zeroes a fraction p."""
+    from joligen_amd import ops
+    from joligen_amd.modules.unet_generator_attn import ResBlock
+
+    p_drop = 0.25
+    c = dict(ngf=32, mults=[1, 2], res_blocks=[1, 1], attn_res=[], efficient=False, S=32, B=2)
+    net, _ = build_net(c, torch.float16, golden_dir)
+    unet = net.denoise_fn.model
+    net.arena.ensure_fresh()
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    x0 = ops.to_nhwc(torch.randn(c["B"], 6, c["S"], c["S"], generator=g).to(d), torch.float16, 8)
+    emb0 = torch.randn(c["B"], unet.cond_embed_dim, generator=g).to(d)
+    R = ops.to_nhwc(torch.randn(c["B"], 3, c["S"], c["S"], generator=g).to(d), torch.float16, 8)
+    blocks = [m for m in unet.modules() if isinstance(m, ResBlock)]
+    assert len(blocks) >= 5
+    gen = torch.Generator(device=d)
+
+    def src(shape, device):
+        return torch.rand(shape, generator=gen, device=device)
+
+    def set_drop(p, source):
+        unet.dropout = p
+        for rb in blocks:
+            rb.dropout, rb.dropout_rand = p, source
+
+    def run(train=True):
+        unet.train(train)
+        net.arena.g.zero_()
+        x = x0.clone().requires_grad_(True)
+        out = unet(x, emb0.clone())
+        out.backward(R)
+        torch.cuda.synchronize()
+        return out.detach().clone(), x.grad.detach().clone()
+
+    try:
+        set_drop(0.0, None)
+        base_out, base_dx = run()
+        eval_out, _ = run(train=False)
+        # (a) dropout inside the blocks, injected uniforms
+        set_drop(p_drop, src)
+        gen.manual_seed(11)
+        out_a, dx_a = run()
+        # (b) dropout 0, the same mask applied in front of the second convolution from outside
+        set_drop(0.0, None)
+        unet.jg_fused = False
+        zero_frac = []
+
+        def hook(mod, args, kwargs):
+            h = args[0]
+            u = src(h.shape, h.device)
+            zero_frac.append(float((u >= 1.0 - p_drop).float().mean()))
+            return (h * ((u < 1.0 - p_drop).to(h.dtype) * (1.0 / (1.0 - p_drop))),) + tuple(args[1:]), kwargs
+
+        hs = [rb.out_layers[3].register_forward_pre_hook(hook, with_kwargs=True) for rb in blocks]
+        gen.manual_seed(11)
+        out_b, dx_b = run()
+        for h_ in hs:
+            h_.remove()
+        unet.jg_fused = True
+        # (not bit-identical: the GroupNorm statistics are fp32 atomics, their summation order differs from run to run)
+        assert relerr(out_a, out_b) < 2e-3 and relerr(dx_a, dx_b) < 1e-2, (relerr(out_a, out_b), relerr(dx_a, dx_b))
+        assert relerr(out_a, base_out) > 0.05          # it did something
+        assert abs(sum(zero_frac) / len(zero_frac) - p_drop) < 0.02
+        # (c) eval mode: the mask is off, the fused schedule runs
+        set_drop(p_drop, None)
+        eval_drop, _ = run(train=False)
+        assert relerr(eval_drop, eval_out) < 2e-3, relerr(eval_drop, eval_out)
+        # (d) default source: runs, finite, differs from the undropped output
+        out_d, dx_d = run()
+        assert torch.isfinite(out_d.float()).all() and torch.isfinite(dx_d.float()).all() and relerr(out_d, base_out) > 0.05
+    finally:
+        set_drop(0.0, None)
+        unet.jg_fused = True
+        unet.train(True)
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("efficient", [True, False])
 def test_fused_schedule_matches_module_graph(golden_dir, efficient, dtype):
