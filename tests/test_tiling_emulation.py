@@ -530,3 +530,26 @@ def test_subpixel_backward_identities():
                             dW[:, :, r, s] += dwk
     torch.testing.assert_close(dL[:, :, 1:-1, 1:-1], L.grad, rtol=1e-12, atol=1e-12)
     torch.testing.assert_close(dW, w.grad, rtol=1e-12, atol=1e-12)
+
+
+def test_subpixel_input_gradient_is_a_4x4_stride2_convolution():
+    """The gather form of the sub-pixel input gradient: the gradient w.r.t. the LOW-resolution map of
+    conv3x3(Upsample(L)) is ONE 4x4, stride-2, pad-1 convolution of dO whose taps along an axis are [w2, w1 + w2, w0 + w1, w0]
+    (rows 2i-1 .. 2i+2 of dO feed low-resolution row i): the four phase planes of dO accumulate into the same output tile, which is
+    what the halo kernel's K loop over (phase, tap) pairs would execute -- 16 tap-MACs per low-resolution pixel instead of 36."""
+    import torch
+    import torch.nn.functional as F
+
+    g = torch.Generator().manual_seed(2)
+    L = torch.randn(2, 5, 6, 8, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(4, 5, 3, 3, generator=g, dtype=torch.float64)
+    dO = torch.randn(2, 4, 12, 16, generator=g, dtype=torch.float64)
+    F.conv2d(F.interpolate(L, scale_factor=2, mode="nearest"), w, padding=1).backward(dO)
+    fold = [[2], [1, 2], [0, 1], [0]]                       # 4x4 tap u (row 2i-1+u of dO) <- summed original taps
+    K = torch.zeros(5, 4, 4, 4, dtype=torch.float64)        # [Cin (output of this conv)][Cout (its input)][u][v]
+    for u in range(4):
+        for v in range(4):
+            K[:, :, u, v] = w[:, :, fold[u]][:, :, :, fold[v]].sum((2, 3)).t()
+    dL = F.conv2d(dO, K, stride=2, padding=1)
+    torch.testing.assert_close(dL, L.grad, rtol=1e-12, atol=1e-12)
+
