@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import copy
 import json
+import os
 from types import SimpleNamespace
 
 # defaults of the fields the training step reads (reference default in the cited file)
@@ -76,4 +77,30 @@ def opt_from_json(cfg, overrides=None, is_train=True):
         opt.gpu_ids = [int(s) for s in opt.gpu_ids.split(",") if s.strip() != "" and int(s) >= 0]
     # options/train_options.py sanity: G_dropout False -> 0
     opt.G_dropout = float(opt.G_dropout) if not isinstance(opt.G_dropout, bool) else (0.5 if opt.G_dropout else 0.0)
+    # options/train_options.py: resuming a run in place and starting from another run's checkpoints exclude each other
+    if opt.train_continue and opt.train_continue_from:
+        raise ValueError("--train_continue and --train_continue_from are mutually exclusive")
     return opt
+
+
+def get_train_load_suffix(opt):
+    """train.py:92-95: the checkpoint suffix `setup` loads -- `iter_<n>` when train_load_iter > 0, else train_epoch ("latest")"""
+    return "iter_%d" % opt.train_load_iter if opt.train_load_iter > 0 else opt.train_epoch
+
+
+def save_finetune_source_metadata(opt, command_line, model_names):
+    """train.py:98-120: with train_continue_from, record where the run's initial weights came from as
+    `<checkpoints_dir>/<name>/finetune_source.json` (same keys as the reference writes); no-op otherwise."""
+    if not getattr(opt, "train_continue_from", ""):
+        return None
+    suffix = get_train_load_suffix(opt)
+    src = opt.train_continue_from
+    meta = {"train_continue_from": src, "train_continue_from_abs": os.path.abspath(os.path.expanduser(src)), "load_suffix": suffix,
+            "checkpoint_files": [os.path.join(src, "%s_net_%s.pth" % (suffix, n)) for n in model_names if isinstance(n, str)],
+            "command_line": command_line}
+    save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+    os.makedirs(save_dir, exist_ok=True)
+    path = os.path.join(save_dir, "finetune_source.json")
+    with open(path, "w") as f:
+        json.dump(meta, f, indent=4)
+    return path

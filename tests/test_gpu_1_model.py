@@ -406,6 +406,32 @@ def test_checkpoint_roundtrip_reference_layout(golden_dir, tmp_path):
     model.export_networks("latest")       # palette: nothing to export, like the reference
 
 
+def test_train_continue_from_loads_source_run(golden_dir, tmp_path):
+    """The device half of /root/reference/tests/test_train_continue_from.py (`test_train_continue_from_loads_weights_from_source_dir`,
+    `..._uses_train_load_iter_suffix`) on a real model: `setup()` with `train_continue_from=<dir>` loads `<dir>/<suffix>_net_G_A.pth`
+    (suffix = `latest`, or `iter_<n>` with `train_load_iter`), and the run keeps saving under ITS OWN `<checkpoints_dir>/<name>`."""
+    g = load(golden_dir, "palette_step_tiny_eff.pt")
+    ck = str(tmp_path) + "/"
+    src = make_model(g["cfg"], "bf16", golden_dir, checkpoints_dir=ck, name="source_run")
+
+    base = {k: v.clone() for k, v in src.netG_A.state_dict().items()}
+    src.netG_A.load_state_dict({k: (v + 0.25 if v.is_floating_point() and not O._is_buffer(k) else v) for k, v in base.items()})
+    src.save_networks("latest")
+    src.netG_A.load_state_dict({k: (v + 0.5 if v.is_floating_point() and not O._is_buffer(k) else v) for k, v in base.items()})
+    src.save_networks("iter_123")
+    source_dir = os.path.join(ck, "source_run")
+    for extra, suffix in ((dict(), "latest"), (dict(train_load_iter=123), "iter_123")):
+        tgt = make_model(g["cfg"], "bf16", golden_dir, checkpoints_dir=ck, name="target_run", train_continue_from=source_dir, **extra)
+        assert tgt.save_dir == os.path.join(ck, "target_run")
+        want = torch.load(os.path.join(source_dir, f"{suffix}_net_G_A.pth"), map_location="cpu")
+        got = tgt.netG_A.state_dict()
+        moved = 0
+        for k in want:
+            assert torch.equal(got[k].cpu(), want[k]), (suffix, k)
+            moved += int(not torch.equal(want[k], base[k].cpu()))
+        assert moved > 100            # the checkpoint really differs from the weights the model was built with
+
+
 def test_full_size_properties():
     """BASELINE config-2 layer sizes (B=4 instead of 32 to bound test time): properties that do not
     need the CPU oracle -- linearity of the conv kernels and agreement of the MFMA conv with

@@ -112,6 +112,30 @@ def test_options_flatten_reference_json_layout():
     assert opt_from_json({}, {"gpu_ids": "-1"}).gpu_ids == []
 
 
+def test_train_continue_from_option_contract(tmp_path):
+    """The host half of /root/reference/tests/test_train_continue_from.py: `train_continue` and `train_continue_from` exclude each other
+    (options/train_options.py:694-697), the load suffix is `iter_<n>` when `train_load_iter > 0` (train.py:92-95), and
+    `finetune_source.json` records the source checkpoints with the reference's keys (train.py:98-120).  The device half (setup() loads
+    `<source>/<suffix>_net_<name>.pth`, save_dir stays the target run's) is tests/test_gpu_1_model.py::test_train_continue_from_loads_source_run."""
+    import json
+
+    import pytest
+
+    from joligen_amd.options import get_train_load_suffix, opt_from_json, save_finetune_source_metadata
+
+    with pytest.raises(ValueError, match="mutually exclusive"):
+        opt_from_json({}, {"train_continue": True, "train_continue_from": "/tmp/source_run"})
+    opt = opt_from_json({}, {"train_continue_from": "source_run", "train_load_iter": 123, "checkpoints_dir": str(tmp_path), "name": "target_run"})
+    assert get_train_load_suffix(opt) == "iter_123"
+    assert get_train_load_suffix(opt_from_json({}, {})) == "latest"
+    path = save_finetune_source_metadata(opt, "python train.py ...", ["G_A"])
+    meta = json.loads(open(path).read())
+    assert path == str(tmp_path / "target_run" / "finetune_source.json")
+    assert meta["train_continue_from"] == "source_run" and meta["load_suffix"] == "iter_123"
+    assert meta["checkpoint_files"] == ["source_run/iter_123_net_G_A.pth"] and meta["command_line"] == "python train.py ..."
+    assert save_finetune_source_metadata(opt_from_json({}, {}), "x", ["G_A"]) is None
+
+
 def test_param_arena_layout_on_cpu():
     """The arena itself is plain tensor-view bookkeeping and can be exercised on the CPU device
     (only refresh()/adamw_step() launch kernels)."""
