@@ -195,6 +195,36 @@ def test_palette_three_steps_vs_reference_golden(golden_dir, name, dtype_name):
         f.write("\n".join(log))
 
 
+@pytest.mark.skipif(os.environ.get("JG_UNVALIDATED_TESTS") != "1",
+                    reason="written at the end of round 3 with the round's GPU budget spent: the fixture and the CPU oracle are pinned "
+                           "(tests/test_oracle_golden.py::test_palette_pix2pix_three_steps); this device half has not run on a GPU yet")
+@pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
+def test_palette_pix2pix_three_steps_vs_reference_golden(golden_dir, dtype_name):
+    """alg_diffusion_task = "pix2pix" (paired conditioning image, no mask: no ground-truth blend, loss over every pixel;
+    models/palette_model.py:360-363): the teacher-forced three-step comparison of test_palette_three_steps_vs_reference_golden on the
+    fixture of oracle/make_golden_pix2pix.py."""
+    import parity_util as PU
+
+    g = load(golden_dir, "palette_step_pix2pix_tiny.pt")
+    model = make_model(g["cfg"], dtype_name, golden_dir, g["hp"], alg_diffusion_task="pix2pix")
+    dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
+    net = model.netG_A
+    sd0 = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    tr = palette_trainer(sd0, g["cfg"], g["hp"])
+    for it, s in enumerate(g["steps"]):
+        PU.force_state(net, {k: tr.P[k] for k in tr.param_names}, tr.m, tr.v, tr.step, tr.ema)
+        before, ref_before = PU.snapshot(net), {k: tr.P[k].clone() for k in tr.param_names}
+        model.rng_injection = lambda b, s=s: (s["t"], s["u"], s["noise"])
+        model.set_input({"A": s["A"], "B": s["B"], "A_img_paths": ["x"]})
+        assert model.mask is None
+        model.optimize_parameters()
+        loss = float(model.get_current_losses()["G_tot"])
+        loss_ref = float(tr.optimize_parameters(s["B"], s["A"], None, s["noise"], s["t"], s["u"]))
+        assert abs(loss_ref - float(s["loss"])) < 2e-4 * abs(float(s["loss"])) + 1e-6        # oracle == reference fixture
+        assert abs(loss - loss_ref) < TOL_LOSS_FWD[dtype] * abs(loss_ref), (it, loss, loss_ref)
+        PU.check_update(f"pix2pix {dtype_name} it{it}", before, PU.snapshot(net), ref_before, {k: tr.P[k] for k in tr.param_names}, COS_UPDATE[dtype])
+
+
 @pytest.mark.parametrize("dtype_name", ["fp16"])
 def test_first_step_gradients_vs_oracle_medium(golden_dir, dtype_name):
     """A larger seeded case than the fixtures (64x64, B=2, ngf 32, 3 levels) against the CPU oracle:

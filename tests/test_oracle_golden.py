@@ -100,6 +100,26 @@ def test_palette_three_steps(golden_dir, name):
         torch.testing.assert_close(tr.P[k].flatten()[:8], ref, rtol=1e-3, atol=2e-5, msg=k)
 
 
+def test_palette_pix2pix_three_steps(golden_dir):
+    """alg_diffusion_task = "pix2pix" (models/palette_model.py:360-363; examples/example_ddpm_SEN2VEN.json): conditioning on the paired
+    image A, no mask -- no ground-truth blend of the noisy image, loss over every pixel.  Three optimize_parameters() of the unmodified
+    reference (oracle/make_golden_pix2pix.py) against the CPU restatement."""
+    g = load(golden_dir, "palette_step_pix2pix_tiny.pt")
+    sched = load(golden_dir, "schedule.pt")
+    sd = O.synth_state_dict({k: (sched[k.split(".")[-1]] if O._is_buffer(k) else torch.empty(g["shapes"][k])) for k in g["keys"]}, seed=0)
+    hp = g["hp"]
+    tr = O.OraclePaletteTrainer(sd, cfg_of(g["cfg"]), lr=hp["lr"], beta1=hp["beta1"], beta2=hp["beta2"], eps=hp["eps"], weight_decay=hp["weight_decay"],
+                                ema_beta=hp["ema_beta"], lambda_G=hp["lambda_G"], optim=hp["optim"])
+    for s in g["steps"]:
+        loss = tr.optimize_parameters(s["B"], s["A"], None, s["noise"], s["t"], s["u"])
+        torch.testing.assert_close(loss, s["loss"], rtol=2e-4, atol=1e-6)
+        for which, store in (("param_checks", tr.P), ("ema_checks", tr.ema)):
+            for k, ref in s.get(which, {}).items():
+                v = store[k]
+                mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+                torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
+
+
 # ---- consistency model (cm_model): oracle/make_golden_cm.py fixtures --------------------------------------
 CM_CFGS = ["tiny_eff", "tiny_attn"]
 
@@ -813,7 +833,7 @@ def test_pil_resize_restatement(golden_dir):
 
 
 # ---- the committed fixtures regenerate from the committed recipes ------------------------------------------------
-RECIPES = ["make_golden_resize.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
+RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
            "make_golden_projd.py", "make_golden_resattn.py", "make_golden_sampling.py", "make_golden_segformer.py"]
 
 
