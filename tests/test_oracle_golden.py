@@ -120,6 +120,32 @@ def test_palette_pix2pix_three_steps(golden_dir):
                 torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
 
 
+def test_palette_gradient_accumulation(golden_dir):
+    """`train_iter_size = 2` (models/base_model.py:1250-1282,1302-1377; the shipped DDPM example trains with 16): four calls of the
+    unmodified reference's optimize_parameters() = two optimizer steps (oracle/make_golden_accum.py).  Pinned per call: the raw loss, the
+    parameters (unchanged on a non-boundary call), the EMA copy (updated on EVERY call), and the `G_tot_avg` the loss log reports."""
+    g = load(golden_dir, "palette_step_accum_tiny.pt")
+    sched = load(golden_dir, "schedule.pt")
+    sd = O.synth_state_dict({k: (sched[k.split(".")[-1]] if O._is_buffer(k) else torch.empty(g["shapes"][k])) for k in g["keys"]}, seed=0)
+    hp = g["hp"]
+    tr = O.OraclePaletteTrainer(sd, cfg_of(g["cfg"]), lr=hp["lr"], beta1=hp["beta1"], beta2=hp["beta2"], eps=hp["eps"], weight_decay=hp["weight_decay"],
+                                ema_beta=hp["ema_beta"], lambda_G=hp["lambda_G"], optim=hp["optim"])
+    start = {k: tr.P[k].clone() for k in tr.param_names}
+    for it, s in enumerate(g["steps"]):
+        loss, reported = tr.iteration(s["B"], s["A"], s["mask"], s["noise"], s["t"], s["u"], iter_size=g["iter_size"])
+        torch.testing.assert_close(loss, s["loss_raw"], rtol=2e-4, atol=1e-6)
+        if it == 0:      # first call of a window: nothing stepped yet
+            assert all(torch.equal(tr.P[k], start[k]) for k in tr.param_names)
+        assert (reported is not None) == ("losses_reported" in s)
+        if reported is not None:
+            torch.testing.assert_close(reported, s["losses_reported"]["G_tot_avg"], rtol=2e-4, atol=1e-6)
+        for which, store in (("param_checks", tr.P), ("ema_checks", tr.ema)):
+            for k, ref in s[which].items():
+                v = store[k]
+                mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+                torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=f"{which} it{it} {k}")
+
+
 # ---- consistency model (cm_model): oracle/make_golden_cm.py fixtures --------------------------------------
 CM_CFGS = ["tiny_eff", "tiny_attn"]
 
@@ -833,7 +859,7 @@ def test_pil_resize_restatement(golden_dir):
 
 
 # ---- the committed fixtures regenerate from the committed recipes ------------------------------------------------
-RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
+RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
            "make_golden_projd.py", "make_golden_resattn.py", "make_golden_sampling.py", "make_golden_segformer.py"]
 
 
