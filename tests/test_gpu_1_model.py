@@ -227,6 +227,36 @@ def test_palette_pix2pix_three_steps_vs_reference_golden(golden_dir, dtype_name)
 
 @pytest.mark.skipif(os.environ.get("JG_UNVALIDATED_TESTS") != "1",
                     reason="written at the end of round 3 with the round's GPU budget spent: the fixture and the CPU oracle are pinned "
+                           "(tests/test_oracle_golden.py::test_palette_minsnr_three_steps); this device half has not run on a GPU yet")
+@pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
+def test_palette_minsnr_three_steps_vs_reference_golden(golden_dir, dtype_name):
+    """`alg_palette_minsnr = True` (the reference's own run tests select it): teacher-forced three-step comparison on the fixture of
+    oracle/make_golden_minsnr.py -- the per-sample weight min(SNR, 5) / SNR enters jg_ddpm_mse_loss and its gradient."""
+    import parity_util as PU
+
+    g = load(golden_dir, "palette_step_minsnr_tiny.pt")
+    model = make_model(g["cfg"], dtype_name, golden_dir, g["hp"], alg_palette_minsnr=True)
+    dtype = torch.float16 if dtype_name == "fp16" else torch.bfloat16
+    net = model.netG_A
+    hp = g["hp"]
+    tr = O.OraclePaletteTrainer({k: v.detach().float().cpu() for k, v in net.state_dict().items()}, cfg_of(g["cfg"]), lr=hp["lr"], beta1=hp["beta1"],
+                                beta2=hp["beta2"], eps=hp["eps"], weight_decay=hp["weight_decay"], ema_beta=hp["ema_beta"], lambda_G=hp["lambda_G"],
+                                optim=hp["optim"], minsnr=True)
+    for it, s in enumerate(g["steps"]):
+        PU.force_state(net, {k: tr.P[k] for k in tr.param_names}, tr.m, tr.v, tr.step, tr.ema)
+        before, ref_before = PU.snapshot(net), {k: tr.P[k].clone() for k in tr.param_names}
+        model.rng_injection = lambda b, s=s: (s["t"], s["u"], s["noise"])
+        model.set_input({"A": s["A"], "B": s["B"], "B_label_mask": s["mask"], "A_img_paths": ["x"]})
+        model.optimize_parameters()
+        loss = float(model.get_current_losses()["G_tot"])
+        loss_ref = float(tr.optimize_parameters(s["B"], s["A"], s["mask"], s["noise"], s["t"], s["u"]))
+        assert abs(loss_ref - float(s["loss"])) < 2e-4 * abs(float(s["loss"])) + 1e-6
+        assert abs(loss - loss_ref) < TOL_LOSS_FWD[dtype] * abs(loss_ref), (it, loss, loss_ref)
+        PU.check_update(f"minsnr {dtype_name} it{it}", before, PU.snapshot(net), ref_before, {k: tr.P[k] for k in tr.param_names}, COS_UPDATE[dtype])
+
+
+@pytest.mark.skipif(os.environ.get("JG_UNVALIDATED_TESTS") != "1",
+                    reason="written at the end of round 3 with the round's GPU budget spent: the fixture and the CPU oracle are pinned "
                            "(tests/test_oracle_golden.py::test_palette_gradient_accumulation); this device half has not run on a GPU yet")
 @pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
 def test_palette_gradient_accumulation_vs_reference_golden(golden_dir, dtype_name):

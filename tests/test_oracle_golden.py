@@ -120,6 +120,28 @@ def test_palette_pix2pix_three_steps(golden_dir):
                 torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
 
 
+def test_palette_minsnr_three_steps(golden_dir):
+    """`alg_palette_minsnr = True` (what tests/test_run_diffusion.py of the reference selects): min(SNR, 5) / SNR per sample on both
+    operands of the loss.  Three optimize_parameters() of the unmodified reference (oracle/make_golden_minsnr.py) against the restatement."""
+    g = load(golden_dir, "palette_step_minsnr_tiny.pt")
+    sched = load(golden_dir, "schedule.pt")
+    sd = O.synth_state_dict({k: (sched[k.split(".")[-1]] if O._is_buffer(k) else torch.empty(g["shapes"][k])) for k in g["keys"]}, seed=0)
+    hp = g["hp"]
+    tr = O.OraclePaletteTrainer(sd, cfg_of(g["cfg"]), lr=hp["lr"], beta1=hp["beta1"], beta2=hp["beta2"], eps=hp["eps"], weight_decay=hp["weight_decay"],
+                                ema_beta=hp["ema_beta"], lambda_G=hp["lambda_G"], optim=hp["optim"], minsnr=True)
+    plain = O.OraclePaletteTrainer(sd, cfg_of(g["cfg"]), lambda_G=hp["lambda_G"])
+    for it, s in enumerate(g["steps"]):
+        if it == 0:      # the weight matters: the unweighted loss of the same step is another number
+            assert abs(float(plain.loss_and_grads(s["B"], s["A"], s["mask"], s["noise"], s["t"], s["u"])[0]) - float(s["loss"])) > 1e-3 * float(s["loss"])
+        loss = tr.optimize_parameters(s["B"], s["A"], s["mask"], s["noise"], s["t"], s["u"])
+        torch.testing.assert_close(loss, s["loss"], rtol=2e-4, atol=1e-6)
+        for which, store in (("param_checks", tr.P), ("ema_checks", tr.ema)):
+            for k, ref in s.get(which, {}).items():
+                v = store[k]
+                mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+                torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-4 * float(ref[0]) + 1e-6, msg=k)
+
+
 def test_palette_gradient_accumulation(golden_dir):
     """`train_iter_size = 2` (models/base_model.py:1250-1282,1302-1377; the shipped DDPM example trains with 16): four calls of the
     unmodified reference's optimize_parameters() = two optimizer steps (oracle/make_golden_accum.py).  Pinned per call: the raw loss, the
@@ -859,7 +881,7 @@ def test_pil_resize_restatement(golden_dir):
 
 
 # ---- the committed fixtures regenerate from the committed recipes ------------------------------------------------
-RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
+RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden_minsnr.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
            "make_golden_projd.py", "make_golden_resattn.py", "make_golden_sampling.py", "make_golden_segformer.py"]
 
 
