@@ -61,6 +61,32 @@ def test_unet_forward_backward(golden_dir, name):
         torch.testing.assert_close(mine, ref, rtol=2e-4, atol=2e-4 * float(ref[0]) + 1e-6, msg=k)
 
 
+def test_unet_attention_heads_of_16_channels(golden_dir):
+    """`G_unet_mha_num_head_channels = 16` (what the reference's own run tests select, tests/test_run_diffusion.py:24): 64 channels = 4 heads
+    of 16 in every AttentionBlock.  UNet forward + backward of the unmodified reference (oracle/make_golden_heads16.py) vs the restatement."""
+    g = load(golden_dir, "unet_heads16.pt")
+    sched = load(golden_dir, "schedule.pt")
+    sd = O.synth_state_dict({k: (sched[k.split(".")[-1]] if O._is_buffer(k) else torch.empty(g["shapes"][k])) for k in g["keys"]}, seed=0)
+    c = g["cfg"]
+    cfg = O.UNetCfg(in_channel=6, inner_channel=c["ngf"], out_channel=3, res_blocks=c["res_blocks"], attn_res=c["attn_res"], channel_mults=c["mults"],
+                    efficient=c["efficient"], num_head_channels=c["num_head_channels"])
+    pre = "denoise_fn.model."
+    P = {k[len(pre):]: v.clone().requires_grad_(not O._is_buffer(k)) for k, v in sd.items() if k.startswith(pre)}
+    x, emb = g["x"].clone().requires_grad_(True), g["emb"].clone().requires_grad_(True)
+    out = O.unet_forward(P, x, emb, cfg)
+    torch.testing.assert_close(out, g["out"], rtol=1e-4, atol=1e-5)
+    (out * g["R"]).sum().backward()
+    torch.testing.assert_close(x.grad, g["dx"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(emb.grad, g["demb"], rtol=1e-4, atol=1e-3)
+    for k, ref in g["grad_checks"].items():
+        v = P[k].grad
+        torch.testing.assert_close(torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()]), ref, rtol=2e-4, atol=2e-4 * float(ref[0]) + 1e-6, msg=k)
+    # and it is not the 32-channel split in disguise
+    out32 = O.unet_forward({k: v.detach() for k, v in P.items()}, g["x"], g["emb"], O.UNetCfg(in_channel=6, inner_channel=c["ngf"], out_channel=3,
+                           res_blocks=c["res_blocks"], attn_res=c["attn_res"], channel_mults=c["mults"], efficient=c["efficient"], num_head_channels=32))
+    assert float((out32 - g["out"]).norm() / g["out"].norm()) > 1e-3
+
+
 @pytest.mark.parametrize("name", CFGS)
 def test_diffusion_generator_forward(golden_dir, name):
     sd, _ = synth_for(golden_dir, name)
@@ -881,7 +907,7 @@ def test_pil_resize_restatement(golden_dir):
 
 
 # ---- the committed fixtures regenerate from the committed recipes ------------------------------------------------
-RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden_minsnr.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
+RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden_minsnr.py", "make_golden_heads16.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
            "make_golden_projd.py", "make_golden_resattn.py", "make_golden_sampling.py", "make_golden_segformer.py"]
 
 
