@@ -195,9 +195,6 @@ def test_palette_three_steps_vs_reference_golden(golden_dir, name, dtype_name):
         f.write("\n".join(log))
 
 
-@pytest.mark.skipif(os.environ.get("JG_UNVALIDATED_TESTS") != "1",
-                    reason="written at the end of round 3 with the round's GPU budget spent: the fixture and the CPU oracle are pinned "
-                           "(tests/test_oracle_golden.py::test_palette_pix2pix_three_steps); this device half has not run on a GPU yet")
 @pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
 def test_palette_pix2pix_three_steps_vs_reference_golden(golden_dir, dtype_name):
     """alg_diffusion_task = "pix2pix" (paired conditioning image, no mask: no ground-truth blend, loss over every pixel;
@@ -225,9 +222,6 @@ def test_palette_pix2pix_three_steps_vs_reference_golden(golden_dir, dtype_name)
         PU.check_update(f"pix2pix {dtype_name} it{it}", before, PU.snapshot(net), ref_before, {k: tr.P[k] for k in tr.param_names}, COS_UPDATE[dtype])
 
 
-@pytest.mark.skipif(os.environ.get("JG_UNVALIDATED_TESTS") != "1",
-                    reason="written at the end of round 3 with the round's GPU budget spent: the fixture and the CPU oracle are pinned "
-                           "(tests/test_oracle_golden.py::test_unet_attention_heads_of_16_channels); this device half has not run on a GPU yet")
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_unet_attention_heads_of_16_channels_vs_reference_golden(golden_dir, dtype):
     """`G_unet_mha_num_head_channels = 16` (the reference's own run tests): 4 heads of 16 channels -- the unfused attention path (batched
@@ -260,9 +254,6 @@ def test_unet_attention_heads_of_16_channels_vs_reference_golden(golden_dir, dty
     assert not bad, bad[:6]
 
 
-@pytest.mark.skipif(os.environ.get("JG_UNVALIDATED_TESTS") != "1",
-                    reason="written at the end of round 3 with the round's GPU budget spent: the fixture and the CPU oracle are pinned "
-                           "(tests/test_oracle_golden.py::test_palette_minsnr_three_steps); this device half has not run on a GPU yet")
 @pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
 def test_palette_minsnr_three_steps_vs_reference_golden(golden_dir, dtype_name):
     """`alg_palette_minsnr = True` (the reference's own run tests select it): teacher-forced three-step comparison on the fixture of
@@ -290,9 +281,6 @@ def test_palette_minsnr_three_steps_vs_reference_golden(golden_dir, dtype_name):
         PU.check_update(f"minsnr {dtype_name} it{it}", before, PU.snapshot(net), ref_before, {k: tr.P[k] for k in tr.param_names}, COS_UPDATE[dtype])
 
 
-@pytest.mark.skipif(os.environ.get("JG_UNVALIDATED_TESTS") != "1",
-                    reason="written at the end of round 3 with the round's GPU budget spent: the fixture and the CPU oracle are pinned "
-                           "(tests/test_oracle_golden.py::test_palette_gradient_accumulation); this device half has not run on a GPU yet")
 @pytest.mark.parametrize("dtype_name", ["fp16", "bf16"])
 def test_palette_gradient_accumulation_vs_reference_golden(golden_dir, dtype_name):
     """`train_iter_size = 2` (models/base_model.py:1250-1282,1302-1377) on the fixture of oracle/make_golden_accum.py: per window of two
