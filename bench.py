@@ -16,7 +16,9 @@ G_unet_mha_vit_efficient true).  A step = set_input(device-resident batch) + opt
 Default run: 50 timed steps; `ms_per_step` / `value` follow the contract (K steps / total time, max over ranks),
 `ms_per_step_median` is the median of the per-step HIP-event times of the same region.  With the default flags (N = 1, palette) the
 line also carries a `cut` object: the CUT G+D step of BASELINE configs[2] (SegFormer-attn G + [projected_d, basic] D + MoNCE,
-256x256, batch 16) measured in the same process right after the palette leg, with its own roofline and CPU baseline.
+256x256, batch 16) measured in the same process right after the palette leg, with its own roofline and CPU baseline, and the objects
+`c4_512` (configs[3]: DDPM UNet 512x512, batch 8) and `cm` (configs[4]: consistency-model step 256x256, batch 64): value, ms per step,
+fraction of the MFMA peak.
 
 Extra objects on the JSON line:
   roofline     -- dominant kernel = the one with the largest summed time (conv3x3_halo_kernel: halo-resident
@@ -370,6 +372,36 @@ def cut_leg(local_rank, no_cpu):
             "roofline": roof, "cpu_baseline": cpu}
 
 
+def unet_leg(local_rank, model_kind, size, batch, efficient, steps=10, warmup=3):
+    """One more single-GPU configuration of BASELINE.json on the default line: `c4_512` = configs[3] (palette_model DDPM, UNet with mid-block
+    self-attention, 512x512, batch 8 per GPU) and `cm` = configs[4] (cm_model consistency step, 256x256, batch 64 per GPU, fused AdamW):
+    value, ms per step, the step's algorithmic FLOPs as a fraction of the bf16 MFMA peak.  Same step definition as the palette leg
+    (set_input on a device-resident batch + optimize_parameters()); ~2 - 3 s each."""
+    ns = argparse.Namespace(model=model_kind, netG="resnet", netDs="basic", batch=batch, size=size, dtype="bf16", efficient=int(efficient),
+                            force_exchange=False)
+    model, _ = build_model(ns, 0, local_rank, 1)
+    data = synth_batch(batch, size, 4321, torch.device("cuda", local_rank))
+
+    def step():
+        model.set_input(data)
+        model.optimize_parameters()
+
+    dt, per_step = timed_region(step, steps, warmup, torch.cuda.synchronize)
+    ms = dt / steps * 1e3
+    mult = 3 if model_kind == "palette" else 4          # SURVEY.md 8(d): cm = student forward + teacher forward + backward
+    tflop = mult * FWD_GFLOP_PER_IMG[(size, bool(efficient))] * batch / 1e3
+    loss = float(model.get_current_losses()["G_tot"].detach())
+    del model
+    torch.cuda.empty_cache()
+    return {"metric": f"train images/sec at {size}x{size} ({'DDPM UNet' if model_kind == 'palette' else 'CM UNet'} step)",
+            "value": round(batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(ms, 3),
+            "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2], 3), "steps": steps, "warmup": warmup, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{'palette_model DDPM' if model_kind == 'palette' else 'cm_model consistency'}, {'efficient ' if efficient else ''}UNet unet_mha "
+                                   f"ngf64 mults[1,2,4,8] res_blocks[2,2,2,2] mid-attn 16x32, {size}x{size}, batch {batch}/GPU, inpainting synthetic masks, "
+                                   "AdamW+EMA, iter_size 1", "global_batch": batch, "final_loss": round(loss, 6)},
+            "step_algorithmic_tflop": round(tflop, 3), "step_frac_of_mfma_peak": round(tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -557,6 +589,18 @@ def main():
         except Exception as e:
             cut = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
 
+    extra = {}
+    if rank == 0 and world == 1 and args.model == "palette" and not args.no_cut_leg and not args.force_exchange:
+        # BASELINE configs[3] and configs[4] at their own shapes, after everything the palette line needs
+        del model
+        torch.cuda.empty_cache()
+        for key, kw in (("c4_512", dict(model_kind="palette", size=512, batch=8, efficient=False)),
+                        ("cm", dict(model_kind="cm", size=256, batch=64, efficient=True))):
+            try:
+                extra[key] = unet_leg(local_rank, **kw)
+            except Exception as e:
+                extra[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         line = {
             "metric": f"train images/sec at {args.size}x{args.size} ({'DDPM UNet' if args.model == 'palette' else 'CM UNet' if args.model == 'cm' else 'CUT'} step)",
@@ -574,6 +618,7 @@ def main():
                        "n_ranks_seen": n_ranks_seen},
             "roofline": roofline, "cpu_baseline": cpu, "cut": cut,
         }
+        line.update(extra)
         if per_rank is not None:
             line["per_rank"] = per_rank
         if exch is not None:

@@ -125,13 +125,20 @@ class BaseModel:
         kernels drop a step with non-finite gradients on their own (no host sync per step); every `jg_overflow_poll` OPTIMIZER steps
         (default 50) the dropped-step counters are read back.  A dropped step halves the loss scale (backoff_factor 0.5) and is taken
         out of the optimizers' bias-correction step count; `jg_loss_scale_growth_interval` clean optimizer steps in a row (default
-        2000, GradScaler's growth_interval) double it again (growth_factor 2).  The scale only changes on an accumulation boundary
+        2000, GradScaler's growth_interval; <= 0 = never) double it again (growth_factor 2); for `jg_overflow_poll` steps after a growth
+        event the counters are read on EVERY optimizer step, so an overflowing probe loses one update, not fifty.  The scale only changes on an accumulation boundary
         (niter % train_iter_size == 0): gradients already in the arena were scaled with the old value.
         Approximation, documented: between a dropped step and the poll that sees it (< jg_overflow_poll steps) the bias correction runs
         one step ahead per drop (torch steps `step` only on applied updates)."""
         every = int(getattr(self.opt, "jg_overflow_poll", 50) or 50)
         iter_size = max(1, int(getattr(self.opt, "train_iter_size", 1) or 1))
-        if self.act_dtype != torch.float16 or self.niter % iter_size != 0 or (self.niter // iter_size) % every != 0:
+        if self.act_dtype != torch.float16 or self.niter % iter_size != 0:
+            return
+        ostep = self.niter // iter_size
+        # right after a growth event the doubled scale is a PROBE: poll on every optimizer step of the next window, so that an
+        # overflowing probe costs one dropped update (as with GradScaler) instead of up to `every` (ADVICE r3)
+        probing = ostep <= getattr(self, "_probe_until", 0)
+        if ostep % every != 0 and not probing:
             return
         dropped = 0
         for o in self.optimizers:
@@ -143,16 +150,21 @@ class BaseModel:
             a._dropped_seen = n
             a.step -= new            # a dropped step must not advance the bias correction
             dropped += new
-        growth = int(getattr(self.opt, "jg_loss_scale_growth_interval", 2000) or 2000)
+        g = getattr(self.opt, "jg_loss_scale_growth_interval", 2000)
+        growth = 2000 if g is None else int(g)            # <= 0: never grow (a static jg_loss_scale stays static until an overflow)
+        since = ostep - getattr(self, "_last_poll_step", 0)
+        self._last_poll_step = ostep
         if dropped:
             self._clean_steps = 0
+            self._probe_until = 0
             self.loss_scale = max(1.0, self.loss_scale / 2.0)
             print(f"[joligen_amd] {dropped} optimizer step(s) dropped on non-finite fp16 gradients: loss scale -> {self.loss_scale:g}")
         else:
-            self._clean_steps = getattr(self, "_clean_steps", 0) + every
-            if self._clean_steps >= growth:
+            self._clean_steps = getattr(self, "_clean_steps", 0) + since
+            if growth > 0 and self._clean_steps >= growth:
                 self._clean_steps = 0
                 self.loss_scale = min(self.loss_scale * 2.0, 2.0 ** 24)
+                self._probe_until = ostep + every
         for o in self.optimizers:
             o.grad_scale = 1.0 / self.loss_scale
 

@@ -227,7 +227,7 @@ def test_image_pool_replays_reference_draws():
         assert torch.equal(a, b.cpu())
 
 
-def build_cut_model(g, dtype):
+def build_cut_model(g, dtype, **extra):
     from joligen_amd.models import create_model
     from joligen_amd.options import opt_from_json
 
@@ -236,7 +236,7 @@ def build_cut_model(g, dtype):
            "alg": {"cut": {"nce_layers": c["nce_layers"], "num_patches": c["num_patches"], "nce_loss": c["nce_loss"]}},
            "data": {"crop_size": c["S"], "load_size": c["S"]},
            "train": {"batch_size": c["B"], "pool_size": c["pool"], "G_ema": True, "G_ema_beta": hp["ema_beta"], "G_lr": hp["lr_G"], "D_lr": hp["lr_D"]}}
-    opt = opt_from_json(cfg, overrides={"jg_act_dtype": "fp16" if dtype == torch.float16 else "bf16", "gpu_ids": "0"})
+    opt = opt_from_json(cfg, overrides={"jg_act_dtype": "fp16" if dtype == torch.float16 else "bf16", "gpu_ids": "0", **extra})
     return create_model(opt, 0)
 
 
@@ -330,21 +330,78 @@ def test_cut_model_steps_vs_reference_golden(golden_dir, name, dtype):
         f.write("\n".join(log))
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_cut_gradient_accumulation_vs_reference_golden(golden_dir, dtype):
+    """`train_iter_size = 2` on the CUT step (models/base_model.py:1250-1282,1302-1377; examples/example_gan_horse2zebra.json trains with
+    8) on the fixture of oracle/make_golden_cutaccum.py, teacher-forced per WINDOW: the HIP model starts a window from the oracle's state,
+    both calls see identical weights (their losses are forward quantities), G / F / D must not move on the first call (each group's
+    gradients accumulate in its own arena; a network outside the group receives none), the three optimizer updates at the boundary are
+    compared with the oracle's, the EMA of G_A runs on EVERY call, and `get_current_losses()` reports the `<name>_avg` values."""
+    import parity_util as PU
+    from test_oracle_golden import cut_ntaps, cut_trainer_for
+
+    g = load(golden_dir, "cutstep_accum.pt")
+    c, n = g["cfg"], g["iter_size"]
+    model = build_cut_model(g, dtype, train_iter_size=n)
+    s0 = g["steps"][0]
+    model.data_dependent_initialize({"A": s0["A"], "B": s0["B"]})
+    assert sorted(model.loss_names) == sorted(g["loss_names"])
+    tr, rng_ref = cut_trainer_for(g)
+    model.set_pool_rng(ReplayRandom([d for s in g["steps"] for d in s["pool_draws"]]))
+    nl, tol = cut_ntaps(c), TOL_LOSS_FWD[dtype]
+    names = (("G_tot", "G_tot"), ("G_GAN", "G_GAN_D_B_basic"), ("G_NCE", "G_NCE"), ("G_NCE_Y", "G_NCE_Y"), ("D_tot", "D_tot"))
+    nets = ("G_A", "F", "D_B_basic")
+    for w0 in range(0, len(g["steps"]), n):
+        _sync_cut_from_oracle(PU, model, tr)
+        before = {k: PU.snapshot(getattr(model, "net" + k)) for k in nets}
+        ref_before = {"G_A": {k: v.clone() for k, v in tr.G.items()}, "F": {k: v.clone() for k, v in tr.Fp.items()},
+                      "D_B_basic": {k: v.clone() for k, v in tr.D.items()}}
+        for j in range(n):
+            s = g["steps"][w0 + j]
+            ema_before = None if tr.ema is None else {k: v.clone() for k, v in tr.ema.items()}
+            ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
+            model.patch_ids_injection = lambda call, shapes, a=ids_ab, b=ids_idt: [i.to(D0) for i in (a if call == 0 else b)]
+            model.set_input({"A": s["A"], "B": s["B"]})
+            model.optimize_parameters()
+            torch.cuda.synchronize()
+            lo = tr.iteration(s["A"], s["B"], ids_ab, ids_idt, iter_size=n)
+            for ok, rk in names:
+                ref = s["raw"][rk]
+                assert abs(lo[ok] - ref) <= 2e-4 * (1 + w0 // n) ** 2 * abs(ref) + 1e-5, ("oracle vs fixture", w0 + j, ok, lo[ok], ref)
+                mine = float(getattr(model, "loss_" + rk).detach())
+                assert abs(mine - lo[ok]) <= tol * abs(lo[ok]) + 1e-4, (w0 + j, rk, mine, lo[ok])
+            after = {k: PU.snapshot(getattr(model, "net" + k)) for k in nets}
+            if j < n - 1:
+                for k in nets:
+                    assert all(torch.equal(after[k][q], before[k][q]) for q in before[k]), f"{k} moved inside an accumulation window"
+            else:
+                for k, ref_after, skip in (("G_A", tr.G, _zero_grad_bias(tr.G, "resnet")), ("F", tr.Fp, lambda q: False),
+                                           ("D_B_basic", tr.D, lambda q: q.endswith(".bias") and not q.startswith("model.0."))):
+                    PU.check_update(f"cut accum {k} window{w0 // n}", before[k], after[k], ref_before[k], ref_after, COS_UPDATE[dtype], skip=skip)
+                rep = {k: float(v) for k, v in model.get_current_losses().items()}
+                for ok, rk in names:
+                    ref = tr.reported[ok + "_avg"]
+                    assert abs(rep[rk + "_avg"] - ref) <= tol * abs(ref) + 1e-4, (rk, rep[rk + "_avg"], ref)
+            ema = {k: v.detach().float().cpu() for k, v in model.netG_A_ema.named_parameters()}
+            PU.check_ema(f"cut accum ema call{w0 + j}", ema_before, ema, after["G_A"], g["hp"]["ema_beta"], first=ema_before is None)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
 @pytest.mark.parametrize("name", ["monce", "segformer", "mobile_attn"])
-def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
-    """first G-group backward on identical (fp16-representable) weights and inputs: per-parameter gradients of G and F against the
+def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name, dtype):
+    """first G-group backward on identical (16-bit-representable: fp16 AND bf16, the bench dtype) weights and inputs: per-parameter gradients of G and F against the
     CPU oracle's autograd (includes the k-side path through the negatives and the Sinkhorn reverse sweep; for the SegFormer
     generator: MiT backbone, both heads, the BatchNorm decoder tail and the attention composition, with the reference's recorded
     DropPath / Dropout2d draws).  Per-parameter relative error and cosine; the table goes to gpurun_out/."""
     from test_oracle_golden import cut_gen, cut_ntaps, cut_trainer_for
-    dtype = torch.float16
+    dn = "fp16" if dtype == torch.float16 else "bf16"
     g = load(golden_dir, f"cutstep_{name}.pt")
     c = g["cfg"]
     model = build_cut_model(g, dtype)
     s = g["steps"][0]
     model.data_dependent_initialize({"A": s["A"], "B": s["B"]})
-    sdG = {k: (v.half().float() if torch.is_floating_point(v) else v) for k, v in O.synth_state_dict(model.netG_A.state_dict(), seed=0).items()}
-    sdD = {k: v.half().float() for k, v in O.synth_state_dict(model.netD_B_basic.state_dict(), seed=1).items()}
+    sdG = {k: (v.to(dtype).float() if torch.is_floating_point(v) else v) for k, v in O.synth_state_dict(model.netG_A.state_dict(), seed=0).items()}
+    sdD = {k: v.to(dtype).float() for k, v in O.synth_state_dict(model.netD_B_basic.state_dict(), seed=1).items()}
     sdF = O.synth_state_dict(model.netF.state_dict(), seed=3)
     model.netG_A.load_state_dict(sdG)
     model.netD_B_basic.load_state_dict(sdD)
@@ -355,7 +412,7 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
     if s.get("uniforms"):
         uit = iter(s["uniforms"])
         model.netG_A.rand.source = lambda shape, uit=uit: next(uit)
-    A, Bi = s["A"].half().float(), s["B"].half().float()
+    A, Bi = s["A"].to(dtype).float(), s["B"].to(dtype).float()
     model.set_input({"A": A, "B": Bi})
     for net in ("G_A", "F", "D_B_basic"):
         model.set_requires_grad(getattr(model, "net" + net), net != "D_B_basic")
@@ -376,7 +433,7 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
     # the rounding floor of THIS comparison, measured on CPU: the fp32 oracle against itself with 16-bit storage of every inter-layer
     # activation and activation gradient (tests/test_oracle_golden.py::test_cut_rounding_yardstick -> profiles/r03_rounding_yardstick_cut.json)
     import json
-    yard = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rounding_yardstick_cut.json")))[name]["fp16"]
+    yard = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rounding_yardstick_cut.json")))[name][dn]
     bad, errs, table = [], [], []
     per_key = {"G": [], "F": []}
     for net, key in ((model.netG_A, "G"), (model.netF, "F")):
@@ -399,9 +456,9 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name):
             if rel > 2.0 * yard[key]["grad_worst"] or (float(ref.norm()) > 10 * floor and float(ref.norm()) > 1e-6 and cos < yard[key]["cos_min"] - 0.02):
                 bad.append((key, k, rel, cos, float(ref.norm()), floor, yard[key]["grad_worst"]))
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/grad_table_cut_{name}.txt", "w") as f:
+    with open(f"gpurun_out/grad_table_cut_{name}_{dn}.txt", "w") as f:
         f.write("\n".join(table))
-    with open(f"gpurun_out/grad_table_cut_{name}.txt", "a") as f:
+    with open(f"gpurun_out/grad_table_cut_{name}_{dn}.txt", "a") as f:
         f.write("\n" + "\n".join(f"# {key}: median {sorted(v)[len(v) // 2]:.3e} worst {max(v):.3e} | rounding floor median {yard[key]['grad_median']:.3e} "
                                   f"worst {yard[key]['grad_worst']:.3e}" for key, v in per_key.items()))
     assert not bad, bad[:8]
@@ -508,9 +565,10 @@ def test_cut_full_size_properties(netG):
     assert float((ema[k0] - cur).abs().max()) > 0 and float((ema[k0] - cur).abs().max()) <= 1.02 * n_steps * lrs["G_A"]
 
 
-def test_cut_c3_shape_first_step_gradients_vs_oracle():
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_cut_c3_shape_first_step_gradients_vs_oracle(dtype):
     """BASELINE configs[2] at its own shape: cut_model, SegFormer-attn generator (MiT-b0 + two heads + BatchNorm
-    decoder tail) + [projected_d (tf_efficientnet_lite0 architecture), basic] discriminators + MoNCE, 256x256, batch 1, fp16.  First
+    decoder tail) + [projected_d (tf_efficientnet_lite0 architecture), basic] discriminators + MoNCE, 256x256, batch 1, fp16 and bf16 (the bench dtype).  First
     G-group backward on identical 16-bit-representable weights and inputs against the CPU oracle (oracle/jg_oracle.py OracleCUTTrainer with
     its projected-discriminator term), with injected DropPath / Dropout2d uniforms and patch ids.  Bounds: the losses to the forward
     tolerance; every G / F gradient tensor against TWICE the rounding floor measured here on the same inputs (the oracle with 16-bit
@@ -521,18 +579,19 @@ def test_cut_c3_shape_first_step_gradients_vs_oracle():
     from joligen_amd.models import create_model
     from joligen_amd.options import opt_from_json
 
-    S, Bn, dtype = 256, 1, torch.float16
+    S, Bn = 256, 1
+    dn = "fp16" if dtype == torch.float16 else "bf16"
     cfg = {"model_type": "cut", "G": {"netG": "segformer_attn_conv", "ngf": 64, "nblocks": 9},
            "D": {"netDs": ["projected_d", "basic"], "ndf": 64, "proj_interp": -1}, "alg": {"cut": {"nce_loss": "monce", "num_patches": 256}},
            "data": {"crop_size": S, "load_size": S}, "train": {"batch_size": Bn, "pool_size": 50, "G_ema": True}}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        model = create_model(opt_from_json(cfg, overrides={"jg_act_dtype": "fp16", "gpu_ids": "0"}), 0)
+        model = create_model(opt_from_json(cfg, overrides={"jg_act_dtype": dn, "gpu_ids": "0"}), 0)
     g = torch.Generator().manual_seed(31)
-    A = (torch.rand(Bn, 3, S, S, generator=g) * 2 - 1).half().float()
-    Bi = (torch.rand(Bn, 3, S, S, generator=g) * 2 - 1).half().float()
+    A = (torch.rand(Bn, 3, S, S, generator=g) * 2 - 1).to(dtype).float()
+    Bi = (torch.rand(Bn, 3, S, S, generator=g) * 2 - 1).to(dtype).float()
     model.data_dependent_initialize({"A": A, "B": Bi})
-    r16 = lambda v: v.half().float() if torch.is_floating_point(v) else v
+    r16 = lambda v: v.to(dtype).float() if torch.is_floating_point(v) else v
     sdG = {k: r16(v) for k, v in O.synth_state_dict(model.netG_A.state_dict(), seed=0).items()}
     sdD = {k: r16(v) for k, v in O.synth_state_dict(model.netD_B_basic.state_dict(), seed=1).items()}
     sdF = O.synth_state_dict(model.netF.state_dict(), seed=3)
@@ -563,7 +622,7 @@ def test_cut_c3_shape_first_step_gradients_vs_oracle():
                                 ema_beta=0.999, gen="segformer", sdPD=sdPD, proj_interp=-1)
         if rounded:
             tr.grad_scale = model.loss_scale
-            with O.activation_rounding(torch.float16):
+            with O.activation_rounding(dtype):
                 lo = tr.step(A, Bi, ids[0], ids[1], uniforms=uni)
         else:
             lo = tr.step(A, Bi, ids[0], ids[1], uniforms=uni)
@@ -573,7 +632,7 @@ def test_cut_c3_shape_first_step_gradients_vs_oracle():
     rnd, _ = oracle(True)
     losses = {k: float(getattr(model, "loss_" + k)) for k in ("G_GAN_D_B_basic", "G_GAN_D_B_projected_d", "G_NCE", "G_NCE_Y")}   # the D group has not run
     for ok, rk in (("G_GAN", "G_GAN_D_B_basic"), ("G_GAN_PD", "G_GAN_D_B_projected_d"), ("G_NCE", "G_NCE"), ("G_NCE_Y", "G_NCE_Y")):
-        assert abs(losses[rk] - lo[ok]) <= 6e-3 * abs(lo[ok]) + 2e-3, (rk, losses[rk], lo[ok])
+        assert abs(losses[rk] - lo[ok]) <= TOL_LOSS_FWD[dtype] * abs(lo[ok]) + 2e-3, (rk, losses[rk], lo[ok])
     ls = model.loss_scale
     skip = _zero_grad_bias(ref.G, "segformer")
     table, bad = [], []
@@ -591,7 +650,7 @@ def test_cut_c3_shape_first_step_gradients_vs_oracle():
             per[key][1].append(fl)
             table.append(f"{mine:10.3e} floor={fl:10.3e} {key}.{k}")
     os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/grad_table_cut_c3_shape.txt", "w") as f:
+    with open(f"gpurun_out/grad_table_cut_c3_shape_{dn}.txt", "w") as f:
         f.write("\n".join(table))
         for key, (m_, f_) in per.items():
             f.write(f"\n# {key}: median {sorted(m_)[len(m_) // 2]:.3e} worst {max(m_):.3e} | rounding floor median {sorted(f_)[len(f_) // 2]:.3e} worst {max(f_):.3e}")

@@ -1,9 +1,10 @@
 """GPU: the reference's training loop (train.py:195-301, 351-357) replayed against joligen_amd with the SHIPPED example configurations
 (tests/examples/*.json are verbatim copies of /root/reference/examples/example_ddpm_noglasses2glasses.json and
-example_gan_horse2zebra.json) plus the measurement overrides of SURVEY.md Appendix C:
+example_gan_horse2zebra.json) plus the measurement overrides of SURVEY.md Appendix C (the examples' own train_iter_size 16 / 8 is kept:
+two accumulation windows each):
 
     opt = parse(example JSON + overrides) -> create_model -> data_dependent_initialize -> setup -> single_gpu
-    N x (set_input, optimize_parameters, get_current_losses) -> save_networks("latest") -> export_networks("latest")
+    2 x iter_size x (set_input, optimize_parameters) + get_current_losses -> save_networks("latest") -> export_networks("latest")
     -> update_learning_rate -> a second process-like model continues from the checkpoint (train_continue)
 
 What it pins: the drop-in boundary b1 -- the example JSONs load unchanged, the model API is the one
@@ -18,8 +19,10 @@ pytestmark = pytest.mark.gpu
 EX = os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples")
 
 
-def _loop(opt, data, n_steps):
-    """train.py:194-357 without the dataloader / visualizer / metrics"""
+def _loop(opt, data, n_windows):
+    """train.py:194-357 without the dataloader / visualizer / metrics: n_windows optimizer steps = n_windows * train_iter_size calls of
+    optimize_parameters() (models/base_model.py:1250-1282: gradients accumulate over a window, the optimizers step at its end).  Checked
+    on the way: the parameters of every network stay put inside a window and move at its boundary."""
     from joligen_amd.models import create_model
 
     model = create_model(opt, 0)
@@ -27,16 +30,29 @@ def _loop(opt, data, n_steps):
         model.data_dependent_initialize(data)
     model.setup(opt)
     model.single_gpu()
+    n = opt.train_iter_size
     losses = []
-    for _ in range(n_steps):
-        model.set_input(data)
-        model.optimize_parameters()
+
+    def fingerprint():
+        return {name: float(model._net(name).arena.p.double().sum()) for name in model.model_names}
+
+    for w in range(n_windows):
+        start = fingerprint()
+        for j in range(n):
+            model.set_input(data)
+            model.optimize_parameters()
+            now = fingerprint()
+            if j < n - 1:
+                assert now == start, (w, j, "parameters moved inside an accumulation window")
+            else:
+                assert all(now[k] != start[k] for k in now), (w, "a network did not step at the window boundary", now, start)
         losses.append({k: float(v) for k, v in model.get_current_losses().items()})       # output_print_freq path (:288-303)
     return model, losses
 
 
 def _appendix_c(tmp_path, **kw):
-    ov = dict(train_iter_size=1, output_display_type=["none"], output_print_freq=10 ** 9, checkpoints_dir=str(tmp_path), gpu_ids="0",
+    """the measurement overrides of SURVEY.md Appendix C -- WITHOUT train_iter_size: the examples keep their own (16 / 8)"""
+    ov = dict(output_display_type=["none"], output_print_freq=10 ** 9, checkpoints_dir=str(tmp_path), gpu_ids="0",
               train_metrics_list=[], jg_act_dtype="bf16")
     ov.update(kw)
     return ov
@@ -51,9 +67,10 @@ def test_example_ddpm_json_through_the_train_loop(tmp_path):
     assert opt.model_type == "palette" and opt.G_netG == "unet_mha" and opt.train_G_ema and opt.train_optim == "adamw"
     data = synth_batch(4, 128, 3, torch.device("cuda:0"))
     torch.manual_seed(0)
-    model, losses = _loop(opt, data, 4)
-    assert all(math.isfinite(v) for l in losses for v in l.values()) and "G_tot" in losses[0]
-    assert losses[-1]["G_tot"] < losses[0]["G_tot"] * 1.5
+    assert opt.train_iter_size == 16                      # the JSON's own accumulation window
+    model, losses = _loop(opt, data, 2)
+    assert all(math.isfinite(v) for l in losses for v in l.values()) and "G_tot_avg" in losses[0]
+    assert losses[-1]["G_tot_avg"] < losses[0]["G_tot_avg"] * 1.5
     model.save_networks("latest")
     assert model.export_networks("latest") == []            # the reference skips palette / cm as well (base_model.py:885-891)
     lr0 = model.optimizers[0].param_groups[0]["lr"]
@@ -84,8 +101,9 @@ def test_example_gan_horse2zebra_json_through_the_train_loop(tmp_path):
     data = {"A": torch.rand(4, 3, 256, 256, generator=g) * 2 - 1, "B": torch.rand(4, 3, 256, 256, generator=g) * 2 - 1,
             "A_img_paths": ["synthetic"] * 4, "B_img_paths": ["synthetic"] * 4}
     torch.manual_seed(0)
-    model, losses = _loop(opt, data, 3)
-    assert set(losses[0]) >= {"G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_projected_d", "G_GAN_D_B_basic", "D_tot"}
+    assert opt.train_iter_size == 8                       # the JSON's own accumulation window
+    model, losses = _loop(opt, data, 2)
+    assert set(losses[0]) >= {k + "_avg" for k in ("G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_projected_d", "G_GAN_D_B_basic", "D_tot")}
     assert all(math.isfinite(v) for l in losses for v in l.values()), losses
     model.save_networks("latest")
     written = model.export_networks("latest")          # train.py:352,357: called after EVERY save

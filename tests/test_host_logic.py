@@ -350,3 +350,48 @@ def test_early_exchange_parameter_coverage_of_the_fused_backward():
         for k in list(parallel._EARLY):                                                # keep the module-level registry clean for other tests
             if parallel._EARLY[k] is ex:
                 del parallel._EARLY[k]
+
+
+def test_fp16_loss_scale_policy_polls_every_step_after_growth():
+    """BaseModel.poll_overflow (host half of GradScaler, reference base_model.py:89-90,1268-1274): the dropped-step counter is
+    read every `jg_overflow_poll` optimizer steps, and on EVERY step of the window that follows a growth event (an overflowing probe costs
+    one update, not fifty); `jg_loss_scale_growth_interval <= 0` never grows; the step count of a dropped step is given back."""
+    from types import SimpleNamespace
+
+    from joligen_amd.models.base_model import BaseModel
+
+    class Arena:
+        def __init__(self):
+            self.overflow, self.step = torch.zeros(2, dtype=torch.int64), 0
+
+    def model(growth, every=10):
+        m = object.__new__(BaseModel)
+        m.opt = SimpleNamespace(jg_overflow_poll=every, train_iter_size=1, jg_loss_scale_growth_interval=growth)
+        m.act_dtype, m.niter, m.loss_scale = torch.float16, 0, 1024.0
+        a = Arena()
+        m.optimizers = [SimpleNamespace(arena=a, grad_scale=1.0 / 1024.0)]
+        return m, a
+
+    m, a = model(growth=20)
+    for _ in range(20):                       # 20 clean steps: polled at 10 and 20, grows at 20
+        m.niter += 1; a.step += 1
+        m.poll_overflow()
+    assert m.loss_scale == 2048.0 and m.optimizers[0].grad_scale == 1.0 / 2048.0
+    m.niter += 1; a.step += 1
+    a.overflow[1] += 1                        # the very next step overflows on the doubled scale ...
+    m.poll_overflow()                         # ... and is seen at once (step 21 is not a multiple of 10)
+    assert m.loss_scale == 1024.0 and a.step == 20, (m.loss_scale, a.step)
+    for _ in range(8):                        # back to the sparse schedule: an overflow at step 22 waits for the poll at step 30
+        m.niter += 1; a.step += 1
+        if m.niter == 22:
+            a.overflow[1] += 1
+        m.poll_overflow()
+        assert m.loss_scale == 1024.0
+    m.niter += 1; a.step += 1
+    m.poll_overflow()
+    assert m.niter == 30 and m.loss_scale == 512.0
+    m, a = model(growth=0)                    # static scale: never grows
+    for _ in range(200):
+        m.niter += 1; a.step += 1
+        m.poll_overflow()
+    assert m.loss_scale == 1024.0

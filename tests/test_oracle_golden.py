@@ -469,6 +469,39 @@ def test_cut_steps(golden_dir, name):
     assert rng.i == len(rng.log)
 
 
+def test_cut_gradient_accumulation(golden_dir):
+    """`train_iter_size = 2` on the CUT step (models/base_model.py:1250-1282,1302-1377; the shipped GAN examples train with 8 / 16): four
+    calls of the unmodified reference's CUTModel.optimize_parameters() = two optimizer steps of G, F and D (oracle/make_golden_cutaccum.py).
+    Pinned per call: the raw losses of both groups, G / F / D unchanged on a non-boundary call and equal to the reference's after a
+    boundary, the EMA of G_A updated on EVERY call, the `<name>_avg` values the loss log reports."""
+    g = load(golden_dir, "cutstep_accum.pt")
+    c, n = g["cfg"], g["iter_size"]
+    tr, rng = cut_trainer_for(g)
+    nl = cut_ntaps(c)
+    names = (("G_tot", "G_tot"), ("G_GAN", "G_GAN_D_B_basic"), ("G_NCE", "G_NCE"), ("G_NCE_Y", "G_NCE_Y"), ("D_tot", "D_tot"))
+    lg, ld = g["hp"]["lr_G"], g["hp"]["lr_D"]
+    for it, s in enumerate(g["steps"]):
+        before = {k: v.clone() for d in (tr.G, tr.Fp, tr.D) for k, v in d.items()}
+        ids_ab, ids_idt = cut_ids(s, nl, c["num_patches"])
+        losses = tr.iteration(s["A"], s["B"], ids_ab, ids_idt, iter_size=n)
+        w = it // n          # optimizer steps taken before this call
+        for mine_k, ref_k in names:
+            assert abs(losses[mine_k] - s["raw"][ref_k]) <= 2e-4 * (1 + w) ** 2 * abs(s["raw"][ref_k]) + 1e-5, (it, mine_k, losses[mine_k], s["raw"][ref_k])
+        if (it + 1) % n:
+            assert tr.reported is None and "losses_reported" not in s
+            assert all(torch.equal(v, before[k]) for d in (tr.G, tr.Fp, tr.D) for k, v in d.items()), "parameters moved inside a window"
+        else:
+            for mine_k, ref_k in names:
+                ref = s["losses_reported"][ref_k + "_avg"]
+                assert abs(tr.reported[mine_k + "_avg"] - ref) <= 2e-4 * (1 + w) ** 2 * abs(ref) + 1e-5, (it, mine_k)
+        steps_done = (it + 1) // n
+        _chk(tr.G, s["G_checks"], 2e-4, f"G call{it} ", bias_slack=lg * steps_done, flip_slack=lg * max(0, steps_done - 1))
+        _chk(tr.Fp, s["F_checks"], 2e-4, f"F call{it} ", flip_slack=lg * max(0, steps_done - 1))
+        _chk(tr.D, s["D_checks"], 2e-4, f"D call{it} ", bias_slack=ld * steps_done, flip_slack=ld * max(0, steps_done - 1))
+        _chk(tr.ema, s["ema_checks"], 2e-4, f"ema call{it} ", bias_slack=lg * steps_done, flip_slack=lg * max(0, steps_done - 1))
+    assert rng.i == len(rng.log)
+
+
 def test_torch_cpu_instance_norm_channels_last_backward():
     """Documents why oracle._inorm / ref_shim wrap instance_norm: with a channels-last grad_output the stock CPU backward disagrees
     with central finite differences (float64), the wrapped one agrees.  If a future torch fixes the bug both agree -- still green."""
@@ -907,7 +940,7 @@ def test_pil_resize_restatement(golden_dir):
 
 
 # ---- the committed fixtures regenerate from the committed recipes ------------------------------------------------
-RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden_minsnr.py", "make_golden_heads16.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
+RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden_cutaccum.py", "make_golden_minsnr.py", "make_golden_heads16.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py", "make_golden_cutstep.py", "make_golden_palette_loss.py",
            "make_golden_projd.py", "make_golden_resattn.py", "make_golden_sampling.py", "make_golden_segformer.py"]
 
 
