@@ -204,6 +204,16 @@ int jg_gn_bwd_apply_fc(int dtype, int up, const void* x, int64_t ldx, const void
                        const float* gamma, const float* beta, const float* film, int64_t ldfilm, const float* mr, float* dgamma, float* dbeta,
                        float* dfilm, int64_t lddfilm, int G, void* dx, int64_t lddx, const void* add1, int64_t ldadd1, float scale1,
                        const void* add2, int64_t ldadd2, float scale2, int B, int H, int W, int C, int act, jg_stream_t s);
+/* GroupNorm backward in ONE launch with x and dy resident on chip between the reduction and the apply step (csrc/gn_fused.hip): replaces
+ * jg_gn_bwd_reduce_* + jg_gn_bwd_coef + jg_gn_bwd_apply_* (autograd of `GroupNorm32` + FiLM + SiLU, unet_attn_utils.py:42-48,
+ * unet_generator_attn.py:233-266) at 6 instead of 10 bytes per element.  `red` ([B][C][2] floats) and `counters` ([B] words: arrival
+ * counter of every image's workgroups) must be ZERO at launch; *status (one word, sticky) becomes 1 if an inter-workgroup wait expired
+ * (results of that launch are then invalid; the kernel never hangs).  up != 0: dy / add1 at the 2x2-pooled resolution. */
+int jg_gn_bwd_fused(int dtype, int up, const void* x, int64_t ldx, const void* dy, int64_t lddy, float dy_scale, const float* ab, float* red,
+                    uint32_t* counters, uint32_t* status, const float* gamma, const float* beta, const float* film, int64_t ldfilm,
+                    const float* mr, float* dgamma, float* dbeta, float* dfilm, int64_t lddfilm, int G, void* dx, int64_t lddx,
+                    const void* add1, int64_t ldadd1, float scale1, const void* add2, int64_t ldadd2, float scale2, int B, int H, int W,
+                    int C, int act, jg_stream_t s);
 /* jg_gn_bwd_reduce_ld / _up ACCUMULATING into `red` instead of clearing it first: the UNet executor hands over zeroed rows of a pool it
  * clears once per backward pass (57 memset launches per step fewer) */
 int jg_gn_bwd_reduce_ld_acc(int dtype, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* ab, float* red, int B, int HW,

@@ -13,8 +13,12 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libjg355.so")
-SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "conv_p64.hip", "conv1x1.hip", "gemm_tn.hip", "wgrad_halo.hip", "wgrad_kxk.hip", "nce.hip", "segformer.hip", "projected_d.hip", "effnet.hip", "norm.hip", "elementwise.hip", "optim.hip", "capi.hip"]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics"]
+SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "conv_p64.hip", "conv1x1.hip", "gemm_tn.hip", "wgrad_halo.hip", "wgrad_kxk.hip", "nce.hip", "segformer.hip", "projected_d.hip", "effnet.hip", "norm.hip", "gn_fused.hip", "elementwise.hip", "optim.hip", "capi.hip"]
+# -fno-slp-vectorize: the SLP vectoriser packs independent fp32 chains into v_pk_* pairs (register tuples: gn_fused.hip went from 150 spilled
+# registers to none without it) -- "an anti-lever beside MFMAs" in the MI355X guide; same-box A/B of the whole step: 52.2 -> 52.0 ms
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
+
+FILE_FLAGS = {}      # per-source extra flags
 
 JG_F16, JG_BF16 = 0, 1
 JG_ACT_NONE, JG_ACT_SILU, JG_ACT_RELU, JG_ACT_LRELU, JG_ACT_TANH = 0, 1, 2, 3, 4
@@ -63,6 +67,8 @@ SIGNATURES = {
     "jg_gn_apply_pool": [c_i32, c_p, c_i64, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_gn_bwd_reduce_up": [c_i32, c_p, c_i64, c_p, c_i64, c_f32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_gn_bwd_reduce_up_acc": [c_i32, c_p, c_i64, c_p, c_i64, c_f32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_bwd_fused": [c_i32, c_i32, c_p, c_i64, c_p, c_i64, c_f32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_i64,
+                        c_p, c_i64, c_f32, c_p, c_i64, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_gn_bwd_apply_fc": [c_i32, c_i32, c_p, c_i64, c_p, c_i64, c_f32, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p, c_i64,
                            c_p, c_i64, c_f32, c_p, c_i64, c_f32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_gn_bwd_reduce_ld_acc": [c_i32, c_p, c_i64, c_p, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
@@ -185,7 +191,7 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
 
     def cc(job):
         sp, op = job
-        cmd = [hipcc] + cflags + ["-c", sp, "-o", op]
+        cmd = [hipcc] + cflags + FILE_FLAGS.get(os.path.basename(sp), []) + ["-c", sp, "-o", op]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=CSRC)

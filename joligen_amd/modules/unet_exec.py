@@ -73,6 +73,10 @@ WGRAD_STREAM = os.environ.get("JG_WGRAD_STREAM", "1") != "0"
 # (A/B on one box): the ~50 us a 6 us coefficient kernel spends waiting next to the weight-gradient stream is paid by the next kernel
 # instead, and the per-workgroup prologue costs what the launch saved -- off by default, kept for single-stream configurations.
 FUSE_GN_COEF = os.environ.get("JG_FUSE_GN_COEF", "0") != "0"
+# GroupNorm backward as ONE launch with x / dy resident in registers between the reduction and the apply step (csrc/gn_fused.hip,
+# DESIGN.md 4.5b): 6 instead of 10 bytes per element on paper.  MEASURED SLOWER on every UNet shape (round 4: 399 vs 310 us at 64 ch x
+# 256^2 x 32: the wait for the image's other workgroups idles the CU slots that hold the data): off; 1 = use it (kept, tested).
+GN_FUSED = os.environ.get("JG_GN_FUSED", "0") != "0"
 
 
 class _Pool:
@@ -211,8 +215,34 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
     B, H, W, C = x.shape
     HW = H * W
     dev, dt = x.device, _dt(x)
-    pqr = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
     nslots = NSLOT
+    if red is None and GN_FUSED and pool is not None and G <= 2048 and C <= 2048:
+        rows, cnt = pool.take_rows(B, C), pool.take_rows(B, 1)
+        if rows is not None and cnt is not None:
+            dgamma = gamma.grad if gamma is not None else None
+            dbeta = beta.grad if beta is not None else None
+            if gamma is not None and dgamma is None:
+                raise RuntimeError("norm weight has no arena-backed .grad")
+            if out is None:
+                out = torch.empty((B, H, W, C), device=dev, dtype=x.dtype)
+            adds = list(adds)
+            if pooled is not None:
+                if len(adds) > 1:
+                    raise RuntimeError("at most one full-resolution addend next to the pooled one")
+                a1, s1 = pooled[1] if pooled[1] is not None else (None, 0.0)
+                a2, s2 = adds[0] if adds else (None, 0.0)
+            else:
+                if len(adds) > 2:
+                    raise RuntimeError("at most two fused gradient addends")
+                a1, s1 = adds[0] if len(adds) > 0 else (None, 0.0)
+                a2, s2 = adds[1] if len(adds) > 1 else (None, 0.0)
+            check(L.jg_gn_bwd_fused(dt, int(pooled is not None), x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy),
+                                    pooled[0] if pooled is not None else 1.0, ab.data_ptr(), rows.data_ptr(), cnt.data_ptr(),
+                                    ops.gn_status(dev).data_ptr(), _p(gamma), _p(beta), _p(film), film.stride(0) if film is not None else 0,
+                                    mr.data_ptr(), _p(dgamma), _p(dbeta), _p(dfilm), dfilm.stride(0) if dfilm is not None else 0, G,
+                                    out.data_ptr(), _ld(out), _p(a1), _ld(a1) if a1 is not None else 0, s1, _p(a2),
+                                    _ld(a2) if a2 is not None else 0, s2, B, H, W, C, act, _st()), "jg_gn_bwd_fused")
+            return out
     if red is None:
         nslots = 1
         red = pool.take_rows(B, C) if pool is not None else None      # zeroed once per backward pass: no memset launch per layer
@@ -251,6 +281,7 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
                                    _ld(a1) if a1 is not None else 0, s1, _p(a2), _ld(a2) if a2 is not None else 0, s2, B, H, W, C, act, _st()),
               "jg_gn_bwd_apply_fc")
         return out
+    pqr = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
     check(L.jg_gn_bwd_coef_slots(red.data_ptr(), nslots, _p(gamma), _p(beta), _p(film),
                                  film.stride(0) if film is not None else 0, mr.data_ptr(), pqr.data_ptr(), _p(dgamma),
                                  _p(dbeta), _p(dfilm), dfilm.stride(0) if dfilm is not None else 0, B, HW, C, G, _st()),

@@ -215,7 +215,7 @@ class UNet(nn.Module):
     # -- forward ---------------------------------------------------------------------------
     def _emb_all(self, emb):
         arena = getattr(self, "_jg_arena_ref", None)
-        if arena is None:
+        if arena is None or ops.TORCH_OPS_BOUNDARY:
             return emb  # per-block projection
         W = arena.group_view("emb_layers.1.weight").view(self.emb_total, self.cond_embed_dim)
         b = arena.group_view("emb_layers.1.bias")
@@ -246,7 +246,8 @@ class UNet(nn.Module):
         unet_exec.py (same kernels, no concat / statistics / gradient-add passes); `jg_fused = False`
         selects the module-by-module graph below (what the parity tests compare it against)."""
         drop = bool(self.dropout) and self.training        # dropout > 0 in training: the module-by-module graph (ResBlock.forward) has the mask
-        if getattr(self, "jg_fused", True) and getattr(self, "_jg_arena_ref", None) is not None and input.is_cuda and not drop:
+        if getattr(self, "jg_fused", True) and getattr(self, "_jg_arena_ref", None) is not None and input.is_cuda and not drop \
+                and not ops.TORCH_OPS_BOUNDARY:
             from .unet_exec import fused_unet
 
             if embed_gammas is None:

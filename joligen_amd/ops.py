@@ -282,8 +282,42 @@ class _Conv2dFn(torch.autograd.Function):
         return dx, None, None, dres, None, None, None
 
 
+# torch.ops boundary mode: inside `with torch_ops_boundary():` every op of the palette step -- convolutions, norms,
+# attention, resampling, the embedding MLPs, q_sample and the loss -- is a call of `torch.ops.jg355.*` (torch.library custom ops with
+# fake kernels and autograd formulas) on the fp32 master parameters; concatenations / scalings are plain ATen ops and autograd assembles
+# the backward.  Same kernels through the same C ABI; what it gives up is what the arena-accumulating nodes and the fused UNet schedule
+# exist for (no gradient copies, one autograd node).  tests/test_gpu_1_model.py::test_palette_step_through_torch_ops pins the two forms.
+TORCH_OPS_BOUNDARY = False
+
+
+class torch_ops_boundary:
+    def __enter__(self):
+        global TORCH_OPS_BOUNDARY
+        self.prev, TORCH_OPS_BOUNDARY = TORCH_OPS_BOUNDARY, True
+
+    def __exit__(self, *a):
+        global TORCH_OPS_BOUNDARY
+        TORCH_OPS_BOUNDARY = self.prev
+
+
+def _conv2d_via_torch_ops(x, m: ConvMeta, res, res_scale, alpha):
+    """the layer on torch.ops.jg355.conv2d_nt with its fp32 MASTER weight as a differentiable input ([Cout, R, S, Cin], zero-padded to
+    the 8-channel granularity of the activations like the arena's working copy)"""
+    import torch.nn.functional as F
+
+    w = m.weight.reshape(m.Cout_real, m.Cin_real, m.R, m.S).permute(0, 2, 3, 1)
+    b = m.bias
+    if m.Cin != m.Cin_real or m.Cout != m.Cout_real:
+        w = F.pad(w, (0, m.Cin - m.Cin_real, 0, 0, 0, 0, 0, m.Cout - m.Cout_real))
+        if b is not None:
+            b = F.pad(b, (0, m.Cout - m.Cout_real))
+    return torch.ops.jg355.conv2d_nt(x, w, b, res, m.pad, m.stride, alpha, res_scale if res is not None else 0.0)
+
+
 def conv2d(x, meta: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
     """y = alpha*conv(x) + bias + res_scale*res   (nn.Conv2d / Conv1d(k=1) of the reference)."""
+    if TORCH_OPS_BOUNDARY:
+        return _conv2d_via_torch_ops(x, meta, res, res_scale, alpha)
     return _Conv2dFn.apply(x, meta.weight, meta.bias, res, meta, res_scale, alpha)
 
 
@@ -394,8 +428,29 @@ class _GroupNormFn(torch.autograd.Function):
         return dx, None, None, dfilm, None, None, None
 
 
+_GN_STATUS = {}
+
+
+def gn_status(device):
+    """the sticky error word of jg_gn_bwd_fused (one per device): non-zero = an inter-workgroup wait of a fused GroupNorm backward
+    expired (that launch's numbers are invalid).  `check_gn_status()` reads it (host synchronisation: tests, bench, smoke)."""
+    key = torch.device(device).index or 0
+    t = _GN_STATUS.get(key)
+    if t is None:
+        t = _GN_STATUS[key] = torch.zeros(4, device=device, dtype=torch.int32)
+    return t
+
+
+def check_gn_status():
+    for k, t in _GN_STATUS.items():
+        if int(t[0]) != 0:
+            raise RuntimeError(f"jg_gn_bwd_fused: an inter-workgroup wait expired on cuda:{k} (results of that launch are invalid)")
+
+
 def group_norm(x, G, gamma=None, beta=None, film=None, act=JG_ACT_NONE, eps=1e-5):
     """act(GroupNorm_G(x) * gamma + beta [* (1 + scale) + shift]); statistics in fp32."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.group_norm_act(x, gamma, beta, film, G, act, eps)
     return _GroupNormFn.apply(x, gamma, beta, film, G, act, eps)
 
 
@@ -615,6 +670,8 @@ class _CatFn(torch.autograd.Function):
 
 def cat_channels(a, b):
     """torch.cat([a, b], dim=1) of the reference (NCHW) == last-dim concat in NHWC."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.cat([a, b], dim=-1)
     return _CatFn.apply(a, b)
 
 
@@ -765,6 +822,8 @@ class _LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, act=JG_ACT_NONE):
     """y = act(x) @ weight.T + bias in fp32 (nn.Linear preceded by an optional SiLU)."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.linear_act(x, weight, bias, act)
     track = (weight,) if bias is None else (weight, bias)
     return _LinearFn.apply(x, weight, bias, act, weight.grad, None if bias is None else bias.grad, *track)
 
@@ -776,6 +835,8 @@ def linear_stacked(x, W, b, dW, db, act, track):
 
 def gamma_embedding(gammas, dim, max_period=10000.0):
     """models/modules/diffusion_utils.py:8-42 for gammas [B,1] (or [B])."""
+    if TORCH_OPS_BOUNDARY and not _IN_OP:
+        return torch.ops.jg355.gamma_embedding(gammas, dim, float(max_period))
     g = gammas.reshape(-1).contiguous().float()
     emb = torch.empty((g.shape[0], dim), device=g.device, dtype=torch.float32)
     check(_lib.lib().jg_gamma_embedding(g.data_ptr(), emb.data_ptr(), g.shape[0], dim, float(max_period), _st()),
@@ -959,7 +1020,12 @@ def gan_loss(pred, mode, target, scale=1.0):
 # ======================================================================================
 # DDPM glue + layout converters
 # ======================================================================================
+_IN_OP = False      # set while a torch.ops.jg355 implementation calls back into the plain helpers of this module
+
+
 def ddpm_prepare(y0, ycond, noise, mask, gammas, act_dtype, cpad=8):
+    if TORCH_OPS_BOUNDARY and not _IN_OP:
+        return torch.ops.jg355.ddpm_prepare(y0, ycond, noise, mask, gammas, act_dtype == torch.float16, cpad)
     _require_cuda(y0, ycond, noise)
     B, Cc, H, W = y0.shape
     xin = torch.empty((B, H, W, cpad), device=y0.device, dtype=act_dtype)
@@ -1001,6 +1067,8 @@ def ddpm_mse_loss(noise_hat_nhwc, noise, mask, w=None, lam=1.0, grad_scale=1.0):
         if m.dtype != torch.int64:
             m = m.long()
     wv = None if w is None else w.reshape(-1).contiguous().float()
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.ddpm_mse_loss(noise_hat_nhwc, noise.contiguous(), m, wv, float(lam), float(grad_scale), noise.shape[1])[0]
     return _MSELossFn.apply(noise_hat_nhwc, noise.contiguous(), m, wv, float(lam), float(grad_scale), noise.shape[1])
 
 
@@ -1188,12 +1256,13 @@ def _conv_out_hw(H, W, R, S, pad, stride):
 @torch.library.custom_op("jg355::conv2d_nt", mutates_args=())
 def _op_conv2d_nt(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], res: Optional[torch.Tensor], pad: int, stride: int,
                   alpha: float, res_scale: float) -> torch.Tensor:
-    """x [B,H,W,Cin] 16-bit NHWC, w [Cout,R,S,Cin] 16-bit, bias fp32 [Cout], res like y: y = alpha conv(x, w) + bias + res_scale res"""
+    """x [B,H,W,Cin] 16-bit NHWC, w [Cout,R,S,Cin] 16-bit (or the fp32 master weight: rounded to x's type inside, gradient returned in
+    fp32), bias fp32 [Cout], res like y: y = alpha conv(x, w) + bias + res_scale res"""
     B, H, W, Cin = x.shape
     Cout, R, S, _ = w.shape
     Ho, Wo = _conv_out_hw(H, W, R, S, pad, stride)
     y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=x.dtype)
-    x, w = x.contiguous(), w.contiguous()
+    x, w = x.contiguous(), w.to(x.dtype).contiguous()       # an fp32 master weight is rounded here, as the arena's working copy is
     conv_nt(x, w, y, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=R, S=S, pad=pad, stride=stride, Ho=Ho, Wo=Wo, ldx=Cin,
             ldw=R * S * Cin, ldy=Cout, bias=bias, res=None if res is None else res.contiguous(), ldres=Cout, alpha=alpha, res_scale=res_scale)
     return y
@@ -1241,7 +1310,7 @@ def _conv2d_nt_backward(ctx, dy):
     dy = dy.contiguous()
     dx = dw = db = dres = None
     if ctx.needs_input_grad[0]:          # input gradient = the same kernel on the flipped / transposed weights
-        wT = w.permute(3, 1, 2, 0).flip(1, 2).contiguous()
+        wT = w.to(dy.dtype).permute(3, 1, 2, 0).flip(1, 2).contiguous()
         dx = torch.ops.jg355.conv2d_nt(dy, wT, None, None, R - 1 - pad, 1, alpha, 0.0)
     if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
         dwf, dbf = torch.ops.jg355.conv2d_wgrad(dy, x, R, S, pad, stride, alpha)
@@ -1391,3 +1460,117 @@ def _resample_backward(ctx, dy):
 
 
 _op_resample2.register_autograd(_resample_backward, setup_context=_resample_setup)
+
+
+@torch.library.custom_op("jg355::linear_act", mutates_args=())
+def _op_linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int) -> torch.Tensor:
+    """y = act(x) @ weight.T + bias, fp32 (`emb_layers` / `cond_embed` of the UNet: nn.Linear behind an optional SiLU)"""
+    x, weight = x.contiguous(), weight.contiguous()
+    Bn, K = x.shape
+    N = weight.shape[0]
+    y = torch.empty((Bn, N), device=x.device, dtype=torch.float32)
+    check(_lib.lib().jg_linear_fwd(x.data_ptr(), weight.data_ptr(), _p(bias), y.data_ptr(), Bn, K, N, act, _st()), "jg_linear_fwd")
+    return y
+
+
+@_op_linear_act.register_fake
+def _(x, weight, bias, act):
+    return x.new_empty((x.shape[0], weight.shape[0]), dtype=torch.float32)
+
+
+@torch.library.custom_op("jg355::linear_act_bwd", mutates_args=())
+def _op_linear_act_bwd(x: torch.Tensor, weight: torch.Tensor, dy: torch.Tensor, act: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    x, weight, dy = x.contiguous(), weight.contiguous(), dy.contiguous()
+    Bn, K = x.shape
+    N = weight.shape[0]
+    dx, dW, db = torch.empty_like(x), torch.zeros_like(weight), torch.zeros((N,), device=x.device, dtype=torch.float32)
+    check(_lib.lib().jg_linear_bwd(x.data_ptr(), weight.data_ptr(), dy.data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(), Bn, K, N, act,
+                                   _st()), "jg_linear_bwd")
+    return dx, dW, db
+
+
+@_op_linear_act_bwd.register_fake
+def _(x, weight, dy, act):
+    return torch.empty_like(x), torch.empty_like(weight), x.new_empty((weight.shape[0],), dtype=torch.float32)
+
+
+def _linear_setup(ctx, inputs, output):
+    x, weight, bias, act = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.act, ctx.has_bias = act, bias is not None
+
+
+def _linear_backward(ctx, dy):
+    x, weight = ctx.saved_tensors
+    dx, dW, db = torch.ops.jg355.linear_act_bwd(x, weight, dy.contiguous(), ctx.act)
+    return (dx if ctx.needs_input_grad[0] else None, dW if ctx.needs_input_grad[1] else None,
+            db if (ctx.has_bias and ctx.needs_input_grad[2]) else None, None)
+
+
+_op_linear_act.register_autograd(_linear_backward, setup_context=_linear_setup)
+
+
+@torch.library.custom_op("jg355::gamma_embedding", mutates_args=())
+def _op_gamma_embedding(gammas: torch.Tensor, dim: int, max_period: float) -> torch.Tensor:
+    """sinusoidal noise-level embedding (models/modules/diffusion_utils.py:8-42); not differentiated (the levels are data)"""
+    global _IN_OP
+    prev, _IN_OP = _IN_OP, True
+    try:
+        return gamma_embedding(gammas, dim, max_period)
+    finally:
+        _IN_OP = prev
+
+
+@_op_gamma_embedding.register_fake
+def _(gammas, dim, max_period):
+    return gammas.new_empty((gammas.numel(), dim), dtype=torch.float32)
+
+
+@torch.library.custom_op("jg355::ddpm_prepare", mutates_args=())
+def _op_ddpm_prepare(y0: torch.Tensor, ycond: torch.Tensor, noise: torch.Tensor, mask: Optional[torch.Tensor], gammas: torch.Tensor,
+                     fp16: bool, cpad: int) -> torch.Tensor:
+    """q_sample + mask blend + cat([y_cond, y_noisy]) of DiffusionGenerator.forward (diffusion_generator.py:480-491) -> NHWC 16-bit"""
+    global _IN_OP
+    prev, _IN_OP = _IN_OP, True
+    try:
+        return ddpm_prepare(y0, ycond, noise, mask, gammas, torch.float16 if fp16 else torch.bfloat16, cpad)
+    finally:
+        _IN_OP = prev
+
+
+@_op_ddpm_prepare.register_fake
+def _(y0, ycond, noise, mask, gammas, fp16, cpad):
+    B, _, H, W = y0.shape
+    return y0.new_empty((B, H, W, cpad), dtype=torch.float16 if fp16 else torch.bfloat16)
+
+
+@torch.library.custom_op("jg355::ddpm_mse_loss", mutates_args=())
+def _op_ddpm_mse_loss(nh: torch.Tensor, noise: torch.Tensor, mask: Optional[torch.Tensor], w: Optional[torch.Tensor], lam: float,
+                      grad_scale: float, channels: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(lambda MSE(w m noise, w m noise_hat), its gradient w.r.t. noise_hat times grad_scale) in one pass (palette_model.py:597-620)"""
+    B, H, W, cpad = nh.shape
+    nh = nh.contiguous()
+    loss = torch.zeros((), device=nh.device, dtype=torch.float32)
+    dnh = torch.empty_like(nh)
+    check(_lib.lib().jg_ddpm_mse_loss(_dt(nh), noise.contiguous().data_ptr(), nh.data_ptr(), _p(mask), _p(w), loss.data_ptr(), dnh.data_ptr(), B,
+                                      channels, H, W, cpad, lam, grad_scale, _st()), "jg_ddpm_mse_loss")
+    return loss, dnh
+
+
+@_op_ddpm_mse_loss.register_fake
+def _(nh, noise, mask, w, lam, grad_scale, channels):
+    return nh.new_empty((), dtype=torch.float32), torch.empty_like(nh)
+
+
+def _mse_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+    ctx.set_materialize_grads(False)
+
+
+def _mse_backward(ctx, gloss, gdnh):
+    (dnh,) = ctx.saved_tensors
+    g = None if gloss is None else (dnh.float() * gloss.float()).to(dnh.dtype)
+    return g, None, None, None, None, None, None
+
+
+_op_ddpm_mse_loss.register_autograd(_mse_backward, setup_context=_mse_setup)

@@ -901,6 +901,31 @@ def test_torch_ops_surface(dtype):
     # and the module graph uses them: the pooling / upsampling / attention wrappers of ops.py are these ops
     up = ops.upsample_nearest2(xp)
     assert up.grad_fn is not None and torch.equal(up, torch.ops.jg355.resample2(xp, True, 1.0))
+    # the rest of the palette step's op surface (round 4): embedding MLP, noise-level embedding, q_sample, loss
+    xe = rnd((3, 40), torch.float32, 14).to(d).requires_grad_(True)
+    We = (0.2 * rnd((24, 40), torch.float32, 15)).to(d).requires_grad_(True)
+    be = (0.1 * rnd((24,), torch.float32, 16)).to(d).requires_grad_(True)
+    torch.library.opcheck(torch.ops.jg355.linear_act.default, (xe, We, be, JG_ACT_SILU), test_utils=chk)
+    ye = torch.ops.jg355.linear_act(xe, We, be, JG_ACT_SILU)
+    ye.backward(torch.ones_like(ye))
+    xr_, Wr_, br_ = (t.detach().cpu().clone().requires_grad_(True) for t in (xe, We, be))
+    yr_ = F.linear(F.silu(xr_), Wr_, br_)
+    yr_.backward(torch.ones_like(yr_))
+    assert relerr(ye, yr_) < 1e-5 and relerr(xe.grad, xr_.grad) < 1e-5 and relerr(We.grad, Wr_.grad) < 1e-5 and relerr(be.grad, br_.grad) < 1e-5
+    gam = torch.rand(3, device=d)
+    torch.library.opcheck(torch.ops.jg355.gamma_embedding.default, (gam, 32, 10000.0), test_utils=chk)
+    y0, yc, nz = (rnd((2, 3, 16, 16), torch.float32, 17 + i).to(d) for i in range(3))
+    mk = torch.zeros(2, 1, 16, 16, dtype=torch.int64, device=d)
+    mk[:, :, 3:9, 4:12] = 1
+    torch.library.opcheck(torch.ops.jg355.ddpm_prepare.default, (y0, yc, nz, mk, gam[:2].contiguous(), dtype == torch.float16, 8), test_utils=chk)
+    nh = rnd((2, 16, 16, 8), dtype, 21).to(d).requires_grad_(True)
+    torch.library.opcheck(torch.ops.jg355.ddpm_mse_loss.default, (nh, nz, mk, None, 1.0, 1.0, 3), test_utils=chk)
+    loss = torch.ops.jg355.ddpm_mse_loss(nh, nz, mk, None, 1.0, 1.0, 3)[0]
+    (loss * 2.0).backward()
+    nr = nh.detach().float().cpu().permute(0, 3, 1, 2)[:, :3].clone().requires_grad_(True)
+    lr_ = F.mse_loss(mk.cpu() * nz.cpu(), mk.cpu() * nr)
+    (lr_ * 2.0).backward()
+    assert abs(float(loss) - float(lr_)) < 1e-5 * abs(float(lr_)) and relerr(nh.grad.float().permute(0, 3, 1, 2)[:, :3], nr.grad) < 4 * TOL[dtype]
 
 
 def test_c_abi_rejects_bad_arguments():
@@ -1360,3 +1385,127 @@ def test_crop2d_and_adjoint(dtype):
     ref = torch.zeros_like(x)
     ref[:, 2:9, 3:12] = r
     assert torch.equal(x.grad, ref)
+
+
+# ---- single-pass GroupNorm backward (csrc/gn_fused.hip) against the three-launch form (reduce -> coef -> apply) ---------------------------
+def _gn_bwd_both(B, H, W, C, G, act, up, n_adds, film, dtype, depth, cap, stride_pad=0, seed=0):
+    """returns (dx, dgamma, dbeta, dfilm) of the fused launch and of the three-launch form on the same random inputs"""
+    from joligen_amd import _lib, ops
+
+    L = _lib.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(seed)
+    dt = _lib.JG_F16 if dtype == torch.float16 else _lib.JG_BF16
+    HW = H * W
+    ld = C + stride_pad                                        # a channel slice of a wider buffer (concat halves)
+    x = (torch.randn(B, HW, ld, generator=g) * 1.3 + 0.2).to(dtype).to(d)
+    Hl, Wl = (H // 2, W // 2) if up else (H, W)
+    dy = torch.randn(B, Hl * Wl, ld, generator=g).to(dtype).to(d)
+    add1 = torch.randn(B, Hl * Wl, ld, generator=g).to(dtype).to(d) if n_adds >= 1 else None
+    add2 = torch.randn(B, HW, ld, generator=g).to(dtype).to(d) if n_adds >= 2 else None
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(d)
+    beta = (0.1 * torch.randn(C, generator=g)).to(d)
+    filmt = (0.3 * torch.randn(B, 2 * C + 8, generator=g)).to(d) if film else None
+    # forward coefficients from the real statistics
+    xf = x[:, :, :C].float()
+    cpg = C // G
+    mean = xf.view(B, HW, G, cpg).mean(dim=(1, 3))
+    var = xf.view(B, HW, G, cpg).var(dim=(1, 3), unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    mr = torch.stack([mean, rstd], -1).contiguous()
+    a0 = rstd.repeat_interleave(cpg, 1) * gamma
+    b0 = beta - mean.repeat_interleave(cpg, 1) * a0
+    if film:
+        sc, sh = filmt[:, 4:4 + C], filmt[:, 4 + C:4 + 2 * C]
+        a0, b0 = a0 * (1 + sc), b0 * (1 + sc) + sh
+    ab = torch.stack([a0, b0], -1).contiguous()
+    fptr = filmt[:, 4:].data_ptr() if film else None
+    ldf = filmt.stride(0) if film else 0
+    st = ops._st()
+    out = []
+    for fused in (True, False):
+        dx = torch.zeros(B, HW, ld, device=d, dtype=dtype)
+        dgamma, dbeta = torch.zeros(C, device=d), torch.zeros(C, device=d)
+        dfilm = torch.zeros(B, 2 * C, device=d) if film else None
+        red = torch.zeros(B, C, 2, device=d)
+        dysc = 0.25 if up else 1.0
+        a1p, a2p = (add1.data_ptr() if add1 is not None else None), (add2.data_ptr() if add2 is not None else None)
+        if fused:
+            cnt = torch.zeros(B, 2, device=d, dtype=torch.int32)
+            prev = (_lib.set_tuning("JG_GN_FUSED", depth), _lib.set_tuning("JG_GN_FUSED_CAP", cap))
+            try:
+                _lib.check(L.jg_gn_bwd_fused(dt, int(up), x.data_ptr(), ld, dy.data_ptr(), ld, dysc, ab.data_ptr(), red.data_ptr(), cnt.data_ptr(),
+                                             ops.gn_status(d).data_ptr(), gamma.data_ptr(), beta.data_ptr(), fptr, ldf, mr.data_ptr(),
+                                             dgamma.data_ptr(), dbeta.data_ptr(), dfilm.data_ptr() if film else None, 2 * C, G, dx.data_ptr(), ld,
+                                             a1p, ld, 0.7, a2p, ld, -1.3, B, H, W, C, act, st), "jg_gn_bwd_fused")
+            finally:
+                _lib.set_tuning("JG_GN_FUSED", prev[0]); _lib.set_tuning("JG_GN_FUSED_CAP", prev[1])
+        else:
+            pqr = torch.empty(B, C, 3, device=d)
+            if up:
+                _lib.check(L.jg_gn_bwd_reduce_up_acc(dt, x.data_ptr(), ld, dy.data_ptr(), ld, dysc, ab.data_ptr(), red.data_ptr(), B, H, W, C, act, st))
+            else:
+                _lib.check(L.jg_gn_bwd_reduce_ld_acc(dt, x.data_ptr(), ld, dy.data_ptr(), ld, ab.data_ptr(), red.data_ptr(), B, HW, C, act, st))
+            _lib.check(L.jg_gn_bwd_coef_slots(red.data_ptr(), 1, gamma.data_ptr(), beta.data_ptr(), fptr, ldf, mr.data_ptr(), pqr.data_ptr(),
+                                              dgamma.data_ptr(), dbeta.data_ptr(), dfilm.data_ptr() if film else None, 2 * C, B, HW, C, G, st))
+            if up:
+                _lib.check(L.jg_gn_bwd_apply_up(dt, x.data_ptr(), ld, dy.data_ptr(), ld, dysc, ab.data_ptr(), pqr.data_ptr(), dx.data_ptr(), ld,
+                                                a1p, ld, 0.7, a2p, ld, -1.3, B, H, W, C, act, st))
+            else:
+                _lib.check(L.jg_gn_bwd_apply_ld(dt, x.data_ptr(), ld, dy.data_ptr(), ld, ab.data_ptr(), pqr.data_ptr(), dx.data_ptr(), ld,
+                                                a1p, ld, 0.7, a2p, ld, -1.3, B, HW, C, act, st))
+        torch.cuda.synchronize()
+        out.append((dx[:, :, :C].float().cpu(), dgamma.cpu(), dbeta.cpu(), dfilm.cpu() if film else None, dx[:, :, C:].float().abs().sum().item()))
+    return out
+
+
+GN_FUSED_CASES = [
+    # B, H, W, C, G, act(1 = SiLU, 0 = none), up, addends, film, depth, cap, stride_pad
+    (2, 32, 32, 64, 32, 1, False, 0, False, 16, 256, 0),       # several workgroups per image, everything resident
+    (3, 32, 32, 64, 32, 1, False, 2, True, 8, 256, 64),        # FiLM + two addends, x / dy / dx as channel slices of wider buffers
+    (2, 64, 64, 128, 32, 1, True, 1, False, 12, 256, 0),       # pooled dy + pooled addend
+    (2, 64, 64, 128, 32, 1, True, 2, False, 20, 256, 0),
+    (2, 32, 32, 192, 32, 1, False, 1, False, 16, 256, 0),      # 24 octets: 240 active threads, tail workgroup (1024 px / 160)
+    (2, 48, 48, 64, 32, 1, False, 0, False, 16, 4, 0),         # cluster cap 4: K = 18 > N, streamed + resident pixels, tail
+    (2, 40, 40, 64, 32, 1, False, 1, False, 8, 3, 0),          # K not a divisor of the image: partial last workgroup
+    (2, 16, 16, 512, 32, 1, False, 0, True, 16, 256, 0),       # groups span two octets
+    (2, 8, 8, 1024, 32, 1, False, 0, False, 16, 256, 0),       # 128 octets: two pixel lanes
+    (3, 32, 1, 64, 64, 0, False, 1, False, 16, 256, 0),        # normalization1d of the attention block: G = C, no activation
+    (2, 8, 8, 32, 32, 1, False, 0, False, 16, 256, 0),         # single workgroup per image (no inter-workgroup wait)
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", GN_FUSED_CASES)
+def test_gn_bwd_fused_matches_three_launch_form(case, dtype):
+    from joligen_amd import ops
+
+    B, H, W, C, G, act, up, n_adds, film, depth, cap, pad = case
+    fused, ref = _gn_bwd_both(B, H, W, C, G, act, up, n_adds, film, dtype, depth, cap, pad, seed=C + H)
+    ops.check_gn_status()
+    # same arithmetic, other summation order (and the hardware reciprocal in the SiLU derivative): 16-bit output rounding flips only
+    assert relerr(fused[0], ref[0]) < (2e-3 if dtype == torch.float16 else 8e-3), ("dx", relerr(fused[0], ref[0]))
+    assert relerr(fused[1], ref[1]) < 1e-4 and relerr(fused[2], ref[2]) < 1e-4, ("dgamma/dbeta", relerr(fused[1], ref[1]), relerr(fused[2], ref[2]))
+    if film:
+        assert relerr(fused[3], ref[3]) < 1e-4
+    assert fused[4] == 0.0, "wrote outside its channel slice"
+
+
+def test_gn_bwd_fused_under_uneven_load():
+    """the inter-workgroup hand-off (agent-scope atomics + arrival counter, MI355X guide G16) next to a second stream that keeps part of the
+    chip busy, 30 launches over a 256-workgroup-per-image grid: every launch must agree with the three-launch form and never time out"""
+    from joligen_amd import ops
+
+    side = torch.cuda.Stream()
+    junk = torch.empty(256 << 20, dtype=torch.uint8, device=dev())
+    big = torch.randn(4096, 4096, device=dev(), dtype=torch.bfloat16)
+    for it in range(30):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                junk.add_(1)
+                big @ big
+        fused, ref = _gn_bwd_both(4, 256, 256, 64, 32, 1, False, 1, False, torch.bfloat16, 16, 256, 0, seed=it)
+        assert relerr(fused[0], ref[0]) < 8e-3, (it, relerr(fused[0], ref[0]))
+        assert relerr(fused[1], ref[1]) < 1e-4, (it, relerr(fused[1], ref[1]))
+    torch.cuda.synchronize()
+    ops.check_gn_status()

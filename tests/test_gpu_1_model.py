@@ -1202,3 +1202,70 @@ def test_gn_backward_with_fused_coefficients(golden_dir, efficient, monkeypatch)
     for i, name in enumerate(("dx", "demb", "gradient arena")):
         e = relerr(res[True][i], res[False][i])
         assert e < 5e-3, (name, e)        # same arithmetic, other summation orders (fp32 atomics) in front of fp16 stores
+
+
+@pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
+def test_palette_step_through_torch_ops(golden_dir, dtype_name):
+    """The op boundary of north_star / SURVEY.md 8(b3): ONE palette training step with every op a `torch.ops.jg355.*` call
+    (`ops.torch_ops_boundary()`: conv2d_nt on the fp32 master weights, group_norm_act, attention_core, resample2, linear_act,
+    gamma_embedding, ddpm_prepare, ddpm_mse_loss; concatenation = torch.cat; autograd assembles the backward from the registered
+    formulas) against the same step on the module-by-module graph of ctypes autograd nodes: same kernels behind both, so loss and
+    every parameter gradient agree to the run-to-run floor of the ctypes graph itself (measured here), and after
+    `optimize_parameters()` through the boundary the update has the same direction and length.  (The default step is the fused schedule: one autograd node)"""
+    import parity_util as PU
+    from joligen_amd import ops
+
+    c = dict(ngf=32, mults=[1, 2, 4], res_blocks=[1, 1, 1], attn_res=[4], efficient=True, S=32, B=2)
+    g = torch.Generator().manual_seed(5)
+    Bimg = torch.rand(2, 3, 32, 32, generator=g) * 2 - 1
+    mask = torch.zeros(2, 1, 32, 32, dtype=torch.int64)
+    mask[:, :, 6:20, 10:26] = 1
+    A = Bimg * (1 - mask) + torch.randn(2, 3, 32, 32, generator=g) * mask
+    t, u, noise = O.draw_step_randomness(torch.Generator().manual_seed(9), Bimg, 2000)
+
+    def run(boundary, full_step=False):
+        model = make_model(c, dtype_name, golden_dir, train_G_ema=False)
+        model.netG_A.denoise_fn.model.jg_fused = False           # module-by-module graph on both sides
+        model.rng_injection = lambda b: (t, u, noise)
+        model.set_input({"A": A, "B": Bimg, "B_label_mask": mask})
+        before = PU.snapshot(model.netG_A)
+        ctx = ops.torch_ops_boundary() if boundary else contextlib.nullcontext()
+        with ctx:
+            if full_step:
+                model.optimize_parameters()
+                torch.cuda.synchronize()
+                return float(model.loss_G_tot.detach()), before, PU.snapshot(model.netG_A)
+            model.compute_palette_loss()
+            model.loss_G_tot.backward()
+        torch.cuda.synchronize()
+        return float(model.loss_G_tot.detach()), {k: p.grad.detach().float().cpu().clone() for k, p in model.netG_A.named_parameters()}
+
+    import contextlib
+
+    # yardstick measured on the spot: the SAME ctypes graph run twice.  GroupNorm statistics and split-K weight gradients are summed with
+    # fp32 atomics, so two runs differ in the last bit of a few sums, a handful of 16-bit activations round the other way, and the step
+    # is reproducible only to that floor -- the torch.ops form must sit on it (it launches the same kernels on the same bits).
+    loss_c, grads_c = run(False)
+    loss_c2, grads_c2 = run(False)
+    loss_o, grads_o = run(True)
+    keys = [k for k in grads_c if float(grads_c[k].norm()) > 0]
+    floor_loss = abs(loss_c2 - loss_c) / abs(loss_c)
+    floor_grad = max(relerr(grads_c2[k], grads_c[k]) for k in keys)
+    assert abs(loss_o - loss_c) <= 3 * floor_loss * abs(loss_c) + 2e-4 * abs(loss_c), (loss_o, loss_c, loss_c2)
+    worst = max((relerr(grads_o[k], grads_c[k]), k) for k in keys)
+    assert worst[0] <= 3 * floor_grad + 2e-3, (worst, floor_grad)       # (the floor's worst tensor is a conv bias in front of a GroupNorm: pure noise)
+    cat = lambda gr: torch.cat([gr[k].flatten() for k in keys])
+    whole, floor_whole = relerr(cat(grads_o), cat(grads_c)), relerr(cat(grads_c2), cat(grads_c))
+    assert whole <= 3 * floor_whole + 1e-3, (whole, floor_whole)         # all parameter gradients as one vector
+    zero = [k for k in grads_c if (float(grads_c[k].norm()) == 0) != (float(grads_o[k].norm()) == 0)]
+    assert not zero, zero
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/torch_ops_step_{dtype_name}.txt", "w") as f:
+        f.write(f"loss ctypes {loss_c!r} ctypes again {loss_c2!r} torch.ops {loss_o!r}\nworst gradient tensor torch.ops vs ctypes {worst}\n"
+                f"run-to-run floor of the ctypes graph: loss {floor_loss:.3e} worst tensor {floor_grad:.3e}\n"
+                f"all gradients as one vector: torch.ops vs ctypes {whole:.3e}, ctypes run-to-run {floor_whole:.3e}\n")
+    # the whole optimize_parameters() through the boundary: same update as through the ctypes nodes
+    _, b_c, a_c = run(False, full_step=True)
+    _, b_o, a_o = run(True, full_step=True)
+    cos, ratio, _ = PU.update_agreement(b_o, a_o, b_c, a_c)
+    assert cos > 0.9 and 0.95 < ratio < 1.05, (cos, ratio)
