@@ -287,3 +287,128 @@ def test_cut_model_with_projected_and_basic_discriminators():
         frozen = [k for k in params if k.startswith("freeze")]
         assert all(k not in moved for k in frozen), [k for k in frozen if k in moved][:3]
         assert len(moved) >= 0.8 * (len(params) - len(frozen)), (n, len(moved), len(params))
+
+
+def _timm_style_lite0_state_dict(seed=11):
+    """a state_dict with timm's `tf_efficientnet_lite0` key names and shapes (what `timm.create_model(...).state_dict()` holds: stem,
+    bn1, blocks.<stage>.<block>.*, and the classification tail the projector never uses), filled with seeded non-trivial values
+    (BatchNorm running statistics included).  timm itself is absent offline: the names come from its published definition restated in
+    oracle/efficientnet_lite0_torch.py."""
+    from efficientnet_lite0_torch import TfEfficientNetLite0
+
+    net = TfEfficientNetLite0().eval()
+    g = torch.Generator().manual_seed(seed)
+    sd = net.state_dict()
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.tensor(1234)
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) * 0.8 + 0.4
+        elif k.endswith("running_mean"):
+            sd[k] = torch.randn(v.shape, generator=g) * 0.2
+        elif v.dim() == 1:       # BatchNorm weight / bias
+            sd[k] = torch.randn(v.shape, generator=g) * 0.2 + (1.0 if k.endswith("weight") else 0.0)
+        else:
+            fan = v[0].numel()
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / fan) ** 0.5
+    net.load_state_dict(sd)
+    full = dict(sd)
+    full.update({"conv_head.weight": torch.randn(1280, 320, 1, 1, generator=g), "bn2.weight": torch.ones(1280), "bn2.bias": torch.zeros(1280),
+                 "bn2.running_mean": torch.zeros(1280), "bn2.running_var": torch.ones(1280), "bn2.num_batches_tracked": torch.tensor(0),
+                 "classifier.weight": torch.randn(1000, 1280, generator=g) * 0.01, "classifier.bias": torch.zeros(1000)})
+    return net, sd, full
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pretrained_backbone_loads_and_matches_the_torch_mirror(tmp_path, dtype):
+    """f2: `jg_projd_pretrained` -> ProjectedDiscriminator.load_pretrained_backbone with a timm-keyed
+    `tf_efficientnet_lite0` state_dict (/root/reference/models/modules/projected_d/projector.py:51-59,251-255 loads timm's weights and
+    re-homes the modules into layer0..3): every backbone tensor is consumed, the classification tail is ignored, the frozen BatchNorm
+    statistics are folded as the kernels expect, and the four stage features of the HIP feature network equal the plain-torch mirror's
+    on the same 16-bit-representable input."""
+    import warnings
+
+    from joligen_amd import ops
+    from joligen_amd.modules.projected_d import ProjectedDiscriminator
+
+    mirror, sd_backbone, sd_full = _timm_style_lite0_state_dict()
+    path = os.path.join(str(tmp_path), "tf_efficientnet_lite0.pth")
+    torch.save(sd_full, path)
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter("always")
+        net = ProjectedDiscriminator("efficientnet", interp=-1, img_size=64, pretrained_path=path)
+    assert net.backbone_pretrained and not [w for w in wlist if "RANDOM frozen weights" in str(w.message)]
+    pre = net.freeze_feature_network.pretrained.state_dict()
+    assert len(pre) == len(sd_backbone)                      # every timm backbone entry has a home, nothing else lives there
+    # re-homing as in _make_efficientnet: layer0 = conv_stem + bn1 + act + blocks[0:2], layer1 = blocks[2], layer2 = blocks[3:5], layer3 = blocks[5:]
+    assert torch.equal(pre["layer0.0.weight"], sd_backbone["conv_stem.weight"]) and torch.equal(pre["layer0.1.running_var"], sd_backbone["bn1.running_var"])
+    assert torch.equal(pre["layer1.0.0.conv_dw.weight"], sd_backbone["blocks.2.0.conv_dw.weight"])
+    assert torch.equal(pre["layer3.1.0.bn3.running_mean"], sd_backbone["blocks.6.0.bn3.running_mean"])
+    net.jg_finalize(torch.device(D0), dtype)
+    net.eval()
+    g = torch.Generator().manual_seed(3)
+    img = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).to(dtype).float()
+    x = ops.to_nhwc(img.to(D0), dtype, 8)
+    p = net.freeze_feature_network.pretrained
+    with torch.no_grad():
+        net.arena.ensure_fresh()
+        o0 = p.layer0(x); o1 = p.layer1(o0); o2 = p.layer2(o1); o3 = p.layer3(o2)
+        h = mirror.bn1(mirror.conv_stem(img))
+        refs = []
+        for i, stage in enumerate(mirror.blocks):
+            h = stage(h)
+            if i in (1, 2, 4, 6):
+                refs.append(h)
+    tol = 6e-3 if dtype == torch.float16 else 4e-2           # 16 frozen layers of 16-bit storage on a random network
+    for i, (mine, ref) in enumerate(zip((o0, o1, o2, o3), refs)):
+        assert mine.shape[-1] == ref.shape[1] and mine.shape[1] == ref.shape[2], (i, mine.shape, ref.shape)
+        e = relerr(mine.permute(0, 3, 1, 2).float(), ref)
+        assert e < tol * (1 + i), (i, e)
+    # a checkpoint WITHOUT one backbone tensor must not load
+    bad = {k: v for k, v in sd_full.items() if k != "blocks.3.1.conv_pw.weight"}
+    torch.save(bad, path)
+    with pytest.raises(RuntimeError):
+        ProjectedDiscriminator("efficientnet", interp=-1, img_size=64, pretrained_path=path)
+
+
+def test_reference_layout_discriminator_checkpoint_restores_the_backbone(tmp_path):
+    """a `<epoch>_net_D_B_projected_d.pth` in the reference's layout (376 keys incl. `freeze_feature_network.pretrained.*`, what the
+    reference writes with timm's weights inside) through BaseModel.load_networks: every backbone tensor arrives, the model knows its
+    feature network is no longer random; the same file without the backbone is refused."""
+    import warnings
+
+    from joligen_amd.models import create_model
+    from joligen_amd.options import opt_from_json
+
+    cfg = {"model_type": "cut", "G": {"netG": "resnet", "ngf": 16, "nblocks": 2}, "D": {"netDs": ["projected_d"], "proj_interp": 64},
+           "alg": {"cut": {"nce_layers": "0,4,8"}}, "data": {"crop_size": 64, "load_size": 64}, "train": {"batch_size": 1}}
+    ov = {"jg_act_dtype": "bf16", "gpu_ids": "0", "checkpoints_dir": str(tmp_path), "name": "pd"}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = create_model(opt_from_json(cfg, overrides=ov), 0)
+    g = torch.Generator().manual_seed(4)
+    data = {"A": torch.rand(1, 3, 64, 64, generator=g) * 2 - 1, "B": torch.rand(1, 3, 64, 64, generator=g) * 2 - 1}
+    model.data_dependent_initialize(data)
+    model.single_gpu()
+    netD = model.netD_B_projected_d
+    assert not netD.backbone_pretrained
+    _, sd_backbone, _ = _timm_style_lite0_state_dict(seed=21)
+    ck = {k: v.detach().cpu().clone() for k, v in netD.state_dict().items()}
+    pre = "freeze_feature_network.pretrained."
+    n_pre = len([k for k in ck if k.startswith(pre)])
+    assert n_pre == len(sd_backbone)
+    probe = {}
+    for k in list(ck):
+        if k.startswith(pre) and torch.is_floating_point(ck[k]) and ck[k].dim() > 0:
+            ck[k] = torch.randn(ck[k].shape, generator=g) * 0.1 + (1.0 if k.endswith("running_var") else 0.0)
+            probe[k] = ck[k]
+    model.save_networks("latest")
+    torch.save(ck, os.path.join(str(tmp_path), "pd", "latest_net_D_B_projected_d.pth"))
+    model.load_networks("latest")
+    now = netD.state_dict()
+    for k, v in probe.items():
+        assert torch.equal(now[k].cpu(), v), k
+    assert netD.backbone_pretrained
+    torch.save({k: v for k, v in ck.items() if not k.startswith(pre)}, os.path.join(str(tmp_path), "pd", "latest_net_D_B_projected_d.pth"))
+    with pytest.raises(RuntimeError):
+        model.load_networks("latest")

@@ -203,8 +203,11 @@ def _worker_early(rank, world, port, sizes, out):
     dist.destroy_process_group()
 
 
-def test_backward_overlapped_exchange(tmp_path):
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_backward_overlapped_exchange(tmp_path, world):
     sizes = (900, 1500, 3000, 40, 5000, 7000, 64, 2048, 6000, 1000)
     n = sum(sizes)
     out = str(tmp_path / "e%d.pt")
@@ -392,3 +395,120 @@ def test_bf16_gradient_wire_format(tmp_path):
     assert float(d.max()) <= 2.1 * 2 * 2e-4                   # two steps of at most lr each way
     assert float((d > 1e-6).float().mean()) < 0.5             # most elements agree to rounding
     assert float(((r0["p"] - ref_p).norm()) / (ref_p.norm())) < 1e-4
+
+
+# ---- the CUT step (three arenas: G, F, D) over two ranks, model level ------------------------------------------------------------------
+CUT_CFG = dict(ngf=8, n_blocks=2, ndf=8, S=32, B=2, nce_layers=[0, 4, 8, 10, 11], num_patches=32)
+
+
+def _cut_inputs():
+    from joligen_amd.modules.cut_networks import PatchSampleF
+    from joligen_amd.modules.discriminators import NLayerDiscriminator
+    from joligen_amd.modules.resnet_generator import ResnetGenerator
+
+    c = CUT_CFG
+    torch.manual_seed(0)
+    netG = ResnetGenerator(3, 3, c["ngf"], n_blocks=c["n_blocks"])
+    netF = PatchSampleF(use_mlp=True, nc=32)
+    netF.data_dependent_initialize(None, netG.feat_channels(c["nce_layers"]))
+    netD = NLayerDiscriminator(3, c["ndf"])
+    sdG = O.synth_state_dict({k: v.detach() for k, v in netG.state_dict().items()}, 0)
+    sdF = O.synth_state_dict({k: v.detach().float() for k, v in netF.state_dict().items()}, 3)
+    sdD = O.synth_state_dict({k: v.detach().float() for k, v in netD.state_dict().items()}, 1)
+    g = torch.Generator().manual_seed(33)
+    steps = []
+    for _ in range(2):
+        A = torch.rand(c["B"], 3, c["S"], c["S"], generator=g) * 2 - 1
+        Bi = torch.rand(c["B"], 3, c["S"], c["S"], generator=g) * 2 - 1
+        steps.append((A, Bi))
+    return sdG, sdF, sdD, steps
+
+
+def _cut_trainer(sdG, sdF, sdD):
+    import random
+
+    c = CUT_CFG
+    return O.OracleCUTTrainer(sdG, sdF, sdD, c["n_blocks"], c["nce_layers"], num_patches=c["num_patches"], T=0.07, monce=False, pool_size=0,
+                              pool_rng=random.Random(0), ema_beta=None)
+
+
+def _cut_ids(tr, A, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        hw = [f.shape[2] * f.shape[3] for f in tr._feats(tr.G, A[:1])]
+    return [[torch.randperm(n, generator=g)[:min(CUT_CFG["num_patches"], n)] for n in hw] for _ in range(2)]
+
+
+class _DictArena(FakeArena):
+    """flat view of one parameter dict of the OracleCUTTrainer (G, F or D)"""
+
+    def __init__(self, params):
+        self.names = list(params.keys())
+        self.shapes = [params[k].shape for k in self.names]
+        self.p = torch.cat([params[k].reshape(-1) for k in self.names])
+        self.numel = self.p.numel()
+        self.g, self.m, self.v = torch.zeros(self.numel), torch.zeros(self.numel), torch.zeros(self.numel)
+        self.ema, self.step, self.dirty, self.calls = None, 0, False, []
+
+    def load_grads(self, grads):
+        self.g += torch.cat([grads[k].reshape(-1) for k in self.names])
+
+    def store(self, params):
+        off = 0
+        for k, s in zip(self.names, self.shapes):
+            n = params[k].numel()
+            params[k] = self.p[off:off + n].reshape(s).clone()
+            off += n
+
+
+def _worker_cut(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from joligen_amd import parallel
+
+    sdG, sdF, sdD, steps = _cut_inputs()
+    tr = _cut_trainer(sdG, sdF, sdD)
+    arenas = {"G": _DictArena(tr.G), "F": _DictArena(tr.Fp), "D": _DictArena(tr.D)}
+    stores = {"G": tr.G, "F": tr.Fp, "D": tr.D}
+    for a in arenas.values():
+        parallel.broadcast_params(a, 0)
+    half = CUT_CFG["B"] // world
+    sl = slice(rank * half, (rank + 1) * half)
+    hpG = dict(lr=2e-4, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, decoupled=False, ema_beta=None, zero_grad=True)
+    hpD = dict(hpG, lr=1e-4)
+    for it, (A, Bi) in enumerate(steps):
+        ids = _cut_ids(tr, A, 70 + it)                     # the same patch ids on every rank (PatchSampleF shares them over the batch)
+        tr.iteration(A[sl], Bi[sl], ids[0], ids[1], iter_size=10 ** 9)      # gradients of this rank's half, no local optimizer step
+        for name, hp in (("G", hpG), ("F", hpG), ("D", hpD)):               # group G's two arenas, then group D's (base_model.py:1302-1377)
+            arenas[name].load_grads(tr.last_grads[name])
+            arenas[name].step += 1
+            parallel.allreduce_and_step(arenas[name], hp, grad_scale=1.0, n_chunks=4)
+            arenas[name].store(stores[name])
+    torch.save({k: a.p for k, a in arenas.items()}, out % rank)
+    dist.destroy_process_group()
+
+
+def test_cut_step_two_ranks_equals_single_process_batch(tmp_path):
+    """the CUT optimisation step (resnet G + PatchGAN D + mlp_sample F, PatchNCE + lsgan; three gradient arenas stepped in the reference's
+    group order) of a batch of 2 split over two ranks through parallel.allreduce_and_step == the single-process step on the whole batch:
+    every term of the step is a mean over images of per-image quantities (InstanceNorm, within-image negatives, patch-logit means), so the
+    mean of the per-rank gradients is the full-batch gradient (DDP semantics, models/base_model.py:725-737)."""
+    world = 2
+    out = str(tmp_path / "cut%d.pt")
+    mp.spawn(_worker_cut, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    sdG, sdF, sdD, steps = _cut_inputs()
+    tr = _cut_trainer(sdG, sdF, sdD)
+    tr.hp.update(lr_G=2e-4, lr_D=1e-4)
+    for it, (A, Bi) in enumerate(steps):
+        ids = _cut_ids(tr, A, 70 + it)
+        tr.step(A, Bi, ids[0], ids[1])
+    for name, params, lr in (("G", tr.G, 2e-4), ("F", tr.Fp, 2e-4), ("D", tr.D, 1e-4)):
+        assert torch.equal(r0[name], r1[name]), name
+        ref = torch.cat([params[k].reshape(-1) for k in params])
+        d = (r0[name] - ref).abs()
+        # sign-like first Adam steps on analytically-zero gradients (conv biases in front of InstanceNorm) differ by up to lr per step
+        assert float((d > 2e-7 + 2e-5 * ref.abs()).float().mean()) < 0.05, (name, float((d > 2e-7 + 2e-5 * ref.abs()).float().mean()))
+        assert float(d.max()) <= 2.1 * 2 * lr, (name, float(d.max()))
+        assert float((r0[name] - ref).norm() / ref.norm()) < 5e-4, (name, float((r0[name] - ref).norm() / ref.norm()))   # those few elements: <= 2 lr each
