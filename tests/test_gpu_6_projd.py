@@ -350,20 +350,35 @@ def test_pretrained_backbone_loads_and_matches_the_torch_mirror(tmp_path, dtype)
     img = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).to(dtype).float()
     x = ops.to_nhwc(img.to(D0), dtype, 8)
     p = net.freeze_feature_network.pretrained
+    def mirror_stages(rounded):
+        """the four stage outputs of the torch mirror; rounded: every convolution / BatchNorm(+ReLU6) / block output is stored in `dtype`
+        (where the HIP network keeps 16-bit tensors) -- the rounding yardstick of THIS random network, measured on the spot"""
+        hooks = []
+        if rounded:
+            rnd = lambda m, i, o: o.to(dtype).float()
+            for m in mirror.modules():
+                if isinstance(m, (torch.nn.Conv2d, torch.nn.BatchNorm2d)) or type(m).__name__ in ("DepthwiseSeparableConv", "InvertedResidual"):
+                    hooks.append(m.register_forward_hook(rnd))
+        try:
+            h, outs = mirror.bn1(mirror.conv_stem(img)), []
+            for i, stage in enumerate(mirror.blocks):
+                h = stage(h)
+                if i in (1, 2, 4, 6):
+                    outs.append(h)
+            return outs
+        finally:
+            for hk in hooks:
+                hk.remove()
+
     with torch.no_grad():
         net.arena.ensure_fresh()
         o0 = p.layer0(x); o1 = p.layer1(o0); o2 = p.layer2(o1); o3 = p.layer3(o2)
-        h = mirror.bn1(mirror.conv_stem(img))
-        refs = []
-        for i, stage in enumerate(mirror.blocks):
-            h = stage(h)
-            if i in (1, 2, 4, 6):
-                refs.append(h)
-    tol = 6e-3 if dtype == torch.float16 else 4e-2           # 16 frozen layers of 16-bit storage on a random network
-    for i, (mine, ref) in enumerate(zip((o0, o1, o2, o3), refs)):
+        refs, floor = mirror_stages(False), mirror_stages(True)
+    for i, (mine, ref, fl) in enumerate(zip((o0, o1, o2, o3), refs, floor)):
         assert mine.shape[-1] == ref.shape[1] and mine.shape[1] == ref.shape[2], (i, mine.shape, ref.shape)
-        e = relerr(mine.permute(0, 3, 1, 2).float(), ref)
-        assert e < tol * (1 + i), (i, e)
+        e, ef = relerr(mine.permute(0, 3, 1, 2).float(), ref), relerr(fl, ref)
+        # a wrong BatchNorm fold / tap alignment / stage cut is an O(1) error; 16-bit storage through 16 random ReLU6 layers costs `ef`
+        assert e < 2.0 * ef + 2e-3, (i, e, ef)
     # a checkpoint WITHOUT one backbone tensor must not load
     bad = {k: v for k, v in sd_full.items() if k != "blocks.3.1.conv_pw.weight"}
     torch.save(bad, path)
