@@ -403,6 +403,11 @@ int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, const void* v, 
 int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
                         float* dkf, float* dvf, void* dk, void* dv, int B, int Tq, int Tkv, int heads, int64_t ldq, int64_t ldkv, int64_t ldo,
                         float scale, jg_stream_t s);
+/* the same with dk / dv written as 16-bit rows of pitch lddkv (dk = buffer, dv = buffer + C of a [B, Tkv, 2 C] gradient of the packed kv
+ * projection: no concatenation afterwards); a contiguous (dkf, dvf) accumulator pair is cleared with one fill */
+int jg_attn_smallkv_bwd2(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,
+                         float* dkf, float* dvf, void* dk, void* dv, int64_t lddkv, int B, int Tq, int Tkv, int heads, int64_t ldq, int64_t ldkv,
+                         int64_t ldo, float scale, jg_stream_t s);
 /* the same with align_corners selectable (1: FeatureFusionBlockMatrix of the projected discriminator, projected_d/blocks.py:276-287) */
 int jg_bilinear2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, int align_corners, jg_stream_t s);
 int jg_bilinear2_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, int align_corners, jg_stream_t s);
@@ -432,6 +437,19 @@ int jg_spectral_weights(int dtype, const float* W, const float* sigma, void* w16
                         jg_stream_t s);
 int jg_spectral_wgrad_fix(const float* dWsn, const float* W, const float* u, const float* v, const float* sigma, float* g, float* ws, int Cout,
                           int RS, int Cin, jg_stream_t s);
+/* The three steps above for ALL spectral-norm layers of a discriminator in table-driven launches (4 per forward instead of 5 per layer,
+ * 2 per backward instead of 3 per layer).  `table`: device array of L jg_sn_desc records (pointers into the arena / the u, v buffers and
+ * offsets into the caller's scratch buffers: fbuf fp32 = per layer ws [K + Cout + 2] (cleared by the call over the first zero_floats
+ * floats) and the forward's snapshot sigma | u | v; hbuf 16-bit = w16 | w16T per layer; dbuf fp32 = dWsn per layer). */
+typedef struct jg_sn_desc {
+  const float* W; float* u; float* v; float* g;
+  int64_t ws_off, snap_off, w16_off, dw_off;
+  int32_t Cout, RS, Cin, CoutP, CinP, pad_;
+} jg_sn_desc;
+int jg_spectral_group_forward(int dtype, const void* table, int L, float* fbuf, int64_t zero_floats, void* hbuf, int max_K, int max_Cout,
+                              int64_t max_w, float eps, jg_stream_t s);
+int jg_spectral_group_wgrad_fix(const void* table, int L, const float* fbuf, const float* dbuf, float* dots, uint64_t mask, int64_t max_n,
+                                jg_stream_t s);
 int jg_hinge_loss(int dtype, const void* pred, float* loss, void* dpred, int64_t npix, int cpad, int cvalid, int mode, float scale,
                   float grad_scale, jg_stream_t s);
 

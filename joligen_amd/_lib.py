@@ -128,6 +128,8 @@ SIGNATURES = {
     "jg_attn_smallkv_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f32, c_p],
     "jg_attn_smallkv_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64,
                             c_f32, c_p],
+    "jg_attn_smallkv_bwd2": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64,
+                             c_f32, c_p],
     "jg_bilinear_fwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_p],
     "jg_bilinear_bwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_p],
     "jg_bilinear2_fwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_p],
@@ -135,6 +137,8 @@ SIGNATURES = {
     "jg_spectral_power_iter": [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_spectral_weights": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_spectral_wgrad_fix": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_p],
+    "jg_spectral_group_forward": [c_i32, c_p, c_i32, c_p, c_i64, c_p, c_i32, c_i32, c_i64, c_f32, c_p],
+    "jg_spectral_group_wgrad_fix": [c_p, c_i32, c_p, c_p, c_p, C.c_uint64, c_i64, c_p],
     "jg_dwconv_affine_act_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p] + [c_i32] * 11 + [c_p],
     "jg_dwconv_affine_act_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p] + [c_i32] * 11 + [c_p],
     "jg_chan_affine_act_fwd": [c_i32, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_p],

@@ -110,6 +110,119 @@ __global__ __launch_bounds__(256) void hinge_kernel(const T* __restrict__ pred, 
   if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv * scale);
 }
 
+// ---- the same steps for ALL spectral-norm layers of a discriminator in one launch each (blockIdx.z / .y = layer) -----------------------------
+// A projected discriminator has 14 such convolutions and runs three times per CUT iteration: per-layer launches were 14 x (fill + 3 + 1)
+// per forward and 14 x (fill + 2) per backward, ~20 us of work each.  The layers do not depend on activations, so one table-driven
+// pass ahead of the forward serves them all.
+struct SnDesc {
+  const float* W;     // fp32 master weight [Cout][RS][Cin] (arena slice)
+  float* u;           // weight_u [Cout]
+  float* v;           // weight_v [RS * Cin], reference order
+  float* g;           // gradient arena slice of W (the fix step adds into it)
+  long ws_off;        // floats into fbuf: t [K] | s [Cout] | nrm [2]      (zero at launch)
+  long snap_off;      // floats into fbuf: sigma [1] | u snapshot [Cout] | v snapshot [K]
+  long w16_off;       // elements into hbuf: w16 [CoutP][RS][CinP] | w16T [CinP][RS][CoutP]
+  long dw_off;        // floats into dbuf: dWsn [Cout][K]
+  int Cout, RS, Cin, CoutP, CinP, pad_;
+};
+
+__global__ __launch_bounds__(256) void sn_wtu_group_kernel(const SnDesc* __restrict__ tab, float* __restrict__ fbuf) {
+  const SnDesc d = tab[blockIdx.z];
+  const int K = d.RS * d.Cin;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * 16, r1 = min(d.Cout, r0 + 16);
+  if (k >= K || r0 >= d.Cout) return;
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += d.W[(long)r * K + k] * d.u[r];
+  atomicAdd(fbuf + d.ws_off + k, acc);
+}
+__global__ __launch_bounds__(256) void sn_wv_group_kernel(const SnDesc* __restrict__ tab, float* __restrict__ fbuf, float eps) {
+  const SnDesc d = tab[blockIdx.y];
+  const int K = d.RS * d.Cin;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= d.Cout) return;
+  const float* t = fbuf + d.ws_off;
+  float* sv = fbuf + d.ws_off + K;
+  float* nrm = sv + d.Cout;
+  float tt = 0.f;
+  for (int k = lane; k < K; k += 64) tt += t[k] * t[k];
+  tt = wave_sum(tt);
+  if (r == 0 && lane == 0) nrm[0] = tt;
+  const float inv = 1.0f / fmaxf(sqrtf(tt), eps);
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += d.W[(long)r * K + k] * (t[k] * inv);
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    sv[r] = acc;
+    atomicAdd(nrm + 1, acc * acc);
+  }
+}
+__global__ __launch_bounds__(256) void sn_finish_group_kernel(const SnDesc* __restrict__ tab, float* __restrict__ fbuf, float eps) {
+  const SnDesc d = tab[blockIdx.y];
+  const int K = d.RS * d.Cin;
+  const float* t = fbuf + d.ws_off;
+  const float* sv = t + K;
+  const float* nrm = sv + d.Cout;
+  float* snap = fbuf + d.snap_off;
+  const float n1 = fmaxf(sqrtf(nrm[0]), eps), n2 = fmaxf(sqrtf(nrm[1]), eps);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < K; i += gridDim.x * 256) {
+    const float val = t[i] / n1;
+    const int kr = kref(i, d.RS, d.Cin);
+    d.v[kr] = val;
+    snap[1 + d.Cout + kr] = val;          // this forward's (u, v): the backward of THIS forward reads them, later forwards iterate on
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < d.Cout; i += gridDim.x * 256) {
+    const float val = sv[i] / n2;
+    d.u[i] = val;
+    snap[1 + i] = val;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) snap[0] = nrm[1] / n2;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sn_weights_group_kernel(const SnDesc* __restrict__ tab, const float* __restrict__ fbuf, T* __restrict__ hbuf) {
+  const SnDesc d = tab[blockIdx.y];
+  const float inv = 1.0f / fbuf[d.snap_off];
+  const long n = (long)d.CoutP * d.RS * d.CinP;
+  T* w16 = hbuf + d.w16_off;
+  T* w16T = w16 + n;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int ci = (int)(i % d.CinP);
+    const long q = i / d.CinP;
+    const int rs = (int)(q % d.RS), co = (int)(q / d.RS);
+    const float v = (co < d.Cout && ci < d.Cin) ? d.W[((long)co * d.RS + rs) * d.Cin + ci] * inv : 0.f;
+    w16[i] = from_f32<T>(v);
+    w16T[((long)ci * d.RS + (d.RS - 1 - rs)) * d.CoutP + co] = from_f32<T>(v);
+  }
+}
+// backward: dot[l] = <dWsn_l, W_l>, then g_l += (dWsn_l - (dot / sigma) u v^T) / sigma; `mask` bit l = layer l takes part
+__global__ __launch_bounds__(256) void sn_dot_group_kernel(const SnDesc* __restrict__ tab, const float* __restrict__ dbuf, float* __restrict__ dots,
+                                                           unsigned long long mask) {
+  if (!((mask >> blockIdx.y) & 1ull)) return;
+  const SnDesc d = tab[blockIdx.y];
+  const long n = (long)d.Cout * d.RS * d.Cin;
+  const float* a = dbuf + d.dw_off;
+  float acc = 0.f;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += a[i] * d.W[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(dots + blockIdx.y, acc);
+}
+__global__ __launch_bounds__(256) void sn_fix_group_kernel(const SnDesc* __restrict__ tab, const float* __restrict__ fbuf, const float* __restrict__ dbuf,
+                                                           const float* __restrict__ dots, unsigned long long mask) {
+  if (!((mask >> blockIdx.y) & 1ull)) return;
+  const SnDesc d = tab[blockIdx.y];
+  const int K = d.RS * d.Cin;
+  const float* snap = fbuf + d.snap_off;
+  const float sg = snap[0], proj = dots[blockIdx.y] / sg;
+  const float* u = snap + 1;
+  const float* v = snap + 1 + d.Cout;
+  const float* dW = dbuf + d.dw_off;
+  const long n = (long)d.Cout * K;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % K), r = (int)(i / K);
+    d.g[i] += (dW[i] - proj * u[r] * v[kref(k, d.RS, d.Cin)]) / sg;
+  }
+}
+
 inline unsigned grid1(long n, long cap = 4096) {
   long g = (n + 255) / 256;
   return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -158,6 +271,38 @@ extern "C" int jg_hinge_loss(int dtype, const void* pred, float* loss, void* dpr
   if (!pred || !loss || npix < 1 || cpad < cvalid || cvalid < 1 || mode < 0 || mode > 2) return JG_ERR_BAD_ARG;
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((hinge_kernel<T>), dim3(grid1(npix * cpad, 1024)), dim3(256), 0, (hipStream_t)s, (const T*)pred, loss,
                                               (T*)dpred, (long)npix, cpad, cvalid, mode, scale, grad_scale););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+// One power iteration + the 16-bit working copies (straight and flipped / transposed) for ALL `L` spectral-norm layers described by `table`
+// (device array of L records, layout `jg_sn_desc` of include/jg355.h).  fbuf: fp32 scratch, its first `zero_floats` floats (the ws regions)
+// are cleared here; hbuf: 16-bit scratch for the working copies.  max_K / max_Cout / max_w: the largest K = RS Cin, Cout and padded weight
+// element count over the layers (grid sizes).
+extern "C" int jg_spectral_group_forward(int dtype, const void* table, int L, float* fbuf, int64_t zero_floats, void* hbuf, int max_K, int max_Cout,
+                                         int64_t max_w, float eps, jg_stream_t s) {
+  if (!table || !fbuf || !hbuf || L < 1 || L > 64 || max_K < 1 || max_Cout < 1 || max_w < 1 || zero_floats < 0) return JG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const SnDesc* tab = (const SnDesc*)table;
+  if (zero_floats && hipMemsetAsync(fbuf, 0, (size_t)zero_floats * sizeof(float), st) != hipSuccess) return JG_ERR_LAUNCH;
+  hipLaunchKernelGGL(sn_wtu_group_kernel, dim3((max_K + 255) / 256, (max_Cout + 15) / 16, L), dim3(256), 0, st, tab, fbuf);
+  hipLaunchKernelGGL(sn_wv_group_kernel, dim3((max_Cout + 3) / 4, L), dim3(256), 0, st, tab, fbuf, eps);
+  hipLaunchKernelGGL(sn_finish_group_kernel, dim3(grid1(max_K, 16), L), dim3(256), 0, st, tab, fbuf, eps);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((sn_weights_group_kernel<T>), dim3(grid1(max_w, 256), L), dim3(256), 0, st, tab, (const float*)fbuf,
+                                              (T*)hbuf););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+// Backward companion: for every layer l with bit l of `mask` set, g_l += (dWsn_l - <dWsn_l, W_sn,l> u v^T) / sigma with (sigma, u, v) of the forward
+// that filled fbuf; dbuf holds the dWsn_l ([Cout][K] fp32 at dw_off) and `dots` (L floats, ZERO at launch) is scratch.
+extern "C" int jg_spectral_group_wgrad_fix(const void* table, int L, const float* fbuf, const float* dbuf, float* dots, uint64_t mask, int64_t max_n,
+                                           jg_stream_t s) {
+  if (!table || !fbuf || !dbuf || !dots || L < 1 || L > 64 || max_n < 1) return JG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)s;
+  const SnDesc* tab = (const SnDesc*)table;
+  hipLaunchKernelGGL(sn_dot_group_kernel, dim3(grid1(max_n, 256), L), dim3(256), 0, st, tab, dbuf, dots, (unsigned long long)mask);
+  hipLaunchKernelGGL(sn_fix_group_kernel, dim3(grid1(max_n, 512), L), dim3(256), 0, st, tab, fbuf, dbuf, (const float*)dots, (unsigned long long)mask);
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

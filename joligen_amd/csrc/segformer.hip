@@ -1194,6 +1194,19 @@ template <typename T>
 __global__ void f32_to_t_kernel(const float* __restrict__ x, T* __restrict__ y, long n) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = from_f32<T>(x[i]);
 }
+// (dk, dv) fp32 [rows][C] each -> 16-bit rows of pitch ldo (dk) / ldo (dv): one launch for both, straight into a [rows][2 C] buffer
+template <typename T>
+__global__ void f32x2_to_t_kernel(const float* __restrict__ a, const float* __restrict__ b, T* __restrict__ ya, T* __restrict__ yb, long rows, int C,
+                                  long ldo) {
+  const long n = rows * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < 2 * n; i += (long)gridDim.x * blockDim.x) {
+    const bool second = i >= n;
+    const long j = second ? i - n : i;
+    const long r = j / C;
+    const int c = (int)(j - r * C);
+    (second ? yb : ya)[r * ldo + c] = from_f32<T>((second ? b : a)[j]);
+  }
+}
 
 int lanes_per_row(int C) {
   int chunks = C / 8, l = 1;
@@ -1271,15 +1284,18 @@ extern "C" int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, cons
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
-extern "C" int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                                   void* dq, float* dkf, float* dvf, void* dk, void* dv, int B, int Tq, int Tkv, int heads, int64_t ldq,
-                                   int64_t ldkv, int64_t ldo, float scale, jg_stream_t s) {
-  if (!q || !k || !v || !o || !dout || !lse || !dq || !dkf || !dvf || !dk || !dv) return JG_ERR_BAD_ARG;
+extern "C" int jg_attn_smallkv_bwd2(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                    void* dq, float* dkf, float* dvf, void* dk, void* dv, int64_t lddkv, int B, int Tq, int Tkv, int heads,
+                                    int64_t ldq, int64_t ldkv, int64_t ldo, float scale, jg_stream_t s) {
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !dkf || !dvf || !dk || !dv || lddkv < (int64_t)heads * 32) return JG_ERR_BAD_ARG;
   if (Tkv > AKV_MAX || B > 65535 || heads > 65535) return JG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)s;
   const long nkv = (long)B * Tkv * heads * 32;
-  if (hipMemsetAsync(dkf, 0, nkv * sizeof(float), st) != hipSuccess || hipMemsetAsync(dvf, 0, nkv * sizeof(float), st) != hipSuccess)
+  if (dvf == dkf + nkv) {          // one contiguous accumulator pair: one fill
+    if (hipMemsetAsync(dkf, 0, 2 * nkv * sizeof(float), st) != hipSuccess) return JG_ERR_LAUNCH;
+  } else if (hipMemsetAsync(dkf, 0, nkv * sizeof(float), st) != hipSuccess || hipMemsetAsync(dvf, 0, nkv * sizeof(float), st) != hipSuccess) {
     return JG_ERR_LAUNCH;
+  }
   const dim3 grid((Tq + 63) / 64, heads, B);
   if (Tkv <= 64 && ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 8 == 0) {
     // matrix-core kernel: a wave per 64-query tile, 4 waves per block; tiles per wave chosen so that the grid still has >= 512 blocks
@@ -1300,10 +1316,15 @@ extern "C" int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, cons
                                                 (const T*)o, (const T*)dout, lse, (T*)dq, dkf, dvf, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo,
                                                 scale););
   }
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((f32_to_t_kernel<T>), dim3(grid_for(nkv)), dim3(256), 0, st, dkf, (T*)dk, nkv);
-                    hipLaunchKernelGGL((f32_to_t_kernel<T>), dim3(grid_for(nkv)), dim3(256), 0, st, dvf, (T*)dv, nkv););
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((f32x2_to_t_kernel<T>), dim3(grid_for(2 * nkv)), dim3(256), 0, st, dkf, dvf, (T*)dk, (T*)dv,
+                                              (long)B * Tkv, heads * 32, (long)lddkv););
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+extern "C" int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                   void* dq, float* dkf, float* dvf, void* dk, void* dv, int B, int Tq, int Tkv, int heads, int64_t ldq,
+                                   int64_t ldkv, int64_t ldo, float scale, jg_stream_t s) {
+  return jg_attn_smallkv_bwd2(dtype, q, k, v, o, dout, lse, dq, dkf, dvf, dk, dv, (int64_t)heads * 32, B, Tq, Tkv, heads, ldq, ldkv, ldo, scale, s);
 }
 extern "C" int jg_bilinear2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, int align_corners,
                                 jg_stream_t s) {

@@ -17,6 +17,8 @@ What is and is not here
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -94,6 +96,103 @@ def hinge_loss(pred, target_is_real, relu=True, scale=1.0):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# all spectral-norm layers of a discriminator in table-driven launches (csrc/projected_d.hip, jg_spectral_group_*)
+# ---------------------------------------------------------------------------------------------------------------------
+SN_GROUPED = os.environ.get("JG_SN_GROUPED", "1") != "0"
+
+
+class _SnGroup:
+    """the static side: the 14 SpectralConv2d modules of a ProjectedDiscriminator, their descriptor table on the device (pointers into
+    the arena and the u / v buffers, offsets into per-forward scratch) and the scratch sizes"""
+
+    def __init__(self, mods, dtype):
+        import ctypes as C
+        import numpy as np
+
+        self.mods, self.dtype, self.L = mods, dtype, len(mods)
+        assert self.L <= 64
+        dev = mods[0].weight_orig.device
+        ws = snap = w16 = dw = 0
+        rec = []
+        for mod in mods:
+            m = mod.meta
+            K, RS = m.R * m.S * m.Cin_real, m.R * m.S
+            rec.append(dict(ws=ws, snap=0, w16=w16, dw=dw, Cout=m.Cout_real, RS=RS, Cin=m.Cin_real, CoutP=m.Cout, CinP=m.Cin, K=K))
+            ws += K + m.Cout_real + 2
+            w16 += 2 * m.Cout * RS * m.Cin
+            dw += m.Cout_real * K
+        self.zero_floats = ws
+        for r in rec:                       # snapshots behind the (cleared) workspaces
+            r["snap"] = ws + snap
+            snap += 1 + r["Cout"] + r["K"]
+        self.fbuf_floats, self.hbuf_elems, self.dbuf_floats = ws + snap, w16, dw + self.L      # dbuf: dWsn of every layer | L dot products
+        self.dots_off = dw
+        self.rec = rec
+        self.max_K = max(r["K"] for r in rec)
+        self.max_Cout = max(r["Cout"] for r in rec)
+        self.max_w = max(r["CoutP"] * r["RS"] * r["CinP"] for r in rec)
+        self.max_n = max(r["Cout"] * r["K"] for r in rec)
+        tab = np.zeros((self.L, 11), dtype=np.int64)         # 8 x 8-byte fields + 6 x int32 = 88 bytes per record
+        ints = tab.view(np.int32).reshape(self.L, 22)
+        self.ptrs = []
+        for i, (mod, r) in enumerate(zip(mods, rec)):
+            g = mod.weight_orig.grad
+            if g is None:
+                raise RuntimeError("spectral conv weight has no arena-backed .grad")
+            p = (mod.weight_orig.data_ptr(), mod.weight_u.data_ptr(), mod.weight_v.data_ptr(), g.data_ptr())
+            self.ptrs.append(p)
+            tab[i, 0:4] = p
+            tab[i, 4:8] = (r["ws"], r["snap"], r["w16"], r["dw"])
+            ints[i, 16:22] = (r["Cout"], r["RS"], r["Cin"], r["CoutP"], r["CinP"], 0)
+        self.table = torch.from_numpy(tab).to(dev)
+
+    def still_valid(self):
+        return all(p == (m.weight_orig.data_ptr(), m.weight_u.data_ptr(), m.weight_v.data_ptr(), m.weight_orig.grad.data_ptr())
+                   for p, m in zip(self.ptrs, self.mods))
+
+
+class _SnPass:
+    """one forward of the discriminator: power iteration + working copies of every layer (4 launches + 1 fill), and -- when the weights take
+    a gradient -- the dWsn buffers of its backward, fixed up by 2 launches once every layer has delivered"""
+
+    def __init__(self, group):
+        L = _lib.lib()
+        self.g = g = group
+        dev = g.table.device
+        self.fbuf = torch.empty(g.fbuf_floats, device=dev, dtype=torch.float32)
+        self.hbuf = torch.empty(g.hbuf_elems, device=dev, dtype=g.dtype)
+        check(L.jg_spectral_group_forward(_lib.JG_F16 if g.dtype == torch.float16 else _lib.JG_BF16, g.table.data_ptr(), g.L, self.fbuf.data_ptr(),
+                                          g.zero_floats, self.hbuf.data_ptr(), g.max_K, g.max_Cout, g.max_w, 1e-12, _st()), "jg_spectral_group_forward")
+        self.dbuf, self.mask, self.flushed = None, 0, False
+
+    def views(self, i):
+        r = self.g.rec[i]
+        n = r["CoutP"] * r["RS"] * r["CinP"]
+        w16 = self.hbuf[r["w16"]:r["w16"] + n].view(r["CoutP"], -1, r["CinP"])
+        w16T = self.hbuf[r["w16"] + n:r["w16"] + 2 * n].view(r["CinP"], -1, r["CoutP"])
+        return w16, w16T
+
+    def dwsn(self, i):
+        if self.dbuf is None:
+            self.dbuf = torch.zeros(self.g.dbuf_floats, device=self.fbuf.device, dtype=torch.float32)
+        r = self.g.rec[i]
+        return self.dbuf[r["dw"]:r["dw"] + r["Cout"] * r["K"]].view(r["Cout"], r["K"])
+
+    def delivered(self, i):
+        self.mask |= 1 << i
+        if self.mask == (1 << self.g.L) - 1:
+            self.flush()
+
+    def flush(self):
+        if self.flushed or not self.mask:
+            return
+        g = self.g
+        check(_lib.lib().jg_spectral_group_wgrad_fix(g.table.data_ptr(), g.L, self.fbuf.data_ptr(), self.dbuf.data_ptr(),
+                                                     self.dbuf.data_ptr() + 4 * g.dots_off, self.mask, g.max_n, _st()), "jg_spectral_group_wgrad_fix")
+        self.flushed = True
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # spectral-norm convolution (blocks.py:11-13)
 # ---------------------------------------------------------------------------------------------------------------------
 class _SpectralConvFn(torch.autograd.Function):
@@ -111,6 +210,19 @@ class _SpectralConvFn(torch.autograd.Function):
         assert Cin == m.Cin, (Cin, m.Cin)
         dev = x.device
         K = m.R * m.S * m.Cin_real
+        prepared = getattr(mod, "_sn_pass", None)
+        if prepared is not None:               # this layer's power iteration and working copies were made with all the others'
+            mod._sn_pass = None
+            sn, idx = prepared
+            w16, w16T = sn.views(idx)
+            Ho, Wo = m.out_hw(H, W_)
+            y = torch.empty((B, Ho, Wo, m.Cout), device=dev, dtype=x.dtype)
+            conv_nt(x, w16, y, B=B, H=H, W=W_, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo, ldx=Cin,
+                    ldw=m.R * m.S * Cin, ldy=m.Cout, bias=m.bias_pad if m.bias_pad is not None else bias)
+            ctx.save_for_backward(x, w16T)
+            ctx.mod, ctx.sn = mod, (sn, idx)
+            return y
+        ctx.sn = None
         sigma = torch.empty(1, device=dev, dtype=torch.float32)
         Wp = weight_orig.data_ptr()            # arena slice: physical [Cout][R][S][Cin] fp32
         if mod.training:
@@ -135,7 +247,11 @@ class _SpectralConvFn(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        x, w16T, sigma, u, v = ctx.saved_tensors
+        if ctx.sn is not None:
+            x, w16T = ctx.saved_tensors
+            sigma = u = v = None
+        else:
+            x, w16T, sigma, u, v = ctx.saved_tensors
         mod = ctx.mod
         m = mod.meta
         L = _lib.lib()
@@ -158,11 +274,14 @@ class _SpectralConvFn(torch.autograd.Function):
             if wg is None:
                 raise RuntimeError("spectral conv weight has no arena-backed .grad")
             K = m.R * m.S * m.Cin_real
-            dwsn = torch.zeros((m.Cout_real, K), device=dy.device, dtype=torch.float32)
+            dwsn = ctx.sn[0].dwsn(ctx.sn[1]) if ctx.sn is not None else torch.zeros((m.Cout_real, K), device=dy.device, dtype=torch.float32)
             ktot = m.R * m.S * Cin
             splitk = ops._wgrad_splitk(((Cout + 127) // 128) * ((ktot + 127) // 128), B * Ho * Wo)
             wgrad_tn(dy, x, dwsn, B=B, H=H, W=W_, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo, lddy=Cout, ldx=Cin,
                      lddw=K, dbias=mod.bias.grad if mod.bias is not None else None, Cin_out=m.Cin_real, Cout_out=m.Cout_real, splitk=splitk)
+            if ctx.sn is not None:             # the sigma-gradient fix of all layers runs once, when the last one has delivered its dWsn
+                ctx.sn[0].delivered(ctx.sn[1])
+                return dx, None, None, None
             ws = torch.empty(1, device=dy.device, dtype=torch.float32)
             check(L.jg_spectral_wgrad_fix(dwsn.data_ptr(), mod.weight_orig.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), wg.data_ptr(),
                                           ws.data_ptr(), m.Cout_real, m.R * m.S, m.Cin_real, _st()), "jg_spectral_wgrad_fix")
@@ -693,4 +812,21 @@ class ProjectedDiscriminator(nn.Module):
         if self.interp > 0 and (x.shape[1] != self.interp or x.shape[2] != self.interp):
             x = bilinear(x, self.interp, self.interp, False)
         feats = self.freeze_feature_network(x)
+        if SN_GROUPED and self.discriminator.training and self.arena is not None:
+            self._sn_prepare(x.dtype)
         return self.discriminator(feats)
+
+    def _sn_prepare(self, dtype):
+        """one power iteration + the 16-bit working copies of ALL spectral-norm convolutions ahead of the heads (they depend on the
+        weights only): every SpectralConv2d finds its share in `_sn_pass` and skips its own five launches"""
+        grp = getattr(self, "_sn_group", None)
+        if grp is None or grp.dtype != dtype or not grp.still_valid():
+            mods = [m for m in self.discriminator.modules() if isinstance(m, SpectralConv2d)]
+            grp = self._sn_group = _SnGroup(mods, dtype)
+        last = getattr(self, "_sn_last", None)
+        if last is not None:
+            last.flush()                     # a previous pass whose backward ended early (never in the CUT step: every head feeds the loss)
+        sn = _SnPass(grp)
+        self._sn_last = sn
+        for i, mod in enumerate(grp.mods):
+            mod._sn_pass = (sn, i)

@@ -45,6 +45,17 @@ class _Rand:
             return torch.rand(shape, device=device)
         return self.source(shape).to(device=device, dtype=torch.float32).reshape(shape)
 
+    def droppath_scales(self, probs, batch, device):
+        """floor(keep + U) / keep for ALL DropPath sites of one backbone pass at once ([len(probs), batch]; three launches instead of four
+        per site -- the CUT step runs 70 sites); None when the uniforms are injected (parity runs draw site by site, in the reference's
+        order)"""
+        if self.source is not None:
+            return None
+        keep = getattr(self, "_keep", None)
+        if keep is None or keep.device != device or keep.shape[0] != len(probs):
+            keep = self._keep = (1.0 - torch.tensor(probs, dtype=torch.float32)).to(device).view(-1, 1)
+        return torch.rand((len(probs), batch), device=device).add_(keep).floor_().div_(keep)
+
 
 class DropPath(nn.Module):
     """backbone.py:700-726; here fused with the residual add: identity + x * floor(keep + U) / keep."""
@@ -57,6 +68,10 @@ class DropPath(nn.Module):
     def add(self, identity, x):
         if self.drop_prob == 0.0 or not self.training:
             return _add(identity, x)
+        pre = getattr(self, "_scale_row", None)      # this pass's row of _Rand.droppath_scales (set by MixVisionTransformer.compute_feat)
+        if pre is not None:
+            self._scale_row = None
+            return S.scale_add(x, pre, identity)
         keep = 1.0 - self.drop_prob
         u = self._rand[0]((x.shape[0],), x.device)
         return S.scale_add(x, (keep + u).floor() / keep, identity)
@@ -185,6 +200,15 @@ class MixVisionTransformer(nn.Module):
 
     def compute_feat(self, x, extract_layer_ids=()):
         outs, feats = [], []
+        if self.training:         # every DropPath scale of this pass from one draw (the sites consume their rows in execution order)
+            sites = getattr(self, "_dp_sites", None)
+            if sites is None:
+                sites = self._dp_sites = [m for m in self.modules() if isinstance(m, DropPath) and m.drop_prob > 0.0]
+            if sites:
+                sc = sites[0]._rand[0].droppath_scales([m.drop_prob for m in sites], x.shape[0], x.device)
+                if sc is not None:
+                    for m, row in zip(sites, sc):
+                        m._scale_row = row
         for i, layer in enumerate(self.layers):
             x, hw = layer[0](x)
             for block in layer[1]:

@@ -117,15 +117,13 @@ class _AttnSmallKVFn(torch.autograd.Function):
         B, Tq, C = q.shape
         Tkv = kv.shape[1]
         dq = torch.empty_like(q)
-        dkf = torch.empty((B, Tkv, C), device=q.device, dtype=torch.float32)
-        dvf = torch.empty_like(dkf)
-        dk = torch.empty((B, Tkv, C), device=q.device, dtype=q.dtype)
-        dv = torch.empty_like(dk)
+        acc = torch.empty((2, B, Tkv, C), device=q.device, dtype=torch.float32)       # dk | dv fp32 accumulators: one buffer, one fill
+        dkv = torch.empty((B, Tkv, 2 * C), device=q.device, dtype=q.dtype)             # gradient of the packed kv projection, written in place
         es = q.element_size()
-        check(_lib.lib().jg_attn_smallkv_bwd(_dt(q), q.data_ptr(), kv.data_ptr(), kv.data_ptr() + C * es, o.data_ptr(), do.data_ptr(), lse.data_ptr(),
-                                             dq.data_ptr(), dkf.data_ptr(), dvf.data_ptr(), dk.data_ptr(), dv.data_ptr(), B, Tq, Tkv, ctx.heads, C,
-                                             2 * C, C, 1.0 / math.sqrt(32.0), _st()), "jg_attn_smallkv_bwd")
-        return dq, torch.cat((dk, dv), dim=2), None
+        check(_lib.lib().jg_attn_smallkv_bwd2(_dt(q), q.data_ptr(), kv.data_ptr(), kv.data_ptr() + C * es, o.data_ptr(), do.data_ptr(), lse.data_ptr(),
+                                              dq.data_ptr(), acc[0].data_ptr(), acc[1].data_ptr(), dkv.data_ptr(), dkv.data_ptr() + C * es, 2 * C, B, Tq,
+                                              Tkv, ctx.heads, C, 2 * C, C, 1.0 / math.sqrt(32.0), _st()), "jg_attn_smallkv_bwd2")
+        return dq, dkv, None
 
 
 def attention_smallkv(q, kv, heads):

@@ -11,9 +11,18 @@ from torch.profiler import ProfilerActivity, profile
 
 import bench
 
-args = argparse.Namespace(model="palette", efficient=1, size=256, batch=32, dtype="bf16", netG="resnet", netDs="basic", force_exchange=False)
-model, opt = bench.build_model(args, 0, 0, 1)
-batch = bench.synth_batch(32, 256, 1234, torch.device("cuda:0"))
+which = sys.argv[1] if len(sys.argv) > 1 else "palette"
+if which == "cut":      # BASELINE configs[2] shape
+    args = argparse.Namespace(model="cut", efficient=1, size=256, batch=16, dtype="bf16", netG="segformer_attn_conv", netDs="projected_d,basic", force_exchange=False)
+    import warnings
+    warnings.simplefilter("ignore")
+    model, opt = bench.build_model(args, 0, 0, 1)
+    g = torch.Generator().manual_seed(77)
+    batch = {"A": (torch.rand(16, 3, 256, 256, generator=g) * 2 - 1).cuda(), "B": (torch.rand(16, 3, 256, 256, generator=g) * 2 - 1).cuda()}
+else:
+    args = argparse.Namespace(model="palette", efficient=1, size=256, batch=32, dtype="bf16", netG="resnet", netDs="basic", force_exchange=False)
+    model, opt = bench.build_model(args, 0, 0, 1)
+    batch = bench.synth_batch(32, 256, 1234, torch.device("cuda:0"))
 for _ in range(3):
     model.set_input(batch)
     model.optimize_parameters()
@@ -30,5 +39,13 @@ for ev in prof.events():
                                                           "aten::lift_fresh", "aten::is_nonzero", "aten::item", "aten::_local_scalar_dense", "aten::contiguous", "aten::stride"):
         st = [s for s in (ev.stack or []) if "joligen_amd" in s or "bench.py" in s]
         cnt[(ev.name, st[0].strip() if st else "?")] += 1
-for (name, site), n in cnt.most_common(40):
+print("total ATen ops with a device kernel candidate:", sum(cnt.values()))
+kern = Counter()
+for ev in prof.events():
+    if ev.device_type is not None and str(ev.device_type).endswith("CUDA"):
+        kern[ev.name[:60]] += 1
+print("device kernels:", sum(kern.values()))
+for k, n in kern.most_common(25):
+    print(f"   {n:5d} {k}")
+for (name, site), n in cnt.most_common(60):
     print(f"{n:5d} {name:28s} {site[:150]}")
