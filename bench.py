@@ -284,6 +284,9 @@ def timed_region(step, steps, warmup, fence):
     for _ in range(warmup):
         step()
     fence()
+    mark = os.environ.get("JG_TRACE_MARK", "0") != "0"      # profiling runs: a uniquely named kernel (at::cuda's spin_kernel) brackets the
+    if mark:                                                 # timed steps, tools/rocpd_stats.py then counts the steady-state window only
+        torch.cuda._sleep(2000)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()
@@ -292,6 +295,9 @@ def timed_region(step, steps, warmup, fence):
         evs[i + 1].record()
     fence()
     dt = time.perf_counter() - t0
+    if mark:
+        torch.cuda._sleep(2000)
+        torch.cuda.synchronize()
     return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
 
 
@@ -344,13 +350,13 @@ def cut_leg(local_rank, no_cpu):
     recs, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     table = kernel_table(recs, 1)
     dom = max(table, key=lambda k: table[k]["time_per_step_ms"])
-    # HBM traffic of the dominant instance: the committed rocprofv3 PMC passes of this step (profiles/r03_cut_pmc.json, tools/collect_evidence.sh)
+    # HBM traffic of the dominant instance: the committed rocprofv3 PMC passes of this step (profiles/r04_cut_pmc.json, tools/collect_evidence.sh cutpmc: a filtered PMC pass over the conv / weight-gradient family)
     traffic, traffic_build, traffic_file = None, None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_cut_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_cut_pmc.json")))
         row = pmc.get(dom) or pmc.get(dom.split("<")[0])
         if row:
-            traffic, traffic_build, traffic_file = round(row["bytes_per_launch"], 1), pmc.get("_meta", {}).get("build"), "profiles/r03_cut_pmc.json"
+            traffic, traffic_build, traffic_file = round(row["bytes_per_launch"], 1), pmc.get("_meta", {}).get("build"), "profiles/r04_cut_pmc.json"
     except Exception:
         pass
     roof = dict(table[dom], kernel=dom, traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",

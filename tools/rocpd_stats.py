@@ -23,9 +23,18 @@ def short(name: str) -> str:
 def main():
     db = sqlite3.connect(sys.argv[1])
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+    # steady state only: bench.py (JG_TRACE_MARK=1) brackets its timed steps with at::cuda's spin_kernel; without markers the whole trace
+    # (model construction, warm-up) is summarised and `steps` must count every step in it
+    marks = [r[0] for r in db.execute("select start from kernels where name like '%spin_kernel%' order by start").fetchall()]
+    where, note = "", "whole trace"
+    if len(marks) >= 2:
+        where = f" where start > {marks[0]} and start < {marks[-1]} and name not like '%spin_kernel%'"
+        note = f"steady-state window between the two marker kernels ({(marks[-1] - marks[0]) / 1e6:.2f} ms of wall time = {(marks[-1] - marks[0]) / 1e6 / steps:.2f} ms/step)"
+    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels" + where +
+                      " group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows)
-    print(f"total kernel time {total / 1e6:.2f} ms over {steps} step(s) = {total / 1e6 / steps:.2f} ms/step\n")
+    nl = sum(r[1] for r in rows)
+    print(f"total kernel time {total / 1e6:.2f} ms over {steps} step(s) = {total / 1e6 / steps:.2f} ms/step; {nl} launches = {nl / steps:.0f} per step; {note}\n")
     print("| kernel | calls | total ms | ms/step | avg us | min us | max us | % |")
     print("|---|---|---|---|---|---|---|---|")
     for name, n, tot, avg, mn, mx in rows:
