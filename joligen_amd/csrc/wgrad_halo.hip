@@ -353,9 +353,12 @@ void launch_wg(const WgP& p, hipStream_t st) {
   const int ncot = p.Cout / BCO, npairs = ncot * (p.Cin / 64);
   const int ntiles = p.B * (p.H / TH) * (p.W >> 4);
   int per, splitk;
-  pick_split(npairs, ntiles, TH == 16 ? 6 : 10, WMR == 1 ? 512 : 256, &per, &splitk);
-  if (pipe) hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE, CPW == 2>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot, jg_tune(JG_TUNE_HALO_DBG));
-  else hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE>), dim3(npairs * splitk), dim3(WMR * 256), 0, st, p, ntiles, per, npairs, ncot, jg_tune(JG_TUNE_HALO_DBG));
+  pick_split(npairs, ntiles, TH == 16 ? 6 : 10, WMR == 1 && jg_tune(JG_TUNE_WGRAD_LDS_PAD) < 4096 ? 512 : 256, &per, &splitk);
+  // JG_WGRAD_LDS_PAD: extra (unused) dynamic LDS bytes, an occupancy lever for A/B runs: e.g. the 4-wave configuration at one workgroup per
+  // CU instead of two leaves half of every SIMD's register file to the kernels of the other stream
+  const size_t pad = (size_t)jg_tune(JG_TUNE_WGRAD_LDS_PAD);
+  if (pipe) hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE, CPW == 2>), dim3(npairs * splitk), dim3(WMR * 256), pad, st, p, ntiles, per, npairs, ncot, jg_tune(JG_TUNE_HALO_DBG));
+  else hipLaunchKernelGGL((wgrad3x3_halo_kernel<T, TH, CPW, WMR, XMODE>), dim3(npairs * splitk), dim3(WMR * 256), pad, st, p, ntiles, per, npairs, ncot, jg_tune(JG_TUNE_HALO_DBG));
 }
 
 template <typename T>

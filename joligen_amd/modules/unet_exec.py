@@ -369,10 +369,12 @@ class UNetExecutor:
             self._side = torch.cuda.Stream(device=dy.device)
             # a gradient chunk's all-reduce is ordered behind the CURRENT stream only: the weight gradients of the side stream are
             # brought in right before a chunk leaves (parallel.EarlyExchange._launch), not after every layer
-            parallel.PRE_LAUNCH_HOOKS.append(self.wgrad_join)
+            import weakref
+
+            parallel.PRE_LAUNCH_HOOKS.append(weakref.WeakMethod(self.wgrad_join))      # weak: the hooks die with this executor
             # ... and an EARLY chunk (launched from inside this backward) is enqueued FROM the side stream: ordered behind every weight
             # gradient launched so far without the compute stream waiting for them (parallel.LAUNCH_CONTEXTS)
-            parallel.LAUNCH_CONTEXTS.append(self.exchange_context)
+            parallel.LAUNCH_CONTEXTS.append(weakref.WeakMethod(self.exchange_context))
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             conv_wgrad(dy, x, m, **kw)

@@ -35,7 +35,9 @@ def _dt(t: torch.Tensor) -> int:
         raise TypeError(f"joligen_amd activations must be float16/bfloat16, got {t.dtype}") from None
 
 
-_raw_stream = torch._C._cuda_getCurrentRawStream     # torch.cuda.current_stream() builds a Stream object per call (~8 us): too slow for a per-launch lookup
+# torch.cuda.current_stream() builds a Stream object per call (~8 us): too slow for a per-launch lookup.  The raw accessor is a private
+# symbol: a torch build without it (or without CUDA / HIP at all) falls back to the public API instead of failing at import time
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda dev: torch.cuda.current_stream(dev).cuda_stream)
 _cur_device = torch.cuda.current_device
 
 

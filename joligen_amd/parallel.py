@@ -58,6 +58,24 @@ _EARLY = {}
 # callables run right before a gradient chunk's all-reduce is enqueued: schedules that launch gradient kernels on a second stream
 # (modules/unet_exec.py: weight gradients) register their join here, because the collective is ordered behind the current stream only
 PRE_LAUNCH_HOOKS = []
+
+
+def _live(hooks):
+    """the callables of a hook list; entries may be weakref.WeakMethod (an executor's bound methods: a network that is gone takes its
+    hooks -- and its side stream -- with it instead of living in a process-global list for ever), dead ones are dropped"""
+    import weakref
+
+    out = []
+    for h in list(hooks):
+        if isinstance(h, weakref.WeakMethod):
+            f = h()
+            if f is None:
+                hooks.remove(h)
+                continue
+            out.append(f)
+        else:
+            out.append(h)
+    return out
 # context-manager factories entered around the LAUNCH of an early chunk (EarlyExchange._launch).  The UNet executor registers one that
 # enqueues the collective from its weight-gradient stream (after making that stream wait for the compute stream): the chunk is then
 # ordered behind the weight gradients WITHOUT the compute stream having to wait for them -- joining the two streams before every chunk
@@ -135,13 +153,13 @@ class EarlyExchange:
     def _launch(self, c):
         lo, hi = self.bounds[c]
         self.sent[c] = True
-        if LAUNCH_CONTEXTS:
+        if _live(LAUNCH_CONTEXTS):
             with contextlib.ExitStack() as stack:
-                for make in LAUNCH_CONTEXTS:
+                for make in _live(LAUNCH_CONTEXTS):
                     stack.enter_context(make())
                 work = _launch_allreduce(self.arena.g[lo:hi])
         else:
-            for hook in PRE_LAUNCH_HOOKS:
+            for hook in _live(PRE_LAUNCH_HOOKS):
                 hook()
             work = _launch_allreduce(self.arena.g[lo:hi])
         self.launched.append((c, work))
@@ -185,7 +203,7 @@ def allreduce_and_step(arena, hp, grad_scale, n_chunks=4):
     overflow = getattr(arena, "overflow", None)
     # every gradient kernel launched on another stream is joined FIRST: from here on the whole arena is final on the current stream
     # (the overflow scan below reads all of it, and the chunks that have not left yet are enqueued behind the current stream)
-    for hook in PRE_LAUNCH_HOOKS:
+    for hook in _live(PRE_LAUNCH_HOOKS):
         hook()
     ex = getattr(arena, "early_exchange", None)
     if overflow is not None and (ex is None or not ex.launched):

@@ -24,7 +24,7 @@ model.set_input(data)
 def fb():
     model.compute_palette_loss()
     model.loss_G_tot.backward()
-    for h in parallel.PRE_LAUNCH_HOOKS:      # join the side stream (what the optimizer launch does)
+    for h in parallel._live(parallel.PRE_LAUNCH_HOOKS):      # join the side stream (what the optimizer launch does)
         h()
 
 
