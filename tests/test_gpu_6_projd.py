@@ -427,3 +427,71 @@ def test_reference_layout_discriminator_checkpoint_restores_the_backbone(tmp_pat
     torch.save({k: v for k, v in ck.items() if not k.startswith(pre)}, os.path.join(str(tmp_path), "pd", "latest_net_D_B_projected_d.pth"))
     with pytest.raises(RuntimeError):
         model.load_networks("latest")
+
+
+# ---- tf_efficientnet_lite0 kernels in isolation: depth-wise k x k + frozen-BatchNorm affine + ReLU6, TF "SAME" padding -------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,stride,H,W", [(3, 1, 12, 12), (3, 2, 13, 11), (5, 1, 9, 14), (5, 2, 14, 15), (5, 2, 16, 16), (3, 2, 7, 7)])
+def test_dwconv_affine_relu6_vs_torch(k, stride, H, W, dtype):
+    """jg_dwconv_affine_act_fwd / _bwd against F.conv2d(groups = C) on TF-SAME padded input, per-channel affine, ReLU6 (forward and input
+    gradient) on 16-bit-representable inputs: a wrong tap alignment under the asymmetric stride-2 padding, or a wrong pass-through set of
+    the ReLU6 backward, is an O(1) error here -- the end-to-end fixture bounds it only through 16 layers of rounding."""
+    from joligen_amd import _lib, ops
+    from joligen_amd.modules.projected_d import tf_same_pad
+
+    L = _lib.lib()
+    B, C = 2, 24
+    g = torch.Generator().manual_seed(k * 100 + stride * 10 + H)
+    x = (torch.randn(B, C, H, W, generator=g) * 2).to(dtype).float()
+    w = torch.randn(C, 1, k, k, generator=g) * 0.4
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    (pt, pb), (pl, pr) = tf_same_pad(H, k, stride), tf_same_pad(W, k, stride)
+    xr = x.clone().requires_grad_(True)
+    pre = F.conv2d(F.pad(xr, (pl, pr, pt, pb)), w, stride=stride, groups=C) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    yr = pre.clamp(0.0, 6.0)
+    Ho, Wo = yr.shape[2], yr.shape[3]
+    gy = torch.randn(yr.shape, generator=g).to(dtype).float()
+    # keep the comparison away from the two kinks: pre-activations within rounding distance of 0 or 6 may pass the gradient on one side only
+    safe = ((pre.detach().abs() > 0.05) & ((pre.detach() - 6.0).abs() > 0.05)).float()
+    (yr * gy * safe).sum().backward()
+    dt = _lib.JG_F16 if dtype == torch.float16 else _lib.JG_BF16
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dtype).to(D0)
+    wd = w.view(C, k * k).t().contiguous().to(D0)              # [k*k][C]
+    sc, sh = scale.to(D0), shift.to(D0)
+    y = torch.empty(B, Ho, Wo, C, device=D0, dtype=dtype)
+    _lib.check(L.jg_dwconv_affine_act_fwd(dt, xd.data_ptr(), wd.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), B, H, W, C, k, stride, pt, pl,
+                                          Ho, Wo, 1, ops._st()))
+    tol = 2e-3 if dtype == torch.float16 else 1e-2
+    assert relerr(y.permute(0, 3, 1, 2).float(), yr.detach()) < tol
+    dyd = (gy * safe).permute(0, 2, 3, 1).contiguous().to(dtype).to(D0)
+    dx = torch.empty_like(xd)
+    _lib.check(L.jg_dwconv_affine_act_bwd(dt, dyd.data_ptr(), y.data_ptr(), wd.data_ptr(), sc.data_ptr(), dx.data_ptr(), B, H, W, C, k, stride, pt, pl,
+                                          Ho, Wo, 1, ops._st()))
+    torch.cuda.synchronize()
+    assert relerr(dx.permute(0, 3, 1, 2).float(), xr.grad) < 2 * tol, relerr(dx.permute(0, 3, 1, 2).float(), xr.grad)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_chan_affine_relu6_vs_torch(dtype):
+    from joligen_amd import _lib, ops
+
+    L = _lib.lib()
+    P, C = 300, 40
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(P, C, generator=g) * 3).to(dtype).float()
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xr = x.clone().requires_grad_(True)
+    pre = xr * scale + shift
+    yr = pre.clamp(0.0, 6.0)
+    gy = torch.randn(P, C, generator=g).to(dtype).float()
+    safe = ((pre.detach().abs() > 0.05) & ((pre.detach() - 6.0).abs() > 0.05)).float()
+    (yr * gy * safe).sum().backward()
+    dt = _lib.JG_F16 if dtype == torch.float16 else _lib.JG_BF16
+    xd, sc, sh = x.to(dtype).to(D0), scale.to(D0), shift.to(D0)
+    y, dx = torch.empty_like(xd), torch.empty_like(xd)
+    _lib.check(L.jg_chan_affine_act_fwd(dt, xd.data_ptr(), sc.data_ptr(), sh.data_ptr(), y.data_ptr(), P, C, 1, ops._st()))
+    dyd = (gy * safe).to(dtype).to(D0)
+    _lib.check(L.jg_chan_affine_act_bwd(dt, dyd.data_ptr(), y.data_ptr(), sc.data_ptr(), dx.data_ptr(), P, C, 1, ops._st()))
+    torch.cuda.synchronize()
+    tol = 2e-3 if dtype == torch.float16 else 1e-2
+    assert relerr(y.float(), yr.detach()) < tol and relerr(dx.float(), xr.grad) < 2 * tol
