@@ -110,6 +110,13 @@ typedef struct {
   void* ws; int64_t ws_bytes;
 } jg_conv_args;
 int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
+/* 1x1 convolution of x WITH the GroupNorm apply pass of x in the same launch (round 4): y = conv(x) exactly as jg_conv2d_nt, plus
+ * y_norm[m][c] = act(ab[b][c][0] * x[m][c] + ab[b][c][1]) for the Cin input channels (pixel stride ldyn, ab from jg_gn_coef).  A ResBlock
+ * whose channel count changes reads its input twice -- `self.skip_connection(x)` and `self.in_layers(x)` = conv(SiLU(GroupNorm(x)))
+ * (unet_generator_attn.py:233-266) -- here both readers share ONE pass over x.  Only the shapes of the streaming 1x1 kernel (R = S = 1,
+ * stride 1, Cin % 32 == 0, Cin <= 256, Cout % 64 == 0, >= 65536 pixels, H W % 16 == 0, no statistics): JG_ERR_UNSUPPORTED otherwise
+ * (nothing is launched; callers fall back to jg_gn_apply_ld + jg_conv2d_nt). */
+int jg_conv1x1_gn_apply(int dtype, const jg_conv_args* a, const float* ab, void* y_norm, int64_t ldyn, int act, jg_stream_t stream);
 /* Folded weights of x_mode 2 from the fp32 master weights w32 [Cout][3][3][Cin]: out[py*2+px][co][a][b][ci] (dtype) = sum of the
  * 3x3 taps that land on tap (a, b) of output phase (py, px) of conv3x3(Upsample_nearest(x)) -- per axis {w0 | w1+w2} for phase 0,
  * {w0+w1 | w2} for phase 1 (fp32 sum, one rounding). */

@@ -20,6 +20,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
 
 FILE_FLAGS = {}      # per-source extra flags
 
+JG_OK, JG_ERR_BAD_ARG, JG_ERR_UNSUPPORTED, JG_ERR_LAUNCH = 0, -1, -2, -3
 JG_F16, JG_BF16 = 0, 1
 JG_ACT_NONE, JG_ACT_SILU, JG_ACT_RELU, JG_ACT_LRELU, JG_ACT_TANH = 0, 1, 2, 3, 4
 JG_OUT_ATOMIC_F32, JG_OUT_STORE_F32, JG_OUT_STORE_T = 0, 1, 2
@@ -58,6 +59,7 @@ SIGNATURES = {
     "jg_get_tuning": [C.c_char_p],
     "jg_last_kernel": [],
     "jg_conv2d_nt": [c_i32, C.POINTER(ConvArgs), c_p],
+    "jg_conv1x1_gn_apply": [c_i32, C.POINTER(ConvArgs), c_p, c_p, c_i64, c_i32, c_p],
     "jg_conv2d_wgrad_tn": [c_i32, C.POINTER(WgradArgs), c_p],
     "jg_gn_stats": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_p],
     "jg_gn_coef": [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],

@@ -17,8 +17,16 @@
 
 namespace {
 
-template <typename T, int PAIRS, int KS>
+__device__ __forceinline__ float act_rt(float u, int act) {
+  return act == JG_ACT_SILU ? silu_f(u) : act == JG_ACT_RELU ? fmaxf(u, 0.f) : act == JG_ACT_LRELU ? (u > 0.f ? u : 0.2f * u) : u;
+}
+
+// APPLY: the launch also writes act(a x + b) of its INPUT (the GroupNorm apply pass of x, ConvP.aab / ay): the block column
+// blockIdx.y == 0 transforms every 16-byte fragment it has loaded anyway and stores it; the (a, b) rows of the wave's current image
+// are staged in a wave-private LDS slot (2 Cin floats) and re-staged when the wave's tile sequence crosses an image boundary.
+template <typename T, int PAIRS, int KS, bool APPLY = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float s_ab[APPLY ? 4 * 2 * KS * 32 : 4];
   const int lane = threadIdx.x & 63;
   const int a = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * (PAIRS * 32);
@@ -50,6 +58,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int nti
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const uint4*>(px + ks * 32);
   };
+  const bool do_apply = APPLY && blockIdx.y == 0;
+  float* wab = s_ab + (threadIdx.x >> 6) * (APPLY ? 2 * KS * 32 : 1);       // this wave's (a, b) rows: [Cin][2]
+  const int tiles_per_img = (p.Ho * p.Wo) >> 4;
+  int cur_b = -1;
   // PF tiles of input fragments in flight per wave (a memory-bound stream needs ~64 KB in flight per CU)
   constexpr int PF = KS <= 2 ? 4 : (KS <= 4 ? 2 : 1);
   uint4 ring[PF][KS];
@@ -75,6 +87,29 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int nti
         for (int ks = 0; ks < KS; ++ks) {
           acc[pr][0] = Mfma<T>::run(wf[pr][0][ks], ring[s][ks], acc[pr][0]);
           acc[pr][1] = Mfma<T>::run(wf[pr][1][ks], ring[s][ks], acc[pr][1]);
+        }
+      }
+      if (do_apply) {
+        const int b = t / tiles_per_img;
+        if (b != cur_b) {               // wave-uniform: stage the image's coefficient rows (same-wave LDS writes are read back in order)
+          cur_b = b;
+          const float* src = p.aab + (long)b * (2 * KS * 32);
+          for (int i = lane; i < 2 * KS * 32 / 4; i += 64) reinterpret_cast<float4*>(wab)[i] = reinterpret_cast<const float4*>(src)[i];
+        }
+        T* ay = (T*)p.ay + prow * p.lday + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          float f[8];
+          unpack8<T>(ring[s][ks], f);
+          const float4* c4 = reinterpret_cast<const float4*>(wab + (ks * 32 + g * 8) * 2);
+#pragma unroll
+          for (int k4 = 0; k4 < 4; ++k4) {
+            const float4 c = c4[k4];      // (a, b) of channels 2 k4, 2 k4 + 1 of the octet
+            const float u0 = c.x * f[2 * k4] + c.y, u1 = c.z * f[2 * k4 + 1] + c.w;
+            f[2 * k4] = p.aact == JG_ACT_SILU ? silu_f(u0) : act_rt(u0, p.aact);
+            f[2 * k4 + 1] = p.aact == JG_ACT_SILU ? silu_f(u1) : act_rt(u1, p.aact);
+          }
+          *reinterpret_cast<uint4*>(ay + ks * 32) = pack8<T>(f);
         }
       }
       const int tn = t + PF * nwaves;       // refill this slot as soon as its fragments have been consumed
@@ -235,7 +270,12 @@ void launch_1x1(const ConvP& p, hipStream_t st) {
   int bx = (ntiles + 3) / 4;                 // one tile per wave at least
   const int cap = 256 * 8 / ngroups > 64 ? 256 * 8 / ngroups : 64;
   if (bx > cap) bx = cap;
-  hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
+  if (p.aab) {
+    jg_note_kernel("conv1x1_stream_kernel+gn_apply");
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS, true>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
+  } else {
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
+  }
 }
 
 template <typename T>
@@ -257,8 +297,8 @@ bool dispatch_1x1(const ConvP& p, hipStream_t st) {
 bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   if (p.res_up || p.x_up || p.y_pool) return false;   // half-resolution residuals / inputs: LDS-staged kernels only
   const bool off = jg_tune(JG_TUNE_CONV1X1) == 0;
-  if (off) return false;
-  if (nbatch == 1 && p.nh == 1 && p.R == 3 && p.S == 3 && p.pad == 1 && p.stride == 1 && !p.out_f32 && !(p.stats && p.stats_mode) && !p.reflect &&
+  if (off && !p.aab) return false;
+  if (!p.aab && nbatch == 1 && p.nh == 1 && p.R == 3 && p.S == 3 && p.pad == 1 && p.stride == 1 && !p.out_f32 && !(p.stats && p.stats_mode) && !p.reflect &&
       p.Cin == 8 && ((p.H * p.W) & 15) == 0 &&
       p.ldx == 8 && p.ldw == 72 && p.N % 64 == 0 && !(p.M & 15) && p.H == p.Ho && p.W == p.Wo && p.ldy % 8 == 0 && (!p.res || p.ldres % 8 == 0) &&
       (long)p.M >= 65536) {

@@ -31,6 +31,9 @@ struct ConvP {
   // split-K of the generic LDS-DMA kernel (gemm_nt.hip): splitk > 1 = blockIdx.y owns a slice of the K loop and stores its raw fp32
   // partial tile to ws[((split * nbatch + z) * M + m) * N + n]; jg_splitk_finalize sums the slices in a fixed order (deterministic)
   float* ws; int splitk;
+  // streaming 1x1 kernel only (jg_conv1x1_gn_apply): ALSO write ay[m][c] = act(aab[b][c][0] * x[m][c] + aab[b][c][1]) for the Cin input
+  // channels -- the GroupNorm apply pass of the tensor this convolution reads (ResBlock: skip_connection(x) next to act(norm(x)))
+  const float* aab; char* ay; long lday; int aact;
 };
 
 // output pixel row m = (b * Ho + oh) * Wo + ow  ->  row of the half-resolution residual

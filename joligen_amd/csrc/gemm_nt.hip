@@ -527,8 +527,35 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st, long ws_bytes) {
 
 }  // namespace
 
+static int conv_args_to_params(const jg_conv_args* a, ConvP& p);
+
 extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream) {
   jg_note_kernel("");      // the dispatch sites that record their instance overwrite it (jg_last_kernel)
+  ConvP p;
+  const int rc = conv_args_to_params(a, p);
+  if (rc != JG_OK) return rc;
+  JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream, a->ws ? (long)a->ws_bytes : 0););
+}
+
+// 1x1 convolution of x WITH the GroupNorm apply pass of x in the same launch: y = conv(x) as jg_conv2d_nt, and additionally
+// y_norm[m][c] = act(ab[b][c][0] x[m][c] + ab[b][c][1]) (pixel stride ldyn) -- the two readers of a ResBlock input whose channel count
+// changes (`skip_connection(x)` and `act(norm(x))`, unet_generator_attn.py:233-266) share ONE pass over x.  Streaming kernel shapes only
+// (1x1, stride 1, Cin % 32 == 0, Cin <= 256, Cout % 64 == 0, >= 65536 pixels in multiples of 16, whole images per 16-pixel tile row):
+// JG_ERR_UNSUPPORTED otherwise, nothing launched.
+extern "C" int jg_conv1x1_gn_apply(int dtype, const jg_conv_args* a, const float* ab, void* y_norm, int64_t ldyn, int act, jg_stream_t stream) {
+  jg_note_kernel("");
+  if (!ab || !y_norm || !a || ldyn < a->Cin || (ldyn % 8)) return JG_ERR_BAD_ARG;
+  ConvP p;
+  const int rc = conv_args_to_params(a, p);
+  if (rc != JG_OK) return rc;
+  if (((long)a->Ho * a->Wo) % 16 || a->nbatch != 1) return JG_ERR_UNSUPPORTED;
+  p.aab = ab; p.ay = (char*)y_norm; p.lday = ldyn; p.aact = act;
+  if (!jg_conv1x1_try(dtype, p, a->nbatch, (hipStream_t)stream)) return JG_ERR_UNSUPPORTED;
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+static int conv_args_to_params(const jg_conv_args* a, ConvP& p) {
   if (!a || !a->x || !a->w || !a->y) return JG_ERR_BAD_ARG;
   if (a->Cin % 8 || a->Cout % 4 || a->ldx % 8 || a->ldw % 8 || a->ldy % 4) return JG_ERR_BAD_ARG;
   if (a->res && (a->ldres % 4)) return JG_ERR_BAD_ARG;
@@ -536,8 +563,8 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   if (a->R < 1 || a->S < 1 || a->stride < 1) return JG_ERR_BAD_ARG;
   const long M = (long)a->B * a->Ho * a->Wo;
   if (M <= 0 || M > (1L << 30)) return JG_ERR_BAD_ARG;
-  ConvP p;
   p.x = (const char*)a->x; p.w = (const char*)a->w; p.y = (char*)a->y; p.bias = a->bias; p.res = (const char*)a->res;
+  p.aab = nullptr; p.ay = nullptr; p.lday = 0; p.aact = 0;
   p.M = (int)M; p.N = a->Cout; p.K = a->R * a->S * a->Cin;
   p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.R = a->R; p.S = a->S; p.pad = a->pad; p.stride = a->stride;
   p.Ho = a->Ho; p.Wo = a->Wo;
@@ -568,5 +595,5 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   }
   p.ws = (float*)a->ws; p.splitk = 1;
   if (a->ws && (a->ws_bytes < 0 || ((uintptr_t)a->ws & 15))) return JG_ERR_BAD_ARG;
-  JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream, a->ws ? (long)a->ws_bytes : 0););
+  return JG_OK;
 }

@@ -77,6 +77,9 @@ FUSE_GN_COEF = os.environ.get("JG_FUSE_GN_COEF", "0") != "0"
 # DESIGN.md 4.5b): 6 instead of 10 bytes per element on paper.  MEASURED SLOWER on every UNet shape (round 4: 399 vs 310 us at 64 ch x
 # 256^2 x 32: the wait for the image's other workgroups idles the CU slots that hold the data): off; 1 = use it (kept, tested).
 GN_FUSED = os.environ.get("JG_GN_FUSED", "0") != "0"
+# ResBlocks whose channel count changes read their input twice (act(norm(x)) and skip_connection(x)): one launch does both
+# (jg_conv1x1_gn_apply, the streaming 1x1 kernel also writes the normalised activation).  0 = gn_apply + 1x1 convolution.
+FUSE_SKIP_APPLY = os.environ.get("JG_FUSE_SKIP_APPLY", "1") != "0"
 
 
 class _Pool:
@@ -144,6 +147,18 @@ def conv_fwd(x, m, out=None, res=None, res_scale=1.0, alpha=1.0, stats=None, res
         check(_lib.lib().jg_gn_stats_ld(_dt(out), out.data_ptr(), _ld(out), stats.data_ptr(), stats.stride(0) // 2, B, Ho * Wo,  # replica 0
                                         m.Cout, _st()), "jg_gn_stats_ld")
     return out
+
+
+def conv1x1_gn_apply(x, m, ab, act):
+    """(act(a x + b), conv1x1(x)) in one launch, or None when the layer is not a streaming-kernel shape"""
+    B, H, W, Cin = x.shape
+    if m.R != 1 or m.S != 1 or m.stride != 1 or m.pad != 0:
+        return None
+    y = torch.empty((B, H, W, m.Cout), device=x.device, dtype=x.dtype)
+    yn = torch.empty((B, H, W, Cin), device=x.device, dtype=x.dtype)
+    ok = conv_nt(x, m.w16, y, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=_ld(x), ldw=Cin, ldy=m.Cout,
+                 bias=m.bias_pad if m.bias_pad is not None else m.bias, apply=(ab, yn, Cin, act))
+    return (yn, y) if ok is not False else None
 
 
 def conv_dgrad(dy, m, x_shape, out=None, res=None, alpha=1.0, gn=None, pool=None, pool_out=False):
@@ -482,7 +497,13 @@ class UNetExecutor:
         gn2, c2m = rb.out_layers[0].norm, rb.out_layers[3].meta
         ab1, mr1 = gn_coef(X.st, X.hw, gn1.weight, gn1.bias, None, gn1.num_groups, gn1.eps)
         fuse_down = rb.updown and rb.down and FUSE_DOWN_POOL
-        h1 = None if fuse_down else gn_apply(x, ab1, JG_ACT_SILU)
+        sk_pre = None
+        if FUSE_SKIP_APPLY and not rb.updown and not isinstance(rb.skip_connection, nn.Identity):
+            both = conv1x1_gn_apply(x, rb.skip_connection.meta, ab1, JG_ACT_SILU)      # x is read once for its two consumers
+            if both is not None:
+                h1, sk_pre = both
+        if sk_pre is None:
+            h1 = None if fuse_down else gn_apply(x, ab1, JG_ACT_SILU)
         st1 = self.pool.take(B, Cout)
         Ho, Wo = H, W
         if rb.updown:
@@ -526,7 +547,7 @@ class UNetExecutor:
             h2_up = False
         skipw = 1.0 / math.sqrt(2) if rb.efficient else 1.0
         identity = isinstance(rb.skip_connection, nn.Identity)
-        sk = xs if identity else conv_fwd(xs, rb.skip_connection.meta)
+        sk = xs if identity else (sk_pre if sk_pre is not None else conv_fwd(xs, rb.skip_connection.meta))
         out_t, out_st = dest(B, Ho, Wo, Cout)
         wfold = subpixel_fold(c2m, h2.dtype) if (h2_up and SUBPIXEL_CONV and subpixel_ok(c2m, Ho, Wo)) else None
         conv_fwd(h2, c2m, out=out_t, res=sk, res_scale=skipw, stats=out_st, res_up=res_up, x_up=h2_up, wfold=wfold)

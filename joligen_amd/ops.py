@@ -103,8 +103,11 @@ def _conv_ws(dev):
 
 def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
             ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
-            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0, x_mode=0, y_mode=0):
-    """jg_conv2d_nt with element offsets into the operand tensors."""
+            sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0, x_mode=0, y_mode=0,
+            apply=None):
+    """jg_conv2d_nt with element offsets into the operand tensors.
+    apply = (ab, y_norm, ldyn, act): jg_conv1x1_gn_apply -- the launch also writes act(a x + b) of its input; returns False (nothing
+    launched) when the shape is not the streaming 1x1 kernel's."""
     a = ConvArgs()
     es = 2
     a.x = x.data_ptr() + x_off * es
@@ -134,7 +137,14 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()  # current stream == the stream the kernel is launched on
-    check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
+    if apply is not None:
+        ab, yn, ldyn, act = apply
+        rc = _lib.lib().jg_conv1x1_gn_apply(dtype if dtype is not None else _dt(x), C.byref(a), ab.data_ptr(), yn.data_ptr(), ldyn, act, _st())
+        if rc == _lib.JG_ERR_UNSUPPORTED:
+            return False
+        check(rc, "jg_conv1x1_gn_apply")
+    else:
+        check(_lib.lib().jg_conv2d_nt(dtype if dtype is not None else _dt(x), C.byref(a), _st()), "jg_conv2d_nt")
     if KERNEL_TIMING is not None:
         ev1.record()
         ran = _lib.lib().jg_last_kernel().decode()      # the instance the dispatch picked ("" where the site records none)
