@@ -117,6 +117,15 @@ int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream);
  * stride 1, Cin % 32 == 0, Cin <= 256, Cout % 64 == 0, >= 65536 pixels, H W % 16 == 0, no statistics): JG_ERR_UNSUPPORTED otherwise
  * (nothing is launched; callers fall back to jg_gn_apply_ld + jg_conv2d_nt). */
 int jg_conv1x1_gn_apply(int dtype, const jg_conv_args* a, const float* ab, void* y_norm, int64_t ldyn, int act, jg_stream_t stream);
+/* The backward counterpart: the input gradient of the 1x1 skip convolution WITH the GroupNorm-backward apply step of the same tensor in
+ * its epilogue,  y = alpha (dO . W^T) + du P + gx Q + R (+ scale1 add1 + scale2 add2),  du = gdy act'(a gx + b),  (a, b) = ab[b][c] and
+ * (P, Q, R) = pqr[b][c] of jg_gn_coef / jg_gn_bwd_coef(_slots): replaces jg_gn_bwd_apply_ld followed by jg_conv2d_nt(res = its result) --
+ * the gradient fan-in of a ResBlock input that feeds `in_layers` and `skip_connection` (unet_generator_attn.py:233-266) without the
+ * intermediate tensor (one write and one read of [M][Cout] less).  a->x = dO, a->w = the flipped / transposed weights, a->Cout = channel
+ * count of gx / gdy / add1 / add2 / y; a->bias and a->res must be NULL.  Streaming-kernel shapes only, else JG_ERR_UNSUPPORTED. */
+int jg_conv1x1_gn_bwd_apply(int dtype, const jg_conv_args* a, const void* gn_x, int64_t ldgx, const void* gn_dy, int64_t ldgdy, const float* ab,
+                            const float* pqr, const void* add1, int64_t ldadd1, float scale1, const void* add2, int64_t ldadd2, float scale2,
+                            int act, jg_stream_t stream);
 /* Folded weights of x_mode 2 from the fp32 master weights w32 [Cout][3][3][Cin]: out[py*2+px][co][a][b][ci] (dtype) = sum of the
  * 3x3 taps that land on tap (a, b) of output phase (py, px) of conv3x3(Upsample_nearest(x)) -- per axis {w0 | w1+w2} for phase 0,
  * {w0+w1 | w2} for phase 1 (fp32 sum, one rounding). */

@@ -24,9 +24,12 @@ __device__ __forceinline__ float act_rt(float u, int act) {
 // APPLY: the launch also writes act(a x + b) of its INPUT (the GroupNorm apply pass of x, ConvP.aab / ay): the block column
 // blockIdx.y == 0 transforms every 16-byte fragment it has loaded anyway and stores it; the (a, b) rows of the wave's current image
 // are staged in a wave-private LDS slot (2 Cin floats) and re-staged when the wave's tile sequence crosses an image boundary.
-template <typename T, int PAIRS, int KS, bool APPLY = false>
+// GNB: the epilogue adds the GroupNorm-backward apply step of the output tensor (ConvP.bgx ...): per lane and tile pair two more 16-byte
+// loads (gx, gdy; + the optional addends) and the per-channel coefficients (a, b, P, Q, R) of the block's PAIRS * 32 output channels from
+// a wave-private LDS slot laid out [5][PAIRS * 32] (re-staged at image boundaries).
+template <typename T, int PAIRS, int KS, bool APPLY = false, bool GNB = false>
 __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int ntiles) {
-  __shared__ __attribute__((aligned(16))) float s_ab[APPLY ? 4 * 2 * KS * 32 : 4];
+  __shared__ __attribute__((aligned(16))) float s_ab[APPLY ? 4 * 2 * KS * 32 : (GNB ? 4 * 5 * PAIRS * 32 : 4)];
   const int lane = threadIdx.x & 63;
   const int a = lane & 15, g = lane >> 4;
   const int n0 = blockIdx.y * (PAIRS * 32);
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int nti
 #pragma unroll
   for (int pr = 0; pr < PAIRS; ++pr)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bs[pr][j] = p.bias ? p.bias[n0 + pr * 32 + g * 8 + j] : 0.f;
+    for (int j = 0; j < 8; ++j) bs[pr][j] = (!GNB && p.bias) ? p.bias[n0 + pr * 32 + g * 8 + j] : 0.f;      // GNB: an input gradient has no bias
 
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
   auto load_tile = [&](int t, uint4* xf) {
@@ -59,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int nti
     for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const uint4*>(px + ks * 32);
   };
   const bool do_apply = APPLY && blockIdx.y == 0;
-  float* wab = s_ab + (threadIdx.x >> 6) * (APPLY ? 2 * KS * 32 : 1);       // this wave's (a, b) rows: [Cin][2]
+  float* wab = s_ab + (threadIdx.x >> 6) * (APPLY ? 2 * KS * 32 : (GNB ? 5 * PAIRS * 32 : 1));       // this wave's coefficient rows
   const int tiles_per_img = (p.Ho * p.Wo) >> 4;
   int cur_b = -1;
   // PF tiles of input fragments in flight per wave (a memory-bound stream needs ~64 KB in flight per CU)
@@ -74,6 +77,21 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int nti
       const int t = base + s * nwaves;
       if (t >= ntiles) break;
       const long prow = ((long)t * 16 + a);
+      if (GNB) {
+        const int b = t / tiles_per_img;
+        if (b != cur_b) {               // wave-uniform: (a, b, P, Q, R) of this block's channels for the new image -> [5][PAIRS * 32]
+          cur_b = b;
+          constexpr int NC = PAIRS * 32;
+          for (int c = lane; c < NC; c += 64) {
+            const long row = (long)b * p.N + n0 + c;
+            wab[c] = p.bab[row * 2];
+            wab[NC + c] = p.bab[row * 2 + 1];
+            wab[2 * NC + c] = p.bpqr[row * 3];
+            wab[3 * NC + c] = p.bpqr[row * 3 + 1];
+            wab[4 * NC + c] = p.bpqr[row * 3 + 2];
+          }
+        }
+      }
       uint4 rf[PAIRS];
       if (res) {
 #pragma unroll
@@ -120,8 +138,42 @@ __global__ __launch_bounds__(256, 2) void conv1x1_stream_kernel(ConvP p, int nti
         float r8[8];
         if (res) unpack8<T>(rf[pr], r8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = p.alpha * o[j] + bs[pr][j] + (res ? p.res_scale * r8[j] : 0.f);
+        for (int j = 0; j < 8; ++j) o[j] = GNB ? p.alpha * o[j] : p.alpha * o[j] + bs[pr][j] + (res ? p.res_scale * r8[j] : 0.f);
+        if (GNB) {
+          constexpr int NC = PAIRS * 32;
+          const int cl = pr * 32 + g * 8, cg = n0 + cl;
+          float fx[8], fd[8], ca[8], cb[8], cP[8], cQ[8], cR[8];
+          unpack8<T>(*reinterpret_cast<const uint4*>((const T*)p.bgx + prow * p.bldgx + cg), fx);
+          unpack8<T>(*reinterpret_cast<const uint4*>((const T*)p.bgdy + prow * p.bldgdy + cg), fd);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(ca + 4 * h) = *reinterpret_cast<const float4*>(wab + cl + 4 * h);
+            *reinterpret_cast<float4*>(cb + 4 * h) = *reinterpret_cast<const float4*>(wab + NC + cl + 4 * h);
+            *reinterpret_cast<float4*>(cP + 4 * h) = *reinterpret_cast<const float4*>(wab + 2 * NC + cl + 4 * h);
+            *reinterpret_cast<float4*>(cQ + 4 * h) = *reinterpret_cast<const float4*>(wab + 3 * NC + cl + 4 * h);
+            *reinterpret_cast<float4*>(cR + 4 * h) = *reinterpret_cast<const float4*>(wab + 4 * NC + cl + 4 * h);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float du = fd[j];
+            if (p.bact != JG_ACT_NONE) du *= act_grad_rt(ca[j] * fx[j] + cb[j], p.bact);
+            o[j] += du * cP[j] + fx[j] * cQ[j] + cR[j];
+          }
+          if (p.badd1) {
+            float fa[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>((const T*)p.badd1 + prow * p.bldadd1 + cg), fa);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += p.bsc1 * fa[j];
+          }
+          if (p.badd2) {
+            float fa[8];
+            unpack8<T>(*reinterpret_cast<const uint4*>((const T*)p.badd2 + prow * p.bldadd2 + cg), fa);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += p.bsc2 * fa[j];
+          }
+        }
         *reinterpret_cast<uint4*>(y + prow * p.ldy + n0 + pr * 32 + g * 8) = pack8<T>(o);
+        if (GNB) __builtin_amdgcn_sched_barrier(0);      // one channel group at a time: its operand vectors and coefficient octets die here
       }
     }
   }
@@ -273,6 +325,9 @@ void launch_1x1(const ConvP& p, hipStream_t st) {
   if (p.aab) {
     jg_note_kernel("conv1x1_stream_kernel+gn_apply");
     hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS, true>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
+  } else if (p.bgx) {
+    jg_note_kernel("conv1x1_stream_kernel+gn_bwd_apply");
+    hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS, false, true>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
   } else {
     hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
   }
@@ -297,8 +352,8 @@ bool dispatch_1x1(const ConvP& p, hipStream_t st) {
 bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   if (p.res_up || p.x_up || p.y_pool) return false;   // half-resolution residuals / inputs: LDS-staged kernels only
   const bool off = jg_tune(JG_TUNE_CONV1X1) == 0;
-  if (off && !p.aab) return false;
-  if (!p.aab && nbatch == 1 && p.nh == 1 && p.R == 3 && p.S == 3 && p.pad == 1 && p.stride == 1 && !p.out_f32 && !(p.stats && p.stats_mode) && !p.reflect &&
+  if (off && !p.aab && !p.bgx) return false;
+  if (!p.aab && !p.bgx && nbatch == 1 && p.nh == 1 && p.R == 3 && p.S == 3 && p.pad == 1 && p.stride == 1 && !p.out_f32 && !(p.stats && p.stats_mode) && !p.reflect &&
       p.Cin == 8 && ((p.H * p.W) & 15) == 0 &&
       p.ldx == 8 && p.ldw == 72 && p.N % 64 == 0 && !(p.M & 15) && p.H == p.Ho && p.W == p.Wo && p.ldy % 8 == 0 && (!p.res || p.ldres % 8 == 0) &&
       (long)p.M >= 65536) {

@@ -34,6 +34,10 @@ struct ConvP {
   // streaming 1x1 kernel only (jg_conv1x1_gn_apply): ALSO write ay[m][c] = act(aab[b][c][0] * x[m][c] + aab[b][c][1]) for the Cin input
   // channels -- the GroupNorm apply pass of the tensor this convolution reads (ResBlock: skip_connection(x) next to act(norm(x)))
   const float* aab; char* ay; long lday; int aact;
+  // streaming 1x1 kernel only (jg_conv1x1_gn_bwd_apply): the epilogue ADDS the GroupNorm-backward apply step of the tensor whose gradient
+  // this convolution produces: y += du P + gx Q + R (+ sc1 add1 + sc2 add2), du = gdy act'(a gx + b); bab [B][N][2], bpqr [B][N][3]
+  const char* bgx; long bldgx; const char* bgdy; long bldgdy; const float* bab; const float* bpqr;
+  const char* badd1; long bldadd1; float bsc1; const char* badd2; long bldadd2; float bsc2; int bact;
 };
 
 // output pixel row m = (b * Ho + oh) * Wo + ow  ->  row of the half-resolution residual

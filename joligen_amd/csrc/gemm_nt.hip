@@ -555,6 +555,29 @@ extern "C" int jg_conv1x1_gn_apply(int dtype, const jg_conv_args* a, const float
   return JG_OK;
 }
 
+// Input gradient of a 1x1 (skip) convolution WITH the GroupNorm-backward apply step of the same tensor in its epilogue:
+//   y[m][c] = alpha (dO . W^T)[m][c] + bias + du P + gx Q + R (+ scale1 add1 + scale2 add2),   du = gdy act'(a gx + b)
+// with (a, b) = ab[b][c], (P, Q, R) = pqr[b][c] from jg_gn_coef / jg_gn_bwd_coef -- what jg_gn_bwd_apply_ld followed by jg_conv2d_nt(res =
+// its result) compute in two passes (autograd fan-in of a ResBlock input that feeds both `in_layers` and `skip_connection`,
+// unet_generator_attn.py:233-266).  gx / gdy / add1 / add2: [M][Cout] 16-bit with their own pixel strides.  Streaming-kernel shapes
+// only (see jg_conv1x1_gn_apply): JG_ERR_UNSUPPORTED otherwise, nothing launched.
+extern "C" int jg_conv1x1_gn_bwd_apply(int dtype, const jg_conv_args* a, const void* gn_x, int64_t ldgx, const void* gn_dy, int64_t ldgdy,
+                                       const float* ab, const float* pqr, const void* add1, int64_t ldadd1, float scale1, const void* add2,
+                                       int64_t ldadd2, float scale2, int act, jg_stream_t stream) {
+  jg_note_kernel("");
+  if (!a || !gn_x || !gn_dy || !ab || !pqr || ldgx < a->Cout || ldgdy < a->Cout || (ldgx % 8) || (ldgdy % 8)) return JG_ERR_BAD_ARG;
+  if ((add1 && (ldadd1 < a->Cout || ldadd1 % 8)) || (add2 && (ldadd2 < a->Cout || ldadd2 % 8)) || a->res || a->bias) return JG_ERR_BAD_ARG;
+  ConvP p;
+  const int rc = conv_args_to_params(a, p);
+  if (rc != JG_OK) return rc;
+  if (((long)a->Ho * a->Wo) % 16 || a->nbatch != 1) return JG_ERR_UNSUPPORTED;
+  p.bgx = (const char*)gn_x; p.bldgx = ldgx; p.bgdy = (const char*)gn_dy; p.bldgdy = ldgdy; p.bab = ab; p.bpqr = pqr;
+  p.badd1 = (const char*)add1; p.bldadd1 = ldadd1; p.bsc1 = scale1; p.badd2 = (const char*)add2; p.bldadd2 = ldadd2; p.bsc2 = scale2; p.bact = act;
+  if (!jg_conv1x1_try(dtype, p, a->nbatch, (hipStream_t)stream)) return JG_ERR_UNSUPPORTED;
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
 static int conv_args_to_params(const jg_conv_args* a, ConvP& p) {
   if (!a || !a->x || !a->w || !a->y) return JG_ERR_BAD_ARG;
   if (a->Cin % 8 || a->Cout % 4 || a->ldx % 8 || a->ldw % 8 || a->ldy % 4) return JG_ERR_BAD_ARG;
@@ -565,6 +588,7 @@ static int conv_args_to_params(const jg_conv_args* a, ConvP& p) {
   if (M <= 0 || M > (1L << 30)) return JG_ERR_BAD_ARG;
   p.x = (const char*)a->x; p.w = (const char*)a->w; p.y = (char*)a->y; p.bias = a->bias; p.res = (const char*)a->res;
   p.aab = nullptr; p.ay = nullptr; p.lday = 0; p.aact = 0;
+  p.bgx = p.bgdy = p.badd1 = p.badd2 = nullptr; p.bab = p.bpqr = nullptr; p.bldgx = p.bldgdy = p.bldadd1 = p.bldadd2 = 0; p.bsc1 = p.bsc2 = 0.f; p.bact = 0;
   p.M = (int)M; p.N = a->Cout; p.K = a->R * a->S * a->Cin;
   p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.R = a->R; p.S = a->S; p.pad = a->pad; p.stride = a->stride;
   p.Ho = a->Ho; p.Wo = a->Wo;

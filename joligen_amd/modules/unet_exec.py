@@ -80,6 +80,9 @@ GN_FUSED = os.environ.get("JG_GN_FUSED", "0") != "0"
 # ResBlocks whose channel count changes read their input twice (act(norm(x)) and skip_connection(x)): one launch does both
 # (jg_conv1x1_gn_apply, the streaming 1x1 kernel also writes the normalised activation).  0 = gn_apply + 1x1 convolution.
 FUSE_SKIP_APPLY = os.environ.get("JG_FUSE_SKIP_APPLY", "1") != "0"
+# ... and in the backward the input gradient of that skip convolution carries the GroupNorm-backward apply step of the same tensor in its
+# epilogue (jg_conv1x1_gn_bwd_apply): the [M][Cin] intermediate between the two launches is neither written nor read.
+FUSE_SKIP_BWD = os.environ.get("JG_FUSE_SKIP_BWD", "1") != "0"
 
 
 class _Pool:
@@ -221,17 +224,19 @@ def gn_apply(x, ab, act):
     return y
 
 
-def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=(), red=None, pooled=None, pool=None):
+def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=(), red=None, pooled=None, pool=None, skip=None):
     """dx = GroupNorm-backward(x, dy) + sum_i scale_i * add_i  (at most two addends, fused).
     `red`: reductions already accumulated by the convolution that produced dy ([B, NSLOT, C, 2]).
     `pooled`: (dy_scale, low_add): dy (and the optional addend `low_add` = (tensor, scale)) live at the 2x2-POOLED resolution; the
-    kernels read them through the nearest-upsample map (adjoint of the average pool) instead of materialising the upsampled copy."""
+    kernels read them through the nearest-upsample map (adjoint of the average pool) instead of materialising the upsampled copy.
+    `skip` = (dO, m, alpha): x also feeds the 1x1 convolution m (the ResBlock's skip_connection) whose output gradient is dO: the result is
+    alpha * dgrad_m(dO) + GroupNorm-backward(x, dy) + addends, the apply step running in the epilogue of the input-gradient launch."""
     L = _lib.lib()
     B, H, W, C = x.shape
     HW = H * W
     dev, dt = x.device, _dt(x)
     nslots = NSLOT
-    if red is None and GN_FUSED and pool is not None and G <= 2048 and C <= 2048:
+    if red is None and GN_FUSED and skip is None and pool is not None and G <= 2048 and C <= 2048:
         rows, cnt = pool.take_rows(B, C), pool.take_rows(B, 1)
         if rows is not None and cnt is not None:
             dgamma = gamma.grad if gamma is not None else None
@@ -274,7 +279,7 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
     dbeta = beta.grad if beta is not None else None
     if gamma is not None and dgamma is None:
         raise RuntimeError("norm weight has no arena-backed .grad")
-    if FUSE_GN_COEF and nslots == 1 and G <= 256:
+    if FUSE_GN_COEF and skip is None and nslots == 1 and G <= 256:
         # the coefficient step runs inside the apply pass (jg_gn_bwd_apply_fc): one launch fewer per GroupNorm backward
         if out is None:
             out = torch.empty((B, H, W, C), device=dev, dtype=x.dtype)
@@ -317,9 +322,19 @@ def gn_bwd(x, dy, ab, mr, gamma, beta, film, G, act, dfilm=None, out=None, adds=
         raise RuntimeError("at most two fused gradient addends")
     a1, s1 = adds[0] if len(adds) > 0 else (None, 0.0)
     a2, s2 = adds[1] if len(adds) > 1 else (None, 0.0)
+    if skip is not None:
+        dO, m, alpha = skip
+        if FUSE_SKIP_BWD and m.R == 1 and m.S == 1 and m.stride == 1 and m.pad == 0:
+            ok = conv_nt(dO, m.w16T, out, B=B, H=H, W=W, Cin=m.Cout, Cout=C, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=_ld(dO), ldw=m.Cout,
+                         ldy=_ld(out), alpha=alpha, gn_bwd_apply=(x, dy, ab, pqr, a1, s1, a2, s2, act))
+            if ok is not False:
+                return out
     check(L.jg_gn_bwd_apply_ld(dt, x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), ab.data_ptr(), pqr.data_ptr(), out.data_ptr(),
                                _ld(out), _p(a1), _ld(a1) if a1 is not None else 0, s1, _p(a2),
                                _ld(a2) if a2 is not None else 0, s2, B, HW, C, act, _st()), "jg_gn_bwd_apply_ld")
+    if skip is not None:      # two-launch form: the GroupNorm-backward result enters the input gradient as its epilogue residual
+        dO, m, alpha = skip
+        return conv_dgrad(dO, m, x.shape, res=out, alpha=alpha)
     return out
 
 
@@ -685,9 +700,9 @@ class UNetExecutor:
             raise NotImplementedError("resampling ResBlock with a 1x1 skip convolution")
         skm = rb.skip_connection.meta
         self.wgrad(dO, rec["xs"], skm, alpha=skipw, dbias_scale=skipw)
-        dxg = gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
-                     red=red1, pool=self.bpool)
-        return conv_dgrad(dO, skm, x.shape, res=dxg, alpha=skipw)   # skipw * (dO . Wskip) + dxg in one epilogue
+        # skipw * (dO . Wskip) + GroupNorm-backward(x, dh1) + addends: one launch behind the reduction + coefficient steps
+        return gn_bwd(x, dh1, rec["ab1"], rec["mr1"], gn1.weight, gn1.bias, None, gn1.num_groups, JG_ACT_SILU, adds=adds,
+                      red=red1, pool=self.bpool, skip=(dO, skm, skipw))
 
     def attn_bwd(self, rec, dO, adds):
         blk = rec["blk"]

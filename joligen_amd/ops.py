@@ -104,10 +104,12 @@ def _conv_ws(dev):
 def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw, ldy, bias=None, res=None,
             ldres=0, alpha=1.0, res_scale=1.0, out_f32=False, nbatch=1, nh=1, sx=(0, 0), sw=(0, 0), sy=(0, 0),
             sr=(0, 0), x_off=0, w_off=0, y_off=0, dtype=None, stats=None, ldstats=0, stats_slots=1, gn_reduce=None, pad_mode=0, res_mode=0, x_mode=0, y_mode=0,
-            apply=None):
+            apply=None, gn_bwd_apply=None):
     """jg_conv2d_nt with element offsets into the operand tensors.
     apply = (ab, y_norm, ldyn, act): jg_conv1x1_gn_apply -- the launch also writes act(a x + b) of its input; returns False (nothing
-    launched) when the shape is not the streaming 1x1 kernel's."""
+    launched) when the shape is not the streaming 1x1 kernel's.
+    gn_bwd_apply = (gx, gdy, ab, pqr, add1, scale1, add2, scale2, act): jg_conv1x1_gn_bwd_apply -- the epilogue adds the GroupNorm-backward
+    apply step of the output tensor; returns False likewise."""
     a = ConvArgs()
     es = 2
     a.x = x.data_ptr() + x_off * es
@@ -137,7 +139,15 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()  # current stream == the stream the kernel is launched on
-    if apply is not None:
+    if gn_bwd_apply is not None:
+        gx, gdy, gab, gpqr, a1, s1, a2, s2, gact = gn_bwd_apply
+        rc = _lib.lib().jg_conv1x1_gn_bwd_apply(dtype if dtype is not None else _dt(x), C.byref(a), gx.data_ptr(), gx.stride(-2), gdy.data_ptr(),
+                                                gdy.stride(-2), gab.data_ptr(), gpqr.data_ptr(), _p(a1), a1.stride(-2) if a1 is not None else 0, s1,
+                                                _p(a2), a2.stride(-2) if a2 is not None else 0, s2, gact, _st())
+        if rc == _lib.JG_ERR_UNSUPPORTED:
+            return False
+        check(rc, "jg_conv1x1_gn_bwd_apply")
+    elif apply is not None:
         ab, yn, ldyn, act = apply
         rc = _lib.lib().jg_conv1x1_gn_apply(dtype if dtype is not None else _dt(x), C.byref(a), ab.data_ptr(), yn.data_ptr(), ldyn, act, _st())
         if rc == _lib.JG_ERR_UNSUPPORTED:

@@ -1547,3 +1547,54 @@ def test_conv1x1_gn_apply_matches_the_two_passes(cin, cout, B, H, W, dtype):
     assert ops.conv_nt(xs, w, ys, B=B, H=16, W=16, Cin=cin, Cout=cout, R=1, S=1, pad=0, stride=1, Ho=16, Wo=16, ldx=cin, ldw=cin, ldy=cout,
                        bias=bias, apply=(ab, yns, cin, ops.JG_ACT_SILU)) is False
     assert float(ys.abs().sum()) == 0.0 and float(yns.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfwd_in,cfwd_out,B,H,W,nadd", [(128, 64, 4, 128, 128, 0), (192, 64, 2, 256, 128, 1), (64, 128, 4, 128, 128, 2), (256, 128, 4, 128, 128, 1),
+                                                         (384, 128, 4, 128, 128, 0), (768, 256, 4, 128, 128, 1)])
+def test_conv1x1_gn_bwd_apply_matches_the_two_launch_form(cfwd_in, cfwd_out, B, H, W, nadd, dtype):
+    """jg_conv1x1_gn_bwd_apply (input gradient of a 1x1 skip convolution cfwd_in -> cfwd_out with the GroupNorm-backward apply step of its
+    input in the epilogue) against jg_gn_bwd_apply_ld followed by jg_conv2d_nt(res = its result): same arithmetic except that the
+    two-launch form rounds the intermediate to 16 bits once more -- the fused result must agree with an fp32 evaluation at least as well."""
+    from joligen_amd import _lib, ops
+
+    L = _lib.lib()
+    d = dev()
+    g = torch.Generator().manual_seed(cfwd_in * 7 + cfwd_out)
+    C = cfwd_in                                  # channels of x / dy / dx
+    x = (torch.randn(B, H, W, C, generator=g) * 1.3).to(dtype).to(d)
+    dy = torch.randn(B, H, W, C, generator=g).to(dtype).to(d)
+    dO = torch.randn(B, H, W, cfwd_out, generator=g).to(dtype).to(d)
+    wT = (torch.randn(C, 1, 1, cfwd_out, generator=g) * 0.1).to(dtype).to(d)       # [Cin_fwd][1][1][Cout_fwd]: the input-gradient weights
+    ab = torch.stack([torch.rand(B, C, generator=g) + 0.5, torch.randn(B, C, generator=g)], -1).contiguous().to(d)
+    pqr = torch.stack([torch.rand(B, C, generator=g) + 0.5, 0.1 * torch.randn(B, C, generator=g), 0.1 * torch.randn(B, C, generator=g)], -1).contiguous().to(d)
+    adds = [torch.randn(B, H, W, C, generator=g).to(dtype).to(d) for _ in range(nadd)]
+    a1, a2 = (adds + [None, None])[:2]
+    s1, s2, alpha = 0.7, -1.3, 0.70710678
+    # two-launch form
+    dxg = torch.empty_like(x)
+    _lib.check(L.jg_gn_bwd_apply_ld(ops._dt(x), x.data_ptr(), C, dy.data_ptr(), C, ab.data_ptr(), pqr.data_ptr(), dxg.data_ptr(), C, ops._p(a1), C, s1,
+                                    ops._p(a2), C, s2, B, H * W, C, ops.JG_ACT_SILU, ops._st()))
+    ref2 = torch.empty_like(x)
+    ops.conv_nt(dO, wT, ref2, B=B, H=H, W=W, Cin=cfwd_out, Cout=C, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=cfwd_out, ldw=cfwd_out, ldy=C, alpha=alpha,
+                res=dxg, ldres=C, res_scale=1.0)
+    # fused
+    out = torch.full_like(x, float("nan"))
+    ok = ops.conv_nt(dO, wT, out, B=B, H=H, W=W, Cin=cfwd_out, Cout=C, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=cfwd_out, ldw=cfwd_out, ldy=C,
+                     alpha=alpha, gn_bwd_apply=(x, dy, ab, pqr, a1, s1, a2, s2, ops.JG_ACT_SILU))
+    torch.cuda.synchronize()
+    assert ok is not False
+    # fp32 evaluation
+    xf, dyf = x.float(), dy.float()
+    u = ab[:, None, None, :, 0] * xf + ab[:, None, None, :, 1]
+    sg = torch.sigmoid(u)
+    du = dyf * (sg * (1 + u * (1 - sg)))
+    want = du * pqr[:, None, None, :, 0] + xf * pqr[:, None, None, :, 1] + pqr[:, None, None, :, 2]
+    if a1 is not None:
+        want = want + s1 * a1.float()
+    if a2 is not None:
+        want = want + s2 * a2.float()
+    want = want + alpha * (dO.float().reshape(-1, cfwd_out) @ wT.float().reshape(C, cfwd_out).t()).reshape(B, H, W, C)
+    e_fused, e_two = relerr(out.float(), want), relerr(ref2.float(), want)
+    assert e_fused < (1e-3 if dtype == torch.float16 else 6e-3), e_fused
+    assert e_fused <= e_two * 1.05 + 1e-6, (e_fused, e_two)
