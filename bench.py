@@ -378,11 +378,11 @@ def cut_leg(local_rank, no_cpu):
             "roofline": roof, "cpu_baseline": cpu}
 
 
-def unet_leg(local_rank, model_kind, size, batch, efficient, steps=10, warmup=3):
+def unet_leg(local_rank, model_kind, size, batch, efficient, steps=20, warmup=5):
     """One more single-GPU configuration of BASELINE.json on the default line: `c4_512` = configs[3] (palette_model DDPM, UNet with mid-block
     self-attention, 512x512, batch 8 per GPU) and `cm` = configs[4] (cm_model consistency step, 256x256, batch 64 per GPU, fused AdamW):
     value, ms per step, the step's algorithmic FLOPs as a fraction of the bf16 MFMA peak.  Same step definition as the palette leg
-    (set_input on a device-resident batch + optimize_parameters()); ~2 - 3 s each."""
+    (set_input on a device-resident batch + optimize_parameters()); run by `leg_subprocess` in a process of its own."""
     ns = argparse.Namespace(model=model_kind, netG="resnet", netDs="basic", batch=batch, size=size, dtype="bf16", efficient=int(efficient),
                             force_exchange=False)
     model, _ = build_model(ns, 0, local_rank, 1)
@@ -397,8 +397,6 @@ def unet_leg(local_rank, model_kind, size, batch, efficient, steps=10, warmup=3)
     mult = 3 if model_kind == "palette" else 4          # cm = student forward + teacher forward + backward
     tflop = mult * FWD_GFLOP_PER_IMG[(size, bool(efficient))] * batch / 1e3
     loss = float(model.get_current_losses()["G_tot"].detach())
-    del model
-    torch.cuda.empty_cache()
     return {"metric": f"train images/sec at {size}x{size} ({'DDPM UNet' if model_kind == 'palette' else 'CM UNet'} step)",
             "value": round(batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(ms, 3),
             "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2], 3), "steps": steps, "warmup": warmup, "dtype": "bf16", "data": "synthetic",
@@ -406,6 +404,27 @@ def unet_leg(local_rank, model_kind, size, batch, efficient, steps=10, warmup=3)
                                    f"ngf64 mults[1,2,4,8] res_blocks[2,2,2,2] mid-attn 16x32, {size}x{size}, batch {batch}/GPU, inpainting synthetic masks, "
                                    "AdamW+EMA, iter_size 1", "global_batch": batch, "final_loss": round(loss, 6)},
             "step_algorithmic_tflop": round(tflop, 3), "step_frac_of_mfma_peak": round(tflop / (ms * 1e-3) / PEAK_BF16_TFLOPS, 4)}
+
+
+# BASELINE configs[3] and configs[4] at their own shapes
+EXTRA_LEGS = {"c4_512": dict(model_kind="palette", size=512, batch=8, efficient=False), "cm": dict(model_kind="cm", size=256, batch=64, efficient=True)}
+
+
+def leg_subprocess(name, no_cpu, timeout_s=420):
+    """One extra leg of the default line in its OWN process: every leg starts from an empty allocator (in one process the legs inherited
+    each other's 100+ GB of cached blocks, and one step in ten of the 512x512 leg stalled for ~2 s in hipMalloc), and a leg that dies
+    cannot take the palette line with it."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name] + (["--no-cpu-baseline"] if no_cpu else [])
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        for line in reversed(out.stdout.splitlines()):
+            if line.startswith("{"):
+                return json.loads(line)
+        return {"value": None, "error": ("leg failed: " + out.stderr[-300:])}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "error": f"leg exceeded its {timeout_s}s bound"}
 
 
 def main():
@@ -427,10 +446,16 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-exchange", action="store_true", help="dev: run the multi-GPU gradient exchange path on one GPU (1-rank RCCL group)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--leg", default="", help=argparse.SUPPRESS)      # child mode: run ONE extra leg of the default line (cut | c4_512 | cm), print its JSON object
     ap.add_argument("--dump-kernel-timing", default="", help="write the per-shape conv kernel timing table here")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args)), flush=True)
+        return
+    if args.leg:
+        torch.cuda.set_device(0)
+        obj = cut_leg(0, args.no_cpu_baseline) if args.leg == "cut" else unet_leg(0, **EXTRA_LEGS[args.leg])
+        print(json.dumps(obj), flush=True)
         return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -588,24 +613,15 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_subprocess(args)
-    cut = None
+    cut, extra = None, {}
     if rank == 0 and world == 1 and args.model == "palette" and not args.no_cut_leg and not args.force_exchange:
-        try:       # the CUT half of BASELINE's metric ("DDPM UNet & CUT G+D step") on the same line; never at the palette line's expense
-            cut = cut_leg(local_rank, args.no_cpu_baseline)
-        except Exception as e:
-            cut = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
-
-    extra = {}
-    if rank == 0 and world == 1 and args.model == "palette" and not args.no_cut_leg and not args.force_exchange:
-        # BASELINE configs[3] and configs[4] at their own shapes, after everything the palette line needs
-        del model
-        torch.cuda.empty_cache()
-        for key, kw in (("c4_512", dict(model_kind="palette", size=512, batch=8, efficient=False)),
-                        ("cm", dict(model_kind="cm", size=256, batch=64, efficient=True))):
-            try:
-                extra[key] = unet_leg(local_rank, **kw)
-            except Exception as e:
-                extra[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+        # the CUT half of BASELINE's metric ("DDPM UNet & CUT G+D step") and configs[3] / configs[4] on the same line, each in its own
+        # process and never at the palette line's expense
+        print("[bench] cut leg", file=sys.stderr, flush=True)
+        cut = leg_subprocess("cut", args.no_cpu_baseline)
+        for key in EXTRA_LEGS:
+            print(f"[bench] {key} leg", file=sys.stderr, flush=True)
+            extra[key] = leg_subprocess(key, True)
 
     if rank == 0:
         line = {
