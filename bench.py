@@ -576,7 +576,7 @@ def main():
         # read from inside the timed process: `traffic` is that committed measurement, `traffic_build` says which build it is from and
         # `running_build` which one produced every other number of this line.
         traffic, traffic_build, traffic_file = None, None, None
-        for cand in ("r03_pmc.json", "r02_pmc.json"):
+        for cand in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
             try:
                 if args.model != "palette":
                     break

@@ -164,8 +164,11 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
         else:
             KERNEL_TIMING.append((ran or _conv_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, B * Ho * Wo if (stats is None or (R == 3 and Cin == 8 and gn_reduce is None)) else 0), ev0, ev1,
                                   2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R),
-                                  # algorithmic HBM bytes: every input / output / residual element once (16-bit), the weights once
-                                  2.0 * nbatch * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if res is not None else 1)) + 2.0 * R * S * Cin * Cout))
+                                  # algorithmic HBM bytes: every input / output / residual element once (16-bit), the weights once; the fused
+                                  # launches also move the normalised copy of the input (apply) or gx, gdy and the addends (gn_bwd_apply)
+                                  2.0 * nbatch * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if res is not None else 1)) + 2.0 * R * S * Cin * Cout
+                                  + (2.0 * B * H * W * Cin if apply is not None else 0.0)
+                                  + (2.0 * B * Ho * Wo * Cout * (2 + (gn_bwd_apply[4] is not None) + (gn_bwd_apply[6] is not None)) if gn_bwd_apply is not None else 0.0)))
 
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
