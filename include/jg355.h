@@ -414,6 +414,11 @@ int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias
                      jg_stream_t s);
 int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw, float* dbias,
                      int B, int H, int W, int C, int gelu, jg_stream_t s);
+/* the same with the weight / bias partials of the blocks staged in `ws` (>= jg_dwconv3x3_bwd_ws_floats(B, H, W, C) floats, need not be
+ * zeroed) and summed by a second launch instead of one atomic per block and destination; ws NULL = jg_dwconv3x3_bwd */
+int jg_dwconv3x3_bwd_ws(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
+                        float* dbias, float* ws, int64_t ws_floats, int B, int H, int W, int C, int gelu, jg_stream_t s);
+int64_t jg_dwconv3x3_bwd_ws_floats(int B, int H, int W, int C);
 int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tkv, int heads,
                         int64_t ldq, int64_t ldkv, int64_t ldo, float scale, jg_stream_t s);
 int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,

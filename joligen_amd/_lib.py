@@ -128,6 +128,8 @@ SIGNATURES = {
     "jg_layernorm_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p],
     "jg_dwconv3x3_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dwconv3x3_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_dwconv3x3_bwd_ws": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_dwconv3x3_bwd_ws_floats": [c_i32, c_i32, c_i32, c_i32],
     "jg_attn_smallkv_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f32, c_p],
     "jg_attn_smallkv_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64,
                             c_f32, c_p],
@@ -237,7 +239,7 @@ def lib():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the symbol is absent
         fn.argtypes = argtypes
-        fn.restype = C.c_char_p if name in ("jg_strerror", "jg_last_kernel") else c_i32
+        fn.restype = C.c_char_p if name in ("jg_strerror", "jg_last_kernel") else c_i64 if name.endswith("_ws_floats") else c_i32
     _lib = L
     return L
 

@@ -16,12 +16,43 @@ inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-// nn.GELU() (exact form) with the library erff / expf.  (tried: erf by Abramowitz & Stegun 7.1.26 on one fast exponential, |error| 2e-7:
-//  no measurable gain -- the depth-wise kernels are bound by their load chains and reductions, not by the vector unit -- so the
-//  reference-exact form stays)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+// nn.GELU() (erf form) and its derivative Phi(x) + x phi(x).  The depth-wise kernels are bound by their vector instructions (8 channels
+// x 9 taps of fp32 FMAs per 16-byte chunk); with the library erff / expf, which branch per element, and a 64-bit p % W, (p / W) % H per
+// step a pixel chunk of the weight gradient was ~850 instructions, ~110 of them useful.  Here erf is Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, well below the 16-bit rounding of the result), whose e^{-z^2} at z = x / sqrt 2 is the e^{-x^2/2} of the density
+// term: ONE v_exp_f32 and one v_rcp_f32 per element, no branches.  (Round 3 tried the same formula while the kernels still spent their
+// time in 1024-deep atomic chains and 64-bit divisions and saw nothing; after those went -- DwWalk, dw_partials_sum_kernel -- it pays.)
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);          // e^{-x^2/2}
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float erf_abs = fmaf(-p * t, e, 1.0f);                                      // erf(|x| / sqrt 2)
+  return fmaf(x * 0.3989422804014327f, e, fmaf(0.5f, copysignf(erf_abs, x), 0.5f));
+}
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  return x * fmaf(0.5f, copysignf(fmaf(-p * t, e, 1.0f), x), 0.5f);
+}
+typedef float dw_f32x2 __attribute__((ext_vector_type(2)));
+// two 16-bit values of one dword -> fp32 pair (bf16: a shift and a mask)
+template <typename T> __device__ __forceinline__ dw_f32x2 dw_unpack2(uint32_t w) {
+  dw_f32x2 r;
+  if constexpr (sizeof(T) == 2 && __is_same(T, bf16_t)) {
+    r.x = __uint_as_float(w << 16);
+    r.y = __uint_as_float(w & 0xffff0000u);
+  } else {
+    r.x = to_f32(bits_to<T>((uint16_t)(w & 0xffffu)));
+    r.y = to_f32(bits_to<T>((uint16_t)(w >> 16)));
+  }
+  return r;
 }
 
 // the nine 16-byte neighbour loads of a 3x3 window issued back to back with ONE wait, as a single asm statement (clang puts an ordinary
@@ -54,6 +85,26 @@ __device__ __forceinline__ void dw_load11(uint4 (&v)[11], const void* const (&p)
 #pragma unroll
   for (int i = 0; i < 11; ++i) v[i] = make_uint4(r[i].x, r[i].y, r[i].z, r[i].w);
 }
+// (px, py) of a pixel index that advances by a fixed stride: one 32-bit division pair up front, then adds and two wrap-arounds per step
+// (the loops used to compute p % W and (p / W) % H on a 64-bit p every iteration: ~400 of the ~850 instructions of a pixel chunk)
+struct DwWalk {
+  int px, py, sx, sy, W, H;
+  __device__ __forceinline__ DwWalk(unsigned p0, unsigned stride, int W_, int H_) : W(W_), H(H_) {
+    px = (int)(p0 % (unsigned)W_);
+    py = (int)((p0 / (unsigned)W_) % (unsigned)H_);
+    sx = (int)(stride % (unsigned)W_);
+    sy = (int)((stride / (unsigned)W_) % (unsigned)H_);
+  }
+  __device__ __forceinline__ void step() {
+    px += sx;
+    py += sy;
+    if (px >= W) {
+      px -= W;
+      py += 1;
+    }
+    if (py >= H) py -= H;
+  }
+};
 // window of pixel (py, px) of an [H, W, C] image row-major at `base` (pointer to the centre pixel's chunk): pointers + validity of the 9 taps
 template <typename T, bool FLIP>
 __device__ __forceinline__ void dw_window(const T* centre, int px, int py, int H, int W, int C, const void* (&ptr)[9], bool (&ok)[9]) {
@@ -135,37 +186,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     g[j] = act ? gamma[sub * 8 + j] : 0.f;
     ag[j] = ab[j] = 0.f;
   }
-  for (long r0 = wave * rpw; r0 < R; r0 += nwaves * rpw) {
-    const long row = r0 + rsub;
-    const bool ok = act && row < R;
-    float xh[8], gy[8], d8[8];
-    float s1 = 0.f, s2 = 0.f, mean = 0.f, rstd = 0.f;
-    if (ok) {
-      float f[8];
-      unpack8<T>(*reinterpret_cast<const uint4*>(x + row * C + sub * 8), f);
-      unpack8<T>(*reinterpret_cast<const uint4*>(dy + row * C + sub * 8), d8);
-      mean = mr[row * 2];
-      rstd = mr[row * 2 + 1];
+  // two row groups per trip: the eight loads (x, dy, mean, rstd of both) are in flight together -- with one group per trip a wave spent
+  // the launch waiting out one HBM round trip after another (8 trips at [131072, 32])
+  const float inv_c = 1.0f / (float)C;
+  for (long r0 = wave * rpw; r0 < R; r0 += 2 * nwaves * rpw) {
+    long row[2];
+    bool ok[2];
+    uint4 vx[2], vd[2];
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      row[u] = r0 + u * nwaves * rpw + rsub;
+      ok[u] = act && row[u] < R;
+      const long rr = ok[u] ? row[u] : 0;            // clamped (valid) address: the loads are unconditional, the results masked
+      const int cc = act ? sub * 8 : 0;
+      vx[u] = *reinterpret_cast<const uint4*>(x + rr * C + cc);
+      vd[u] = *reinterpret_cast<const uint4*>(dy + rr * C + cc);
+      mean[u] = mr[rr * 2];
+      rstd[u] = mr[rr * 2 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float xh[8], gy[8], d8[8], f[8];
+      float s1 = 0.f, s2 = 0.f;
+      unpack8<T>(vx[u], f);
+      unpack8<T>(vd[u], d8);
+      const float live = ok[u] ? 1.f : 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        xh[j] = (f[j] - mean) * rstd;
+        d8[j] *= live;
+        xh[j] = (f[j] - mean[u]) * rstd[u];
         gy[j] = d8[j] * g[j];
         s1 += gy[j];
         s2 += gy[j] * xh[j];
         ag[j] += d8[j] * xh[j];
         ab[j] += d8[j];
       }
-    }
-    for (int o = 1; o < lpr; o <<= 1) {
-      s1 += __shfl_xor(s1, o);
-      s2 += __shfl_xor(s2, o);
-    }
-    if (ok && dx) {
-      const float m1 = s1 / (float)C, m2 = s2 / (float)C;
-      float o8[8];
+      for (int o = 1; o < lpr; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+      }
+      if (ok[u] && dx) {
+        const float m1 = s1 * inv_c, m2 = s2 * inv_c;
+        float o8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o8[j] = rstd * (gy[j] - m1 - xh[j] * m2);
-      *reinterpret_cast<uint4*>(dx + row * C + sub * 8) = pack8<T>(o8);
+        for (int j = 0; j < 8; ++j) o8[j] = rstd[u] * (gy[j] - m1 - xh[j] * m2);
+        *reinterpret_cast<uint4*>(dx + row[u] * C + sub * 8) = pack8<T>(o8);
+      }
     }
   }
   if (!dgamma) return;
@@ -229,14 +296,15 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
     for (int t = 0; t < 9; ++t) wr[j][t] = w[(c8 * 8 + j) * 9 + t];
   }
   const long npix = (long)B * H * W;
-  for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb) {
-    const int px = p % W, py = (p / W) % H;
+  DwWalk wk(blockIdx.x * (unsigned)tpb + pl, gridDim.x * (unsigned)tpb, W, H);
+  for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb, wk.step()) {
+    const int px = wk.px, py = wk.py;
     float acc[8];
     dw_apply<T, false>(x, wr, bs, p, px, py, H, W, C, c8, acc);
     if (pre) *reinterpret_cast<uint4*>(pre + p * C + c8 * 8) = pack8<T>(acc);
     if (gelu) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = gelu_f(acc[j]);
+      for (int j = 0; j < 8; ++j) acc[j] = gelu_fast(acc[j]);
     }
     *reinterpret_cast<uint4*>(y + p * C + c8 * 8) = pack8<T>(acc);
   }
@@ -246,24 +314,27 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 // chunk and strides over pixels, block partials through LDS, one atomic per (channel, tap) per block
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restrict__ x, const T* __restrict__ pre, const T* __restrict__ dy,
-                                                              T* __restrict__ du, float* __restrict__ dw, float* __restrict__ dbias, int B,
-                                                              int H, int W, int C, int gelu) {
-  extern __shared__ float s_acc[];   // [c8n * 8][10]
+                                                              T* __restrict__ du, float* __restrict__ dw, float* __restrict__ dbias,
+                                                              float* __restrict__ ws, int B, int H, int W, int C, int gelu) {
+  __shared__ float s_acc[40 * 256];
   const int c8n = C >> 3;
   const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;          // pixel lanes per block (c8n <= 256)
   const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
   const bool act = pl < tpb;
-  float aw[8][9], ab[8];
+  // accumulators as fp32 PAIRS (channels 2k, 2k+1): the 72 tap FMAs of a chunk are 36 v_pk_fma_f32; out-of-image taps are zeroed on
+  // the raw dwords (4 ANDs per tap) instead of 8 multiplies
+  dw_f32x2 aw2[4][9], ab2[4];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ab[j] = 0.f;
+  for (int k = 0; k < 4; ++k) {
+    ab2[k] = (dw_f32x2)(0.f);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) aw[j][t] = 0.f;
+    for (int t = 0; t < 9; ++t) aw2[k][t] = (dw_f32x2)(0.f);
   }
   const long npix = (long)B * H * W;
   if (act) {
-    for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb) {
-      const int px = p % W, py = (p / W) % H;
+    DwWalk wk(blockIdx.x * (unsigned)tpb + pl, gridDim.x * (unsigned)tpb, W, H);
+    for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb, wk.step()) {
+      const int px = wk.px, py = wk.py;
       const void* ptr9[9];
       bool ok[9];
       dw_window<T, false>(x + p * C + c8 * 8, px, py, H, W, C, ptr9, ok);
@@ -274,55 +345,91 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restric
       for (int t = 0; t < 9; ++t) ptr[2 + t] = ptr9[t];
       uint4 v[11];
       dw_load11(v, ptr);        // one round trip per pixel: dy, pre and the 3x3 window of x
-      float d[8];
-      unpack8<T>(v[0], d);
-      if (gelu) {
-        float q[8];
-        unpack8<T>(v[1], q);
+      const uint32_t dw_[4] = {v[0].x, v[0].y, v[0].z, v[0].w}, pw_[4] = {v[1].x, v[1].y, v[1].z, v[1].w};
+      dw_f32x2 d2[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] *= gelu_grad_f(q[j]);
+      for (int k = 0; k < 4; ++k) {
+        d2[k] = dw_unpack2<T>(dw_[k]);
+        if (gelu) {
+          const dw_f32x2 q = dw_unpack2<T>(pw_[k]);
+          d2[k].x *= gelu_grad_fast(q.x);
+          d2[k].y *= gelu_grad_fast(q.y);
+        }
+        ab2[k] += d2[k];
       }
-      if (du) *reinterpret_cast<uint4*>(du + p * C + c8 * 8) = pack8<T>(d);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ab[j] += d[j];
+      if (du) {
+        const float d[8] = {d2[0].x, d2[0].y, d2[1].x, d2[1].y, d2[2].x, d2[2].y, d2[3].x, d2[3].y};
+        *reinterpret_cast<uint4*>(du + p * C + c8 * 8) = pack8<T>(d);
+      }
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        float f[8];
-        unpack8<T>(v[2 + t], f);
-        const float m = ok[t] ? 1.f : 0.f;
+        const uint32_t mk = ok[t] ? 0xffffffffu : 0u;
+        const uint32_t xw[4] = {v[2 + t].x & mk, v[2 + t].y & mk, v[2 + t].z & mk, v[2 + t].w & mk};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) aw[j][t] += d[j] * (f[j] * m);
+        for (int k = 0; k < 4; ++k) aw2[k][t] += d2[k] * dw_unpack2<T>(xw[k]);
       }
     }
   }
-  for (int i = threadIdx.x; i < C * 10; i += 256) s_acc[i] = 0.f;
-  __syncthreads();
-  // lanes of a wave that hold the same channel chunk (lane % c8n, when c8n is a power of two below 64) are summed by xor-shuffles first;
-  // inactive pixel lanes contribute zeros.  Every lane of the wave takes part in the shuffles.
-  const bool p2 = (c8n & (c8n - 1)) == 0 && c8n < 64;
-  if (p2) {
+  // Block reduction over the pixel lanes that share a channel chunk.  Accumulator k = tap * 8 + j (k < 72: weight of channel c8 * 8 + j)
+  // or 72 + j (bias).  Every thread parks its 80 values in LDS at [k][thread] (conflict-free), then output (k, c8) sums the `tpb` pixel
+  // lanes -- in two rounds of 40 values = 40 KB.  (Before: LDS atomics at [(c8 * 8 + j) * 10 + t], a lane stride of 80 floats = 16 lanes
+  // per bank on every one of 80 atomics per thread; the per-block epilogue, not the pixel loop, was what the kernel's time went into.)
+  float acc[80];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+  for (int k = 0; k < 4; ++k) {
+    acc[72 + 2 * k] = ab2[k].x;
+    acc[72 + 2 * k + 1] = ab2[k].y;
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        for (int o = c8n; o < 64; o <<= 1) aw[j][t] += __shfl_xor(aw[j][t], o);
-      for (int o = c8n; o < 64; o <<= 1) ab[j] += __shfl_xor(ab[j], o);
+    for (int t = 0; t < 9; ++t) {
+      acc[t * 8 + 2 * k] = aw2[k][t].x;
+      acc[t * 8 + 2 * k + 1] = aw2[k][t].y;
     }
   }
-  if (p2 ? (int)(threadIdx.x & 63) < c8n : act) {
+  const int n = 80 * c8n;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+  for (int r = 0; r < 2; ++r) {
+    if (r) __syncthreads();
 #pragma unroll
-      for (int t = 0; t < 9; ++t) atomicAdd(&s_acc[(c8 * 8 + j) * 10 + t], aw[j][t]);
-      atomicAdd(&s_acc[(c8 * 8 + j) * 10 + 9], ab[j]);
+    for (int q = 0; q < 40; ++q) s_acc[q * 256 + threadIdx.x] = acc[r * 40 + q];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 40 * c8n; o += 256) {
+      const int q = o / c8n, cc = o - q * c8n;
+      float a = 0.f;
+      for (int l = 0; l < tpb; ++l) a += s_acc[q * 256 + l * c8n + cc];
+      const int k = r * 40 + q;
+      if (ws) ws[(long)blockIdx.x * n + k * c8n + cc] = a;   // two-phase form: plain stores, dw_partials_sum_kernel adds the blocks up
+      else if (k < 72) {
+        if (dw) atomicAdd(dw + (cc * 8 + (k & 7)) * 9 + (k >> 3), a);
+      } else if (dbias) atomicAdd(dbias + cc * 8 + (k - 72), a);
     }
   }
+}
+
+// Second phase of the depth-wise weight gradient: ws is [G][n], n = 80 * c8n = C * 10, column k * c8n + c8 (k as in the first phase).  With atomics
+// straight from the G <= 1024 blocks of the first phase every one of the n addresses carries a G-deep same-address chain (measured: the
+// kernel took 54 - 135 us for 3 - 27 us of HBM traffic); here a block sums 64 rows of 64 columns and the chains are G / 64 deep.
+__global__ __launch_bounds__(256) void dw_partials_sum_kernel(const float* __restrict__ ws, int G, int n, int c8n, float* __restrict__ dw,
+                                                              float* __restrict__ dbias) {
+  __shared__ float s_p[4][64];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + l;
+  const int g0 = blockIdx.y * 64 + w * 16;
+  float a = 0.f;
+  if (i < n) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int g = g0 + k;
+      if (g < G) a += ws[(long)g * n + i];
+    }
+  }
+  s_p[w][l] = a;
   __syncthreads();
-  for (int i = threadIdx.x; i < C * 10; i += 256) {
-    const int c = i / 10, t = i % 10;
-    if (t < 9) {
-      if (dw) atomicAdd(dw + c * 9 + t, s_acc[i]);
-    } else if (dbias) atomicAdd(dbias + c, s_acc[i]);
+  if (w == 0 && i < n) {
+    a = (s_p[0][l] + s_p[1][l]) + (s_p[2][l] + s_p[3][l]);
+    const int k = i / c8n, cc = i - k * c8n;
+    if (k < 72) {
+      if (dw) atomicAdd(dw + (cc * 8 + (k & 7)) * 9 + (k >> 3), a);
+    } else if (dbias) atomicAdd(dbias + cc * 8 + (k - 72), a);
   }
 }
 
@@ -340,8 +447,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_x_kernel(const T* __restric
 #pragma unroll
     for (int t = 0; t < 9; ++t) wr[j][t] = w[(c8 * 8 + j) * 9 + t];
   const long npix = (long)B * H * W;
-  for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb) {
-    const int px = p % W, py = (p / W) % H;
+  DwWalk wk(blockIdx.x * (unsigned)tpb + pl, gridDim.x * (unsigned)tpb, W, H);
+  for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb, wk.step()) {
+    const int px = wk.px, py = wk.py;
     float acc[8];
     dw_apply<T, true>(du, wr, nullptr, p, px, py, H, W, C, c8, acc);
     *reinterpret_cast<uint4*>(dx + p * C + c8 * 8) = pack8<T>(acc);
@@ -1233,7 +1341,7 @@ extern "C" int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const 
   //  that chain short -- it, not the streaming, set the 20 us floor of this launch)
   const int lpr = lanes_per_row(C);
   const long waves = (R + 64 / lpr - 1) / (64 / lpr);
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, dgamma ? 256 : 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, dgamma ? jg_tune(JG_TUNE_LN_BWD_CAP) : 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
                                               (const T*)dy, gamma, mr, (T*)dx, dgamma, dbeta, (long)R, C, lpr););
   JG_CHECK_LAUNCH();
   return JG_OK;
@@ -1248,22 +1356,42 @@ extern "C" int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const 
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
-extern "C" int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
-                                float* dbias, int B, int H, int W, int C, int gelu, jg_stream_t s) {
-  if (!x || !dy || !w || !du || B < 1 || C < 8 || C % 8 || (gelu && !pre)) return JG_ERR_BAD_ARG;
-  if (C > 1536) return JG_ERR_UNSUPPORTED;   // C * 10 floats of LDS partials
+static int dw_bwd_blocks(long npix, int C) {
+  const int c8n = C / 8;
+  const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;
+  const int ppt = jg_tune(JG_TUNE_DW_BWD_PPT) > 0 ? jg_tune(JG_TUNE_DW_BWD_PPT) : 8;   // pixels per thread
+  return grid_for(npix, tpb * ppt, jg_tune(JG_TUNE_DW_BWD_CAP));
+}
+extern "C" int64_t jg_dwconv3x3_bwd_ws_floats(int B, int H, int W, int C) {
+  if (B < 1 || H < 1 || W < 1 || C < 8 || C % 8) return 0;
+  return (int64_t)dw_bwd_blocks((long)B * H * W, C) * C * 10;
+}
+extern "C" int jg_dwconv3x3_bwd_ws(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
+                                   float* dbias, float* ws, int64_t ws_floats, int B, int H, int W, int C, int gelu, jg_stream_t s) {
+  if (!x || !dy || !w || !du || B < 1 || H < 1 || W < 1 || C < 8 || C % 8 || (gelu && !pre)) return JG_ERR_BAD_ARG;
+  if (C > 2048) return JG_ERR_UNSUPPORTED;   // one 8-channel chunk per thread of a 256-thread block
   hipStream_t st = (hipStream_t)s;
   const int c8n = C / 8;
   const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;
   const long npix = (long)B * H * W;
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_w_kernel<T>), dim3(grid_for(npix, tpb * 8, 1024)), dim3(256), C * 10 * sizeof(float), st,
-                                              (const T*)x, (const T*)pre, (const T*)dy, (T*)du, dw, dbias, B, H, W, C, gelu););
+  const int G = dw_bwd_blocks(npix, C);
+  if (ws && ws_floats < (int64_t)G * C * 10) return JG_ERR_BAD_ARG;
+  if (!dw && !dbias) ws = nullptr;   // nothing to reduce: the kernel only writes du
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_w_kernel<T>), dim3(G), dim3(256), 0, st,
+                                              (const T*)x, (const T*)pre, (const T*)dy, (T*)du, dw, dbias, ws, B, H, W, C, gelu););
+  if (ws) {
+    hipLaunchKernelGGL(dw_partials_sum_kernel, dim3((C * 10 + 63) / 64, (G + 63) / 64), dim3(256), 0, st, (const float*)ws, G, C * 10, c8n, dw, dbias);
+  }
   if (dx) {
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_x_kernel<T>), dim3(grid_for(npix, tpb * 4, 4096)), dim3(256), 0, st, (const T*)du, w,
                                                 (T*)dx, B, H, W, C););
   }
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+extern "C" int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
+                                float* dbias, int B, int H, int W, int C, int gelu, jg_stream_t s) {
+  return jg_dwconv3x3_bwd_ws(dtype, x, pre, dy, w, du, dx, dw, dbias, nullptr, 0, B, H, W, C, gelu, s);
 }
 extern "C" int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tkv, int heads,
                                    int64_t ldq, int64_t ldkv, int64_t ldo, float scale, jg_stream_t s) {

@@ -5,6 +5,7 @@ whose `.grad` the backward kernels accumulate into."""
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 
@@ -13,6 +14,8 @@ from ._lib import check
 from .ops import _DT, _dt, _p, _require_cuda, _st, copy_channels
 
 JG_ACT_NONE, JG_ACT_RELU = 0, 2
+# depth-wise 3x3 weight gradient: per-block partials through a workspace + one summing launch (1) or atomics from every block (0)
+DW_TWO_PHASE = os.environ.get("JG_DW_TWO_PHASE", "1") != "0"
 
 
 # ---- LayerNorm ---------------------------------------------------------------------------------------------------------------
@@ -78,9 +81,15 @@ class _DWConvGeluFn(torch.autograd.Function):
         want_w = ctx.needs_input_grad[1]
         if want_w and ctx.gw is None:
             raise RuntimeError("depth-wise conv weight has no arena-backed .grad")
-        check(_lib.lib().jg_dwconv3x3_bwd(_dt(x), x.data_ptr(), _p(pre), dy.data_ptr(), weight.data_ptr(), du.data_ptr(), _p(dx),
-                                          _p(ctx.gw) if want_w else None, _p(ctx.gb) if (want_w and ctx.gb is not None) else None, B, H, W, C,
-                                          int(ctx.gelu), _st()), "jg_dwconv3x3_bwd")
+        # weight / bias partials of the blocks go through a workspace and a second launch (DW_TWO_PHASE): straight atomics put a
+        # 1024-deep same-address chain on every one of the C * 10 destinations
+        ws, nws = None, 0
+        if want_w and DW_TWO_PHASE:
+            nws = int(_lib.lib().jg_dwconv3x3_bwd_ws_floats(B, H, W, C))
+            ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+        check(_lib.lib().jg_dwconv3x3_bwd_ws(_dt(x), x.data_ptr(), _p(pre), dy.data_ptr(), weight.data_ptr(), du.data_ptr(), _p(dx),
+                                             _p(ctx.gw) if want_w else None, _p(ctx.gb) if (want_w and ctx.gb is not None) else None, _p(ws), nws,
+                                             B, H, W, C, int(ctx.gelu), _st()), "jg_dwconv3x3_bwd_ws")
         return dx, None, None, None
 
 

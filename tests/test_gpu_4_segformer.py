@@ -50,9 +50,13 @@ def test_layernorm(R, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 128), (1, 9, 7, 256), (2, 4, 4, 1024), (1, 32, 32, 64)])
-def test_dwconv3x3_gelu(B, H, W, C, dtype):
+@pytest.mark.parametrize("two_phase", [True, False])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 128), (1, 9, 7, 256), (2, 4, 4, 1024), (1, 32, 32, 64), (8, 64, 64, 128), (4, 16, 16, 640)])
+def test_dwconv3x3_gelu(B, H, W, C, dtype, two_phase, monkeypatch):
+    """two_phase: the weight / bias partials of the blocks through a workspace and a summing launch (the default), or atomics from
+    every block; (8, 64, 64, 128) runs 1024 first-phase blocks = 16 row groups of the summing grid."""
     from joligen_amd import ops_segformer as S
+    monkeypatch.setattr(S, "DW_TWO_PHASE", two_phase)
     x, gy = rnd((B, C, H, W), dtype, 5), rnd((B, C, H, W), dtype, 6)
     w, b = rnd((C, 1, 3, 3), torch.float32, 7, 0.4), rnd((C,), torch.float32, 8, 0.1)
     xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
