@@ -137,8 +137,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const int pbeg = blockIdx.x * mp.chunk;
   const int pend = min(HW, pbeg + mp.chunk);
   const long row0 = (long)b * HW;
-  for (int p = pbeg + pl; p < pend; p += mp.pl) {
-    const uint4 v = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
+  auto one = [&](const uint4& v, int p) {
     float f[8];
     unpack8<T>(v, f);
 #pragma unroll
@@ -147,7 +146,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       f[q] = act_f<ACT>(u);
     }
     *reinterpret_cast<uint4*>(y + (row0 + p) * ldy + co * 8) = pack8<T>(f);
+  };
+  // four pixels per trip, their loads issued together (one load in flight per wave otherwise: see gn_bwd_reduce_kernel)
+  int p = pbeg + pl;
+  for (; p + 3 * mp.pl < pend; p += 4 * mp.pl) {
+    uint4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(x + (row0 + p + u * mp.pl) * ldx + co * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) one(v[u], p + u * mp.pl);
   }
+  for (; p < pend; p += mp.pl) one(*reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8), p);
 }
 
 // y[B, H/2, W/2, C] = scale * sum over the 2x2 window of act(a * x + b): the ResBlock-down path's pool(act(norm(x))) without the
@@ -214,11 +223,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const int pbeg = blockIdx.x * mp.chunk;
     const int pend = min(HW, pbeg + mp.chunk);
     const long row0 = (long)b * HW;
-#pragma unroll 4
-    for (int p = pbeg + pl; p < pend; p += mp.pl) {
-      const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
-      const long pg = UP ? ((long)b * (HW >> 2) + (long)((p / W) >> 1) * (W >> 1) + ((p % W) >> 1)) : row0 + p;
-      const uint4 vg = *reinterpret_cast<const uint4*>(dy + pg * lddy + co * 8);
+    auto dy_row = [&](int p) -> long {
+      return UP ? ((long)b * (HW >> 2) + (long)((p / W) >> 1) * (W >> 1) + ((p % W) >> 1)) : row0 + p;
+    };
+    auto accumulate = [&](const uint4& vx, const uint4& vg) {
       float fx[8], fg[8];
       unpack8<T>(vx, fx);
       unpack8<T>(vg, fg);
@@ -229,6 +237,25 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         s1[q] += du;
         s2[q] += du * fx[q];
       }
+    };
+    // four pixels per trip with all eight 16-byte loads issued before the first use.  (`#pragma unroll 4` alone left every pair of
+    // loads next to its arithmetic: two loads in flight per wave, 32 KB per CU, which at ~2 us of latency is the 4.1 TB/s this
+    // read-only pass measured against 5.3 TB/s of the apply pass -- profiles/r04_pmc_hbm_traffic.md.)
+    int p = pbeg + pl;
+    for (; p + 3 * mp.pl < pend; p += 4 * mp.pl) {
+      uint4 vx[4], vg[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        vx[u] = *reinterpret_cast<const uint4*>(x + (row0 + p + u * mp.pl) * ldx + co * 8);
+        vg[u] = *reinterpret_cast<const uint4*>(dy + dy_row(p + u * mp.pl) * lddy + co * 8);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) accumulate(vx[u], vg[u]);
+    }
+    for (; p < pend; p += mp.pl) {
+      const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
+      const uint4 vg = *reinterpret_cast<const uint4*>(dy + dy_row(p) * lddy + co * 8);
+      accumulate(vx, vg);
     }
     // lanes of a wave that share the channel octet (tid % noct, noct a power of two < 64) combine by xor-shuffle
     // first: one LDS atomic per wave and channel instead of up to 32 colliding ones
@@ -379,10 +406,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
   const int pbeg = (rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * mp.chunk;
   const int pend = min(HW, pbeg + mp.chunk);
   const long row0 = (long)b * HW;
-  for (int p = pbeg + pl; p < pend; p += mp.pl) {
-    const uint4 vx = *reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8);
-    const long pg = UP ? ((long)b * (HW >> 2) + (long)((p / W) >> 1) * (W >> 1) + ((p % W) >> 1)) : row0 + p;
-    const uint4 vg = *reinterpret_cast<const uint4*>(dy + pg * lddy + co * 8);
+  auto dy_row = [&](int p) -> long {
+    return UP ? ((long)b * (HW >> 2) + (long)((p / W) >> 1) * (W >> 1) + ((p % W) >> 1)) : row0 + p;
+  };
+  auto one = [&](const uint4& vx, const uint4& vg, const uint4& va1, const uint4& va2, int p) {
     float fx[8], fg[8];
     unpack8<T>(vx, fx);
     unpack8<T>(vg, fg);
@@ -394,17 +421,39 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
     if (add1) {   // fused gradient accumulation of the other consumers of x (residual / skip / concat paths)
       float fa[8];
-      unpack8<T>(*reinterpret_cast<const uint4*>(add1 + pg * ldadd1 + co * 8), fa);
+      unpack8<T>(va1, fa);
 #pragma unroll
       for (int q = 0; q < 8; ++q) fg[q] += sc1 * fa[q];
     }
     if (add2) {
       float fa[8];
-      unpack8<T>(*reinterpret_cast<const uint4*>(add2 + (row0 + p) * ldadd2 + co * 8), fa);
+      unpack8<T>(va2, fa);
 #pragma unroll
       for (int q = 0; q < 8; ++q) fg[q] += sc2 * fa[q];
     }
     *reinterpret_cast<uint4*>(dx + (row0 + p) * lddx + co * 8) = pack8<T>(fg);
+  };
+  // two pixels per trip: their four to eight loads are issued together (see gn_bwd_reduce_kernel)
+  int p = pbeg + pl;
+  for (; p + mp.pl < pend; p += 2 * mp.pl) {
+    uint4 vx[2], vg[2], va1[2], va2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int pp = p + u * mp.pl;
+      const long pg = dy_row(pp);
+      vx[u] = *reinterpret_cast<const uint4*>(x + (row0 + pp) * ldx + co * 8);
+      vg[u] = *reinterpret_cast<const uint4*>(dy + pg * lddy + co * 8);
+      va1[u] = add1 ? *reinterpret_cast<const uint4*>(add1 + pg * ldadd1 + co * 8) : make_uint4(0, 0, 0, 0);
+      va2[u] = add2 ? *reinterpret_cast<const uint4*>(add2 + (row0 + pp) * ldadd2 + co * 8) : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) one(vx[u], vg[u], va1[u], va2[u], p + u * mp.pl);
+  }
+  for (; p < pend; p += mp.pl) {
+    const long pg = dy_row(p);
+    one(*reinterpret_cast<const uint4*>(x + (row0 + p) * ldx + co * 8), *reinterpret_cast<const uint4*>(dy + pg * lddy + co * 8),
+        add1 ? *reinterpret_cast<const uint4*>(add1 + pg * ldadd1 + co * 8) : make_uint4(0, 0, 0, 0),
+        add2 ? *reinterpret_cast<const uint4*>(add2 + (row0 + p) * ldadd2 + co * 8) : make_uint4(0, 0, 0, 0), p);
   }
 }
 

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import torch
 
+from .._autograd import JGFunction
 from .. import ops
 from ..modules.NCE.patchnce import MoNCELoss, PatchNCELoss
 from ..modules.cut_networks import PatchSampleF
@@ -32,7 +33,7 @@ CUT_DEFAULTS = dict(
 )
 
 
-class _ScaleGradFn(torch.autograd.Function):
+class _ScaleGradFn(JGFunction):
     """identity on the loss value; multiplies the gradient by the static fp16 loss scale (1 for bf16)."""
 
     @staticmethod

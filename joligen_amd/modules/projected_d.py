@@ -22,6 +22,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .._autograd import JGFunction
 from .. import _lib, ops
 from .._lib import check
 from ..ops import JG_ACT_LRELU, _dt, _p, _st, conv_nt, wgrad_tn
@@ -33,7 +34,7 @@ TF_EFFICIENTNET_LITE0_WIDTHS = (24, 40, 112, 320)
 # ---------------------------------------------------------------------------------------------------------------------
 # small autograd nodes
 # ---------------------------------------------------------------------------------------------------------------------
-class _Bilinear2Fn(torch.autograd.Function):
+class _Bilinear2Fn(JGFunction):
     """F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=align) on an NHWC map (up-sampling)."""
 
     @staticmethod
@@ -60,7 +61,7 @@ def bilinear(x, Ho, Wo, align_corners):
     return _Bilinear2Fn.apply(x, Ho, Wo, align_corners)
 
 
-class _AddFn(torch.autograd.Function):
+class _AddFn(JGFunction):
     @staticmethod
     def forward(ctx, a, b):
         return ops.axpby(a.contiguous(), 1.0, b.contiguous(), 1.0)
@@ -70,7 +71,7 @@ class _AddFn(torch.autograd.Function):
         return dy, dy
 
 
-class _HingeFn(torch.autograd.Function):
+class _HingeFn(JGFunction):
     @staticmethod
     def forward(ctx, pred, mode, scale):
         pred = pred.contiguous()
@@ -195,7 +196,7 @@ class _SnPass:
 # ---------------------------------------------------------------------------------------------------------------------
 # spectral-norm convolution (blocks.py:11-13)
 # ---------------------------------------------------------------------------------------------------------------------
-class _SpectralConvFn(torch.autograd.Function):
+class _SpectralConvFn(JGFunction):
     """y = conv(x, W / sigma) + bias with torch.nn.utils.spectral_norm semantics: one power iteration per TRAINING forward (u, v
     updated in place), sigma = u . W v; the gradient reaches W through 1 / sigma as well, with u and v held constant.
     Every forward owns the 16-bit copies of ITS W / sigma (a discriminator runs twice per step -- real and fake -- before one
@@ -502,7 +503,7 @@ class _DWWeight(nn.Module):
         return self._taps
 
 
-class _DWAffineActFn(torch.autograd.Function):
+class _DWAffineActFn(JGFunction):
     """relu6(scale * dwconv_kxk(x) + shift), TF SAME padding; backward = input gradient only (frozen weights)"""
 
     @staticmethod
@@ -530,7 +531,7 @@ class _DWAffineActFn(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
-class _ChanAffineActFn(torch.autograd.Function):
+class _ChanAffineActFn(JGFunction):
     @staticmethod
     def forward(ctx, x, scale, shift, act):
         x = x.contiguous()
@@ -564,7 +565,7 @@ def _dw_bn_act(x, dw, bn):
     return _DWAffineActFn.apply(x, dw.taps(), sc, sh, dw.k, dw.stride, 1)
 
 
-class _ZeroPadFn(torch.autograd.Function):
+class _ZeroPadFn(JGFunction):
     """zero padding (top, left, bottom, right) of an NHWC map = the adjoint of a window crop (jg_crop2d)"""
 
     @staticmethod

@@ -16,6 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .._autograd import JGFunction
 from .. import ops
 from ..ops import JG_ACT_NONE, JG_ACT_RELU, JG_ACT_TANH
 from .layers import JGConv2d, JGConvTranspose2d
@@ -83,7 +84,7 @@ class ResnetBlock(nn.Module):
         return _AddFn.apply(x, _run(self.conv_block, x))     # out = x + conv_block(x)
 
 
-class _AddFn(torch.autograd.Function):
+class _AddFn(JGFunction):
     @staticmethod
     def forward(ctx, a, b):
         return ops.axpby(a, 1.0, b, 1.0)

@@ -20,6 +20,7 @@ from collections import OrderedDict
 import torch
 import torch.nn as nn
 
+from .._autograd import JGFunction
 from .. import ops
 from .. import ops_segformer as S
 from ..ops import JG_ACT_RELU, JG_ACT_TANH
@@ -77,7 +78,7 @@ class DropPath(nn.Module):
         return S.scale_add(x, (keep + u).floor() / keep, identity)
 
 
-class _AddFn(torch.autograd.Function):
+class _AddFn(JGFunction):
     @staticmethod
     def forward(ctx, a, b):
         return ops.axpby(a, 1.0, b, 1.0)

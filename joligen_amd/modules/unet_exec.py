@@ -24,6 +24,7 @@ import os
 import torch
 import torch.nn as nn
 
+from .._autograd import JGFunction
 from .. import _lib, ops, parallel
 from .._lib import JG_ACT_NONE, JG_ACT_SILU, check
 from ..ops import _dt, _p, _st, attn_core_bwd, attn_core_fwd, conv_nt, wgrad_tn
@@ -746,7 +747,7 @@ def _own_params(rec):
     return out
 
 
-class _FusedUNetFn(torch.autograd.Function):
+class _FusedUNetFn(JGFunction):
     """(xin, emb_all) -> UNet output; `exe` carries the tape between forward and backward."""
 
     @staticmethod

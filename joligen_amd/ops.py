@@ -21,6 +21,7 @@ from typing import Optional, Tuple
 
 import torch
 
+from ._autograd import JGFunction
 from . import _lib
 from ._lib import (JG_ACT_LRELU, JG_ACT_NONE, JG_ACT_RELU, JG_ACT_SILU, JG_ACT_TANH, JG_OUT_ATOMIC_F32, JG_OUT_STORE_T, ConvArgs,
                    WgradArgs, check)
@@ -283,7 +284,7 @@ def conv2d_wgrad(dy, x, m: ConvMeta, alpha=1.0, want_w=True, want_b=True):
              splitk=splitk, alpha=alpha)
 
 
-class _Conv2dFn(torch.autograd.Function):
+class _Conv2dFn(JGFunction):
     @staticmethod
     def forward(ctx, x, weight, bias, res, meta, res_scale, alpha):
         y = conv2d_forward(x, meta, res, res_scale, alpha)
@@ -353,7 +354,7 @@ def reflect_conv_ok(x, m: ConvMeta):
             and W % 16 == 0 and H >= 16 and W >= 16 and B * H * W * max(Cin, m.Cout) < (1 << 31))
 
 
-class _ReflectConv2dFn(torch.autograd.Function):
+class _ReflectConv2dFn(JGFunction):
     """nn.ReflectionPad2d(1) -> nn.Conv2d(3x3, padding 0) as one launch: the halo-resident kernel mirrors the border pixels while
     it loads its halo, so the padded tensor is never written.  Backward: the weight gradient reads x with the same mirrored halo;
     the input gradient is the full convolution over the (H+2, W+2) padded domain folded back by the reflection's adjoint."""
@@ -402,7 +403,7 @@ def reflect_conv2d(x, meta: ConvMeta):
 # ======================================================================================
 # GroupNorm (+FiLM, +SiLU) / InstanceNorm1d
 # ======================================================================================
-class _GroupNormFn(torch.autograd.Function):
+class _GroupNormFn(JGFunction):
     @staticmethod
     def forward(ctx, x, gamma, beta, film, G, act, eps):
         _require_cuda(x)
@@ -498,7 +499,7 @@ def conv_transpose2d_forward(x, m: ConvMeta, output_padding=0):
     return y
 
 
-class _ConvTranspose2dFn(torch.autograd.Function):
+class _ConvTranspose2dFn(JGFunction):
     @staticmethod
     def forward(ctx, x, weight, bias, meta, output_padding):
         _require_cuda(x)
@@ -538,7 +539,7 @@ def conv_transpose2d(x, meta: ConvMeta, output_padding=0):
     return _ConvTranspose2dFn.apply(x, meta.weight, meta.bias, meta, output_padding)
 
 
-class _ReflectPadFn(torch.autograd.Function):
+class _ReflectPadFn(JGFunction):
     @staticmethod
     def forward(ctx, x, pad):
         _require_cuda(x)
@@ -563,7 +564,7 @@ def reflect_pad2d(x, pad):
     return _ReflectPadFn.apply(x, pad)
 
 
-class _CropFn(torch.autograd.Function):
+class _CropFn(JGFunction):
     @staticmethod
     def forward(ctx, x, top, left, Ho, Wo):
         _require_cuda(x)
@@ -590,7 +591,7 @@ def crop2d(x, top, left, Ho, Wo):
     return _CropFn.apply(x, top, left, Ho, Wo)
 
 
-class _ActFn(torch.autograd.Function):
+class _ActFn(JGFunction):
     @staticmethod
     def forward(ctx, x, act):
         _require_cuda(x)
@@ -633,7 +634,7 @@ def _up(x, scale):
     return y
 
 
-class _AvgPool2Fn(torch.autograd.Function):
+class _AvgPool2Fn(JGFunction):
     @staticmethod
     def forward(ctx, x):
         return _pool(x, 0.25)
@@ -644,7 +645,7 @@ class _AvgPool2Fn(torch.autograd.Function):
         return _up(dy.contiguous(), 0.25)
 
 
-class _Upsample2Fn(torch.autograd.Function):
+class _Upsample2Fn(JGFunction):
     @staticmethod
     def forward(ctx, x):
         return _up(x, 1.0)
@@ -669,7 +670,7 @@ def copy_channels(src, soff, dst, doff, n):
                                       n, _st()), "jg_copy_channels")
 
 
-class _CatFn(torch.autograd.Function):
+class _CatFn(JGFunction):
     @staticmethod
     def forward(ctx, a, b):
         Ca, Cb = a.shape[-1], b.shape[-1]
@@ -785,7 +786,7 @@ def attn_core_bwd(qkv, P, da, nh, a=None):
     return dqkv
 
 
-class _AttnCoreFn(torch.autograd.Function):
+class _AttnCoreFn(JGFunction):
     @staticmethod
     def forward(ctx, qkv, nh):
         a, P = attn_core_fwd(qkv, nh)
@@ -807,7 +808,7 @@ def attention_core(qkv, n_heads):
 # ======================================================================================
 # small fp32 linear (embedding path)
 # ======================================================================================
-class _LinearFn(torch.autograd.Function):
+class _LinearFn(JGFunction):
     """inputs: x, W, b, act, dW, db, *track -- dW/db are the arena gradient views the kernel accumulates
     into; `track` are the nn.Parameters behind W/b, passed only so that autograd records the node."""
 
@@ -880,7 +881,7 @@ def sgemm(A, B, C, M, N, K, sa, sb, sc, nbatch=1, bstr=(0, 0, 0), bias=None, E=N
     return C
 
 
-class _GatherPatchesFn(torch.autograd.Function):
+class _GatherPatchesFn(JGFunction):
     @staticmethod
     def forward(ctx, feat, ids, C):
         _require_cuda(feat, ids)
@@ -911,7 +912,7 @@ def gather_patches(feat, ids, C):
     return _GatherPatchesFn.apply(feat, ids.contiguous().long(), C)
 
 
-class _L2NormFn(torch.autograd.Function):
+class _L2NormFn(JGFunction):
     @staticmethod
     def forward(ctx, x, eps):
         x = x.contiguous()
@@ -942,7 +943,7 @@ def l2_normalize(x, eps=1e-7):
 SINKHORN_ITERS = 50  # monce.py:24
 
 
-class _PatchNCEFn(torch.autograd.Function):
+class _PatchNCEFn(JGFunction):
     """Per-patch PatchNCE / MoNCE loss.  q, k: [nimg*P, D] fp32, L2-normalised.  k is detached in the positive logit and in the
     optimal-transport weights but NOT in the negative logits (base_NCE.py:52-66, monce.py:21-22), reproduced here."""
 
@@ -1010,7 +1011,7 @@ def patch_nce_loss(q, k, nimg, T, num_patches, monce=False):
 GAN_MODES = {"lsgan": 0, "vanilla": 1, "wgangp": 2}
 
 
-class _LSGANLossFn(torch.autograd.Function):
+class _LSGANLossFn(JGFunction):
     @staticmethod
     def forward(ctx, pred, target, scale, mode=0):
         _require_cuda(pred)
@@ -1065,7 +1066,7 @@ def ddpm_prepare(y0, ycond, noise, mask, gammas, act_dtype, cpad=8):
     return xin
 
 
-class _MSELossFn(torch.autograd.Function):
+class _MSELossFn(JGFunction):
     @staticmethod
     def forward(ctx, nh, noise, mask, w, lam, grad_scale, Cc):
         B, H, W, cpad = nh.shape
@@ -1097,7 +1098,7 @@ def ddpm_mse_loss(noise_hat_nhwc, noise, mask, w=None, lam=1.0, grad_scale=1.0):
     return _MSELossFn.apply(noise_hat_nhwc, noise.contiguous(), m, wv, float(lam), float(grad_scale), noise.shape[1])
 
 
-class _MultiScaleLossFn(torch.autograd.Function):
+class _MultiScaleLossFn(JGFunction):
     @staticmethod
     def forward(ctx, nh, noise, mask, w, lam, grad_scale, Cc, nlevels, l1, multiscale):
         B, H, W, cpad = nh.shape
@@ -1147,7 +1148,7 @@ def ddpm_loss(noise_hat_nhwc, noise, mask, w=None, lam=1.0, grad_scale=1.0, loss
 # ======================================================================================
 # consistency-model glue (cm_generator.py / cm_model.py of the reference)
 # ======================================================================================
-class _NoiseLevelEmbFn(torch.autograd.Function):
+class _NoiseLevelEmbFn(JGFunction):
     @staticmethod
     def forward(ctx, sigmas, W, dW):
         s = sigmas.reshape(-1).contiguous().float()
@@ -1203,7 +1204,7 @@ def cm_combine(noisy, F_nhwc, cskip, cout):
     return out
 
 
-class _CMLossFn(torch.autograd.Function):
+class _CMLossFn(JGFunction):
     @staticmethod
     def forward(ctx, Fn, Fc, noisy_n, noisy_c, cs_n, co_n, cs_c, co_c, mask, w, chub, lam, grad_scale):
         B, Cc, H, W = noisy_n.shape
@@ -1237,7 +1238,7 @@ def cm_loss(F_next, F_cur, noisy_next, noisy_cur, cs_n, co_n, cs_c, co_c, mask, 
                            chub, float(lam), float(grad_scale))
 
 
-class _ToNCHWFn(torch.autograd.Function):
+class _ToNCHWFn(JGFunction):
     @staticmethod
     def forward(ctx, x, Cc):
         B, H, W, cpad = x.shape

@@ -9,6 +9,7 @@ import os
 
 import torch
 
+from ._autograd import JGFunction
 from . import _lib
 from ._lib import check
 from .ops import _DT, _dt, _p, _require_cuda, _st, copy_channels
@@ -19,7 +20,7 @@ DW_TWO_PHASE = os.environ.get("JG_DW_TWO_PHASE", "1") != "0"
 
 
 # ---- LayerNorm ---------------------------------------------------------------------------------------------------------------
-class _LayerNormFn(torch.autograd.Function):
+class _LayerNormFn(JGFunction):
     @staticmethod
     def forward(ctx, x, weight, bias, eps):
         _require_cuda(x)
@@ -56,7 +57,7 @@ def layer_norm(x, weight, bias, eps=1e-6):
 
 
 # ---- depth-wise 3x3 + GELU ---------------------------------------------------------------------------------------------------------
-class _DWConvGeluFn(torch.autograd.Function):
+class _DWConvGeluFn(JGFunction):
     @staticmethod
     def forward(ctx, x, weight, bias, gelu):
         _require_cuda(x)
@@ -99,7 +100,7 @@ def dwconv3x3(x, weight, bias, gelu=True):
 
 
 # ---- attention with a spatially reduced key / value set ---------------------------------------------------------------------------------
-class _AttnSmallKVFn(torch.autograd.Function):
+class _AttnSmallKVFn(JGFunction):
     """q: [B, Tq, C]; kv: [B, Tkv, 2C] packed (k | v) -- the output of ONE projection with the stacked (W_k; W_v) rows."""
 
     @staticmethod
@@ -140,7 +141,7 @@ def attention_smallkv(q, kv, heads):
 
 
 # ---- bilinear resize of several maps into one channel-concatenated buffer -------------------------------------------------------------
-class _ResizeConcatFn(torch.autograd.Function):
+class _ResizeConcatFn(JGFunction):
     @staticmethod
     def forward(ctx, Ho, Wo, *xs):
         _require_cuda(*xs)
@@ -208,7 +209,7 @@ def _all_reduce_sum(t):
     return 1
 
 
-class _BatchNormFn(torch.autograd.Function):
+class _BatchNormFn(JGFunction):
     @staticmethod
     def forward(ctx, x, weight, bias, running_mean, running_var, training, momentum, eps, act):
         _require_cuda(x)
@@ -291,7 +292,7 @@ def batch_norm(x, bn, act=JG_ACT_NONE):
 
 
 # ---- attention-mask composition ---------------------------------------------------------------------------------------------------------------
-class _AttnComposeFn(torch.autograd.Function):
+class _AttnComposeFn(JGFunction):
     @staticmethod
     def forward(ctx, img, logits, xin, na, ni, nc):
         _require_cuda(img, logits, xin)
@@ -327,7 +328,7 @@ def attention_compose(img, logits, xin, na, ni, nc):
 
 
 # ---- DropPath / Dropout2d as given factors ----------------------------------------------------------------------------------------------------
-class _ScaleFn(torch.autograd.Function):
+class _ScaleFn(JGFunction):
     @staticmethod
     def forward(ctx, x, s, res, per_channel):
         _require_cuda(x)
@@ -361,7 +362,7 @@ def scale_add(x, s, res=None, per_channel=False):
 
 
 # ---- linear on a row slice of a stacked projection (nn.MultiheadAttention's packed in_proj) -----------------------------------------------
-class _SlicedLinearFn(torch.autograd.Function):
+class _SlicedLinearFn(JGFunction):
     """y = x W[row0 : row0 + n]^T + b[row0 : row0 + n] for a ConvMeta that holds the stacked [rows, Cin] projection."""
 
     @staticmethod

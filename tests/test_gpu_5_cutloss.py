@@ -453,7 +453,12 @@ def test_cut_model_first_step_gradients_vs_oracle(golden_dir, name, dtype):
             table.append(f"{rel:10.3e} cos={cos:7.4f} ref={float(ref.norm()):10.3e} mine={float(mine.norm()):10.3e} floor={floor:9.2e} {key}.{k}")
             # per tensor: direction first (a wrong kernel shows as a cosine well below the floor's own minimum), then the amplitude
             # against TWICE the worst tensor of the measured rounding floor of the same network (round 2 used a fitted 0.20 for all)
-            if rel > 2.0 * yard[key]["grad_worst"] or (float(ref.norm()) > 10 * floor and float(ref.norm()) > 1e-6 and cos < yard[key]["cos_min"] - 0.02):
+            # direction: the device's rounding is another draw from the distribution the CPU yardstick sampled once, and 1 - cos goes
+            # with the square of the relative error: allow twice the yardstick's worst angular deficit (bf16 G: 0.962 -> 0.923), and never
+            # less than the 0.02 margin the fp16 cases were tuned with (a fixed 0.02 under a bf16 cos_min of 0.962 left 0.007 of headroom
+            # on G.deconv3_content.bias and failed one run in ~10 on atomics ordering alone)
+            cos_lo = min(yard[key]["cos_min"] - 0.02, 1.0 - 2.0 * (1.0 - yard[key]["cos_min"]))
+            if rel > 2.0 * yard[key]["grad_worst"] or (float(ref.norm()) > 10 * floor and float(ref.norm()) > 1e-6 and cos < cos_lo):
                 bad.append((key, k, rel, cos, float(ref.norm()), floor, yard[key]["grad_worst"]))
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/grad_table_cut_{name}_{dn}.txt", "w") as f:
