@@ -34,7 +34,9 @@ const char* jg_strerror(int code);
 
 /* Dispatch switches.  Each switch is read once from the environment variable of the same name
  * ("JG_HALO_CFG", "JG_WGRAD_HALO_CFG", "JG_CONV_VARIANT", "JG_WGRAD_VARIANT", "JG_SINKHORN_GENERIC", "JG_CONV1X1",
- * "JG_GN_REVERSE", "JG_HALO_DBG", "JG_PERSIST64", "JG_HALO_PIPE", "JG_WGRAD_PIPE", "JG_CONV_SPLITK", "JG_CONV_SMALL_TILE");
+ * "JG_GN_REVERSE", "JG_HALO_DBG", "JG_PERSIST64", "JG_HALO_PIPE", "JG_WGRAD_PIPE", "JG_CONV_SPLITK", "JG_CONV_SMALL_TILE",
+ * "JG_GN_FUSED", "JG_GN_FUSED_CAP", "JG_GN_FUSED_DBG", "JG_GN_FUSED_SLEEP", "JG_WGRAD_LDS_PAD", and the grid shapes of the SegFormer
+ * backward kernels "JG_LN_BWD_CAP" (256 workgroups), "JG_DW_BWD_CAP" (512) and "JG_DW_BWD_PPT" (8 pixels per thread));
  * jg_set_tuning overrides it for the rest of the process (parity tests use
  * it to force a tile configuration that the automatic choice only takes at bench-sized grids).  No reference counterpart:
  * the reference delegates kernel choice to cuDNN's heuristics (torch.backends.cudnn.benchmark, train.py:38-48).

@@ -433,12 +433,14 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
     *reinterpret_cast<uint4*>(dx + (row0 + p) * lddx + co * 8) = pack8<T>(fg);
   };
-  // two pixels per trip: their four to eight loads are issued together (see gn_bwd_reduce_kernel)
+  // NB pixels per trip: their 2 NB to 4 NB loads are issued together (see gn_bwd_reduce_kernel).  NB = 4 (137 VGPRs, an occupancy step
+  // down) measured 0.5 ms/step SLOWER than 2 on the palette step (profiles/r04_gn_load_batching_ab.log)
+  constexpr int NB = 2;
   int p = pbeg + pl;
-  for (; p + mp.pl < pend; p += 2 * mp.pl) {
-    uint4 vx[2], vg[2], va1[2], va2[2];
+  for (; p + (NB - 1) * mp.pl < pend; p += NB * mp.pl) {
+    uint4 vx[NB], vg[NB], va1[NB], va2[NB];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NB; ++u) {
       const int pp = p + u * mp.pl;
       const long pg = dy_row(pp);
       vx[u] = *reinterpret_cast<const uint4*>(x + (row0 + pp) * ldx + co * 8);
@@ -447,7 +449,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
       va2[u] = add2 ? *reinterpret_cast<const uint4*>(add2 + (row0 + pp) * ldadd2 + co * 8) : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 2; ++u) one(vx[u], vg[u], va1[u], va2[u], p + u * mp.pl);
+    for (int u = 0; u < NB; ++u) one(vx[u], vg[u], va1[u], va2[u], p + u * mp.pl);
   }
   for (; p < pend; p += mp.pl) {
     const long pg = dy_row(p);

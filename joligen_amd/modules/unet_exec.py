@@ -70,6 +70,10 @@ FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 # kernels run underneath the HBM-bound GroupNorm-backward passes of the chain instead of in front of them.  The streams meet again at
 # the end of the backward (and before a gradient chunk leaves for the all-reduce).
 WGRAD_STREAM = os.environ.get("JG_WGRAD_STREAM", "1") != "0"
+# issue order of a 3x3 layer's two backward convolutions: 1 = weight gradient first (it starts together with the input gradient and has
+# that kernel's time plus the GroupNorm-backward passes behind it to finish in); 0 = input gradient first (the side stream then waits
+# for it as well).  Same-box A/B, two runs each: 49.19 vs 49.49 ms/step (profiles/r04_wgrad_first_ab.log).
+WGRAD_FIRST = os.environ.get("JG_WGRAD_FIRST", "1") != "0"
 # GroupNorm backward: coefficient step inside the apply pass (jg_gn_bwd_apply_fc, 57 launches per step fewer).  Measured 51.9 vs 51.6 ms
 # (A/B on one box): the ~50 us a 6 us coefficient kernel spends waiting next to the weight-gradient stream is paid by the next kernel
 # instead, and the per-workgroup prologue costs what the launch saved -- off by default, kept for single-stream configurations.
@@ -649,6 +653,8 @@ class UNetExecutor:
         gn2, c2m = rb.out_layers[0].norm, rb.out_layers[3].meta
         skipw = rec["skipw"]
         # conv2
+        if WGRAD_FIRST:
+            self.wgrad(dO, rec["h2"], c2m, x_up=rec["h2_up"])
         if rec.get("low2"):
             hb, hh, hw_, hc = rec["h2"].shape
             full = (hb, 2 * hh, 2 * hw_, hc) if rec["h2_up"] else (hb, hh, hw_, hc)
@@ -659,7 +665,8 @@ class UNetExecutor:
                 dh2, red2 = pool2(conv_dgrad(dO, c2m, full), 1.0), None
         else:
             dh2, red2 = conv_dgrad(dO, c2m, rec["h2"].shape, gn=(rec["c1"], rec["ab2"], JG_ACT_SILU), pool=self.bpool)
-        self.wgrad(dO, rec["h2"], c2m, x_up=rec["h2_up"])
+        if not WGRAD_FIRST:
+            self.wgrad(dO, rec["h2"], c2m, x_up=rec["h2_up"])
         # GroupNorm 2 (+FiLM +SiLU)
         off, n = rb.emb_slice
         dc1 = gn_bwd(rec["c1"], dh2, rec["ab2"], rec["mr2"], gn2.weight, gn2.bias, rec["film"], gn2.num_groups, JG_ACT_SILU,
@@ -669,11 +676,14 @@ class UNetExecutor:
             dc1 = pool2(dc1, 1.0)          # backward of the nearest upsample that follows conv1
         # conv1
         direct = (not rb.updown) or (rb.up and rb.efficient)   # da1 IS the output-gradient of GroupNorm 1
+        if WGRAD_FIRST:
+            self.wgrad(dc1, rec["a1"], c1m)
         if direct:
             da1, red1 = conv_dgrad(dc1, c1m, rec["a1"].shape, gn=(x, rec["ab1"], JG_ACT_SILU), pool=self.bpool)
         else:
             da1, red1 = conv_dgrad(dc1, c1m, rec["a1"].shape), None
-        self.wgrad(dc1, rec["a1"], c1m)
+        if not WGRAD_FIRST:
+            self.wgrad(dc1, rec["a1"], c1m)
         del dc1
         pooled = None
         if rb.down and FUSE_DOWN_POOL:
