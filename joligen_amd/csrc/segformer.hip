@@ -316,7 +316,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restrict__ x, const T* __restrict__ pre, const T* __restrict__ dy,
                                                               T* __restrict__ du, float* __restrict__ dw, float* __restrict__ dbias,
                                                               float* __restrict__ ws, int B, int H, int W, int C, int gelu) {
-  __shared__ float s_acc[40 * 256];
+  __shared__ float s_acc[40 * 257];
   const int c8n = C >> 3;
   const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;          // pixel lanes per block (c8n <= 256)
   const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
@@ -386,21 +386,30 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restric
     }
   }
   const int n = 80 * c8n;
+  constexpr int LD = 257;   // row stride of the parking area: odd, so that both walks below (thread-major and k-major) are conflict-free
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
     if (r) __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 40; ++q) s_acc[q * 256 + threadIdx.x] = acc[r * 40 + q];
+    for (int q = 0; q < 40; ++q) s_acc[q * LD + threadIdx.x] = acc[r * 40 + q];
     __syncthreads();
-    for (int o = threadIdx.x; o < 40 * c8n; o += 256) {
-      const int q = o / c8n, cc = o - q * c8n;
-      float a = 0.f;
-      for (int l = 0; l < tpb; ++l) a += s_acc[q * 256 + l * c8n + cc];
-      const int k = r * 40 + q;
-      if (ws) ws[(long)blockIdx.x * n + k * c8n + cc] = a;   // two-phase form: plain stores, dw_partials_sum_kernel adds the blocks up
-      else if (k < 72) {
-        if (dw) atomicAdd(dw + (cc * 8 + (k & 7)) * 9 + (k >> 3), a);
-      } else if (dbias) atomicAdd(dbias + cc * 8 + (k - 72), a);
+    if (ws) {   // two-phase form: plain coalesced stores (chunk index fastest), dw_partials_sum_kernel adds the blocks up
+      for (int o = threadIdx.x; o < 40 * c8n; o += 256) {
+        const int q = o / c8n, cc = o - q * c8n;
+        float a = 0.f;
+        for (int l = 0; l < tpb; ++l) a += s_acc[q * LD + l * c8n + cc];
+        ws[(long)blockIdx.x * n + (r * 40 + q) * c8n + cc] = a;
+      }
+    } else {    // no workspace: atomics, k fastest -- a wave's 64 destinations lie in the 288-byte weight rows of two channel chunks
+      for (int o = threadIdx.x; o < 40 * c8n; o += 256) {
+        const int cc = o / 40, q = o - cc * 40;
+        float a = 0.f;
+        for (int l = 0; l < tpb; ++l) a += s_acc[q * LD + l * c8n + cc];
+        const int k = r * 40 + q;
+        if (k < 72) {
+          if (dw) atomicAdd(dw + (cc * 8 + (k & 7)) * 9 + (k >> 3), a);
+        } else if (dbias) atomicAdd(dbias + cc * 8 + (k - 72), a);
+      }
     }
   }
 }
