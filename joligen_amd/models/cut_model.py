@@ -348,9 +348,10 @@ class CUTModel(BaseModel):
         bench.py and the tests set it when it is unset) and the configs[2]-shaped step then tracks the eager drivers step for step
         (tools/dbg_graph_d.py).  But a library cannot know whether the runtime read the variable; the canary below (replay, 8192 tiny
         eager launches, replay, compare; side effects undone from snapshots) catches the corruption at the bench shape and MISSED it on a
-        64 x 64 test model; and on that small model the projected discriminator's loss left the eager drivers' from the first pure replay
-        on even with the variable set (tests/test_gpu_5_cutloss.py::test_cut_step_drivers_agree with JG_TEST_GRAPH_D=1).  Until both are
-        understood the default driver is the eager half on the side stream.
+        64 x 64 test model; and on that small model the projected discriminator's logits are 1.3 - 3x too large from the first pure replay
+        on even with the variable set, while the PatchGAN discriminator in the same graph is exact (DESIGN.md 11.2;
+        tests/test_gpu_5_cutloss.py::test_cut_step_drivers_agree with JG_TEST_GRAPH_D=1, DBG_SMALL=1 tools/dbg_graph_d.py).  Until both
+        are understood the default driver is the eager half on the side stream.
         Returns False when the eager path has to run (not enabled, not applicable, capture failed, canary failed)."""
         want = os.environ.get("JG_GRAPH_D", "")
         if not ((getattr(self.opt, "jg_graph_D", False) or want == "1") and want != "0"):

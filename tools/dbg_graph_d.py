@@ -5,6 +5,19 @@ import torch
 import bench
 
 def make(graph, its):
+    if os.environ.get("DBG_SMALL"):
+        from joligen_amd.models import create_model
+        from joligen_amd.options import opt_from_json
+        cfg = {"model_type": "cut", "G": {"netG": "resnet", "ngf": 32, "nblocks": 2}, "D": {"netDs": os.environ.get("DBG_NETDS", "projected_d,basic").split(","), "ndf": 32, "proj_interp": 128},
+               "alg": {"cut": {"nce_layers": "0,4,8"}}, "data": {"crop_size": 64, "load_size": 64},
+               "train": {"batch_size": 2, "G_ema": True, "iter_size": its, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0}}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = create_model(opt_from_json(cfg, overrides={"jg_act_dtype": "bf16", "gpu_ids": "0", "jg_graph_D": graph}), 0)
+            model.data_dependent_initialize(batch)
+            model.setup(model.opt)
+            model.single_gpu()
+        return model
     ns = argparse.Namespace(model="cut", netG="segformer_attn_conv", netDs=os.environ.get("DBG_NETDS", "projected_d,basic"), batch=4, size=256, dtype="bf16", efficient=1, force_exchange=False)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -18,7 +31,8 @@ def make(graph, its):
 its = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(77)
-batch = {"A": (torch.rand(4, 3, 256, 256, generator=g) * 2 - 1).to(dev), "B": (torch.rand(4, 3, 256, 256, generator=g) * 2 - 1).to(dev)}
+SZ = (2, 64) if os.environ.get("DBG_SMALL") else (4, 256)
+batch = {"A": (torch.rand(SZ[0], 3, SZ[1], SZ[1], generator=g) * 2 - 1).to(dev), "B": (torch.rand(SZ[0], 3, SZ[1], SZ[1], generator=g) * 2 - 1).to(dev)}
 for graph in (False, True):
     os.environ["JG_GRAPH_D"] = "1" if graph else "0"
     torch.manual_seed(0)
