@@ -334,27 +334,32 @@ class CUTModel(BaseModel):
         return vals, tot
 
     def _d_half_from_graph(self, side, its):
-        """EXPERIMENTAL, OFF by default (`jg_graph_D=True` or `JG_GRAPH_D=1` turns it on): the discriminator half -- ~700 launches whose
-        operands are two images and the discriminators' arenas -- captured once (third step on) and replayed.  It holds no host-side
-        random draw (the pool queries stay outside), no optimizer step and no host-computed scalar that changes between steps (16-bit
+        """`jg_graph_D` (default on; `JG_GRAPH_D=0` / `1` overrides the option): the discriminator half -- ~700 launches whose operands
+        are two images and the discriminators' arenas -- is captured once (third step on) and replayed.  It holds no host-side random
+        draw (the pool queries stay outside), no optimizer step and no host-computed scalar that changes between steps (16-bit
         activations other than fp16: the loss scale is 1).  What it buys is host time: the eager half costs 7.8 ms of enqueue per step,
-        and the step's wall time is the enqueue time on hosts slower than the GPU side: 380 images/s instead of 310 - 350 on the
-        configs[2] shape.
+        and the step's wall time is the enqueue time on hosts slower than the GPU side: 380 images/s on every box instead of 300 - 370
+        on the configs[2] shape.
 
-        Why it is off: ROCm 7.2's hipGraph replays go wrong when thousands of eager launches run between two replays -- its AQL-packet
-        capture keeps the nodes' kernel arguments where later launches overwrite them (profiles/r04_graph_replay_probe.txt: the loss of an
-        untouched graph moves after 3000 one-element `add_` launches on another stream, NaN gradients after a generator backward).
-        `DEBUG_CLR_GRAPH_PACKET_CAPTURE=0` in the environment BEFORE the HIP runtime initialises switches that path off (joligen_amd,
-        bench.py and the tests set it when it is unset) and the configs[2]-shaped step then tracks the eager drivers step for step
-        (tools/dbg_graph_d.py).  But a library cannot know whether the runtime read the variable; the canary below (replay, 8192 tiny
-        eager launches, replay, compare; side effects undone from snapshots) catches the corruption at the bench shape and MISSED it on a
-        64 x 64 test model; and on that small model the projected discriminator's logits are 1.3 - 3x too large from the first pure replay
-        on even with the variable set, while the PatchGAN discriminator in the same graph is exact (DESIGN.md 11.2;
-        tests/test_gpu_5_cutloss.py::test_cut_step_drivers_agree with JG_TEST_GRAPH_D=1, DBG_SMALL=1 tools/dbg_graph_d.py).  Until both
-        are understood the default driver is the eager half on the side stream.
+        Two conditions, both checked.  (1) ROCm 7.2's hipGraph replays go wrong when thousands of eager launches run between two
+        replays -- its AQL-packet capture keeps the nodes' kernel arguments where later launches overwrite them
+        (profiles/r04_graph_replay_probe.txt: the loss of an untouched graph moves after 3000 one-element `add_` launches on another
+        stream, NaN gradients after a generator backward).  `DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`, read by the runtime when it
+        initialises, switches that path off; `joligen_amd/__init__.py` sets it when the package is imported before the first HIP call
+        and records in `HIP_GRAPHS_SAFE` whether it could -- without that the eager half runs.  As a second net the capture is
+        followed once by a canary: replay, 8192 tiny eager launches, replay; if the two losses differ the graph is dropped for good
+        (with a warning); the canary's side effects (gradient accumulation, spectral-norm power iterations, running statistics) are
+        undone from snapshots.  (2) Every tensor the graph reads has to keep its address: the lazily derived tables of the frozen
+        feature network (`_FrozenBN.affine`, `_DWWeight.taps`) are refreshed in place for that reason -- re-created, their old storage
+        went back to the allocator and the replays read whatever was written there next (found as projected-discriminator logits 1.3 -
+        3x too large on a 64 x 64 model; tests/test_gpu_5_cutloss.py::test_cut_step_drivers_agree holds the three drivers together).
         Returns False when the eager path has to run (not enabled, not applicable, capture failed, canary failed)."""
         want = os.environ.get("JG_GRAPH_D", "")
-        if not ((getattr(self.opt, "jg_graph_D", False) or want == "1") and want != "0"):
+        if not ((getattr(self.opt, "jg_graph_D", True) or want == "1") and want != "0"):
+            return False
+        import joligen_amd
+
+        if not joligen_amd.HIP_GRAPHS_SAFE:
             return False
         if self.act_dtype == torch.float16 or self.niter <= 2 or ops.KERNEL_TIMING is not None or self.__dict__.get("_dg_failed"):
             return False
@@ -412,6 +417,8 @@ class CUTModel(BaseModel):
                 t.copy_(t0)
             return None
         st["graph"] = graph
+        if os.environ.get("JG_DBG_GRAPH_KEEP"):     # dev: keep every capture-time object that owns device memory alive with the graph
+            st["keep"] = [getattr(n, "_sn_last", None) for n in nets] + [dict(getattr(self, dn + "_loss_calculator").__dict__) for dn in self.discriminators_names]
         return st
 
     def _d_publish(self, vals, tot, clone):

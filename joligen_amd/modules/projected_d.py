@@ -464,7 +464,12 @@ class _FrozenBN(nn.Module):
         if key != self._key:
             with torch.no_grad():
                 sc = self.weight.detach().float() / torch.sqrt(self.running_var.float() + self.eps)
-                self._affine = (sc.contiguous(), (self.bias.detach().float() - self.running_mean.float() * sc).contiguous())
+                sh = self.bias.detach().float() - self.running_mean.float() * sc
+                if self._affine is None or self._affine[0].shape != sc.shape or self._affine[0].device != sc.device:
+                    self._affine = (sc.contiguous(), sh.contiguous())
+                else:       # refreshed IN PLACE: a captured hipGraph (cut_model._d_half_from_graph) holds these addresses
+                    self._affine[0].copy_(sc)
+                    self._affine[1].copy_(sh)
             self._key = key
         return self._affine
 
@@ -498,7 +503,11 @@ class _DWWeight(nn.Module):
         if key != self._key:
             with torch.no_grad():
                 w = self.weight.detach().float()
-                self._taps = w.reshape(w.shape[0], -1).t().contiguous()
+                t = w.reshape(w.shape[0], -1).t()
+                if self._taps is None or self._taps.shape != t.shape or self._taps.device != t.device:
+                    self._taps = t.contiguous()
+                else:       # in place, see FrozenBN.affine
+                    self._taps.copy_(t)
             self._key = key
         return self._taps
 

@@ -44,7 +44,7 @@ DEFAULTS = dict(
     # joligen_amd extensions (not in the reference): activation dtype, fp16 loss scale (0 = default) and how often (in steps) the
     # device-side dropped-step counters are polled to back the scale off (BaseModel.poll_overflow)
     jg_act_dtype="bf16", jg_loss_scale=0.0, jg_overflow_poll=50, jg_async_checkpoint=False, jg_loss_scale_growth_interval=2000,
-    jg_projd_backbone="lite0", jg_projd_pretrained="", jg_early_D=True, jg_graph_D=False,
+    jg_projd_backbone="lite0", jg_projd_pretrained="", jg_early_D=True, jg_graph_D=True,
 )
 
 

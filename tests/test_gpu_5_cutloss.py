@@ -669,8 +669,8 @@ def test_cut_c3_shape_first_step_gradients_vs_oracle(dtype):
 @pytest.mark.parametrize("iter_size", [1, 3])
 def test_cut_step_drivers_agree(iter_size, monkeypatch):
     """The three step drivers of cut_model run the same kernels on the same operands: (a) the reference's order (BaseModel.optimize_parameters),
-    (b) the discriminator half on a side stream under the generator's backward (`jg_early_D`, the default), and -- only with
-    JG_TEST_GRAPH_D=1 -- (c) that half replayed from a hipGraph (`jg_graph_D`, experimental and off).  Seven calls each from the same seed with [projected_d, basic]
+    (b) the discriminator half on a side stream under the generator's backward (`jg_early_D`), (c) that half replayed from a hipGraph
+    (`jg_graph_D`, the default; captured at the third call, with its one-off canary).  Seven calls each from the same seed with [projected_d, basic]
     discriminators and learning rates of ZERO (a free-running small GAN amplifies the fp32-atomics noise of its gradients by 5 % of the
     loss within seven steps, which would hide a wrong driver; with frozen parameters the only state that evolves is the spectral-norm
     power iteration and Adam's moments): the losses of every call and Adam's first moment of every network -- a linear image of every
@@ -709,12 +709,11 @@ def test_cut_step_drivers_agree(iter_size, monkeypatch):
     la2, pa2, _, _ = run(False, False)
     lb, pb, _, _ = run(True, False)
     cases = [("early", lb, pb)]
-    if os.environ.get("JG_TEST_GRAPH_D", "0") != "0":      # experimental driver (cut_model._d_half_from_graph): known to FAIL here, off by default
-        lc, pc, dropped, replayed = run(True, True)
-        assert replayed or dropped, "the graph driver neither captured nor reported why"
-        if dropped:
-            print("graph driver dropped by its canary:", dropped[0][:200])
-        cases.append(("graph", lc, pc))
+    lc, pc, dropped, replayed = run(True, True)
+    assert replayed or dropped, "the graph driver neither captured nor reported why"
+    if dropped:
+        print("graph driver dropped by its canary:", dropped[0][:200])
+    cases.append(("graph", lc, pc))
     floor_l = float(((la - la2).abs() / la.abs()).max())
     floor_p = max(float((pa[n] - pa2[n]).norm() / pa[n].norm()) for n in pa)
     print("run-to-run floor: losses %.2e, first moments %.2e" % (floor_l, floor_p))
