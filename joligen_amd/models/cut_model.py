@@ -366,12 +366,16 @@ class CUTModel(BaseModel):
         nets = [self._net(dn) for dn in self.discriminators_names]
         key = (tuple(self.real_B.shape), self.real_B.dtype, tuple(self.fake_B.shape), its, float(self.loss_scale),
                tuple(n.arena.p.data_ptr() for n in nets), tuple(n.training for n in nets))
-        st = self.__dict__.get("_dg")
-        if st is None or st["key"] != key:
+        graphs = self.__dict__.setdefault("_dg_graphs", {})      # one graph per operand shape (a last, smaller batch of an epoch): at most three
+        st = graphs.get(key)
+        if st is None:
+            if len(graphs) >= 3:
+                return False
             st = self._d_capture(side, its, key, nets)
             if st is None:
                 return False
-            self._dg = st
+            graphs[key] = st
+        self._dg = st
         fakes = [self.fake_B_pool.query(self.fake_B).detach() for _ in self.discriminators_names]
         st["real"].copy_(self.real_B)
         for dst, f in zip(st["fakes"], fakes):
