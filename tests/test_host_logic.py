@@ -395,3 +395,24 @@ def test_fp16_loss_scale_policy_polls_every_step_after_growth():
         m.niter += 1; a.step += 1
         m.poll_overflow()
     assert m.loss_scale == 1024.0
+
+
+def test_hip_graphs_safe_flag():
+    """joligen_amd/__init__.py: the package switches ROCm's graph AQL-packet capture off when it still can (variable unset, HIP runtime not yet
+    initialised) and records whether replays can be trusted; an explicit user setting is respected either way."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, joligen_amd; print(joligen_amd.HIP_GRAPHS_SAFE, os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'))"
+
+    def run(value):
+        env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+        if value is not None:
+            env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = value
+        env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+        return subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120).stdout.split()
+
+    assert run(None) == ["True", "0"]
+    assert run("0") == ["True", "0"]
+    assert run("1") == ["False", "1"]
