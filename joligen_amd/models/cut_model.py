@@ -421,8 +421,6 @@ class CUTModel(BaseModel):
                 t.copy_(t0)
             return None
         st["graph"] = graph
-        if os.environ.get("JG_DBG_GRAPH_KEEP"):     # dev: keep every capture-time object that owns device memory alive with the graph
-            st["keep"] = [getattr(n, "_sn_last", None) for n in nets] + [dict(getattr(self, dn + "_loss_calculator").__dict__) for dn in self.discriminators_names]
         return st
 
     def _d_publish(self, vals, tot, clone):
