@@ -345,7 +345,19 @@ def cut_leg(local_rank, no_cpu):
         model.optimize_parameters()
 
     steps, warmup = 20, 5
-    dt, per_step = timed_region(step, steps, warmup, torch.cuda.synchronize)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        dt, per_step = timed_region(step, steps, warmup, torch.cuda.synchronize)
+    import joligen_amd
+    # which driver ran the timed steps: "graph" = discriminator half replayed from a hipGraph, "early" = that half eager
+    # on a second stream, "sequential" = the reference's order; the canary's verdict and any jg_graph_D warning travel with the number
+    driver = {"step_driver": model.step_driver, "hip_graphs_safe": bool(joligen_amd.HIP_GRAPHS_SAFE),
+              "graph_canary": ("passed" if model.step_driver == "graph" else ("failed" if "graph dropped" in model.step_driver_note else "not run")),
+              "note": model.step_driver_note, "warnings": [str(w.message)[:300] for w in rec if "jg_" in str(w.message)][:4],
+              "DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}
+    for w in rec:
+        print(f"[cut leg] warning: {w.message}", file=sys.stderr, flush=True)
+    print(f"[cut leg] step_driver={driver['step_driver']} canary={driver['graph_canary']} {driver['note']}", file=sys.stderr, flush=True)
     ops.KERNEL_TIMING = []
     step()
     torch.cuda.synchronize()
@@ -372,7 +384,7 @@ def cut_leg(local_rank, no_cpu):
     loss = float(model.get_current_losses()["G_tot"].detach())
     return {"metric": "train images/sec at 256x256 (CUT G+D step)", "value": round(ns.batch * steps / dt, 3), "unit": "images/sec",
             "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2], 3), "steps": steps, "warmup": warmup,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16", "data": "synthetic", **driver,
             "config": {"workload": "cut_model, segformer_attn_conv G (MiT-b0 + heads + ResnetDecoder tail) + D_netDs [projected_d (tf_efficientnet_lite0 "
                                    "architecture, random frozen weights: timm checkpoint unavailable), basic] + mlp_sample F, MoNCE, nce_idt, hinge / lsgan, "
                                    "256x256, batch 16/GPU, Adam x4 + EMA, iter_size 1 (BASELINE configs[2] shape; example_gan_mario2sonic.json without "
@@ -421,6 +433,8 @@ def leg_subprocess(name, no_cpu, timeout_s=420):
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", name] + (["--no-cpu-baseline"] if no_cpu else [])
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        if out.stderr.strip():              # the leg's own warnings (e.g. a dropped hipGraph) reach the caller's log
+            print(f"[bench leg {name}] stderr tail:\n" + out.stderr[-1500:], file=sys.stderr, flush=True)
         for line in reversed(out.stdout.splitlines()):
             if line.startswith("{"):
                 return json.loads(line)

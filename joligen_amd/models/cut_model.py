@@ -284,8 +284,25 @@ class CUTModel(BaseModel):
                 if network in group.networks_to_ema:
                     self.ema_step(network)
 
+    # which step driver ran the LAST optimize_parameters(): "sequential" (BaseModel's group loop), "early" (discriminator half eager on a
+    # second stream) or "graph" (that half replayed from a hipGraph); `step_driver_note` holds the reason a faster driver was not taken
+    # (bench.py and the driver-agreement tests report both)
+    step_driver = "sequential"
+    step_driver_note = ""
+
+    def _draw_pool_fakes(self, side):
+        """The history-pool draws of compute_D_loss, made on the MAIN stream before the side stream forks: `ImagePool.query` clones a stored
+        image (a view of an earlier generator output, allocated on the main stream) and drops the last reference to it, so on the side
+        stream the clone would only be queued when the caching allocator hands the block back to the main stream's pool (ADVICE r4:
+        cross-stream use-after-free).  The drawn batches are then marked as in use by the side stream."""
+        fakes = [self.fake_B_pool.query(self.fake_B).detach() for _ in self.discriminators_names]
+        for f in fakes:
+            f.record_stream(side)
+        return fakes
+
     def optimize_parameters(self):
         if not self._early_D():
+            self.step_driver = "sequential"
             return super().optimize_parameters()
         self.niter += 1
         self._ema_fused_this_iter = set()
@@ -300,14 +317,20 @@ class CUTModel(BaseModel):
         side = self.__dict__.get("_d_stream")
         if side is None:
             side = self._d_stream = torch.cuda.Stream(device=self.device)
+        self._drawn_fakes = self._draw_pool_fakes(side)
+        self.real_B.record_stream(side)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._group_flags(gD)
-            if not self._d_half_from_graph(side, its):
+            if self._d_half_from_graph(side, its):
+                self.step_driver = "graph"
+            else:
+                self.step_driver = "early"
                 for fn in gD.backward_functions:
                     getattr(self, fn)()
                 for loss in gD.loss_backward:
                     (getattr(self, loss) / its).backward()
+        self._drawn_fakes = None
         if os.environ.get("JG_DBG_EARLY_D_SYNC"):      # dev (tools/dbg_graph_d.py): the two halves one after the other
             torch.cuda.synchronize()
         self._group_flags(gG)
@@ -360,8 +383,11 @@ class CUTModel(BaseModel):
         import joligen_amd
 
         if not joligen_amd.HIP_GRAPHS_SAFE:
+            self.step_driver_note = "HIP_GRAPHS_SAFE is False (HIP initialised before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 could be set)"
             return False
-        if self.act_dtype == torch.float16 or self.niter <= 2 or ops.KERNEL_TIMING is not None or self.__dict__.get("_dg_failed"):
+        if self.__dict__.get("_dg_failed"):
+            return False                       # step_driver_note holds the capture / canary failure
+        if self.act_dtype == torch.float16 or self.niter <= 2 or ops.KERNEL_TIMING is not None:
             return False
         nets = [self._net(dn) for dn in self.discriminators_names]
         key = (tuple(self.real_B.shape), self.real_B.dtype, tuple(self.fake_B.shape), its, float(self.loss_scale),
@@ -376,7 +402,7 @@ class CUTModel(BaseModel):
                 return False
             graphs[key] = st
         self._dg = st
-        fakes = [self.fake_B_pool.query(self.fake_B).detach() for _ in self.discriminators_names]
+        fakes = self._drawn_fakes
         st["real"].copy_(self.real_B)
         for dst, f in zip(st["fakes"], fakes):
             dst.copy_(f)
@@ -392,7 +418,7 @@ class CUTModel(BaseModel):
         saved = [t.clone() for t in state]
         try:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):      # other threads (pinned staging, checkpoint writer) may allocate
                 st["vals"], st["tot"] = self._d_half_body(st["real"], st["fakes"], its)
             graph.replay()
             first = st["tot"].detach().clone()
@@ -407,6 +433,8 @@ class CUTModel(BaseModel):
                 t.copy_(t0)
             graph.replay()
             second = st["tot"].detach().clone()
+            if os.environ.get("JG_DBG_GRAPH_CANARY_FAIL"):      # tests: the fall-back path of a failing canary
+                second = second * 1.5 + 1.0
             for t, t0 in zip(state, saved):
                 t.copy_(t0)
             ok = bool((torch.isfinite(first) & torch.isfinite(second) & ((first - second).abs() <= 1e-3 * first.abs() + 1e-6)).item())
@@ -415,6 +443,7 @@ class CUTModel(BaseModel):
                                    "export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first HIP call")
         except Exception as e:
             warnings.warn(f"jg_graph_D: the discriminator half stays eager ({e})")
+            self.step_driver_note = f"graph dropped: {e}"
             self._dg_failed = True
             self._dg = None
             for t, t0 in zip(state, saved):
@@ -432,8 +461,9 @@ class CUTModel(BaseModel):
     def compute_D_loss(self):
         """base_gan_model.py:341-419: every discriminator draws ITS OWN fake batch from the history pool (compute_D_loss_generic)."""
         tot = 0
-        for dn in self.discriminators_names:
-            fake = self.fake_B_pool.query(self.fake_B)
+        drawn = self.__dict__.get("_drawn_fakes")          # early-D driver: drawn on the main stream before the fork (same draw order)
+        for i, dn in enumerate(self.discriminators_names):
+            fake = drawn[i] if drawn is not None else self.fake_B_pool.query(self.fake_B)
             val = getattr(self, dn + "_loss_calculator").compute_loss_D(self._net(dn), self.real_B, fake, None)
             setattr(self, "loss_D_GAN_" + dn, val)
             tot = tot + val
