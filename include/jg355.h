@@ -563,6 +563,38 @@ int jg_ema_update(float* ema, const float* p, int64_t n, float beta, jg_stream_t
  * R, S taken from desc RS = R*65536 + S. */
 int jg_refresh_weights(int dtype, const float* p, void* w16, void* w16T, const int64_t* desc, int nlayers, jg_stream_t s);
 
+/* ---- ViT feature network of the projected discriminator (csrc/vit.hip) ------------------------------------------------------
+ * D_proj_network_type "vitsmall" (examples/example_gan_mario2sonic.json): timm `vit_small_patch16_224` created at D_proj_interp, read
+ * through `configure_get_feats_vit_timm` (models/modules/projected_d/projector.py:138-153,252-253,327-331).  Linear layers = jg_conv2d_nt,
+ * LayerNorm forward = jg_layernorm_fwd.
+ *   vit_attention_fwd/bwd : timm Attention.forward -- softmax((q * scale) k^T) v per head -- for token sequences of ANY length T (257 =
+ *                       16 x 16 patches + class token), head_dim 32 or 64.  q / k / v: three views of the packed projection
+ *                       ([B, T, ld] rows, head h at + h * head_stride elements; timm's qkv channel order is [3][heads][head_dim]:
+ *                       q = qkv, k = qkv + C, v = qkv + 2C, ld = 3C, head_stride = head_dim).  o [B, T, heads * head_dim], L [B * heads, T]
+ *                       logsumexp (saved for the backward).  bwd: dq / dk / dv views of the projection gradient (row stride ldd), Dq
+ *                       [B * heads, T] scratch
+ *   vit_tokens_fwd/bwd : cat(cls_token, patch_embed(x)) + pos_embed (projector.py:140-143); bwd = gradient of the patch embeddings
+ *   gelu_fwd/bwd      : nn.GELU() (exact, erf) of timm's Mlp; bwd: dx = dy gelu'(x)
+ *   layernorm_bwd_res : input gradient of a frozen nn.LayerNorm plus the residual branch of a pre-norm block: dx = res + LN'(dy) (res NULL = 0)
+ *   (transpose2d      : below)
+ *   unpatchify        : adjoint of the patch gather of PatchEmbed's Conv2d(k = s = P): dimg[b, ph P + r, pw P + s, ci] =
+ *                       dpatch[(b, ph, pw)][ci P P + (P-1-r) P + (P-1-s)], 8 channels -- dpatch = dy x w16T (jg_refresh_weights layout) */
+int jg_vit_attention_fwd(int dtype, const void* q, const void* k, const void* v, int64_t ld, int64_t head_stride, void* o, float* L, int B,
+                         int T, int heads, int head_dim, float scale, jg_stream_t s);
+int jg_vit_attention_bwd(int dtype, const void* q, const void* k, const void* v, int64_t ld, int64_t head_stride, const void* o, const float* L,
+                         const void* d_o, void* dq, void* dk, void* dv, int64_t ldd, float* Dq, int B, int T, int heads, int head_dim,
+                         float scale, jg_stream_t s);
+int jg_vit_tokens_fwd(int dtype, const void* patch, const float* cls, const float* pos, void* y, int B, int N, int C, jg_stream_t s);
+int jg_vit_tokens_bwd(int dtype, const void* dy, void* dpatch, int B, int N, int C, jg_stream_t s);
+int jg_gelu_fwd(int dtype, const void* x, void* y, int64_t n, jg_stream_t s);
+int jg_gelu_bwd(int dtype, const void* x, const void* dy, void* dx, int64_t n, jg_stream_t s);
+int jg_layernorm_bwd_res(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, const void* res, void* dx, int64_t R,
+                         int C, jg_stream_t s);
+int jg_unpatchify(int dtype, const void* dpatch, void* dimg, int B, int Hp, int Wp, int P, jg_stream_t s);
+/* dst[b][c][r] = src[b][r][c], 16-bit elements: the `x.transpose(2, 1).contiguous()` of configure_get_feats_vit_timm (projector.py:148-150) in
+ * front of nn.Flatten() of the MLP heads (discriminator.py:212), whose weights are laid out for [B, C * T]; its own adjoint */
+int jg_transpose2d(int dtype, const void* src, void* dst, int B, int R, int C, jg_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -685,7 +685,10 @@ template <typename T, bool ALIGN = false>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, long lddy) {
   const int c8n = C >> 3;
   const long total = (long)B * H * W * c8n;
-  const int fy = (Ho + H - 1) / H, fx = (Wo + W - 1) / W;
+  // output rows whose source coordinate lies in (iy - 1, iy + 1): from the REAL scale (any ratio >= 1, e.g. 64 -> 96; round 5: the window
+  // used to be derived from ceil(out / in), which is only right for integer ratios), one output pixel of margin each way
+  const float ry = ALIGN ? (H > 1 ? (float)(Ho - 1) / (float)(H - 1) : (float)Ho) : (float)Ho / (float)H;
+  const float rx = ALIGN ? (W > 1 ? (float)(Wo - 1) / (float)(W - 1) : (float)Wo) : (float)Wo / (float)W;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c8 = i % c8n;
     long p = i / c8n;
@@ -695,9 +698,9 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    // (align_corners: the footprint of an input pixel shifts by up to one output pixel against the half-pixel rule -> one more each way)
-    const int oy_lo = max(0, (iy - 1) * fy - (ALIGN ? fy : 0)), oy_hi = min(Ho - 1, (iy + 2) * fy + (ALIGN ? fy : 0));
-    const int ox_lo = max(0, (ix - 1) * fx - (ALIGN ? fx : 0)), ox_hi = min(Wo - 1, (ix + 2) * fx + (ALIGN ? fx : 0));
+    const float offl = ALIGN ? -1.0f : -0.5f, offh = ALIGN ? 1.0f : 1.5f, sh = ALIGN ? 0.f : 0.5f;
+    const int oy_lo = max(0, (int)floorf(((float)iy + offl) * ry - sh) - 1), oy_hi = min(Ho - 1, (int)ceilf(((float)iy + offh) * ry - sh) + 1);
+    const int ox_lo = max(0, (int)floorf(((float)ix + offl) * rx - sh) - 1), ox_hi = min(Wo - 1, (int)ceilf(((float)ix + offh) * rx - sh) + 1);
     for (int oy = oy_lo; oy <= oy_hi; ++oy) {
       int y0, y1;
       float wy;

@@ -430,13 +430,13 @@ class CUTModel(BaseModel):
                     burst.add_(1.0)
             side.wait_stream(torch.cuda.default_stream(self.device))
             for t, t0 in zip(state, saved):      # both replays start from the same power-iteration vectors / statistics
-                t.copy_(t0)
+                t.data.copy_(t0)      # .data: no version bump (frozen-BN tables key on versions; tensors saved by G's forward stay valid)
             graph.replay()
             second = st["tot"].detach().clone()
             if os.environ.get("JG_DBG_GRAPH_CANARY_FAIL"):      # tests: the fall-back path of a failing canary
                 second = second * 1.5 + 1.0
             for t, t0 in zip(state, saved):
-                t.copy_(t0)
+                t.data.copy_(t0)      # .data: no version bump (frozen-BN tables key on versions; tensors saved by G's forward stay valid)
             ok = bool((torch.isfinite(first) & torch.isfinite(second) & ((first - second).abs() <= 1e-3 * first.abs() + 1e-6)).item())
             if not ok:
                 raise RuntimeError(f"replays of an untouched graph disagree after interleaved eager launches ({float(first)} vs {float(second)}): "
@@ -447,7 +447,7 @@ class CUTModel(BaseModel):
             self._dg_failed = True
             self._dg = None
             for t, t0 in zip(state, saved):
-                t.copy_(t0)
+                t.data.copy_(t0)      # .data: no version bump (frozen-BN tables key on versions; tensors saved by G's forward stay valid)
             return None
         st["graph"] = graph
         return st

@@ -745,15 +745,34 @@ class ProjectedDiscriminator(nn.Module):
 
     def __init__(self, projector_model="efficientnet", interp=-1, img_size=256, cout=64, expand=True, backbone="lite0", pretrained_path=""):
         super().__init__()
-        if projector_model != "efficientnet":
-            raise NotImplementedError(f"D_proj_network_type={projector_model!r}: the convolutional ('efficientnet') projector is built; the "
-                                      "ViT / CLIP / DINOv2 / SegFormer feature networks need pretrained weights that are not available offline")
+        if projector_model not in ("efficientnet", "vitsmall"):
+            raise NotImplementedError(f"D_proj_network_type={projector_model!r}: the convolutional ('efficientnet' = tf_efficientnet_lite0) and the ViT "
+                                      "('vitsmall' = vit_small_patch16_224) projectors are built; vitbase / CLIP / SigLIP / DINOv2 / SegFormer / depth "
+                                      "feature networks are not")
         self.interp = interp
+        self.projector_model = projector_model
         size = interp if interp > 0 else img_size
+        self.backbone_pretrained = False
+        self.arena = None
+        if projector_model == "vitsmall":         # projector.py:327-331 + discriminator.py:208-230 (modules/projected_d_vit.py)
+            from .projected_d_vit import MultiScaleDVit, ProjVit
+
+            self.backbone = "vit_small_patch16_224"
+            self.freeze_feature_network = ProjVit(cout=cout, expand=expand, interp=size)
+            self.freeze_feature_network.requires_grad_(False)
+            if pretrained_path:
+                self.load_pretrained_backbone(pretrained_path)
+            else:
+                import warnings
+
+                warnings.warn("ProjectedDiscriminator: vit_small_patch16_224 is built with RANDOM frozen weights -- timm's pretrained checkpoint "
+                              "cannot be downloaded here.  A projected GAN on random features is not the reference's discriminator: pass "
+                              "jg_projd_pretrained=<vit_small_patch16_224 state_dict .pth> or load a reference D checkpoint.", stacklevel=2)
+            self.discriminator = MultiScaleDVit(self.freeze_feature_network.CHANNELS, self.freeze_feature_network.RESOLUTIONS)
+            return
         self.backbone = backbone
         self.freeze_feature_network = Proj(cout=cout, expand=expand, interp=size, backbone=backbone)
         self.freeze_feature_network.requires_grad_(False)
-        self.backbone_pretrained = False
         if pretrained_path:
             self.load_pretrained_backbone(pretrained_path)
         elif backbone == "standin":
@@ -775,6 +794,10 @@ class ProjectedDiscriminator(nn.Module):
         `_make_efficientnet` re-homes the modules; every backbone entry must be present"""
         sd = torch.load(path, map_location="cpu")
         sd = sd.get("state_dict", sd)
+        if self.projector_model == "vitsmall":       # timm VisionTransformer keys are the module's own
+            res = self.freeze_feature_network.pretrained.load_state_dict(sd, strict=True)
+            self.backbone_pretrained = True
+            return res
         remap = {}
         for k, v in sd.items():
             if k.startswith("conv_stem."):
@@ -822,7 +845,7 @@ class ProjectedDiscriminator(nn.Module):
         if self.interp > 0 and (x.shape[1] != self.interp or x.shape[2] != self.interp):
             x = bilinear(x, self.interp, self.interp, False)
         feats = self.freeze_feature_network(x)
-        if SN_GROUPED and self.discriminator.training and self.arena is not None:
+        if SN_GROUPED and self.discriminator.training and self.arena is not None and self.projector_model == "efficientnet":
             self._sn_prepare(x.dtype)
         return self.discriminator(feats)
 

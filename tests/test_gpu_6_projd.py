@@ -28,17 +28,20 @@ def load(golden_dir, name):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("align", [True, False])
-def test_bilinear_align_corners(dtype, align):
+@pytest.mark.parametrize("hw,out", [((7, 9), (14, 18)), ((64, 64), (96, 96)), ((10, 13), (25, 17)), ((1, 5), (4, 5))])
+def test_bilinear_align_corners(dtype, align, hw, out):
+    """round 5: non-integer ratios as well (the `F.interpolate(x, D_proj_interp)` in front of the projected discriminator with e.g. 64 -> 96:
+    the backward's gather window was only right for integer ratios)"""
     from joligen_amd.modules.projected_d import bilinear
 
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(2, 24, 7, 9, generator=g).to(dtype)
-    gy = torch.randn(2, 24, 14, 18, generator=g).to(dtype)
+    x = torch.randn(2, 24, *hw, generator=g).to(dtype)
+    gy = torch.randn(2, 24, *out, generator=g).to(dtype)
     xr = x.float().requires_grad_(True)
-    yr = F.interpolate(xr, size=(14, 18), mode="bilinear", align_corners=align)
+    yr = F.interpolate(xr, size=out, mode="bilinear", align_corners=align)
     yr.backward(gy.float())
     xd = x.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True)
-    y = bilinear(xd, 14, 18, align)
+    y = bilinear(xd, out[0], out[1], align)
     y.backward(gy.permute(0, 2, 3, 1).contiguous().to(D0))
     assert relerr(y.permute(0, 3, 1, 2), yr.detach()) < TOL[dtype]
     assert relerr(xd.grad.permute(0, 3, 1, 2), xr.grad) < 2 * TOL[dtype], relerr(xd.grad.permute(0, 3, 1, 2), xr.grad)

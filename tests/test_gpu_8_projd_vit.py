@@ -1,0 +1,297 @@
+"""GPU parity tests of the ViT projector of the projected discriminator (`D_proj_network_type = "vitsmall"`, the choice of
+examples/example_gan_mario2sonic.json = BASELINE configs[2]): the kernels of csrc/vit.hip against plain torch fp32, the frozen ViT token
+path against the CPU oracle, and the whole ProjectedDiscriminator("vitsmall") against the fixtures recorded from the UNMODIFIED reference
+(oracle/make_golden_projd_vit.py over oracle/vit_small_torch.py)."""
+import json
+import os
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import jg_oracle as O
+from test_oracle_golden import projd_run_oracle, projd_state
+
+pytestmark = pytest.mark.gpu
+D0 = "cuda:0"
+DTYPES = [torch.float16, torch.bfloat16]
+TOL = {torch.float16: 2e-3, torch.bfloat16: 1.2e-2}
+FIXTURES = ["projd_vit.pt", "projd_vit256.pt"]
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def _yard(fixture, dtype):
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_rounding_yardstick_projd.json")
+    return json.load(open(path))[fixture]["fp16" if dtype == torch.float16 else "bf16"]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("T,heads,hd,B", [(257, 6, 64, 2), (37, 6, 64, 3), (64, 2, 32, 2), (1, 2, 64, 1), (130, 3, 32, 2)])
+def test_vit_attention_vs_torch(T, heads, hd, B, dtype):
+    """jg_vit_attention_fwd / _bwd (timm Attention core: softmax((q * hd ** -0.5) k^T) v, packed qkv in [3][heads][hd] channel order) for
+    ragged token counts (257 = 16 x 16 + class token; 37; a single token) and both head dims against fp32 torch on the rounded operands."""
+    from joligen_amd.modules.projected_d_vit import vit_attention
+
+    C = heads * hd
+    g = torch.Generator().manual_seed(T * 7 + hd)
+    qkv = (torch.randn(B, T, 3 * C, generator=g) * 0.8).to(dtype)
+    da = torch.randn(B, T, C, generator=g).to(dtype)
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = qr.reshape(B, T, 3, heads, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    ar = (((q * hd ** -0.5) @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(B, T, C)
+    ar.backward(da.float())
+    qd = qkv.to(D0).requires_grad_(True)
+    a = vit_attention(qd, heads)
+    a.backward(da.to(D0))
+    torch.cuda.synchronize()
+    assert relerr(a, ar.detach()) < TOL[dtype], relerr(a, ar.detach())
+    gr, gd = qr.grad.reshape(B, T, 3, C), qd.grad.float().cpu().reshape(B, T, 3, C)
+    for i, name in enumerate("qkv"):
+        if T == 1 and name != "v":          # one key: softmax = 1, the gradients to q and k are exactly zero
+            assert float(gd[:, :, i].abs().max()) < 1e-5
+            continue
+        assert relerr(gd[:, :, i], gr[:, :, i]) < 2.5 * TOL[dtype], (name, relerr(gd[:, :, i], gr[:, :, i]))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_vit_elementwise_kernels_vs_torch(dtype):
+    """gelu fwd / bwd (exact erf form), token assembly and its adjoint, LayerNorm input gradient + residual, the 16-bit transposition and the
+    un-patchify scatter, each against plain torch."""
+    from joligen_amd import _lib
+    from joligen_amd._lib import check
+    from joligen_amd.ops import _dt, _st
+
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    # gelu
+    x = (torch.randn(3, 37, 1536, generator=g) * 2).to(dtype)
+    dy = torch.randn(3, 37, 1536, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    yr = F.gelu(xr)
+    yr.backward(dy.float())
+    xd, dyd = x.to(D0), dy.to(D0)
+    y, dx = torch.empty_like(xd), torch.empty_like(xd)
+    check(L.jg_gelu_fwd(_dt(xd), xd.data_ptr(), y.data_ptr(), xd.numel(), _st()), "gelu")
+    check(L.jg_gelu_bwd(_dt(xd), xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), xd.numel(), _st()), "gelu_bwd")
+    assert relerr(y, yr.detach()) < TOL[dtype] and relerr(dx, xr.grad) < TOL[dtype]
+    # tokens
+    B, N, C = 2, 36, 384
+    pe = torch.randn(B, N, C, generator=g).to(dtype)
+    cls, pos = torch.randn(C, generator=g), torch.randn(N + 1, C, generator=g)
+    ref = torch.cat((cls.expand(B, 1, C), pe.float()), 1) + pos
+    ped, t = pe.to(D0), torch.empty(B, N + 1, C, device=D0, dtype=dtype)
+    clsd, posd = cls.to(D0), pos.to(D0)
+    check(L.jg_vit_tokens_fwd(_dt(ped), ped.data_ptr(), clsd.data_ptr(), posd.data_ptr(), t.data_ptr(), B, N, C, _st()), "tokens")
+    assert relerr(t, ref) < TOL[dtype]
+    dpe = torch.empty_like(ped)
+    check(L.jg_vit_tokens_bwd(_dt(t), t.data_ptr(), dpe.data_ptr(), B, N, C, _st()), "tokens_bwd")
+    assert torch.equal(dpe.cpu(), t[:, 1:].cpu())
+    # LayerNorm backward + residual
+    R = B * (N + 1)
+    x = torch.randn(R, C, generator=g).to(dtype)
+    dy = torch.randn(R, C, generator=g).to(dtype)
+    res = torch.randn(R, C, generator=g).to(dtype)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    xr = x.float().requires_grad_(True)
+    F.layer_norm(xr, (C,), gamma, beta, 1e-6).backward(dy.float())
+    xd, dyd, resd = x.to(D0), dy.to(D0), res.to(D0)
+    yd, mr = torch.empty_like(xd), torch.empty(R, 2, device=D0)
+    gd, bd = gamma.to(D0), beta.to(D0)
+    check(L.jg_layernorm_fwd(_dt(xd), xd.data_ptr(), gd.data_ptr(), bd.data_ptr(), yd.data_ptr(), mr.data_ptr(), R, C, 1e-6, _st()), "ln")
+    for rr in (resd, None):
+        dx = torch.empty_like(xd)
+        check(L.jg_layernorm_bwd_res(_dt(xd), xd.data_ptr(), dyd.data_ptr(), gd.data_ptr(), mr.data_ptr(), None if rr is None else rr.data_ptr(),
+                                     dx.data_ptr(), R, C, _st()), "ln_bwd_res")
+        want = xr.grad + (res.float() if rr is not None else 0)
+        assert relerr(dx, want) < TOL[dtype], relerr(dx, want)
+    # transposition
+    src = torch.randn(3, 257, 72, generator=g).to(dtype).to(D0)
+    dst = torch.empty(3, 72, 257, device=D0, dtype=dtype)
+    check(L.jg_transpose2d(_dt(src), src.data_ptr(), dst.data_ptr(), 3, 257, 72, _st()), "transpose2d")
+    assert torch.equal(dst.cpu(), src.transpose(1, 2).contiguous().cpu())
+    # un-patchify: adjoint of F.unfold-style patch gather with the (ci, flipped r, flipped s) column order
+    B, Hp, P = 2, 3, 16
+    dcol = torch.randn(B * Hp * Hp, 8 * P * P, generator=g).to(dtype)
+    dimg = torch.empty(B, Hp * P, Hp * P, 8, device=D0, dtype=dtype)
+    dcd = dcol.to(D0)
+    check(L.jg_unpatchify(_dt(dcd), dcd.data_ptr(), dimg.data_ptr(), B, Hp, Hp, P, _st()), "unpatchify")
+    want = dcol.view(B, Hp, Hp, 8, P, P).flip(4, 5).permute(0, 1, 4, 2, 5, 3).reshape(B, Hp * P, Hp * P, 8)
+    assert torch.equal(dimg.cpu(), want)
+
+
+def _build(g, dtype, P=None):
+    from joligen_amd.modules.projected_d import ProjectedDiscriminator
+
+    c = g["cfg"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")       # "random frozen weights": the fixture's synthetic weights are loaded right below
+        net = ProjectedDiscriminator("vitsmall", interp=c["interp"], img_size=c["S"])
+    assert list(net.state_dict().keys()) == g["keys"]
+    for k, v in net.state_dict().items():
+        assert tuple(v.shape) == tuple(g["shapes"][k]), k
+    net.load_state_dict(projd_state(g) if P is None else P)
+    net.jg_finalize(torch.device(D0), dtype)
+    net.train()
+    for n, p in net.named_parameters():
+        p.requires_grad_(not n.startswith("freeze"))
+    return net
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_vit_tokens_vs_oracle(golden_dir, fixture):
+    """the frozen ViT as one autograd node against the CPU oracle (`vit_small_tokens`, pinned on the reference fixture): the four token
+    sequences and the image gradient of a random linear functional of them, fp16-representable weights and inputs"""
+    from joligen_amd import ops
+
+    dtype = torch.float16
+    g = load(golden_dir, fixture)
+    P0 = {k: (v.half().float() if torch.is_floating_point(v) else v) for k, v in projd_state(g).items()}
+    net = _build(g, dtype, P0)
+    interp = g["cfg"]["interp"]
+    x = F.interpolate(g["real"], interp, mode="bilinear", align_corners=False).half().float()
+    xr = x.clone().requires_grad_(True)
+    toks = O.vit_small_tokens(P0, xr, "freeze_feature_network.pretrained.")
+    gen = torch.Generator().manual_seed(3)
+    ws = [torch.randn(t.shape, generator=gen).half().float() for t in toks]
+    sum((t * w).sum() for t, w in zip(toks, ws)).backward()
+    xd = ops.to_nhwc(x.to(D0), dtype, 8).requires_grad_(True)
+    net.arena.ensure_fresh()                  # (ProjectedDiscriminator.forward does this; here the backbone is called directly)
+    outs = net.freeze_feature_network.pretrained(xd)
+    for i, (o, t) in enumerate(zip(outs, toks)):
+        assert relerr(o, t.detach()) < 3e-3, (i, relerr(o, t.detach()))
+    ls = 64.0
+    torch.autograd.backward(outs, [w.to(D0).half() * (1.0 / ls) for w in ws])
+    dx = xd.grad.permute(0, 3, 1, 2)[:, :3].float() * ls
+    assert relerr(dx, xr.grad) < 1e-2, relerr(dx, xr.grad)
+    # forward-only call (the discriminator update's inputs carry no gradient): same values, nothing kept
+    with torch.no_grad():
+        outs2 = net.freeze_feature_network.pretrained(xd.detach())
+    for o, o2 in zip(outs, outs2):
+        assert torch.equal(o, o2)
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_projected_discriminator_vit_vs_reference_golden(golden_dir, dtype, fixture):
+    """The fixture's sequence on HIP: D(real), D(fake), the hinge discriminator loss and the gradient of the 24 trainable tensors (the MLP
+    heads; projector frozen), then the generator-side loss and its gradient w.r.t. the fake image through the frozen ViT, CCM and CSM.
+    state_dict keys / shapes are the reference's (192 entries).  Tolerances: forward a few 16-bit ulps of the logits; gradients twice the
+    measured rounding floor of this fixture (profiles/r03_rounding_yardstick_projd.json: the oracle with 16-bit storage between layers)."""
+    from joligen_amd import ops
+    from joligen_amd.modules.projected_d import hinge_loss
+
+    g = load(golden_dir, fixture)
+    net = _build(g, dtype)
+    y = _yard(fixture, dtype)
+    real = ops.to_nhwc(g["real"].to(D0), dtype, 8)
+    fake = ops.to_nhwc(g["fake"].to(D0), dtype, 8)
+    pred_real = net(real)
+    pred_fake = net(fake)
+    assert tuple(pred_real.shape) == tuple(g["pred_real"].shape) == (g["cfg"]["B"], 400)
+    tol = 6e-3 if dtype == torch.float16 else 4e-2
+    assert relerr(pred_real, g["pred_real"]) < max(tol, 3 * y["pred_real_rel"]), relerr(pred_real, g["pred_real"])
+    loss_D = (hinge_loss(pred_real, True) + hinge_loss(pred_fake, False)) * 0.5
+    assert abs(float(loss_D) - float(g["loss_D"])) < tol * abs(float(g["loss_D"]))
+    net.arena.g.zero_()
+    loss_D.backward()
+    torch.cuda.synchronize()
+    bad = []
+    P = dict(net.named_parameters())
+    assert len(g["grad_checks"]) == 24
+    for k, ref in g["grad_checks"].items():
+        v = P[k].grad.detach().float().cpu()
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        # (the yardstick is measured on 16-bit-representable weights; here the fixture's fp32 weights are rounded on the way in, and the
+        #  first layers' bias gradients are sums of +-1 hinge / ReLU masks over 2 images: same 0.08 floor as the convolutional projector's test)
+        t = max(4 * tol, 0.08, 2.0 * y["grad_worst"]) * float(ref[0]) + 1e-7
+        if abs(float(mine[0] - ref[0])) > t or abs(float(mine[1] - ref[1])) > 2 * t * max(1.0, v.numel() ** 0.5 / 4):
+            bad.append((k, mine.tolist(), ref.tolist()))
+    assert not bad, bad[:6]
+    fk = ops.to_nhwc(g["fake"].to(D0), dtype, 8).requires_grad_(True)
+    loss_G = hinge_loss(net(fk), True, relu=False)
+    assert abs(float(loss_G) - float(g["loss_G"])) < tol * abs(float(g["loss_G"])) + 2e-3
+    ls = 1024.0 if dtype == torch.float16 else 1.0
+    (loss_G * ls).backward()
+    dfk = fk.grad.permute(0, 3, 1, 2)[:, :3].float() / ls
+    # floor: the 16-bit oracle against the fp32 one on representable weights (dfake_rel) and against the fixture itself (dfake_rel_fixture: weight
+    # rounding flips single ReLUs of the MLP heads; measured 0.1 at 37 tokens in fp16 where dfake_rel is 0.002); test_vit_tokens_vs_oracle
+    # holds the backbone's image gradient to 1e-2 on representable weights
+    floor = max(2.0 * y["dfake_rel"], 3.0 * y["dfake_rel_fixture"])
+    assert relerr(dfk, g["dfake"]) < max(2 * tol, floor), (relerr(dfk, g["dfake"]), y["dfake_rel"], y["dfake_rel_fixture"])
+    for n, p in net.named_parameters():
+        if n.startswith("freeze"):
+            assert not p.requires_grad
+
+
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_projected_discriminator_vit_first_step_vs_oracle(golden_dir, fixture):
+    """per-parameter gradients (not just checksums) of the discriminator loss against the CPU oracle on fp16-representable weights"""
+    from joligen_amd import ops
+    from joligen_amd.modules.projected_d import hinge_loss
+
+    dtype = torch.float16
+    g = load(golden_dir, fixture)
+    g = dict(g, real=g["real"].half().float(), fake=g["fake"].half().float())
+    P0 = {k: (v.half().float() if torch.is_floating_point(v) else v) for k, v in projd_state(g).items()}
+    net = _build(g, dtype, P0)
+    r = projd_run_oracle({k: v.clone() for k, v in P0.items()}, g)
+    real, fake = ops.to_nhwc(g["real"].to(D0), dtype, 8), ops.to_nhwc(g["fake"].to(D0), dtype, 8)
+    loss_D = (hinge_loss(net(real), True) + hinge_loss(net(fake), False)) * 0.5
+    net.arena.g.zero_()
+    loss_D.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss_D) - float(r["loss_D"])) < 6e-3 * abs(float(r["loss_D"]))
+    errs = sorted(((relerr(p.grad, r["grads"][k]), k) for k, p in net.named_parameters() if k in r["grads"]), reverse=True)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(f"gpurun_out/grad_table_{fixture[:-3]}.txt", "w") as f:
+        f.write("\n".join(f"{e:10.3e} {k}" for e, k in errs))
+    y = _yard(fixture, dtype)
+    assert len(errs) == 24
+    assert errs[0][0] < max(2e-2, 2.0 * y["grad_worst"]), (errs[:6], y)
+    assert errs[len(errs) // 2][0] < max(6e-3, 2.0 * y["grad_median"]), (errs[len(errs) // 2], y)
+
+
+def test_vit_pretrained_backbone_loads_timm_keys(tmp_path):
+    """`jg_projd_pretrained`: a timm-keyed `vit_small_patch16_224` state_dict (here: the torch mirror's, random) loads strictly, and a
+    reference-layout discriminator checkpoint round-trips through state_dict() / load_state_dict()"""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    from vit_small_torch import VitSmallPatch16
+
+    from joligen_amd.modules.projected_d import ProjectedDiscriminator
+
+    torch.manual_seed(2)
+    mirror = VitSmallPatch16(96)
+    path = str(tmp_path / "vit_small.pth")
+    torch.save(mirror.state_dict(), path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")          # with a checkpoint there is no "random weights" warning
+        net = ProjectedDiscriminator("vitsmall", interp=96, img_size=64, pretrained_path=path)
+    assert net.backbone_pretrained
+    net.jg_finalize(torch.device(D0), torch.bfloat16)
+    sd = net.state_dict()
+    for k, v in mirror.state_dict().items():
+        assert torch.equal(sd["freeze_feature_network.pretrained." + k].cpu(), v), k
+    x = torch.rand(2, 3, 96, 96) * 2 - 1
+    from joligen_amd import ops
+
+    net.arena.ensure_fresh()
+    with torch.no_grad():
+        mine = net.freeze_feature_network.pretrained(ops.to_nhwc(x.to(D0), torch.bfloat16, 8))
+        mirror.eval()
+        t = mirror.patch_embed(x)
+        t = torch.cat((mirror.cls_token.expand(2, -1, -1), t), 1) + mirror.pos_embed
+        for i, blk in enumerate(mirror.blocks):
+            t = blk(t)
+            if i in (2, 5, 8, 11):
+                assert relerr(mine[(2, 5, 8, 11).index(i)], t) < 3e-2, (i, relerr(mine[(2, 5, 8, 11).index(i)], t))

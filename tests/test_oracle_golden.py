@@ -624,6 +624,32 @@ def test_projected_discriminator(golden_dir, fixture):
             torch.testing.assert_close(mine, ref, rtol=1e-4, atol=1e-5, msg=(name, k))
 
 
+@pytest.mark.parametrize("fixture", ["projd_vit.pt", "projd_vit256.pt"])
+def test_projected_discriminator_vit(golden_dir, fixture):
+    """`D_proj_network_type = "vitsmall"` (examples/example_gan_mario2sonic.json, BASELINE configs[2]): the CPU restatement of the ViT token
+    path (`configure_get_feats_vit_timm`), the Conv1d CCM, the FeatureFusionBlockVector CSM and the MLP heads of MultiScaleD(conv=False)
+    against the unmodified reference run over oracle/vit_small_torch.py (37 tokens at interp 96, 257 tokens at interp 256)"""
+    g = load(golden_dir, fixture)
+    P = projd_state(g)
+    with torch.no_grad():
+        feats = O.projd_features(P, torch.nn.functional.interpolate(g["real"], g["cfg"]["interp"], mode="bilinear", align_corners=False))
+    for i, f in enumerate(feats):
+        v = f.transpose(1, 2)
+        assert tuple(v.shape) == g["feat_shapes"][str(i)]
+        mine = torch.stack([v.norm(), (v * O.projection_vector(str(i), v.shape)).sum()])
+        torch.testing.assert_close(mine, g["feat_checks"][str(i)], rtol=1e-4, atol=1e-4 * float(g["feat_checks"][str(i)][0]) + 1e-6, msg=str(i))
+    r = projd_run_oracle(P, g)
+    torch.testing.assert_close(r["pred_real"], g["pred_real"], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(r["loss_D"], g["loss_D"], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(r["loss_G"], g["loss_G"], rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(r["dfake"], g["dfake"], rtol=1e-3, atol=1e-6 * float(g["dfake"].abs().max()))
+    assert set(r["grads"]) == set(g["grad_checks"]) and len(r["grads"]) == 24
+    for k, ref in g["grad_checks"].items():
+        v = r["grads"][k]
+        mine = torch.stack([v.norm(), (v * O.projection_vector(k, v.shape)).sum()])
+        torch.testing.assert_close(mine, ref, rtol=2e-4, atol=2e-4 * float(ref[0]) + 1e-7, msg=k)
+
+
 # ---- rounding yardstick: fp32 reference arithmetic with 16-bit storage between layers ----------------------------------------
 YARD_C2 = dict(ngf=64, mults=[1, 2, 4, 8], res_blocks=[2, 2, 2, 2], attn_res=[16], efficient=True, S=256, B=1)
 YARD_MED = dict(ngf=32, mults=[1, 2, 4], res_blocks=[1, 1, 1], attn_res=[16], efficient=True, S=64, B=2)
@@ -823,10 +849,14 @@ def projd_rounding_yardstick(golden_dir, fixture):
         out[tag] = dict(pred_real_rel=float((rnd["pred_real"] - ref["pred_real"]).norm() / ref["pred_real"].norm()),
                         dfake_rel=float((rnd["dfake"] - ref["dfake"]).norm() / ref["dfake"].norm()),
                         grad_median=errs[len(errs) // 2], grad_worst=errs[-1])
+        if "vit" in fixture:
+            # round 5: distance of the 16-bit run to the FIXTURE itself (fp32 weights and inputs): rounding the weights on the way in moves the
+            # MLP heads' pre-activations, and ONE ReLU of the 2 x 400 that flips changes the image gradient of that sample by several per cent
+            out[tag]["dfake_rel_fixture"] = float((rnd["dfake"] - g["dfake"]).norm() / g["dfake"].norm())
     return out
 
 
-@pytest.mark.parametrize("fixture", ["projd.pt", "projd_lite0.pt"])
+@pytest.mark.parametrize("fixture", ["projd.pt", "projd_lite0.pt", "projd_vit.pt", "projd_vit256.pt"])
 def test_projd_rounding_yardstick(golden_dir, fixture):
     """committed floor of tests/test_gpu_6_projd.py's gradient tolerances (JG_WRITE_YARDSTICK=1 rewrites the entry)"""
     import json
