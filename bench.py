@@ -87,7 +87,7 @@ def build_model(args, rank, local_rank, world):
     if args.model == "cut":
         # cut_model: resnet_9blocks / SegFormer-attn G + basic PatchGAN D + mlp_sample F, MoNCE, nce_idt, lsgan (example_gan_*.json shape)
         ov = dict(model_type="cut", G_netG=args.netG, G_ngf=64, G_nblocks=9, D_netDs=args.netDs.split(","), D_ndf=64, D_proj_interp=args.size,
-                  data_crop_size=args.size,
+                  D_proj_network_type=getattr(args, "proj", "efficientnet"), data_crop_size=args.size,
                   data_load_size=args.size, train_batch_size=args.batch, train_iter_size=1, train_optim="adam", train_G_ema=True,
                   train_G_ema_beta=0.999, gpu_ids=",".join(str(i) for i in range(world)), jg_act_dtype=args.dtype, name="bench",
                   checkpoints_dir="/tmp/jg_bench_ckpt/")
@@ -144,7 +144,7 @@ def cpu_baseline_subprocess(args, timeout_s=240):
     import subprocess
 
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--size", str(args.size),
-           "--efficient", str(args.efficient), "--model", args.model, "--netG", args.netG, "--netDs", args.netDs]
+           "--efficient", str(args.efficient), "--model", args.model, "--netG", args.netG, "--netDs", args.netDs, "--proj", getattr(args, "proj", "efficientnet")]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=dict(os.environ, HIP_VISIBLE_DEVICES=""))
         for line in out.stdout.splitlines():
@@ -203,10 +203,10 @@ def cpu_baseline(args):
             from joligen_amd.modules.projected_d import ProjectedDiscriminator
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
-                sdPD = {k: v.detach() for k, v in ProjectedDiscriminator(img_size=S).state_dict().items()}
+                sdPD = {k: v.detach() for k, v in ProjectedDiscriminator(getattr(args, "proj", "efficientnet"), interp=S, img_size=S).state_dict().items()}
         tr = O.OracleCUTTrainer(sdG, sdF, sdD, 9, layers, num_patches=256, T=T, monce=True, pool_size=50, pool_rng=random.Random(0),
                                 ema_beta=0.999, gen="segformer" if seg else (args.netG if "resnet_attn" in args.netG else "resnet"),
-                                sdPD=sdPD, proj_interp=-1)
+                                sdPD=sdPD, proj_interp=S if sdPD is not None else -1)
         A, Bm = batch["A"], batch["B"]
         with torch.no_grad():
             hw = [f.shape[2] * f.shape[3] for f in (O.segformer_backbone(sdG, A) if seg else tr._feats(sdG, A))]
@@ -324,15 +324,17 @@ def kernel_table(recs, nsteps):
     return out
 
 
-def cut_leg(local_rank, no_cpu):
-    """BASELINE configs[2] on one GPU: cut_model, SegFormer-attn G + [projected_d (tf_efficientnet_lite0 architecture, random frozen
-    weights), basic] D + mlp_sample F + MoNCE, 256x256, batch 16, bf16.  Returns the `cut` object of the JSON line."""
+def cut_leg(local_rank, no_cpu, proj="vitsmall"):
+    """BASELINE configs[2] on one GPU: cut_model, SegFormer-attn G + [projected_d, basic] D + mlp_sample F + MoNCE, 256x256, batch 16, bf16.
+    `proj` = D_proj_network_type: "vitsmall" (what examples/example_gan_mario2sonic.json selects: vit_small_patch16_224 at proj_interp 256, the
+    `cut` object of the JSON line, round 5) or "efficientnet" (tf_efficientnet_lite0, the `cut_effnet` object = the `cut` selection of rounds
+    3 - 4, kept for continuity); both with random frozen weights (no timm checkpoint offline)."""
     import warnings
 
     from joligen_amd import ops
 
     ns = argparse.Namespace(model="cut", netG="segformer_attn_conv", netDs="projected_d,basic", batch=16, size=256, dtype="bf16", efficient=1,
-                            force_exchange=False)
+                            force_exchange=False, proj=proj)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         model, _ = build_model(ns, 0, local_rank, 1)
@@ -385,8 +387,9 @@ def cut_leg(local_rank, no_cpu):
     return {"metric": "train images/sec at 256x256 (CUT G+D step)", "value": round(ns.batch * steps / dt, 3), "unit": "images/sec",
             "ms_per_step": round(dt / steps * 1e3, 3), "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2], 3), "steps": steps, "warmup": warmup,
             "dtype": "bf16", "data": "synthetic", **driver,
-            "config": {"workload": "cut_model, segformer_attn_conv G (MiT-b0 + heads + ResnetDecoder tail) + D_netDs [projected_d (tf_efficientnet_lite0 "
-                                   "architecture, random frozen weights: timm checkpoint unavailable), basic] + mlp_sample F, MoNCE, nce_idt, hinge / lsgan, "
+            "config": {"workload": "cut_model, segformer_attn_conv G (MiT-b0 + heads + ResnetDecoder tail) + D_netDs [projected_d ("
+                                   + ("vit_small_patch16_224 at proj_interp 256: 257 tokens, Conv1d CCM / vector CSM / 4 MLP heads" if proj == "vitsmall" else "tf_efficientnet_lite0")
+                                   + " architecture, random frozen weights: timm checkpoint unavailable), basic] + mlp_sample F, MoNCE, nce_idt, hinge / lsgan, "
                                    "256x256, batch 16/GPU, Adam x4 + EMA, iter_size 1 (BASELINE configs[2] shape; example_gan_mario2sonic.json without "
                                    "vision_aided / semantic mask)", "global_batch": ns.batch, "final_loss": round(loss, 5)},
             "roofline": roof, "cpu_baseline": cpu}
@@ -455,6 +458,7 @@ def main():
     ap.add_argument("--netG", default="resnet", help="--model cut only: resnet (BASELINE configs[0] generator, 9 blocks) | segformer_attn_conv (configs[2]) | resnet_attn | "
                          "mobile_resnet_attn (examples/example_gan_horse2zebra.json)")
     ap.add_argument("--netDs", default="basic", help="--model cut only: comma list out of basic, projected_d (BASELINE configs[2]: projected_d,basic)")
+    ap.add_argument("--proj", default="efficientnet", choices=["efficientnet", "vitsmall"], help="--model cut only: D_proj_network_type of projected_d")
     ap.add_argument("--model", default="palette", choices=["palette", "cm", "cut"],
                     help="palette = BASELINE configs[1] (the bench line); cm = the consistency-model step of configs[4] (same UNet)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -470,7 +474,8 @@ def main():
         return
     if args.leg:
         torch.cuda.set_device(0)
-        obj = cut_leg(0, args.no_cpu_baseline) if args.leg == "cut" else unet_leg(0, **EXTRA_LEGS[args.leg])
+        obj = (cut_leg(0, args.no_cpu_baseline) if args.leg == "cut" else cut_leg(0, True, proj="efficientnet") if args.leg == "cut_effnet"
+               else unet_leg(0, **EXTRA_LEGS[args.leg]))
         print(json.dumps(obj), flush=True)
         return
 
@@ -635,7 +640,7 @@ def main():
         # process and never at the palette line's expense
         print("[bench] cut leg", file=sys.stderr, flush=True)
         cut = leg_subprocess("cut", args.no_cpu_baseline)
-        for key in EXTRA_LEGS:
+        for key in list(EXTRA_LEGS) + ["cut_effnet"]:
             print(f"[bench] {key} leg", file=sys.stderr, flush=True)
             extra[key] = leg_subprocess(key, True)
 
@@ -645,7 +650,7 @@ def main():
             "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "ms_per_step_median": round(ms_median, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"cut_model, {args.netG} G (ngf 64, 9 blocks) + D_netDs [{args.netDs}] (projected_d: tf_efficientnet_lite0 architecture, random frozen weights, DESIGN.md 14) + mlp_sample F, MoNCE, nce_idt, lsgan / hinge, "
+            "config": {"workload": (f"cut_model, {args.netG} G (ngf 64, 9 blocks) + D_netDs [{args.netDs}] (projected_d: {args.proj} architecture, random frozen weights, DESIGN.md 14) + mlp_sample F, MoNCE, nce_idt, lsgan / hinge, "
                                     f"{args.size}x{args.size}, batch {args.batch}/GPU, Adam x3 + EMA, iter_size 1") if args.model == "cut" else
                                    f"{'palette_model DDPM' if args.model == 'palette' else 'cm_model consistency'}, {'efficient ' if args.efficient else ''}UNet unet_mha ngf64 mults[1,2,4,8] "
                                    f"res_blocks[2,2,2,2] mid-attn 16x32, {args.size}x{args.size}, batch {args.batch}/GPU, "

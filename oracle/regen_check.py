@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE (not product code): proof that tests/golden/ is what the committed recipes write from the UNMODIFIED reference.
 
-Regenerating all fixtures takes ~7 minutes of CPU (16 recipes, each builds reference models).  The outcome can only change when one
+Regenerating all fixtures takes ~7 minutes of CPU (17 recipes, each builds reference models).  The outcome can only change when one
 of its inputs changes, so the full run is keyed on a digest of those inputs:
 
     every oracle/*.py (recipes, ref_shim.py, jg_oracle.py and the helpers they import), every *.py of /root/reference, and the
@@ -26,7 +26,7 @@ REFERENCE = "/root/reference"
 
 RECIPES = ["make_golden_resize.py", "make_golden_pix2pix.py", "make_golden_accum.py", "make_golden_cutaccum.py", "make_golden_minsnr.py",
            "make_golden_heads16.py", "make_golden.py", "make_golden_cm.py", "make_golden_cond.py", "make_golden_cut.py",
-           "make_golden_cutstep.py", "make_golden_palette_loss.py", "make_golden_projd.py", "make_golden_resattn.py",
+           "make_golden_cutstep.py", "make_golden_palette_loss.py", "make_golden_projd.py", "make_golden_projd_vit.py", "make_golden_resattn.py",
            "make_golden_sampling.py", "make_golden_segformer.py"]
 
 

@@ -1,6 +1,6 @@
 """GPU: the reference's training loop (train.py:195-301, 351-357) replayed against joligen_amd with the SHIPPED example configurations
-(tests/examples/*.json are verbatim copies of /root/reference/examples/example_ddpm_noglasses2glasses.json and
-example_gan_horse2zebra.json) plus the measurement overrides of SURVEY.md Appendix C (the examples' own train_iter_size 16 / 8 is kept:
+(tests/examples/*.json are verbatim copies of /root/reference/examples/example_ddpm_noglasses2glasses.json,
+example_gan_horse2zebra.json and example_gan_mario2sonic.json) plus the measurement overrides of SURVEY.md Appendix C (the examples' own train_iter_size 16 / 8 is kept:
 two accumulation windows each):
 
     opt = parse(example JSON + overrides) -> create_model -> data_dependent_initialize -> setup -> single_gpu
@@ -126,6 +126,36 @@ def test_example_gan_horse2zebra_json_through_the_train_loop(tmp_path):
         assert os.path.exists(os.path.join(d, f"latest_net_{name}.pth")), name
     sd = torch.load(os.path.join(d, "latest_net_G_A.pth"), map_location="cpu")
     assert "resnet_blocks.0.conv1.conv.0.weight" in sd and "deconv3_attention.weight" in sd
+
+
+def test_example_gan_mario2sonic_json_through_the_train_loop(tmp_path):
+    """BASELINE configs[2]'s own JSON (examples/example_gan_mario2sonic.json, verbatim): segformer_attn_conv generator, projected discriminator
+    with the ViT projector (`proj_network_type: "vitsmall"`, `proj_interp: 256` -> 257 tokens) + basic, MoNCE, lsgan / hinge, crop 128, batch 2.
+    Two overrides for branches that are out of scope: `vision_aided` dropped from D_netDs (CLIP / DINO / Swin backbones) and
+    the semantic-mask branch (f_s network + online mask dataset) off."""
+    from joligen_amd.options import opt_from_json
+
+    ov = _appendix_c(tmp_path, name="m2s_e2e", D_netDs=["projected_d", "basic"], train_semantic_mask=False, train_mask_out_mask=False)
+    opt = opt_from_json(os.path.join(EX, "example_gan_mario2sonic.json"), ov)
+    assert opt.model_type == "cut" and opt.G_netG == "segformer_attn_conv" and opt.D_proj_network_type == "vitsmall" and opt.D_proj_interp == 256
+    assert opt.train_batch_size == 2 and opt.data_crop_size == 128 and opt.train_iter_size == 1
+    g = torch.Generator().manual_seed(6)
+    data = {"A": torch.rand(2, 3, 128, 128, generator=g) * 2 - 1, "B": torch.rand(2, 3, 128, 128, generator=g) * 2 - 1,
+            "A_img_paths": ["synthetic"] * 2, "B_img_paths": ["synthetic"] * 2}
+    torch.manual_seed(0)
+    model, losses = _loop(opt, data, 4)
+    from joligen_amd.modules.projected_d_vit import MultiScaleDVit, ProjVit
+
+    netD = model.netD_B_projected_d
+    assert isinstance(netD.freeze_feature_network, ProjVit) and isinstance(netD.discriminator, MultiScaleDVit)
+    assert netD.freeze_feature_network.RESOLUTIONS == [257] * 4
+    assert set(losses[0]) >= {"G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_projected_d", "G_GAN_D_B_basic", "D_tot", "D_GAN_D_B_projected_d"}
+    assert all(math.isfinite(v) for l in losses for v in l.values()), losses
+    model.save_networks("latest")
+    sd = torch.load(os.path.join(str(tmp_path), "m2s_e2e", "latest_net_D_B_projected_d.pth"), map_location="cpu")
+    assert sd["freeze_feature_network.pretrained.pos_embed"].shape == (1, 257, 384)
+    assert sd["freeze_feature_network.scratch.layer3_ccm.weight"].shape == (512, 384, 1)
+    assert sd["discriminator.mini_discs.3.1.weight"].shape == (100, 256 * 257)
 
 
 def test_exchange_path_on_one_gpu_costs_under_a_millisecond():
