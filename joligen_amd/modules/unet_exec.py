@@ -70,6 +70,34 @@ FUSE_GN_REDUCE = os.environ.get("JG_FUSE_GN_REDUCE", "0") != "0"
 # kernels run underneath the HBM-bound GroupNorm-backward passes of the chain instead of in front of them.  The streams meet again at
 # the end of the backward (and before a gradient chunk leaves for the all-reduce).
 WGRAD_STREAM = os.environ.get("JG_WGRAD_STREAM", "1") != "0"
+# JG_WGRAD_CU_MASK = "<first>:<count>" (A/B): the weight-gradient stream is created with hipExtStreamCreateWithCUMask over CU-mask bits
+# [first, first + count) of the 256 (bit i = compute unit i / 8 of XCD i % 8): a fixed CU partition for the MFMA-bound weight gradients
+# instead of free competition with the HBM-bound normalisation passes of the chain.  Unset = a plain stream.
+WGRAD_CU_MASK = os.environ.get("JG_WGRAD_CU_MASK", "")
+
+
+def cu_masked_stream(device, first, count, total=256):
+    """a torch stream over `hipExtStreamCreateWithCUMask` (the C ABI takes any hipStream_t: kernels launched on it run on the masked CUs)"""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    words = (total + 31) // 32
+    mask = (C.c_uint32 * words)()
+    for i in range(first, min(total, first + count)):
+        mask[i // 32] |= 1 << (i % 32)
+    st = C.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed with {rc}")
+    return torch.cuda.ExternalStream(st.value, device=device)
+
+
+def _side_stream(device):
+    if WGRAD_CU_MASK:
+        first, count = (int(v) for v in WGRAD_CU_MASK.split(":"))
+        return cu_masked_stream(device, first, count)
+    return torch.cuda.Stream(device=device)
 # issue order of a 3x3 layer's two backward convolutions: 1 = weight gradient first (it starts together with the input gradient and has
 # that kernel's time plus the GroupNorm-backward passes behind it to finish in); 0 = input gradient first (the side stream then waits
 # for it as well).  Same-box A/B, two runs each: 49.19 vs 49.49 ms/step (profiles/r04_wgrad_first_ab.log).
@@ -401,7 +429,7 @@ class UNetExecutor:
             return conv_wgrad(dy, x, m, **kw)
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream(device=dy.device)
+            self._side = _side_stream(dy.device)
             # a gradient chunk's all-reduce is ordered behind the CURRENT stream only: the weight gradients of the side stream are
             # brought in right before a chunk leaves (parallel.EarlyExchange._launch), not after every layer
             import weakref
