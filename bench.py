@@ -351,10 +351,12 @@ def cut_leg(local_rank, no_cpu, proj="vitsmall"):
         warnings.simplefilter("always")
         dt, per_step = timed_region(step, steps, warmup, torch.cuda.synchronize)
     import joligen_amd
-    # which driver ran the timed steps: "graph" = discriminator half replayed from a hipGraph, "early" = that half eager
-    # on a second stream, "sequential" = the reference's order; the canary's verdict and any jg_graph_D warning travel with the number
+    # which driver ran the timed steps: "graph+graphG" = the generator half (forward graph, backward graph) AND the
+    # discriminator half replayed from hipGraphs, "graph" = the discriminator half only, "early" = that half eager on a second stream,
+    # "sequential" = the reference's order; the canary's verdict and any jg_graph_D warning travel with the number
     driver = {"step_driver": model.step_driver, "hip_graphs_safe": bool(joligen_amd.HIP_GRAPHS_SAFE),
-              "graph_canary": ("passed" if model.step_driver == "graph" else ("failed" if "graph dropped" in model.step_driver_note else "not run")),
+              "graph_canary": ("passed" if model.step_driver == "graph+graphG" else ("failed" if "graph dropped" in model.step_driver_note else
+                               "discriminator half only" if model.step_driver == "graph" else "not run")),
               "note": model.step_driver_note, "warnings": [str(w.message)[:300] for w in rec if "jg_" in str(w.message)][:4],
               "DEBUG_CLR_GRAPH_PACKET_CAPTURE": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE")}
     for w in rec:

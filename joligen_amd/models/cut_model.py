@@ -196,10 +196,13 @@ class CUTModel(BaseModel):
             p.rng = rng
 
     def forward(self):
-        B = self.batch_size
         if self.opt.isTrain:
             self.real_A_pool.query(self.real_A)
             self.real_B_pool.query(self.real_B)
+        self._forward_core()
+
+    def _forward_core(self):
+        B = self.batch_size
         self.real = torch.cat((self.real_A, self.real_B), dim=0) if self.opt.alg_cut_nce_idt else self.real_A
         self.fake = self._net("G_A")(self.real)
         self.fake_B = self.fake[:B]
@@ -309,14 +312,16 @@ class CUTModel(BaseModel):
         gG, gD = self.group_G, self.group_D
         its = self.opt.train_iter_size
         self._group_flags(gG)
-        for fn in gG.forward_functions or []:
-            getattr(self, fn)()
-        for fn in gG.backward_functions:
-            getattr(self, fn)()
         main = torch.cuda.current_stream(self.device)
         side = self.__dict__.get("_d_stream")
         if side is None:
             side = self._d_stream = torch.cuda.Stream(device=self.device)
+        gst = self._g_half_from_graph(its)           # forward + losses of the generator group replayed from a hipGraph (None: eager)
+        if gst is None:
+            for fn in gG.forward_functions or []:
+                getattr(self, fn)()
+            for fn in gG.backward_functions:
+                getattr(self, fn)()
         self._drawn_fakes = self._draw_pool_fakes(side)
         self.real_B.record_stream(side)
         side.wait_stream(main)
@@ -334,8 +339,12 @@ class CUTModel(BaseModel):
         if os.environ.get("JG_DBG_EARLY_D_SYNC"):      # dev (tools/dbg_graph_d.py): the two halves one after the other
             torch.cuda.synchronize()
         self._group_flags(gG)
-        for loss in gG.loss_backward:
-            (getattr(self, loss) / its).backward()
+        if gst is not None:
+            gst["bwd"].replay()
+            self.step_driver += "+graphG"
+        else:
+            for loss in gG.loss_backward:
+                (getattr(self, loss) / its).backward()
         self._group_finish(gG)
         main.wait_stream(side)
         self._group_flags(gD)            # the flags end the step as the sequential driver leaves them
@@ -343,6 +352,117 @@ class CUTModel(BaseModel):
         for obj in self.objects_to_update:
             obj.update(self.niter)
         self.poll_overflow()
+
+    # ---- the generator half as two hipGraphs ------------------------------------------------------------------------------
+    def _g_outputs(self):
+        names = ["fake", "fake_B", "loss_G_tot", "loss_G_NCE"] + ["loss_G_GAN_" + dn for dn in self.discriminators_names]
+        if self.opt.alg_cut_nce_idt:
+            names += ["idt_B", "loss_G_NCE_Y"]
+        return names
+
+    def _g_half_from_graph(self, its):
+        """`jg_graph_G` (default on with `jg_graph_D`; `JG_GRAPH_G=0` / `1` overrides): the generator group's forward + losses and its
+        backward -- ~2500 launches, 35 ms of host enqueue per step at the configs[2] shape, which IS the step time on a host slower than
+        the GPU side (336 images/s on the driver's box against 377 here) -- are captured once (third step on) as TWO graphs
+        that share a memory pool: graph F = forward_cut + compute_G_loss on static copies of real_A / real_B, graph B = the backward of
+        loss_G_tot (retain_graph: its saved activations are F's outputs).  A step replays F, enqueues the discriminator half on the side
+        stream (its own graph, `_d_half_from_graph`), replays B under it, and runs the three optimizer launches eagerly (their step
+        count and learning rate are host scalars).  What makes this possible: DropPath / Dropout2d scales and the patch ids are drawn
+        ON THE DEVICE inside the capture (torch's graph-safe Philox state advances per replay; `torch.randperm` is replaced by rand + topk
+        while capturing), the history pools stay outside (the real-image pools before F, the fake pool between F and the discriminator
+        half), and every arena's 16-bit working copies are refreshed INSIDE graph F (captured while dirty).  The same two guards as
+        for the discriminator half: `HIP_GRAPHS_SAFE`, and a canary -- replay F + B twice from the same RNG state with 8192 eager
+        launches in between; losses and the generator's gradient must agree -- after which the touched state (gradient arenas,
+        spectral-norm vectors, BatchNorm statistics, RNG offset) is restored.  Returns the graph state or None (eager half)."""
+        want = os.environ.get("JG_GRAPH_G", "")
+        if not ((getattr(self.opt, "jg_graph_G", True) or want == "1") and want != "0"):
+            return None
+        import joligen_amd
+
+        if not joligen_amd.HIP_GRAPHS_SAFE or self.__dict__.get("_gg_failed"):
+            return None
+        if (self.act_dtype == torch.float16 or self.niter <= 2 or ops.KERNEL_TIMING is not None or self.patch_ids_injection is not None
+                or getattr(getattr(self._net("G_A"), "rand", None), "source", None) is not None):
+            return None
+        nets = [self._net(n) for n in self.model_names]
+        key = (tuple(self.real_A.shape), tuple(self.real_B.shape), self.real_A.dtype, its, float(self.loss_scale),
+               tuple(n.arena.p.data_ptr() for n in nets), tuple(n.training for n in nets))
+        graphs = self.__dict__.setdefault("_gg_graphs", {})
+        st = graphs.get(key)
+        if st is None:
+            if len(graphs) >= 3:
+                return None
+            st = self._g_capture(its, nets)
+            if st is None:
+                return None
+            graphs[key] = st
+        if self.opt.isTrain:               # the metric pools of forward(): host draws in the reference's order, outside the graph
+            self.real_A_pool.query(self.real_A)
+            self.real_B_pool.query(self.real_B)
+        st["real_A"].copy_(self.real_A)
+        st["real_B"].copy_(self.real_B)
+        self.real_A, self.real_B = st["real_A"], st["real_B"]
+        st["fwd"].replay()
+        for k, v in st["outs"].items():
+            setattr(self, k, v)
+        if self.fake_B_pool.pool_size > 0:        # the pool keeps views of what it is handed: not of a buffer the next replay overwrites
+            self.fake_B = self.fake_B.clone()
+        return st
+
+    def _g_capture(self, its, nets):
+        import warnings
+
+        st = dict(real_A=self.real_A.clone(), real_B=self.real_B.clone())
+        state = [n.arena.g for n in nets] + [b for n in nets for b in n.buffers()]
+        saved = [t.clone() for t in state]
+        keep_inputs = (self.real_A, self.real_B)
+        rng = torch.cuda.get_rng_state(self.device)
+        try:
+            for n in nets:
+                n.arena.dirty = True               # the refresh of every working copy belongs to graph F
+            self.real_A, self.real_B = st["real_A"], st["real_B"]
+            gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf, capture_error_mode="thread_local"):
+                self._forward_core()
+                self.compute_G_loss()
+            st["outs"] = {k: getattr(self, k) for k in self._g_outputs()}
+            with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode="thread_local"):
+                (self.loss_G_tot / its).backward(retain_graph=True)
+            st["fwd"], st["bwd"] = gf, gb
+
+            def once():
+                torch.cuda.set_rng_state(rng, self.device)
+                for t, t0 in zip(state, saved):
+                    t.data.copy_(t0)
+                gf.replay()
+                gb.replay()
+                return torch.stack([st["outs"]["loss_G_tot"].detach().float().reshape(()), self._net("G_A").arena.g.norm()]).clone()
+
+            first = once()
+            burst = torch.zeros(64, device=self.device)
+            for _ in range(8192):
+                burst.add_(1.0)
+            second = once()
+            if os.environ.get("JG_DBG_GRAPH_CANARY_FAIL") == "G":      # tests: the fall-back path of a failing canary
+                second = second * 1.5 + 1.0
+            # same RNG state, same operands: the two runs differ by the summation order of the fp32 atomics only (measured 2e-4 on the loss,
+            # 2e-3 on the gradient norm of a small model); the corruption this guards against shows as NaN or a loss that moves by per cents
+            tol = torch.tensor([5e-3, 5e-2], device=first.device)
+            ok = bool((torch.isfinite(first).all() & torch.isfinite(second).all() & ((first - second).abs() <= tol * first.abs() + 1e-6).all()).item())
+            if not ok:
+                raise RuntimeError(f"replays of the generator graphs disagree after interleaved eager launches ({first.tolist()} vs {second.tolist()})")
+        except Exception as e:
+            warnings.warn(f"jg_graph_G: the generator half stays eager ({e})")
+            self.step_driver_note = (self.step_driver_note + "; " if self.step_driver_note else "") + f"generator graph dropped: {e}"
+            self._gg_failed = True
+            st = None
+        for t, t0 in zip(state, saved):
+            t.data.copy_(t0)
+        torch.cuda.set_rng_state(rng, self.device)
+        self.real_A, self.real_B = keep_inputs
+        for n in nets:
+            n.arena.dirty = True
+        return st
 
     # ---- the discriminator half as a hipGraph -----------------------------------------------------------------------------
     def _d_half_body(self, real, fakes, its):
@@ -433,7 +553,7 @@ class CUTModel(BaseModel):
                 t.data.copy_(t0)      # .data: no version bump (frozen-BN tables key on versions; tensors saved by G's forward stay valid)
             graph.replay()
             second = st["tot"].detach().clone()
-            if os.environ.get("JG_DBG_GRAPH_CANARY_FAIL"):      # tests: the fall-back path of a failing canary
+            if os.environ.get("JG_DBG_GRAPH_CANARY_FAIL") == "1":      # tests: the fall-back path of a failing canary
                 second = second * 1.5 + 1.0
             for t, t0 in zip(state, saved):
                 t.data.copy_(t0)      # .data: no version bump (frozen-BN tables key on versions; tensors saved by G's forward stay valid)

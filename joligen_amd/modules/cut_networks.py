@@ -59,7 +59,11 @@ class PatchSampleF(nn.Module):
             if patch_ids is not None:
                 patch_id = patch_ids[feat_id].reshape(-1)
             else:
-                patch_id = torch.randperm(H * W, device=feat.device)[: int(min(num_patches, H * W))]
+                # `torch.randperm(H * W)[:P]` of the reference (cut_networks.py:57-60) as P distinct uniform positions from ONE Philox draw
+                # + top-k: the same distribution, no host synchronisation, and capturable in a hipGraph (cut_model._g_capture) with the
+                # SAME numbers as the eager launch sequence draws from the same generator state
+                P = int(min(num_patches, H * W))
+                patch_id = torch.rand(H * W, device=feat.device).topk(P).indices
             x = ops.gather_patches(feat, patch_id, C)                         # [B*P, C] fp32
             if self.use_mlp:
                 mlp = getattr(self, "mlp_%d" % feat_id)

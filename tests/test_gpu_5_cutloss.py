@@ -666,7 +666,7 @@ def test_cut_c3_shape_first_step_gradients_vs_oracle(dtype):
         assert sorted(m_)[len(m_) // 2] <= 1.5 * sorted(f_)[len(f_) // 2] + 1e-4, (key, sorted(m_)[len(m_) // 2], sorted(f_)[len(f_) // 2])
 
 
-def _run_cut_driver(cfg, data, monkeypatch, early, graph, calls=7, canary_fail=False):
+def _run_cut_driver(cfg, data, monkeypatch, early, graph, calls=7, canary_fail=False, graph_g=True):
     """`calls` x optimize_parameters() from seed 3 under one step driver; returns losses per call, Adam's first moments, the driver that
     ran the LAST call, its note and the jg_graph_D warnings."""
     import random
@@ -677,8 +677,9 @@ def _run_cut_driver(cfg, data, monkeypatch, early, graph, calls=7, canary_fail=F
 
     monkeypatch.setenv("JG_EARLY_D", "1" if early else "0")
     monkeypatch.setenv("JG_GRAPH_D", "1" if graph else "0")
+    monkeypatch.setenv("JG_GRAPH_G", "1" if (graph and graph_g) else "0")
     if canary_fail:
-        monkeypatch.setenv("JG_DBG_GRAPH_CANARY_FAIL", "1")
+        monkeypatch.setenv("JG_DBG_GRAPH_CANARY_FAIL", canary_fail if isinstance(canary_fail, str) else "1")
     else:
         monkeypatch.delenv("JG_DBG_GRAPH_CANARY_FAIL", raising=False)
     torch.manual_seed(3)
@@ -695,18 +696,19 @@ def _run_cut_driver(cfg, data, monkeypatch, early, graph, calls=7, canary_fail=F
             m.optimize_parameters()
             losses.append([float(getattr(m, "loss_D_GAN_" + dn)) for dn in m.discriminators_names] + [float(m.loss_G_tot)])
     torch.cuda.synchronize()
-    dropped = [str(w.message) for w in rec if "jg_graph_D" in str(w.message)]
+    dropped = [str(w.message) for w in rec if "jg_graph_" in str(w.message)]
     params = {n: m._net(n).arena.m.detach().double().cpu() for n in m.model_names}       # Adam's first moment: linear in every gradient
     weights = {n: m._net(n).arena.p.detach().double().cpu() for n in m.model_names}
     return dict(losses=torch.tensor(losses, dtype=torch.float64), m1=params, w=weights, dropped=dropped, driver=m.step_driver, note=m.step_driver_note)
 
 
-def _assert_graph_ran(r):
-    """VERDICT r4 weak #1: where hipGraph replays are safe, a dropped graph FAILS the test (it used to pass with a printed note)."""
+def _assert_graph_ran(r, want="graph+graphG"):
+    """where hipGraph replays are safe, a dropped graph FAILS the test (it used to pass with a printed note).
+    "graph" = the discriminator half replayed, "+graphG" = the generator half (forward and backward graphs) as well."""
     import joligen_amd
 
     if joligen_amd.HIP_GRAPHS_SAFE:
-        assert r["driver"] == "graph" and not r["dropped"], (r["driver"], r["note"], r["dropped"])
+        assert r["driver"] == want and not r["dropped"], (r["driver"], r["note"], r["dropped"])
     else:
         assert r["driver"] == "early" and "HIP_GRAPHS_SAFE" in r["note"], (r["driver"], r["note"])
 
@@ -732,13 +734,15 @@ def test_cut_step_drivers_agree(iter_size, monkeypatch):
     a2 = _run_cut_driver(cfg, data, monkeypatch, False, False)
     b = _run_cut_driver(cfg, data, monkeypatch, True, False)
     c = _run_cut_driver(cfg, data, monkeypatch, True, True)
+    d = _run_cut_driver(cfg, data, monkeypatch, True, True, graph_g=False)
     assert a["driver"] == "sequential" and b["driver"] == "early", (a["driver"], b["driver"])
     _assert_graph_ran(c)
+    _assert_graph_ran(d, "graph")
     la, pa = a["losses"], a["m1"]
     floor_l = float(((la - a2["losses"]).abs() / la.abs()).max())
     floor_p = max(float((pa[n] - a2["m1"][n]).norm() / pa[n].norm()) for n in pa)
     print("run-to-run floor: losses %.2e, first moments %.2e" % (floor_l, floor_p))
-    for tag, r in (("early", b), ("graph", c)):
+    for tag, r in (("early", b), ("graph D + G", c), ("graph D", d)):
         l, p = r["losses"], r["m1"]
         assert torch.isfinite(l).all(), (tag, l)
         assert float(((l - la).abs() / la.abs()).max()) <= 4 * floor_l + 2e-3, (tag, float(((l - la).abs() / la.abs()).max()), floor_l)
@@ -786,8 +790,12 @@ def test_cut_graph_canary_failure_falls_back_to_eager(monkeypatch):
     cfg = dict(_SMALL_CUT, train={"batch_size": 2, "G_ema": True, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0})
     b = _run_cut_driver(cfg, data, monkeypatch, True, False, calls=5)
     c = _run_cut_driver(cfg, data, monkeypatch, True, True, calls=5, canary_fail=True)
-    assert c["driver"] == "early" and c["dropped"] and "graph dropped" in c["note"], (c["driver"], c["note"], c["dropped"])
+    assert c["driver"].startswith("early") and c["dropped"] and "graph dropped" in c["note"], (c["driver"], c["note"], c["dropped"])
     assert float(((c["losses"] - b["losses"]).abs() / b["losses"].abs()).max()) <= 2e-2
+    # the generator graphs' canary: the discriminator half keeps its graph, the generator half goes back to eager launches
+    e = _run_cut_driver(cfg, data, monkeypatch, True, True, calls=5, canary_fail="G")
+    assert e["driver"] == "graph" and any("jg_graph_G" in w for w in e["dropped"]) and "generator graph dropped" in e["note"], (e["driver"], e["note"])
+    assert float(((e["losses"] - b["losses"]).abs() / b["losses"].abs()).max()) <= 2e-2
 
 
 def test_cut_step_drivers_agree_c3_shape(monkeypatch):
