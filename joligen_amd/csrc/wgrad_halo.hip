@@ -44,6 +44,11 @@ typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
 __device__ __forceinline__ int f4(int c) { return ((c >> 1) & 1) | (((c >> 3) & 1) << 1); }
 // 3-bit swizzle of a 256-byte pixel row (8 blocks of 32 B)
 __device__ __forceinline__ int f8(int c) { return (c & 3) | (((c >> 3) & 1) << 2); }
+// 1-bit swizzle of a 64-byte pixel row (2 blocks of 32 B): the 8 pixels {h..h+3, h+8..h+11} of a service group are four bank quarters
+// (pixel % 4) x the two blocks, told apart by bit 3 of the column
+__device__ __forceinline__ int f2(int c) { return (c >> 3) & 1; }
+// block swizzle of a dy pixel row of BCO channels
+template <int BCO> __device__ __forceinline__ int fdy(int c) { return BCO == 32 ? f2(c) : BCO == 64 ? f4(c) : f8(c); }
 
 // XMODE 0: plain zero padding; 1: mirrored borders (REFLECT); 2: x is the half-resolution tensor read through the nearest-upsample map
 //
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
     const int pos = rd * NT + tid;
     const int px = pos / CPP, cpos = pos % CPP;
     const int ty = px >> 4, xx = px & 15;
-    const int blk = (cpos >> 1) ^ (BCO == 64 ? f4(xx) : f8(xx));
+    const int blk = (cpos >> 1) ^ fdy<BCO>(xx);
     d_rel[rd] = (ty * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8;
   }
   }
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
         const int pos = rd * NT + tid;
         const int px = pos / CPP, cpos = pos % CPP;
         const int yy = px >> 4, xx = px & 15;
-        const int blk = (cpos >> 1) ^ (BCO == 64 ? f4(xx) : f8(xx));
+        const int blk = (cpos >> 1) ^ fdy<BCO>(xx);
         glds16(db + (yy * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8, l0 + (HALO_CH + rd * NT) * 16);
       }
   #pragma unroll
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int cb = wm * CPW + i;
-      abase[i][rd] = HALO_CH * 16 + (trow * 16 + xq) * DY_ROWB + ((cb ^ (BCO == 64 ? f4(xq) : f8(xq))) << 5) + (i16 & 3) * 8;
+      abase[i][rd] = HALO_CH * 16 + (trow * 16 + xq) * DY_ROWB + ((cb ^ fdy<BCO>(xq)) << 5) + (i16 & 3) * 8;
     }
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
@@ -363,19 +368,22 @@ void launch_wg(const WgP& p, hipStream_t st) {
 
 template <typename T>
 void dispatch_wg(const WgP& p, hipStream_t st) {
-  const int cfg = jg_tune(JG_TUNE_WGRAD_HALO_CFG);   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co; 3: 8x16 x 64 co, 4 waves
+  const int cfg = jg_tune(JG_TUNE_WGRAD_HALO_CFG);   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co; 3: 8x16 x 64 co, 4 waves; 4: 8x16 x 32 co, 4 waves
   // the 128-channel x 8-row configuration halves the L2->LDS bytes per MFMA but doubles the atomic
   // volume: it pays once a block has >= 64 (16-row) tiles to walk
   const long per1 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.Cout / 64) * (p.Cin / 64) / 256;
   const bool big = cfg == 2 || (cfg == 0 && per1 >= 64);
   // mirrored borders (pad_mode 1) are compiled only into the 16x16 / 64-co configuration: the extra address arithmetic would push
   // the register-tight 8-row configurations into spilling
-  jg_note_kernel(p.reflect || !(big && p.Cout % 128 == 0) ? (cfg == 3 && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,64 co,4 waves>" : "wgrad3x3_halo_kernel<16 rows,64 co>")
+  jg_note_kernel(p.reflect || !(big && p.Cout % 128 == 0) ? (cfg == 3 && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,64 co,4 waves>" :
+                                                             (cfg == 4 || cfg == 5) && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,32 co,4 waves>" : "wgrad3x3_halo_kernel<16 rows,64 co>")
                                                           : "wgrad3x3_halo_kernel<8 rows,128 co>");
   if (p.reflect) launch_wg<T, 16, 2, 2, 1>(p, st);
   else if (p.x_up && big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2, 2>(p, st);   // upsample-on-read: the two shapes the UNet up-blocks use
   else if (p.x_up) launch_wg<T, 16, 2, 2, 2>(p, st);
   else if (cfg == 3) launch_wg<T, 8, 4, 1>(p, st);   // 4 waves, 64 co x 8-row tiles, 2 workgroups / CU
+  else if (cfg == 4 || (cfg == 5 && !(big && p.Cout % 128 == 0)))
+    launch_wg<T, 8, 2, 1>(p, st);   // 4 waves, 32 co x 8-row tiles, pipelined loop, 2 INDEPENDENT workgroups / CU (round 5); 5 = instead of the 16-row tile only
   else if (big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2>(p, st);
   else launch_wg<T, 16, 2, 2>(p, st);
 }

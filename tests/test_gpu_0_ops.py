@@ -361,6 +361,8 @@ WGRAD_FORCED = [
     (2, "wgrad3x3_halo_kernel<8,4,2>  (bench: 128 -> 128 at 256x256)", (2, 32, 32, 128, 128)),
     (2, "wgrad3x3_halo_kernel<8,4,2>", (1, 64, 32, 64, 256)),
     (3, "wgrad3x3_halo_kernel<8,4,1>", (2, 32, 32, 128, 64)),
+    (4, "wgrad3x3_halo_kernel<8,2,1> (round 5: 32 co, two independent workgroups per CU)", (2, 32, 32, 128, 64)),
+    (4, "wgrad3x3_halo_kernel<8,2,1>", (3, 16, 48, 64, 96 + 32)),
 ]
 
 
