@@ -397,6 +397,8 @@ class _ReflectConv2dFn(JGFunction):
 
 def reflect_conv2d(x, meta: ConvMeta):
     """conv(reflection_pad(x, 1)) for a 3x3 / pad-0 ConvMeta (see reflect_conv_ok)."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.reflect_conv2d(x, meta.weight.permute(0, 2, 3, 1), meta.bias)
     return _ReflectConv2dFn.apply(x, meta.weight, meta.bias, meta)
 
 
@@ -536,6 +538,10 @@ class _ConvTranspose2dFn(JGFunction):
 
 
 def conv_transpose2d(x, meta: ConvMeta, output_padding=0):
+    if TORCH_OPS_BOUNDARY:
+        from .ops_library_cut import conv_transpose2d_via_ops
+
+        return conv_transpose2d_via_ops(x, meta, output_padding)
     return _ConvTranspose2dFn.apply(x, meta.weight, meta.bias, meta, output_padding)
 
 
@@ -561,6 +567,8 @@ class _ReflectPadFn(JGFunction):
 
 def reflect_pad2d(x, pad):
     """nn.ReflectionPad2d(pad) on NHWC."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.reflect_pad2d(x, pad)
     return _ReflectPadFn.apply(x, pad)
 
 
@@ -614,6 +622,8 @@ class _ActFn(JGFunction):
 
 def activation(x, act):
     """stand-alone nn.ReLU / nn.LeakyReLU(0.2) / nn.Tanh (JG_ACT_*) where no normalisation precedes the activation."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.act(x, act)
     return _ActFn.apply(x, act)
 
 
@@ -909,6 +919,8 @@ class _GatherPatchesFn(JGFunction):
 def gather_patches(feat, ids, C):
     """feat [B,H,W,ld] 16-bit NHWC -> [B*P, C] fp32 rows at the flattened positions `ids` (shared by the batch):
     `feat.permute(0,2,3,1).flatten(1,2)[:, patch_id, :].flatten(0,1)` of cut_networks.py:45-57."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.gather_patches(feat, ids.contiguous().long(), C)
     return _GatherPatchesFn.apply(feat, ids.contiguous().long(), C)
 
 
@@ -937,6 +949,8 @@ class _L2NormFn(JGFunction):
 
 def l2_normalize(x, eps=1e-7):
     """torch.nn.functional.normalize(x, eps=eps) for fp32 [R, D] (cut_networks.py:66)."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.l2_normalize(x, eps)[0]
     return _L2NormFn.apply(x, eps)
 
 
@@ -1005,6 +1019,8 @@ class _PatchNCEFn(JGFunction):
 
 def patch_nce_loss(q, k, nimg, T, num_patches, monce=False):
     """BaseNCELoss.forward / MoNCELoss (base_NCE.py:17-50, monce.py:16-33): per-patch loss [nimg*P]."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.patch_nce(q, k, nimg, float(T), float(num_patches - 1), bool(monce))[0]
     return _PatchNCEFn.apply(q, k, nimg, float(T), float(num_patches - 1), bool(monce))
 
 
@@ -1034,12 +1050,16 @@ class _LSGANLossFn(JGFunction):
 
 def lsgan_loss(pred, target, scale=1.0):
     """GANLoss('lsgan') (loss.py:69-71): scale * mean((pred[..., 0] - target)^2) on an NHWC logit map whose channel 0 is valid."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.gan_loss(pred, 0, float(target), float(scale))[0]
     return _LSGANLossFn.apply(pred, float(target), float(scale), 0)
 
 
 def gan_loss(pred, mode, target, scale=1.0):
     """GANLoss(mode) for mode in lsgan / vanilla / wgangp (loss.py:59-76) on an NHWC logit map whose channel 0 is valid; `target` is the label
     (real_label / fake_label)."""
+    if TORCH_OPS_BOUNDARY:
+        return torch.ops.jg355.gan_loss(pred, GAN_MODES[mode], float(target), float(scale))[0]
     return _LSGANLossFn.apply(pred, float(target), float(scale), GAN_MODES[mode])
 
 
@@ -1330,14 +1350,16 @@ def _conv2d_nt_setup(ctx, inputs, output):
 def _conv2d_nt_backward(ctx, dy):
     x, w = ctx.saved_tensors
     pad, stride, alpha, res_scale, has_bias, has_res = ctx.geo
-    if stride != 1:
-        raise NotImplementedError("jg355::conv2d_nt autograd: stride 1 only (the strided layers of the networks use their module nodes)")
     Cout, R, S, Cin = w.shape
     dy = dy.contiguous()
     dx = dw = db = dres = None
     if ctx.needs_input_grad[0]:          # input gradient = the same kernel on the flipped / transposed weights
         wT = w.to(dy.dtype).permute(3, 1, 2, 0).flip(1, 2).contiguous()
-        dx = torch.ops.jg355.conv2d_nt(dy, wT, None, None, R - 1 - pad, 1, alpha, 0.0)
+        dyd = dy
+        if stride != 1:                  # stride s: over the zero-dilated dy (length H + 2p - k + 1 per axis), as ops.conv2d_dgrad
+            H, W_ = x.shape[1], x.shape[2]
+            dyd = torch.ops.jg355.dilate2d(dy, H + 2 * pad - R + 1, W_ + 2 * pad - S + 1, stride)
+        dx = torch.ops.jg355.conv2d_nt(dyd, wT, None, None, R - 1 - pad, 1, alpha, 0.0)
     if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
         dwf, dbf = torch.ops.jg355.conv2d_wgrad(dy, x, R, S, pad, stride, alpha)
         dw = dwf.to(w.dtype) if ctx.needs_input_grad[1] else None
@@ -1600,3 +1622,7 @@ def _mse_backward(ctx, gloss, gdnh):
 
 
 _op_ddpm_mse_loss.register_autograd(_mse_backward, setup_context=_mse_setup)
+
+
+
+from . import ops_library_cut  # noqa: E402,F401  (registers the CUT-family torch.ops.jg355.* entries)
