@@ -660,7 +660,7 @@ def main():
                                    "(example_ddpm_noglasses2glasses.json + SURVEY Appendix C overrides)",
                        "global_batch": args.batch * world, "per_gpu_batch": args.batch, "image_size": args.size,
                        "efficient": bool(args.efficient), "parallelism": f"dp{world}", "final_loss": round(loss, 6),
-                       "n_ranks_seen": n_ranks_seen},
+                       "n_ranks_seen": n_ranks_seen, **({"step_driver": model.step_driver, "step_driver_note": model.step_driver_note} if args.model == "cut" else {})},
             "roofline": roofline, "cpu_baseline": cpu, "cut": cut,
         }
         line.update(extra)

