@@ -49,8 +49,8 @@ prof)
   head -12 $O/${TAG}_kernel_stats.md; head -8 $O/${TAG}_mfma_busy.md ;;
 cutprof)
   export JG_TRACE_MARK=1
-  CB="python $R/bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --batch 16 --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing"
-  timeout 120 python bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --dump-kernel-timing $O/${TAG}_cut_per_layer_kernel_timing.txt > /dev/null 2>&1
+  CB="python $R/bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --proj vitsmall --batch 16 --steps 4 --warmup 5 --no-cpu-baseline --no-kernel-timing"
+  timeout 120 python bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --proj vitsmall --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --dump-kernel-timing $O/${TAG}_cut_per_layer_kernel_timing.txt > /dev/null 2>&1
   cd /tmp
   timeout 150 rocprofv3 --kernel-trace -d $O/${TAG}_ckt -o kt -- $CB > $O/${TAG}_ckt.log 2>&1
   cd $R
@@ -60,14 +60,14 @@ cutprof)
 cutpmc)
   # HBM traffic of the CUT step's dominant instances only (--kernel-include-regex): a PMC pass serialises every counted dispatch, the
   # whole 4000-launch step did not finish in 40 minutes in round 3
-  CB="python $R/bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --batch 16 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+  CB="python $R/bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --proj vitsmall --batch 16 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
   RX="wgrad_tn_tr_kernel|conv_nt_glds_kernel"
   cd /tmp
   timeout 280 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex "$RX" -d $O/${TAG}_cpf -o pf -- $CB > $O/${TAG}_cpf.log 2>&1
   timeout 280 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex "$RX" -d $O/${TAG}_cpw -o pw -- $CB > $O/${TAG}_cpw.log 2>&1
   cd $R
   python tools/rocpd_pmc.py $(db cpf) $(db cpw) $O/${TAG}_cut_pmc.json > $O/${TAG}_cut_pmc_hbm_traffic.md 2>> $O/${TAG}_evidence.log
-  meta $O/${TAG}_cut_pmc.json "bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --batch 16 --steps 2 --warmup 1 (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, --kernel-include-regex '$RX')"
+  meta $O/${TAG}_cut_pmc.json "bench.py --model cut --netG segformer_attn_conv --netDs projected_d,basic --proj vitsmall --batch 16 --steps 2 --warmup 1 (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, --kernel-include-regex '$RX')"
   rm -rf $O/${TAG}_cpf $O/${TAG}_cpw
   head -12 $O/${TAG}_cut_pmc_hbm_traffic.md ;;
 lines)
