@@ -1,3 +1,6 @@
+// STATUS: built, tested, measured SLOWER than the three-pass backward on every UNet shape -- NOT on the training step
+// (opt-in: JG_GN_FUSED=1).  Kept as a tested kernel and as the record of the experiment; do not count it as a fusion of the step.
+//
 // Single-pass GroupNorm backward with the activation and its gradient RESIDENT ON CHIP between the reduction and the apply step.
 //
 // norm.hip runs the backward as reduce -> coef -> apply: x and dy cross HBM twice (10 B per element with the dx store).  Here one
