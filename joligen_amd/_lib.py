@@ -62,6 +62,7 @@ SIGNATURES = {
     "jg_conv1x1_gn_apply": [c_i32, C.POINTER(ConvArgs), c_p, c_p, c_i64, c_i32, c_p],
     "jg_conv1x1_gn_bwd_apply": [c_i32, C.POINTER(ConvArgs), c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_i64, c_f32, c_p, c_i64, c_f32, c_i32, c_p],
     "jg_conv2d_wgrad_tn": [c_i32, C.POINTER(WgradArgs), c_p],
+    "jg_conv2d_wgrad_tn_group": [c_i32, C.POINTER(WgradArgs), c_i32, c_p],
     "jg_gn_stats": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_p],
     "jg_gn_coef": [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_gn_apply": [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],

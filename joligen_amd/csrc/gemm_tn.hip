@@ -235,13 +235,15 @@ __device__ __forceinline__ int swz_tr(int row) { return (row & 3) | (((row >> 3)
 
 // WAVES_M = 2: block tile 128 (co) x 128, waves 2x2 of 64x64.  WAVES_M = 1: block tile 64 (co) x 128,
 // waves 1x4 of 64x32 -- for Cout <= 64 layers, where a 128-row tile would waste half of the MFMAs.
+constexpr int TR_TILE = 64 * 16;  // uint4 chunks per operand tile (64 rows x 256 B)
+
+// the body of wgrad_tn_tr_kernel for tile `bx` (column tile fastest) and (batch, split) index `bz` of problem `p`
 template <typename T, int WAVES_M>
-__global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
+__device__ __forceinline__ void wgrad_tn_tr_body(const WgP& p, const int bx, const int bz, uint4 (*sm)[2 * TR_TILE]) {
   constexpr int BM = 64 * WAVES_M, BN = 128, BK = 64;
   constexpr int WAVES_N = 4 / WAVES_M;
   constexpr int TN = BN / WAVES_N / 16;  // 16-wide column tiles per wave: 4 or 2
-  constexpr int TILE = BK * 16;  // uint4 chunks per operand tile (64 rows x 256 B)
-  __shared__ uint4 sm[2][2 * TILE];
+  constexpr int TILE = TR_TILE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -249,10 +251,10 @@ __global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int tilesN = (p.Ktot + BN - 1) / BN;
-  const int n0 = (blockIdx.x % tilesN) * BN;
-  const int m0 = (blockIdx.x / tilesN) * BM;
+  const int n0 = (bx % tilesN) * BN;
+  const int m0 = (bx / tilesN) * BM;
 
-  const int z = blockIdx.z;
+  const int z = bz;
   const int batch = z / p.splitk, split = z % p.splitk;
   const int zb = batch / p.nh, zh = batch % p.nh;
   const T* __restrict__ dy = (const T*)p.dy + zb * p.sdyb + zh * p.sdyh;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
   float bsum[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
-  const bool do_bias = p.dbias != nullptr && (blockIdx.x % tilesN) == 0;
+  const bool do_bias = p.dbias != nullptr && (bx % tilesN) == 0;
 
   auto load_tiles = [&](int kbase) {
     const int p0 = kbase + prow;
@@ -430,10 +432,39 @@ __global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
   }
 }
 
+template <typename T, int WAVES_M>
+__global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
+  __shared__ uint4 sm[2][2 * TR_TILE];
+  wgrad_tn_tr_body<T, WAVES_M>(p, blockIdx.x, blockIdx.z, sm);
+}
+
+// GROUPED launch (round 5): up to GROUP_MAX independent small weight-gradient problems in ONE grid.  The SegFormer generator's backward issues
+// ~190 of these per step (linear layers / 1x1 convolutions of four stages at 8 ... 64 workgroups each, 10 - 40 us apiece because their
+// reduction over 10^4 - 10^5 tokens is a serial K loop per workgroup); side by side they fill the chip and the group costs what its
+// slowest member costs.  The descriptors travel BY VALUE in the kernel argument block (16 x 200 B < 4 KB): no device table to fill, and a
+// hipGraph capture bakes them into the node.
+constexpr int GROUP_MAX = 16;
+struct WgGroup {
+  WgP p[GROUP_MAX];
+  int start[GROUP_MAX + 1];     // first workgroup of problem i in the 1-D grid; start[n] = grid size
+  int tiles[GROUP_MAX];         // output tiles of problem i (its workgroups = tiles x splitk)
+  int n;
+};
+template <typename T, int WAVES_M>
+__global__ __launch_bounds__(256) void wgrad_tn_tr_group_kernel(const WgGroup g) {
+  __shared__ uint4 sm[2][2 * TR_TILE];
+  const int b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k) i += (k < g.n && b >= g.start[k]) ? 1 : 0;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int local = b - g.start[i];
+  wgrad_tn_tr_body<T, WAVES_M>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
+}
+
 }  // namespace
 
-extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream) {
-  jg_note_kernel("");
+static int make_wgp(const jg_wgrad_args* a, WgP& p) {
   if (!a || !a->dy || !a->x || !a->dw) return JG_ERR_BAD_ARG;
   if (a->Cin % 8 || a->Cout % 8 || a->ldx % 8 || a->lddy % 8) return JG_ERR_BAD_ARG;
   if (a->nbatch < 1 || a->nh < 1 || a->splitk < 1) return JG_ERR_BAD_ARG;
@@ -442,7 +473,6 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   if (a->dbias && a->out_mode != JG_OUT_ATOMIC_F32) return JG_ERR_BAD_ARG;
   const long Mpix = (long)a->B * a->Ho * a->Wo;
   if (Mpix <= 0 || Mpix > (1L << 30)) return JG_ERR_BAD_ARG;
-  WgP p;
   p.dy = (const char*)a->dy; p.x = (const char*)a->x; p.dw = (char*)a->dw; p.dbias = a->dbias;
   p.Mpix = (int)Mpix; p.Cout = a->Cout; p.Ktot = a->R * a->S * a->Cin;
   p.H = a->H; p.W = a->W; p.Cin = a->Cin; p.R = a->R; p.S = a->S; p.pad = a->pad; p.stride = a->stride;
@@ -459,6 +489,58 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   if (a->x_mode != 0 && a->x_mode != 1) return JG_ERR_BAD_ARG;
   p.x_up = a->x_mode == 1;
   if (p.x_up && (p.reflect || (a->H & 1) || (a->W & 1) || a->nbatch != 1)) return JG_ERR_BAD_ARG;
+  return JG_OK;
+}
+
+// Up to n independent 1x1 / linear weight-gradient problems (R = S = 1, stride 1, nbatch 1, atomic accumulation) in grouped launches of at most
+// GROUP_MAX: same arithmetic per problem as jg_conv2d_wgrad_tn with JG_WGRAD_VARIANT >= 2 (the summation order of the atomics differs).
+extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n, jg_stream_t stream) {
+  if (!a || n < 1) return JG_ERR_BAD_ARG;
+  for (int wavesm = 1; wavesm <= 2; ++wavesm) {
+    WgGroup g;
+    g.n = 0;
+    g.start[0] = 0;
+    auto flush = [&]() -> int {
+      if (!g.n) return JG_OK;
+      const dim3 grid(g.start[g.n]);
+      if (wavesm == 1) {
+        JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, g););
+      } else {
+        JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, g););
+      }
+      g.n = 0;
+      return JG_OK;
+    };
+    for (int i = 0; i < n; ++i) {
+      WgP p;
+      const int rc = make_wgp(a + i, p);
+      if (rc != JG_OK) return rc;
+      if (a[i].R != 1 || a[i].S != 1 || a[i].stride != 1 || a[i].pad != 0 || a[i].nbatch != 1 || a[i].out_mode != JG_OUT_ATOMIC_F32 || p.reflect || p.x_up)
+        return JG_ERR_UNSUPPORTED;
+      if ((p.Cout <= 64 ? 1 : 2) != wavesm) continue;
+      const int tiles = ((p.Cout + 64 * wavesm - 1) / (64 * wavesm)) * ((p.Ktot + 127) / 128);
+      g.p[g.n] = p;
+      g.tiles[g.n] = tiles;
+      g.start[g.n + 1] = g.start[g.n] + tiles * p.splitk;
+      if (++g.n == GROUP_MAX) {
+        const int rc2 = flush();
+        if (rc2 != JG_OK) return rc2;
+      }
+    }
+    const int rc3 = flush();
+    if (rc3 != JG_OK) return rc3;
+  }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream) {
+  jg_note_kernel("");
+  WgP p;
+  {
+    const int rc = make_wgp(a, p);
+    if (rc != JG_OK) return rc;
+  }
   const int variant = jg_tune(JG_TUNE_WGRAD_VARIANT);  // 1: register transpose; 2: transposing LDS reads; 3: 2 with 128-row tiles only; 4: + halo-resident 3x3
   if (variant >= 4 && (jg_wgrad_halo_try(dtype, p, a->nbatch, (hipStream_t)stream) || jg_wgrad_kxk_try(dtype, p, a->nbatch, (hipStream_t)stream))) {
     JG_CHECK_LAUNCH();

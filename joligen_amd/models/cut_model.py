@@ -346,8 +346,9 @@ class CUTModel(BaseModel):
             gst["bwd"].replay()
             self.step_driver += "+graphG"
         else:
-            for loss in gG.loss_backward:
-                (getattr(self, loss) / its).backward()
+            with ops.deferred_wgrads():
+                for loss in gG.loss_backward:
+                    (getattr(self, loss) / its).backward()
         self._group_finish(gG)
         main.wait_stream(side)
         self._group_flags(gD)            # the flags end the step as the sequential driver leaves them
@@ -434,7 +435,8 @@ class CUTModel(BaseModel):
                 self.compute_G_loss()
             st["outs"] = {k: getattr(self, k) for k in self._g_outputs()}
             with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode="thread_local"):
-                (self.loss_G_tot / its).backward(retain_graph=True)
+                with ops.deferred_wgrads():           # the ~190 linear-layer weight gradients of the generator leave as grouped launches
+                    (self.loss_G_tot / its).backward(retain_graph=True)
             st["fwd"], st["bwd"] = gf, gb
 
             def once():

@@ -190,6 +190,10 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.alpha, a.out_mode, a.dbias_scale = alpha, out_mode, dbias_scale
     a.pad_mode = pad_mode
     a.x_mode = x_mode
+    if (WGRAD_DEFER is not None and R == 1 and S == 1 and stride == 1 and pad == 0 and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32
+            and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None):
+        WGRAD_DEFER.append((_dt(dy), a, (dy, x, dw, dbias)))       # launched with its peers by flush_deferred_wgrads(); operands kept alive
+        return
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -199,6 +203,48 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
         KERNEL_TIMING.append((_lib.lib().jg_last_kernel().decode() or _wgrad_kernel_name(nbatch, H, W, Cin, Cout, R, S, pad, stride, out_mode), ev0, ev1,
                               2.0 * nbatch * B * Ho * Wo * Cout * R * S * Cin, (nbatch, B, Ho, Wo, Cin, Cout, R, splitk),
                               2.0 * nbatch * (B * H * W * Cin + B * Ho * Wo * Cout) + 4.0 * R * S * Cin * Cout))
+
+
+# Deferred small weight gradients (round 5): inside `with deferred_wgrads():` every 1x1 / linear weight-gradient launch of a backward is
+# collected instead of issued, and the context's exit issues them as GROUPED launches (jg_conv2d_wgrad_tn_group, 16 problems per grid).  The
+# SegFormer generator's backward has ~190 of them per cut_model step, each a 10 - 40 us launch on 8 - 64 workgroups; they only feed the gradient
+# arena (fp32 atomics), nothing downstream in the backward reads them.  Their operands (dy, x) stay alive until the flush.
+WGRAD_DEFER = None
+WGRAD_GROUP = os.environ.get("JG_WGRAD_GROUP", "1") != "0"
+
+
+def flush_deferred_wgrads():
+    global WGRAD_DEFER
+    todo, WGRAD_DEFER = WGRAD_DEFER, ([] if WGRAD_DEFER is not None else None)
+    if not todo:
+        return 0
+    by_dt = {}
+    for dt, a, keep in todo:
+        by_dt.setdefault(dt, []).append(a)
+    for dt, args in by_dt.items():
+        arr = (WgradArgs * len(args))(*args)
+        check(_lib.lib().jg_conv2d_wgrad_tn_group(dt, arr, len(args), _st()), "jg_conv2d_wgrad_tn_group")
+    return len(todo)
+
+
+class deferred_wgrads:
+    """collect the 1x1 / linear weight-gradient launches of the enclosed backward and issue them grouped at the exit (JG_WGRAD_GROUP=0: off)"""
+
+    def __enter__(self):
+        global WGRAD_DEFER
+        self.prev = WGRAD_DEFER
+        if WGRAD_GROUP and WGRAD_DEFER is None:
+            WGRAD_DEFER = []
+        return self
+
+    def __exit__(self, *exc):
+        global WGRAD_DEFER
+        if self.prev is None and WGRAD_DEFER is not None:
+            try:
+                if exc[0] is None:
+                    flush_deferred_wgrads()
+            finally:
+                WGRAD_DEFER = None
 
 
 def axpby(a, alpha=1.0, b=None, beta=0.0, alpha_dev=None, out=None):

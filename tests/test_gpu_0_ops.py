@@ -1758,3 +1758,51 @@ def test_torch_ops_surface_cut(dtype):
     xr = xb.detach().float().cpu().requires_grad_(True)
     F.interpolate(xr.permute(0, 3, 1, 2), size=(15, 18), mode="bilinear", align_corners=False).backward(gb.float().cpu().permute(0, 3, 1, 2))
     cmp(xb.grad, xr.grad, msg="bilinear")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_grouped_launch_matches_single_launches(dtype):
+    """jg_conv2d_wgrad_tn_group (round 5): 21 independent linear / 1x1 weight-gradient problems of the SegFormer generator's shapes -- both tile
+    variants (Cout <= 64 and > 64), ragged Cout / Cin / token counts, split-K, with and without a bias gradient, accumulation onto non-zero
+    arenas -- issued through `ops.deferred_wgrads()` in grouped grids of up to 16 against the same problems launched one by one, and against fp32 torch."""
+    from joligen_amd import ops
+
+    d = dev()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(4096, 32, 32), (4096, 32, 128), (4096, 128, 32), (1024, 64, 64), (1024, 64, 256), (1024, 256, 64), (256, 160, 160), (256, 160, 640),
+              (256, 640, 160), (64, 256, 256), (64, 256, 1024), (64, 1024, 256), (8200, 32, 96), (520, 64, 128), (130, 160, 320), (70, 256, 512),
+              (4096, 96, 40), (1000, 200, 72), (333, 24, 264), (64, 8, 8), (2048, 384, 1152)]
+    probs = []
+    for i, (M, Cin, Cout) in enumerate(shapes):
+        x = (torch.randn(M, Cin, generator=g)).to(dtype).to(d)
+        dy = (torch.randn(M, Cout, generator=g)).to(dtype).to(d)
+        base = torch.randn(Cout, Cin, generator=g).to(d)
+        bias = i % 3 != 2
+        probs.append((x, dy, base, torch.randn(Cout, generator=g).to(d) if bias else None, 1 + (i % 4) * 3))
+
+    def run(grouped):
+        outs = []
+        ctx = ops.deferred_wgrads() if grouped else contextlib.nullcontext()
+        with ctx:
+            for x, dy, base, b0, sk in probs:
+                M, Cin = x.shape
+                Cout = dy.shape[1]
+                dw = base.clone()
+                db = None if b0 is None else b0.clone()
+                ops.wgrad_tn(dy, x, dw, B=1, H=1, W=M, Cin=Cin, Cout=Cout, R=1, S=1, pad=0, stride=1, Ho=1, Wo=M, lddy=Cout, ldx=Cin, lddw=Cin, dbias=db,
+                             splitk=sk)
+                outs.append((dw, db))
+        torch.cuda.synchronize()
+        return outs
+
+    import contextlib
+
+    single, grouped = run(False), run(True)
+    assert ops.WGRAD_DEFER is None
+    for (x, dy, base, b0, sk), (dw1, db1), (dw2, db2) in zip(probs, single, grouped):
+        ref = base.double().cpu() + dy.double().cpu().t() @ x.double().cpu()
+        assert relerr(dw2, ref) < TOL[dtype] and relerr(dw1, ref) < TOL[dtype], (tuple(x.shape), dy.shape[1], relerr(dw2, ref), relerr(dw1, ref))
+        assert relerr(dw2, dw1) < 1e-5, (tuple(x.shape), relerr(dw2, dw1))               # same arithmetic, another order of the fp32 atomics
+        if b0 is not None:
+            refb = b0.double().cpu() + dy.double().cpu().sum(0)
+            assert relerr(db2, refb) < TOL[dtype] and relerr(db2, db1) < 1e-5, (tuple(x.shape), relerr(db2, refb))
