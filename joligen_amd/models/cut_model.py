@@ -225,8 +225,57 @@ class CUTModel(BaseModel):
             setattr(self, "loss_G_GAN_" + dn, val)
             self.loss_G_tot = self.loss_G_tot + val
 
+    def _batched_nce(self):
+        """one encoder pass / one PatchSampleF pass / one NCE launch set for BOTH contrastive terms (`jg_batched_nce`, default on): needs the
+        identity term, an un-injected random source (parity runs inject per-call draws in the reference's order) and the per-image negatives"""
+        o = self.opt
+        net = self._net("G_A")
+        return (getattr(o, "jg_batched_nce", True) and os.environ.get("JG_BATCHED_NCE", "1") != "0" and o.alg_cut_nce_idt and o.alg_cut_lambda_NCE > 0.0
+                and self.patch_ids_injection is None and getattr(getattr(net, "rand", None), "source", None) is None
+                and not o.alg_cut_nce_includes_all_negatives_from_minibatch and not ops.TORCH_OPS_BOUNDARY)
+
+    def compute_G_loss_cut_batched(self):
+        """cut_model.py:708-909 with the four encoder passes (translated / source image of the NCE term, identity / target image of the identity
+        term), the four PatchSampleF passes and the 2 x L contrastive problems each run ONCE on the concatenated batch (round 5).  The reference
+        calls `netG.get_feats` four times on B images and `netF` four times; the encoder is per-sample (LayerNorm / InstanceNorm, DropPath draws
+        per sample) and netF's MLPs are per-row, so one pass over 4 B images computes the same features -- with a quarter of the launches, on
+        problems four times the size.  Patch ids: one draw per (term, layer) in the reference's order (the source-image pass draws, the translated
+        image reuses them, cut_networks.py:57-60).  The L problems of a term that share a patch count, and the two terms, are one batched
+        PatchNCE / MoNCE call (images are independent problems in every kernel: the 50 Sinkhorn iterations of 2 L x B images run side by side
+        instead of in 2 L launches of B)."""
+        o = self.opt
+        B = self.batch_size
+        net, netF = self._net("G_A"), self._net("F")
+        feats = net.get_feats(torch.cat((self.fake_B, self.real_A, self.idt_B, self.real_B), dim=0), self.nce_layers)
+        self._feat_calls += 2
+        netF.arena.ensure_fresh()
+        P = o.alg_cut_num_patches
+        rows, counts = [], []
+        ids_all = [[netF.draw_ids(f, P) for f in feats] for _ in range(2)]         # term 0: NCE, term 1: identity NCE (reference draw order)
+        for li, f in enumerate(feats):
+            C = self.feat_channels[li]
+            # rows of a layer: [q0 (translated) | k0 (source) | q1 (identity) | k1 (target)], each B * P_l rows
+            r = torch.cat((ops.gather_patches(f[:2 * B], ids_all[0][li], C), ops.gather_patches(f[2 * B:], ids_all[1][li], C)), dim=0)
+            rows.append(netF.embed(r, li))
+            counts.append(ids_all[0][li].numel())
+        T, monce = o.alg_cut_nce_T, o.alg_cut_nce_loss == "monce"
+        tot = [0.0, 0.0]
+        for Pl in sorted(set(counts)):
+            ls = [i for i, c in enumerate(counts) if c == Pl]
+            n = B * Pl
+            q = torch.cat([rows[i][t * 2 * n:t * 2 * n + n] for i in ls for t in (0, 1)], dim=0)
+            k = torch.cat([rows[i][t * 2 * n + n:(t + 1) * 2 * n] for i in ls for t in (0, 1)], dim=0)
+            loss = ops.patch_nce_loss(q, k, 2 * len(ls) * B, T, P, monce).view(len(ls), 2, n)
+            m = loss.mean(dim=2).sum(dim=0) * o.alg_cut_lambda_NCE
+            tot = [tot[0] + m[0], tot[1] + m[1]]
+        L = len(self.nce_layers)
+        self.loss_G_NCE, self.loss_G_NCE_Y = tot[0] / L, tot[1] / L
+        self.loss_G_tot = self.loss_G_tot + (self.loss_G_NCE + self.loss_G_NCE_Y) * 0.5
+
     def compute_G_loss_cut(self):
         """cut_model.py:708-837 (NCE + identity NCE)."""
+        if self._batched_nce():
+            return self.compute_G_loss_cut_batched()
         fq, fk = self.calculate_feats(self.real_A, self.fake_B)
         self.loss_G_NCE = self.calculate_NCE_loss(fq, fk) if self.opt.alg_cut_lambda_NCE > 0.0 else 0.0
         if self.opt.alg_cut_nce_idt and self.opt.alg_cut_lambda_NCE > 0.0:

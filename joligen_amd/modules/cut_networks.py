@@ -49,6 +49,19 @@ class PatchSampleF(nn.Module):
             self.arena = ParamArena(self, device, act_dtype, priority=())
         return self.arena
 
+    def draw_ids(self, feat, num_patches):
+        """the `torch.randperm(H * W)[:P]` of forward() for one layer (see there)"""
+        HW = feat.shape[1] * feat.shape[2]
+        return torch.rand(HW, device=feat.device).topk(int(min(num_patches, HW))).indices
+
+    def embed(self, x, feat_id):
+        """the MLP + L2 normalisation of forward() on gathered rows [R, C] fp32 of layer `feat_id`"""
+        if self.use_mlp:
+            mlp = getattr(self, "mlp_%d" % feat_id)
+            x = ops.linear(x, mlp[0].weight, mlp[0].bias, JG_ACT_NONE)
+            x = ops.linear(x, mlp[2].weight, mlp[2].bias, JG_ACT_RELU)
+        return ops.l2_normalize(x, 1e-7)
+
     def forward(self, feats, num_patches=64, patch_ids=None, channels=None):
         if num_patches <= 0:
             raise NotImplementedError("num_patches=0 (dense features) is outside the built path")
