@@ -881,3 +881,27 @@ def test_cut_step_through_torch_ops(dtype_name):
         f.write(f"losses ctypes {la} ctypes again {la2} torch.ops {lo}\nworst gradient tensor torch.ops vs ctypes {worst}\n"
                 f"run-to-run floor of the ctypes graph: losses {floor_l:.3e} worst tensor {floor_g:.3e} whole vector {floor_w:.3e}\n"
                 f"all gradients as one vector: torch.ops vs ctypes {rel(cat(go), cat(ga)):.3e}\n")
+
+
+@pytest.mark.parametrize("nce_loss", ["monce", "patchnce"])
+def test_cut_batched_nce_matches_the_four_pass_form(nce_loss, monkeypatch):
+    """`jg_batched_nce` (round 5: ONE encoder pass over cat(fake_B, real_A, idt_B, real_B), one PatchSampleF pass, one batched PatchNCE / MoNCE call
+    for both contrastive terms) against the reference's structure (four `get_feats` passes, four `netF` passes, 2 L loss calls; `JG_BATCHED_NCE=0`)
+    on a resnet generator, where both forms draw the same patch ids from the same generator state (no DropPath): five iterations at learning rate
+    zero, every logged loss and Adam's first moment of G / F / D agree to the run-to-run floor of the four-pass form."""
+    gen = torch.Generator().manual_seed(14)
+    data = {"A": torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1, "B": torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1}
+    cfg = dict(_SMALL_CUT, alg={"cut": {"nce_layers": "0,4,8", "nce_loss": nce_loss, "num_patches": 128}},
+               train={"batch_size": 2, "G_ema": True, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0})
+    monkeypatch.setenv("JG_BATCHED_NCE", "0")
+    a = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
+    a2 = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
+    monkeypatch.setenv("JG_BATCHED_NCE", "1")
+    b = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
+    floor_l = float(((a["losses"] - a2["losses"]).abs() / a["losses"].abs()).max())
+    floor_p = max(float((a["m1"][n] - a2["m1"][n]).norm() / a["m1"][n].norm()) for n in a["m1"])
+    print("run-to-run floor of the four-pass form: losses %.2e, first moments %.2e" % (floor_l, floor_p))
+    assert float(((b["losses"] - a["losses"]).abs() / a["losses"].abs()).max()) <= 4 * floor_l + 2e-3, (b["losses"], a["losses"])
+    for n in a["m1"]:
+        e = float((b["m1"][n] - a["m1"][n]).norm() / a["m1"][n].norm())
+        assert e <= 4 * floor_p + 2e-3, (n, e, floor_p)
