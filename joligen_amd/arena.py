@@ -31,7 +31,11 @@ def _pad8(n):
 
 
 class ParamArena:
-    def __init__(self, module: nn.Module, device, act_dtype, priority=("emb_layers.1.weight", "emb_layers.1.bias")):
+    def __init__(self, module: nn.Module, device, act_dtype, priority=("emb_layers.1.weight", "emb_layers.1.bias"), frozen_prefixes=()):
+        """`frozen_prefixes`: parameter-name prefixes of sub-networks that never train (the projected discriminator's feature network).  Their
+        16-bit working copies are re-derived only after a load (not after every optimizer step), and when they form the LEADING block of the
+        arena the fused optimizer starts behind them -- torch.optim skips parameters without a gradient (no moment update, no weight decay), which
+        is what the reference's optimizer does with them."""
         from .modules.layers import JGConvNd  # local import (layers imports ops)
 
         self.module = module
@@ -100,7 +104,20 @@ class ParamArena:
                 n16t += size
         self.w16 = torch.zeros(max(n16, 8), device=self.device, dtype=act_dtype)
         self.w16T = torch.zeros(max(n16t, 8), device=self.device, dtype=act_dtype)
-        self.desc = torch.tensor(desc, dtype=torch.int64, device=self.device).contiguous() if desc else None
+        is_frozen = [bool(frozen_prefixes) and name.startswith(tuple(frozen_prefixes)) for name, _ in convs]
+        live = [d for d, f in zip(desc, is_frozen) if not f]
+        froz = [d for d, f in zip(desc, is_frozen) if f]
+        self.desc = torch.tensor(live, dtype=torch.int64, device=self.device).contiguous() if live else None
+        self.desc_frozen = torch.tensor(froz, dtype=torch.int64, device=self.device).contiguous() if froz else None
+        self._frozen_dirty = True
+        # leading block of never-trained parameters: the optimizer starts behind it
+        self.frozen_end = 0
+        if frozen_prefixes:
+            for name, prm in ordered:
+                if not name.startswith(tuple(frozen_prefixes)):
+                    break
+                off, n = self.slices[name]
+                self.frozen_end = (off + n + ALIGN - 1) // ALIGN * ALIGN
         self._bias_pads = []
         for (name, conv), d in zip(convs, desc):
             _, dst, dstT, cout, rs, cin, coutp, cinp = d
@@ -116,7 +133,7 @@ class ParamArena:
                 m.bias_pad = torch.zeros(coutp, **f32)
                 self._bias_pads.append((m.bias_pad, m.bias, cout))
             conv.meta = m
-        self.dirty = True
+        self._dirty = True
         module._jg_arena = self
         module.register_state_dict_post_hook(_state_dict_contiguous_hook)
         module.register_load_state_dict_post_hook(_mark_dirty_hook)
@@ -147,15 +164,31 @@ class ParamArena:
         return flat[off0:offl + nl]
 
     # ---- weights -------------------------------------------------------------------------
+    # `arena.dirty = True` from outside (a load, a test that writes parameters) invalidates EVERY working copy; the optimizer step invalidates the
+    # trained ones only (`_dirty`)
+    @property
+    def dirty(self):
+        return self._dirty
+
+    @dirty.setter
+    def dirty(self, v):
+        self._dirty = bool(v)
+        if v:
+            self._frozen_dirty = True
+
     def refresh(self):
         """Re-derive the 16-bit conv weights from the fp32 masters (after an optimizer step or a load)."""
+        dt = _lib.JG_F16 if self.act_dtype == torch.float16 else _lib.JG_BF16
         if self.desc is not None:
-            check(_lib.lib().jg_refresh_weights(_lib.JG_F16 if self.act_dtype == torch.float16 else _lib.JG_BF16,
-                                                self.p.data_ptr(), self.w16.data_ptr(), self.w16T.data_ptr(),
+            check(_lib.lib().jg_refresh_weights(dt, self.p.data_ptr(), self.w16.data_ptr(), self.w16T.data_ptr(),
                                                 self.desc.data_ptr(), self.desc.shape[0], _st()), "jg_refresh_weights")
+        if self._frozen_dirty and self.desc_frozen is not None:
+            check(_lib.lib().jg_refresh_weights(dt, self.p.data_ptr(), self.w16.data_ptr(), self.w16T.data_ptr(),
+                                                self.desc_frozen.data_ptr(), self.desc_frozen.shape[0], _st()), "jg_refresh_weights")
         for pad, bias, n in self._bias_pads:
             pad[:n].copy_(bias.detach())
-        self.dirty = False
+        self._dirty = False
+        self._frozen_dirty = False
 
     def ensure_fresh(self):
         if self.dirty:
@@ -182,6 +215,10 @@ class ParamArena:
         """One fused optimizer(+EMA)(+zero_grad) launch over arena[lo:hi] (Adam / AdamW / RAdam / Lion by `optim_kind`);
         `self.step` must already be advanced."""
         hi = self.numel if hi is None else hi
+        lo = max(lo, self.frozen_end)          # never-trained leading block: untouched, like parameters without a gradient in torch.optim
+        if lo >= hi:
+            self._dirty = True
+            return
         ema_ptr = None
         if ema_beta is not None:
             if self.ema is None:
@@ -195,7 +232,7 @@ class ParamArena:
                                        self.v.data_ptr() + 4 * lo, ema_ptr, hi - lo, lr, beta1, beta2, eps, weight_decay,
                                        self.step, grad_scale, 0.0 if ema_beta is None else ema_beta, int(zero_grad), skip, nsk,
                                        _st()), "jg_optim_step")
-        self.dirty = True
+        self._dirty = True
 
     def ema_create(self):
         self.ema = self.p.clone()

@@ -476,7 +476,8 @@ class CUTModel(BaseModel):
         rng = torch.cuda.get_rng_state(self.device)
         try:
             for n in nets:
-                n.arena.dirty = True               # the refresh of every working copy belongs to graph F
+                n.arena.ensure_fresh()             # (never-trained working copies: derived now, outside the graph)
+                n.arena._dirty = True              # the refresh of every TRAINED working copy belongs to graph F
             self.real_A, self.real_B = st["real_A"], st["real_B"]
             gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(gf, capture_error_mode="thread_local"):
@@ -519,7 +520,7 @@ class CUTModel(BaseModel):
         torch.cuda.set_rng_state(rng, self.device)
         self.real_A, self.real_B = keep_inputs
         for n in nets:
-            n.arena.dirty = True
+            n.arena._dirty = True
         return st
 
     # ---- the discriminator half as a hipGraph -----------------------------------------------------------------------------

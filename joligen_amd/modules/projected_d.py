@@ -836,7 +836,7 @@ class ProjectedDiscriminator(nn.Module):
 
         if self.arena is None:
             self.act_dtype = act_dtype
-            self.arena = ParamArena(self, device, act_dtype, priority=())
+            self.arena = ParamArena(self, device, act_dtype, priority=(), frozen_prefixes=("freeze_feature_network.",))
         return self.arena
 
     def forward(self, x):
