@@ -155,11 +155,11 @@ typedef struct {
   int32_t x_mode;    /* 1: x is the half-resolution tensor of jg_conv_args.x_mode 1 (H, W = the upsampled size); same shape limits */
 } jg_wgrad_args;
 int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t stream);
-/* `n` independent 1x1 / linear weight-gradient problems (R = S = 1, stride 1, pad 0, nbatch 1, out_mode JG_OUT_ATOMIC_F32) in grouped launches of
- * up to 16: the weight / bias gradients of the SegFormer generator's ~190 linear layers and 1x1 convolutions per cut_model step
+/* `n` <= 4096 independent weight-gradient problems (any geometry of jg_conv2d_wgrad_tn with nbatch 1, out_mode JG_OUT_ATOMIC_F32, pad_mode 0,
+ * x_mode 0; those the halo-resident 3x3 / 7x7 kernels serve are launched by them, singly) in grouped launches of up to 16: the weight / bias gradients of the SegFormer generator's ~190 linear layers and 1x1 convolutions per cut_model step
  * (models/modules/segformer/backbone.py:13-88,239-328: autograd's per-layer `grad_weight` GEMMs), which singly occupy 8 - 64 workgroups for
  * 10 - 40 us each.  Descriptors travel by value in the kernel argument block (capturable in a hipGraph as they are).  Same arithmetic per
- * problem as jg_conv2d_wgrad_tn; JG_ERR_UNSUPPORTED (nothing launched for that problem's group) for any other geometry. */
+ * problem as jg_conv2d_wgrad_tn; JG_ERR_UNSUPPORTED for any other mode. */
 int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n, jg_stream_t stream);
 
 /* GroupNorm (+FiLM scale-shift) (+SiLU), NHWC, statistics in fp32.

@@ -492,10 +492,23 @@ static int make_wgp(const jg_wgrad_args* a, WgP& p) {
   return JG_OK;
 }
 
-// Up to n independent 1x1 / linear weight-gradient problems (R = S = 1, stride 1, nbatch 1, atomic accumulation) in grouped launches of at most
-// GROUP_MAX: same arithmetic per problem as jg_conv2d_wgrad_tn with JG_WGRAD_VARIANT >= 2 (the summation order of the atomics differs).
+// n independent weight-gradient problems (any convolution geometry of jg_conv2d_wgrad_tn; nbatch 1, atomic accumulation, no mirrored borders /
+// upsample-on-read) in grouped launches of at most GROUP_MAX: same arithmetic per problem as jg_conv2d_wgrad_tn (the summation order of the
+// atomics differs).
 extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n, jg_stream_t stream) {
-  if (!a || n < 1) return JG_ERR_BAD_ARG;
+  if (!a || n < 1 || n > 4096) return JG_ERR_BAD_ARG;
+  // problems that one of the halo-resident kernels serves (3x3 / 7x7 stride 1 at their channel multiples) are launched by it, singly: those
+  // fill the chip by themselves; everything else is the im2col TN kernel and goes into the groups
+  bool special[4096];
+  const int variant = jg_tune(JG_TUNE_WGRAD_VARIANT);
+  for (int i = 0; i < n; ++i) {
+    WgP p;
+    const int rc = make_wgp(a + i, p);
+    if (rc != JG_OK) return rc;
+    if (a[i].nbatch != 1 || a[i].out_mode != JG_OUT_ATOMIC_F32 || p.reflect || p.x_up) return JG_ERR_UNSUPPORTED;
+    special[i] = variant >= 4 && (a[i].R > 1 || a[i].S > 1) &&
+                 (jg_wgrad_halo_try(dtype, p, 1, (hipStream_t)stream) || jg_wgrad_kxk_try(dtype, p, 1, (hipStream_t)stream));
+  }
   for (int wavesm = 1; wavesm <= 2; ++wavesm) {
     WgGroup g;
     g.n = 0;
@@ -515,9 +528,7 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
       WgP p;
       const int rc = make_wgp(a + i, p);
       if (rc != JG_OK) return rc;
-      if (a[i].R != 1 || a[i].S != 1 || a[i].stride != 1 || a[i].pad != 0 || a[i].nbatch != 1 || a[i].out_mode != JG_OUT_ATOMIC_F32 || p.reflect || p.x_up)
-        return JG_ERR_UNSUPPORTED;
-      if ((p.Cout <= 64 ? 1 : 2) != wavesm) continue;
+      if (special[i] || (p.Cout <= 64 ? 1 : 2) != wavesm) continue;
       const int tiles = ((p.Cout + 64 * wavesm - 1) / (64 * wavesm)) * ((p.Ktot + 127) / 128);
       g.p[g.n] = p;
       g.tiles[g.n] = tiles;

@@ -190,8 +190,7 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.alpha, a.out_mode, a.dbias_scale = alpha, out_mode, dbias_scale
     a.pad_mode = pad_mode
     a.x_mode = x_mode
-    if (WGRAD_DEFER is not None and R == 1 and S == 1 and stride == 1 and pad == 0 and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32
-            and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None):
+    if WGRAD_DEFER is not None and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32 and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None:
         WGRAD_DEFER.append((_dt(dy), a, (dy, x, dw, dbias)))       # launched with its peers by flush_deferred_wgrads(); operands kept alive
         return
     if KERNEL_TIMING is not None:
@@ -205,7 +204,7 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
                               2.0 * nbatch * (B * H * W * Cin + B * Ho * Wo * Cout) + 4.0 * R * S * Cin * Cout))
 
 
-# Deferred small weight gradients (round 5): inside `with deferred_wgrads():` every 1x1 / linear weight-gradient launch of a backward is
+# Deferred small weight gradients (round 5): inside `with deferred_wgrads():` every weight-gradient launch of a backward (plain zero padding) is
 # collected instead of issued, and the context's exit issues them as GROUPED launches (jg_conv2d_wgrad_tn_group, 16 problems per grid).  The
 # SegFormer generator's backward has ~190 of them per cut_model step, each a 10 - 40 us launch on 8 - 64 workgroups; they only feed the gradient
 # arena (fp32 atomics), nothing downstream in the backward reads them.  Their operands (dy, x) stay alive until the flush.

@@ -1797,6 +1797,34 @@ def test_wgrad_grouped_launch_matches_single_launches(dtype):
 
     import contextlib
 
+    # convolution geometries in the same group: 4x4 stride 2 (PatchGAN), 7x7 stride 4 and 3x3 stride 2 (MiT patch embeddings), and a 3x3 / stride 1
+    # layer that the halo-resident kernel takes (launched singly by the group call)
+    convs = []
+    for (Bc, H, Cin, Cout, k, st, pd) in ((2, 32, 64, 128, 4, 2, 1), (2, 64, 8, 32, 7, 4, 3), (2, 32, 32, 64, 3, 2, 1), (2, 32, 64, 64, 3, 1, 1)):
+        Ho = (H + 2 * pd - k) // st + 1
+        xc = torch.randn(Bc, H, H, Cin, generator=g).to(dtype).to(d)
+        dyc = torch.randn(Bc, Ho, Ho, Cout, generator=g).to(dtype).to(d)
+        convs.append((xc, dyc, k, st, pd, Ho))
+
+    def run_convs(grouped):
+        outs = []
+        with (ops.deferred_wgrads() if grouped else contextlib.nullcontext()):
+            for xc, dyc, k, st, pd, Ho in convs:
+                Bc, H, _, Cin = xc.shape
+                Cout = dyc.shape[-1]
+                dw = torch.zeros(Cout, k, k, Cin, device=d)
+                db = torch.zeros(Cout, device=d)
+                ops.wgrad_tn(dyc, xc, dw, B=Bc, H=H, W=H, Cin=Cin, Cout=Cout, R=k, S=k, pad=pd, stride=st, Ho=Ho, Wo=Ho, lddy=Cout, ldx=Cin, lddw=k * k * Cin,
+                             dbias=db, splitk=2)
+                outs.append((dw, db))
+        torch.cuda.synchronize()
+        return outs
+
+    for (xc, dyc, k, st, pd, Ho), (dw1, db1), (dw2, db2) in zip(convs, run_convs(False), run_convs(True)):
+        wr = torch.zeros(dyc.shape[-1], xc.shape[-1], k, k, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xc.double().cpu().permute(0, 3, 1, 2), wr, None, st, pd).backward(dyc.double().cpu().permute(0, 3, 1, 2))
+        assert relerr(dw2.permute(0, 3, 1, 2), wr.grad) < TOL[dtype], (k, st, relerr(dw2.permute(0, 3, 1, 2), wr.grad))
+        assert relerr(dw2, dw1) < 1e-5 and relerr(db2, db1) < 1e-5, (k, st, relerr(dw2, dw1))
     single, grouped = run(False), run(True)
     assert ops.WGRAD_DEFER is None
     for (x, dy, base, b0, sk), (dw1, db1), (dw2, db2) in zip(probs, single, grouped):

@@ -55,6 +55,7 @@ cutprof)
   timeout 150 rocprofv3 --kernel-trace -d $O/${TAG}_ckt -o kt -- $CB > $O/${TAG}_ckt.log 2>&1
   cd $R
   python tools/rocpd_stats.py $(db ckt) 4 > $O/${TAG}_cut_kernel_stats.md 2>> $O/${TAG}_evidence.log
+  python tools/rocpd_overlap.py $(db ckt) > $O/${TAG}_cut_overlap.txt 2>> $O/${TAG}_evidence.log
   rm -rf $O/${TAG}_ckt
   head -14 $O/${TAG}_cut_kernel_stats.md ;;
 cutpmc)
