@@ -345,6 +345,17 @@ class CUTModel(BaseModel):
     step_driver = "sequential"
     step_driver_note = ""
 
+    def _wgrad_stream(self):
+        """`JG_WGRAD_GROUP_STREAM=1` (A/B): the grouped weight-gradient launches of the generator's backward (ops.deferred_wgrads) leave on a third
+        stream every 48 problems instead of on the compute stream at the end.  Measured SLOWER (30.3 vs 29.4 ms/step, same box, everything replayed
+        from graphs: the forked branch costs the graph more than the overlap returns): off."""
+        if os.environ.get("JG_WGRAD_GROUP_STREAM", "0") != "1":
+            return None
+        st = self.__dict__.get("_wg_stream")
+        if st is None:
+            st = self._wg_stream = torch.cuda.Stream(device=self.device)
+        return st
+
     def _draw_pool_fakes(self, side):
         """The history-pool draws of compute_D_loss, made on the MAIN stream before the side stream forks: `ImagePool.query` clones a stored
         image (a view of an earlier generator output, allocated on the main stream) and drops the last reference to it, so on the side
@@ -395,7 +406,7 @@ class CUTModel(BaseModel):
             gst["bwd"].replay()
             self.step_driver += "+graphG"
         else:
-            with ops.deferred_wgrads():
+            with ops.deferred_wgrads(self._wgrad_stream()):
                 for loss in gG.loss_backward:
                     (getattr(self, loss) / its).backward()
         self._group_finish(gG)
@@ -485,7 +496,7 @@ class CUTModel(BaseModel):
                 self.compute_G_loss()
             st["outs"] = {k: getattr(self, k) for k in self._g_outputs()}
             with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode="thread_local"):
-                with ops.deferred_wgrads():           # the ~190 linear-layer weight gradients of the generator leave as grouped launches
+                with ops.deferred_wgrads(self._wgrad_stream()):     # the ~190 weight gradients of the generator leave as grouped launches on a forked stream
                     (self.loss_G_tot / its).backward(retain_graph=True)
             st["fwd"], st["bwd"] = gf, gb
 

@@ -192,6 +192,8 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.x_mode = x_mode
     if WGRAD_DEFER is not None and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32 and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None:
         WGRAD_DEFER.append((_dt(dy), a, (dy, x, dw, dbias)))       # launched with its peers by flush_deferred_wgrads(); operands kept alive
+        if _WGRAD_SIDE is not None and len(WGRAD_DEFER) >= _WGRAD_SIDE[1]:
+            flush_deferred_wgrads()
         return
     if KERNEL_TIMING is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -212,7 +214,13 @@ WGRAD_DEFER = None
 WGRAD_GROUP = os.environ.get("JG_WGRAD_GROUP", "1") != "0"
 
 
+_WGRAD_SIDE = None          # (stream, flush threshold) of the active deferred_wgrads context, or None: flush on the current stream at the exit
+
+
 def flush_deferred_wgrads():
+    """issue the collected problems as grouped launches: on the current stream, or -- inside `deferred_wgrads(stream=...)` -- on that stream,
+    ordered behind everything enqueued on the current stream so far (their operands are complete), leaving the current stream free to go on
+    with the input-gradient chain"""
     global WGRAD_DEFER
     todo, WGRAD_DEFER = WGRAD_DEFER, ([] if WGRAD_DEFER is not None else None)
     if not todo:
@@ -220,30 +228,51 @@ def flush_deferred_wgrads():
     by_dt = {}
     for dt, a, keep in todo:
         by_dt.setdefault(dt, []).append(a)
-    for dt, args in by_dt.items():
-        arr = (WgradArgs * len(args))(*args)
-        check(_lib.lib().jg_conv2d_wgrad_tn_group(dt, arr, len(args), _st()), "jg_conv2d_wgrad_tn_group")
+    side = _WGRAD_SIDE[0] if _WGRAD_SIDE is not None else None
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        for dt, a, keep in todo:
+            for t in keep[:2]:
+                t.record_stream(side)              # dy / x come from the current stream's allocator pool
+        ctx = torch.cuda.stream(side)
+    else:
+        import contextlib
+
+        ctx = contextlib.nullcontext()
+    with ctx:
+        for dt, args in by_dt.items():
+            arr = (WgradArgs * len(args))(*args)
+            check(_lib.lib().jg_conv2d_wgrad_tn_group(dt, arr, len(args), _st()), "jg_conv2d_wgrad_tn_group")
     return len(todo)
 
 
 class deferred_wgrads:
-    """collect the 1x1 / linear weight-gradient launches of the enclosed backward and issue them grouped at the exit (JG_WGRAD_GROUP=0: off)"""
+    """collect the weight-gradient launches of the enclosed backward and issue them grouped (JG_WGRAD_GROUP=0: off).  Without `stream`: one flush at
+    the exit, on the current stream.  With `stream`: a flush onto that stream every `every` collected problems and at the exit, where the current
+    stream joins it -- the grouped launches are bandwidth-bound full-chip kernels, the backward chain next to them is a string of small launches."""
+
+    def __init__(self, stream=None, every=48):
+        self.stream, self.every = stream, every
 
     def __enter__(self):
-        global WGRAD_DEFER
+        global WGRAD_DEFER, _WGRAD_SIDE
         self.prev = WGRAD_DEFER
         if WGRAD_GROUP and WGRAD_DEFER is None:
             WGRAD_DEFER = []
+            _WGRAD_SIDE = (self.stream, self.every) if self.stream is not None else None
         return self
 
     def __exit__(self, *exc):
-        global WGRAD_DEFER
+        global WGRAD_DEFER, _WGRAD_SIDE
         if self.prev is None and WGRAD_DEFER is not None:
             try:
                 if exc[0] is None:
                     flush_deferred_wgrads()
+                    if _WGRAD_SIDE is not None:
+                        torch.cuda.current_stream().wait_stream(_WGRAD_SIDE[0])
             finally:
                 WGRAD_DEFER = None
+                _WGRAD_SIDE = None
 
 
 def axpby(a, alpha=1.0, b=None, beta=0.0, alpha_dev=None, out=None):
