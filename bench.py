@@ -368,13 +368,14 @@ def cut_leg(local_rank, no_cpu, proj="vitsmall"):
     recs, ops.KERNEL_TIMING = ops.KERNEL_TIMING, None
     table = kernel_table(recs, 1)
     dom = max(table, key=lambda k: table[k]["time_per_step_ms"])
-    # HBM traffic of the dominant instance: the committed rocprofv3 PMC passes of this step (profiles/r04_cut_pmc.json, tools/collect_evidence.sh cutpmc: a filtered PMC pass over the conv / weight-gradient family)
+    # HBM traffic of the dominant instance: the committed rocprofv3 PMC passes of this step (profiles/r05_cut_pmc.json, tools/collect_evidence.sh cutpmc: a filtered PMC pass over the conv / weight-gradient family)
     traffic, traffic_build, traffic_file = None, None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r04_cut_pmc.json")))
+        fn = "r05_cut_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_cut_pmc.json")) else "r04_cut_pmc.json"
+        pmc = json.load(open(os.path.join(ROOT, "profiles", fn)))
         row = pmc.get(dom) or pmc.get(dom.split("<")[0])
         if row:
-            traffic, traffic_build, traffic_file = round(row["bytes_per_launch"], 1), pmc.get("_meta", {}).get("build"), "profiles/r04_cut_pmc.json"
+            traffic, traffic_build, traffic_file = round(row["bytes_per_launch"], 1), pmc.get("_meta", {}).get("build"), "profiles/" + fn
     except Exception:
         pass
     roof = dict(table[dom], kernel=dom, traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)",
@@ -599,7 +600,7 @@ def main():
         # read from inside the timed process: `traffic` is that committed measurement, `traffic_build` says which build it is from and
         # `running_build` which one produced every other number of this line.
         traffic, traffic_build, traffic_file = None, None, None
-        for cand in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+        for cand in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
             try:
                 if args.model != "palette":
                     break
