@@ -73,3 +73,5 @@ bool jg_conv_halo_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);
 bool jg_conv_p64_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);
 // conv1x1.hip: returns true when the shape was handled by the streaming (LDS-free) 1x1 kernel.
 bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);
+// conv_kxk.hip: returns true when the shape was handled by the halo-resident 7x7 kernel (few output channels, stride 1).
+bool jg_conv_kxk_try(int dtype, const ConvP& p, int nbatch, hipStream_t st);

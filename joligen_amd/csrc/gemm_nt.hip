@@ -481,6 +481,10 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st, long ws_bytes) {
     JG_CHECK_LAUNCH();
     return JG_OK;
   }
+  if (variant >= 6 && jg_conv_kxk_try(sizeof(T) == 2 && std::is_same<T, f16_t>::value ? JG_F16 : JG_BF16, p, nbatch, st)) {
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   if (p.reflect || p.x_up || p.y_pool) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read / pooled stores exist only in the halo-resident kernel
   if (variant >= 2) {
     // small launches (SegFormer / EfficientNet linear layers, discriminator tails): the default tiles leave most CUs without a workgroup

@@ -1834,3 +1834,34 @@ def test_wgrad_grouped_launch_matches_single_launches(dtype):
         if b0 is not None:
             refb = b0.double().cpu() + dy.double().cpu().sum(0)
             assert relerr(db2, refb) < TOL[dtype] and relerr(db2, db1) < 1e-5, (tuple(x.shape), relerr(db2, refb))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,Hin,Cin,Cout,pad,bias", [(2, 102, 64, 32, 0, True), (2, 96, 32, 64, 6, False), (1, 141, 128, 24, 3, True), (3, 80, 32, 8, 3, True)])
+def test_conv7x7_halo_kernel(B, Hin, Cin, Cout, pad, bias, dtype):
+    """conv_kxk_halo_kernel (round 5): the 7x7 content head of the CUT generators (64 -> 27 padded to 32 channels behind ReflectionPad2d(3)) and
+    its input gradient (32 -> 64 with pad 6 over the padded domain: 102 x 102 outputs, ragged against the 16 x 16 tiles), two channel chunks,
+    zero padding inside the kernel, with and without a bias -- against fp32 torch on the rounded operands and against the im2col kernel it replaces."""
+    from joligen_amd import _lib, ops
+
+    d = dev()
+    Ho = Hin + 2 * pad - 6
+    x = rnd((B, Hin, Hin, Cin), dtype, 41).to(d)
+    w = (rnd((Cout, 7, 7, Cin), dtype, 42).float() / math.sqrt(49 * Cin)).to(dtype).to(d)
+    bv = rnd((Cout,), torch.float32, 43).to(d) if bias else None
+    geo = dict(B=B, H=Hin, W=Hin, Cin=Cin, Cout=Cout, R=7, S=7, pad=pad, stride=1, Ho=Ho, Wo=Ho, ldx=Cin, ldw=49 * Cin, ldy=Cout)
+    y = torch.empty(B, Ho, Ho, Cout, device=d, dtype=dtype)
+    ops.conv_nt(x, w, y, bias=bv, alpha=0.75, **geo)
+    assert _lib.lib().jg_last_kernel().decode() == "conv_kxk_halo_kernel<7x7>"
+    ref = 0.75 * F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), None, 1, pad)
+    if bias:
+        ref = ref + bv.cpu().view(1, -1, 1, 1)
+    assert relerr(y.permute(0, 3, 1, 2), ref) < TOL[dtype], relerr(y.permute(0, 3, 1, 2), ref)
+    prev = _lib.set_tuning("JG_CONV_KXK", 0)
+    try:
+        y2 = torch.empty_like(y)
+        ops.conv_nt(x, w, y2, bias=bv, alpha=0.75, **geo)
+        assert "kxk" not in _lib.lib().jg_last_kernel().decode()
+    finally:
+        _lib.set_tuning("JG_CONV_KXK", prev)
+    assert relerr(y, y2) < TOL[dtype]
