@@ -329,14 +329,48 @@ void launch_1x1(const ConvP& p, hipStream_t st) {
     jg_note_kernel("conv1x1_stream_kernel+gn_bwd_apply");
     hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS, false, true>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
   } else {
+    jg_note_kernel("conv1x1_stream_kernel");
     hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
   }
+}
+
+// the plain streaming kernel only (no fused GroupNorm passes): the extra (PAIRS, KS) combinations of round 5
+template <typename T, int PAIRS, int KS>
+void launch_1x1_plain(const ConvP& p, hipStream_t st) {
+  const int ntiles = p.M / 16;
+  const int ngroups = p.N / (PAIRS * 32);
+  int bx = (ntiles + 3) / 4;
+  const int cap = 256 * 8 / ngroups > 64 ? 256 * 8 / ngroups : 64;
+  if (bx > cap) bx = cap;
+  jg_note_kernel("conv1x1_stream_kernel");
+  hipLaunchKernelGGL((conv1x1_stream_kernel<T, PAIRS, KS>), dim3(bx, ngroups), dim3(256), 0, st, p, ntiles);
 }
 
 template <typename T>
 bool dispatch_1x1(const ConvP& p, hipStream_t st) {
   const int ks = p.Cin / 32;
   const bool wide = p.N % 128 == 0;
+  // round 5: 32-channel inputs (KS 1) and outputs that are a multiple of 32 but not of 64 (PAIRS 1) -- the stage-1 / stage-2 linear layers
+  // of the SegFormer generator (32 -> 32 / 128, 128 -> 32, 64 -> 64 / 256, 256 -> 64 on 65 k - 262 k tokens), which the implicit-GEMM
+  // kernel streams at 2.0 TB/s (profiles/r05_cut_pmc_hbm_traffic.md)
+  if (!p.aab && !p.bgx) {
+    if (ks == 1) {
+      if (wide) launch_1x1_plain<T, 4, 1>(p, st);
+      else if (p.N % 64 == 0) launch_1x1_plain<T, 2, 1>(p, st);
+      else launch_1x1_plain<T, 1, 1>(p, st);
+      return true;
+    }
+    if (p.N % 64) {
+      switch (ks) {
+        case 2: launch_1x1_plain<T, 1, 2>(p, st); return true;
+        case 4: launch_1x1_plain<T, 1, 4>(p, st); return true;
+        case 8: launch_1x1_plain<T, 1, 8>(p, st); return true;
+        default: return false;
+      }
+    }
+  } else if (ks == 1 || p.N % 64) {
+    return false;
+  }
   switch (ks) {
     case 2: wide ? launch_1x1<T, 4, 2>(p, st) : launch_1x1<T, 2, 2>(p, st); return true;
     case 4: launch_1x1<T, 2, 4>(p, st); return true;      // <4, 4> would need 256+ VGPRs
@@ -363,7 +397,7 @@ bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
     return true;
   }
   if (nbatch != 1 || p.nh != 1 || p.R != 1 || p.S != 1 || p.pad != 0 || p.stride != 1 || p.out_f32 || p.stats || p.reflect) return false;
-  if (p.Cin % 32 || p.Cin > 256 || p.N % 64 || (p.M & 15)) return false;
+  if (p.Cin % 32 || p.Cin > 256 || p.N % 32 || (p.M & 15)) return false;
   if (p.ldx % 8 || p.ldy % 8 || p.ldw % 8 || (p.res && p.ldres % 8)) return false;
   // only where the layer is memory-bound: few hundred FLOP per byte; deep / low-resolution layers stay on the MFMA-tiled GEMM
   if ((long)p.M < 65536) return false;

@@ -1116,7 +1116,9 @@ def test_ddpm_loss_variants_vs_reference_golden(golden_dir, lossname, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("Cin,Cout,with_res", [(64, 128, True), (64, 192, False), (128, 64, True), (192, 64, False), (128, 256, True), (256, 64, True)])
+@pytest.mark.parametrize("Cin,Cout,with_res", [(64, 128, True), (64, 192, False), (128, 64, True), (192, 64, False), (128, 256, True), (256, 64, True),
+                                               # round 5: 32-channel inputs and outputs that are a multiple of 32 only (SegFormer stage-1 / stage-2 linear layers)
+                                               (32, 32, True), (32, 128, False), (128, 32, True), (32, 64, False), (64, 96, True), (256, 160, False)])
 def test_conv1x1_streaming_kernel(Cin, Cout, with_res, dtype, monkeypatch):
     """the LDS-free streaming 1x1 kernel (M >= 65536 pixels) against the fp32 reference and against the generic kernel
     (JG_CONV1X1=0 is read once per process, so the generic result comes from a sub-threshold call on a slice)"""
@@ -1133,6 +1135,9 @@ def test_conv1x1_streaming_kernel(Cin, Cout, with_res, dtype, monkeypatch):
     geo = dict(B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=Cin, ldw=Cin, ldy=Cout)
     ops.conv_nt(xd, wd, y, bias=bd, res=rd, ldres=Cout, alpha=0.5, res_scale=0.7, **geo)
     torch.cuda.synchronize()
+    from joligen_amd import _lib
+
+    assert _lib.lib().jg_last_kernel().decode() == "conv1x1_stream_kernel", _lib.lib().jg_last_kernel().decode()      # the streaming kernel took it
     ref = 0.5 * torch.einsum("bhwc,oc->bhwo", x.float(), w.float().view(Cout, Cin)) + bias
     if with_res:
         ref = ref + 0.7 * res.float()
