@@ -497,7 +497,12 @@ int launch_conv(const ConvP& p, int nbatch, hipStream_t st, long ws_bytes) {
     // stats_mode 1 (GroupNorm-backward reductions in the epilogue) exists only in the LDS-transposed epilogue of the 4 x 4-fragment wave
     // tiles: those launches keep the default tiles
     const bool alt_ok = (variant == 3 || variant >= 6) && jg_tune(JG_TUNE_CONV_SMALL_TILE) && !(p.stats && p.stats_mode == 1);
-    const bool small = alt_ok && (p.N <= 64 ? b256 : b128) < 160 && !can_split;
+    // round 5: when 64 x 64 tiles alone fill the chip (>= 256 of them: a few thousand rows, e.g. the ViT projector's 4112-token GEMMs with
+    // N = 384), they are preferred to cutting the K loop of 99 default tiles (1536 -> 384 on 16 x 257 tokens: the split form + its finalize
+    // launch took 30 us)
+    const long b64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * nbatch;
+    const bool fill64 = jg_tune(JG_TUNE_CONV_SMALL_TILE) >= 1 && jg_tune(JG_TUNE_CONV_SMALL_TILE) != 2 && b64 >= 256;
+    const bool small = alt_ok && (p.N <= 64 ? b256 : b128) < 160 && (!can_split || fill64);
     if (small) {
       jg_note_kernel("conv_nt_glds_kernel<64,64,64,2,2>");
       launch_glds<T, 64, 64, 64, 2, 2>(p, nbatch, st, ws_bytes);
