@@ -130,7 +130,8 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
     const int px = pos / CPP, cpos = pos % CPP;
     const int ty = px >> 4, xx = px & 15;
     const int blk = (cpos >> 1) ^ fdy<BCO>(xx);
-    d_rel[rd] = (ty * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8;
+    // (round 5: output-channel counts below the tile width -- the 8-channel head of the UNet -- read the zero page for the missing chunks)
+    d_rel[rd] = co0 + ((blk << 1) | (cpos & 1)) * 8 < p.Cout ? (ty * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8 : -1;
   }
   }
 
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
         const int px = pos / CPP, cpos = pos % CPP;
         const int yy = px >> 4, xx = px & 15;
         const int blk = (cpos >> 1) ^ fdy<BCO>(xx);
-        glds16(db + (yy * p.W + xx) * (int)p.lddy + ((blk << 1) | (cpos & 1)) * 8, l0 + (HALO_CH + rd * NT) * 16);
+        const int dch = ((blk << 1) | (cpos & 1)) * 8;
+        glds16(co0 + dch < p.Cout ? db + (yy * p.W + xx) * (int)p.lddy + dch : zp, l0 + (HALO_CH + rd * NT) * 16);
       }
   #pragma unroll
       for (int rd = 0; rd < A_ROUNDS; ++rd) {
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
       const T* db = dyg + pix * p.lddy;
       const unsigned l0 = lds0 + (buf * BUF_CH + wave * 64) * 16;
   #pragma unroll
-      for (int rd = 0; rd < D_ROUNDS; ++rd) glds16(db + d_rel[rd], l0 + (HALO_CH + rd * NT) * 16);
+      for (int rd = 0; rd < D_ROUNDS; ++rd) glds16(d_rel[rd] >= 0 ? db + d_rel[rd] : zp, l0 + (HALO_CH + rd * NT) * 16);
   #pragma unroll
       for (int rd = 0; rd < A_ROUNDS; ++rd) {
         if (a_yx[rd] >= 0) {
@@ -355,7 +357,7 @@ void launch_wg(const WgP& p, hipStream_t st) {
   // JG_WGRAD_PIPE (1): the software-pipelined MFMA loop for the CPW == 2 tiles (the CPW == 4 tiles have no registers left for the ring)
   const bool pipe = CPW == 2 && jg_tune(JG_TUNE_WGRAD_PIPE) != 0;
   constexpr int BCO = WMR * CPW * 16;
-  const int ncot = p.Cout / BCO, npairs = ncot * (p.Cin / 64);
+  const int ncot = (p.Cout + BCO - 1) / BCO, npairs = ncot * (p.Cin / 64);
   const int ntiles = p.B * (p.H / TH) * (p.W >> 4);
   int per, splitk;
   pick_split(npairs, ntiles, TH == 16 ? 6 : 10, WMR == 1 && jg_tune(JG_TUNE_WGRAD_LDS_PAD) < 4096 ? 512 : 256, &per, &splitk);
@@ -392,7 +394,10 @@ void dispatch_wg(const WgP& p, hipStream_t st) {
 
 bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st) {
   if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_mode != JG_OUT_ATOMIC_F32) return false;
-  if (p.Cin % 64 || p.Cout % 64 || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
+  // Cout: a multiple of 64, or fewer than 64 (one partly filled channel tile: the 3 -> 8-channel head of the UNet at 256 x 256 x 32 images, whose
+  // im2col weight gradient fetched the input once per tap pair: 582 us for 60 us of bytes)
+  if (p.Cin % 64 || (p.Cout % 64 && (p.Cout > 64 || (p.Cout & 7))) || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
+  if (p.Cout < 64 && ((long)p.B * p.H * p.W < 262144 || p.reflect || p.x_up)) return false;      // small launches stay on the im2col kernel
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.B * p.H * p.W * p.lddy >= (1L << 31)) return false;
   if (dtype == JG_F16) dispatch_wg<f16_t>(p, st);
   else if (dtype == JG_BF16) dispatch_wg<bf16_t>(p, st);

@@ -1870,3 +1870,35 @@ def test_conv7x7_halo_kernel(B, Hin, Cin, Cout, pad, bias, dtype):
     finally:
         _lib.set_tuning("JG_CONV_KXK", prev)
     assert relerr(y, y2) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_halo_narrow_output(dtype):
+    """round 5: the halo-resident 3x3 weight gradient with FEWER than 64 output channels (the 64 -> 3 (8) head of the UNet at 256 x 256): the missing
+    channel chunks of the dy tile come from the zero page, only the real rows are written -- against fp32 torch and against the im2col kernel."""
+    from joligen_amd import _lib, ops
+    from joligen_amd.ops import JG_OUT_ATOMIC_F32
+
+    d = dev()
+    B, H, Cin, CoutP, Cout = 4, 256, 64, 8, 3
+    x = rnd((B, H, H, Cin), dtype, 51).to(d)
+    dy = rnd((B, H, H, CoutP), dtype, 52).to(d)
+    dy[..., Cout:] = 0
+    outs = []
+    for variant in (4, 2):
+        prev = _lib.set_tuning("JG_WGRAD_VARIANT", variant)
+        try:
+            dw = torch.zeros(Cout, 3, 3, Cin, device=d)
+            db = torch.zeros(Cout, device=d)
+            ops.wgrad_tn(dy, x, dw, B=B, H=H, W=H, Cin=Cin, Cout=CoutP, R=3, S=3, pad=1, stride=1, Ho=H, Wo=H, lddy=CoutP, ldx=Cin, lddw=9 * Cin, dbias=db,
+                         Cin_out=Cin, Cout_out=Cout, splitk=64, out_mode=JG_OUT_ATOMIC_F32)
+            torch.cuda.synchronize()
+            outs.append((dw, db, _lib.lib().jg_last_kernel().decode()))
+        finally:
+            _lib.set_tuning("JG_WGRAD_VARIANT", prev)
+    assert "wgrad3x3_halo" in outs[0][2], outs[0][2]
+    wr = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wr, None, 1, 1).backward(dy[..., :Cout].double().cpu().permute(0, 3, 1, 2))
+    for dw, db, name in outs:
+        assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL[dtype], (name, relerr(dw.permute(0, 3, 1, 2), wr.grad))
+        assert relerr(db, dy[..., :Cout].double().sum((0, 1, 2)).cpu()) < TOL[dtype], name
