@@ -201,7 +201,20 @@ __device__ uint4 jg_zero_page = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ int swz128r(int row) { return (row >> 1) & 7; }
 
-template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT = false>
+// LDS-DMA from inline asm (as conv_halo.hip): hipcc neither drains nor counts it, which is what lets the ring form below keep NST - 1
+// stages in flight across its one raw s_barrier per K step; every wait on these loads is an explicit wait_vmcnt_nt<N>().
+__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt_nt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NST = 2: double buffer, one drain + __syncthreads per K step (many co-resident workgroups hide the L2 -> LDS latency between them).
+// NST > 2 (round 5): a ring of NST stages with NST - 1 K steps in flight per workgroup and a counted wait -- for the launches whose grid
+// does NOT oversubscribe the CUs (token GEMMs of the ViT / SegFormer blocks, 1x1 layers at 32 x 32), where a K step of 8 - 32 MFMAs per
+// wave is an order of magnitude shorter than the DMA latency it used to wait out.  Same arithmetic, same accumulation order.
+template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool SPLIT = false, int NST = 2>
 __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
   constexpr int CPR = BK / 8;                         // 16-byte chunks per LDS row
   constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small");
 
-  __shared__ uint4 sm[2][(BM + BN) * CPR];
+  __shared__ uint4 sm[NST][(BM + BN) * CPR];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -311,6 +324,40 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
     }
   };
 
+  if constexpr (NST > 2) {
+    constexpr int LPS = A_CH + B_CH;                  // LDS-DMA instructions per thread and stage (dead stages fetch the zero page: the count stays uniform)
+    typedef __attribute__((address_space(3))) char* lds_cptr;
+    const unsigned lds0 = (unsigned)(size_t)(lds_cptr)(char*)&sm[0][0];
+    auto issue_ring = [&](int buf, bool live) {
+      const bool kvalid = live && r < p.R;
+      const unsigned dst = lds0 + (unsigned)(buf * (BM + BN) * CPR + wave * 64) * 16u;
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int ih = ih0[i] + r, iw = iw0[i] + s;
+        const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        glds16_nt(ok ? x + (((long)(pb[i] + ih) * p.W + iw) * p.ldx + c) : zp, dst + 256 * 16 * i);
+      }
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) {
+        const int n = n0 + srow + RSTEP * i;
+        glds16_nt((kvalid && n < p.N) ? w + ((long)n * p.ldw + kg) : zp, dst + (BM * CPR + 256 * i) * 16);
+      }
+      if (live) advance_k();
+    };
+#pragma unroll
+    for (int st = 0; st < NST - 1; ++st) issue_ring(st, st < nk);
+    int cur = 0, nxt = NST - 1;
+    for (int ks = 0; ks < nk; ++ks) {
+      wait_vmcnt_nt<(NST - 2) * LPS>();               // stage ks has landed (this thread's share) ...
+      __builtin_amdgcn_s_barrier();                   // ... everybody's has, and everybody is done reading stage ks - 1
+      issue_ring(nxt, ks + NST - 1 < nk);             // = the buffer of stage ks - 1
+      compute(cur);
+      cur = cur + 1 == NST ? 0 : cur + 1;
+      nxt = nxt + 1 == NST ? 0 : nxt + 1;
+    }
+    wait_vmcnt_nt<0>();                               // the epilogue below may reuse the ring as scratch
+    __builtin_amdgcn_s_barrier();
+  } else {
   if (nk > 0) issue_loads(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -323,6 +370,7 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
     compute(cur);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
   }
 
   // split-K: this K slice's raw fp32 partial tile goes to the workspace through the plain fp32 store path below (no alpha / bias /
@@ -454,6 +502,20 @@ void launch_glds(ConvP p, int nbatch, hipStream_t st, long ws_bytes = 0) {
   if (p.ws && !p.stats && !p.res_up && (p.N & 3) == 0 && jg_tune(JG_TUNE_CONV_SPLITK))
     p.splitk = pick_conv_splitk(blocks, (p.K + BK - 1) / BK, (long)nbatch * p.M * p.N, ws_bytes);
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), p.splitk, nbatch);
+  // ring form (JG_CONV_RING: 0 off, 1 auto, 2 wherever it exists): 64 x 64 (4 stages, 64 KB) and 128 x 128 tiles (3 stages, 96 KB), BK 64,
+  // unsplit, K loops of >= 8 steps, grids that fit the chip in one round at the ring's occupancy (two / one workgroup per CU) -- beyond
+  // that the co-resident workgroups of the double-buffered form hide the latency as well and the ring's LDS footprint costs a round
+  // (tools/ring_probe.py: 1536 -> 384 on 16 x 257 tokens 23.2 -> 18.1 us, 512 -> 256 4x4 on 16 x 32 x 32 147 -> 114 us; 384 -> 1536 on
+  // the same tokens 16.2 -> 23.9 us if forced)
+  constexpr bool has_ring = BK == 64 && BM == BN && (BM == 64 || BM == 128);
+  const int ring = jg_tune(JG_TUNE_CONV_RING);
+  const bool use_ring = has_ring && ring && p.splitk == 1 && (ring >= 2 || ((p.K + BK - 1) / BK >= 8 && blocks <= (BM == 64 ? 512 : 256)));
+  if constexpr (has_ring) {
+    if (use_ring) {
+      hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv, false, BM == 64 ? 4 : 3>), grid, dim3(256), 0, st, p);
+      return;
+    }
+  }
   if (p.splitk > 1) hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv, true>), grid, dim3(256), 0, st, p);
   else hipLaunchKernelGGL((conv_nt_glds_kernel<T, BM, BN, BK, WMv, WNv, false>), grid, dim3(256), 0, st, p);
   if (p.splitk > 1) {

@@ -161,6 +161,39 @@ def test_conv_generic_small_and_narrow_tiles(case, dtype):
     assert torch.equal(y, y_def)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    (3, 1, 257, 1536, 384, 1, 0, 1),     # ViT fc2 on 3 x 257 tokens: 64 x 64 tiles, 24 K steps, ragged last row tile
+    (2, 1, 67, 192, 72, 1, 0, 1),        # 3 K steps (shorter than the ring), N = 72: second column tile 8 wide
+    (2, 9, 9, 64, 200, 3, 1, 1),         # im2col 3x3 below the halo kernel's shapes: 128 x 128 tiles, ragged M and N, K = 576
+    (2, 16, 16, 128, 256, 4, 1, 2),      # strided 4x4 (discriminator): K = 2048
+], ids=["fc2", "shortK", "im2col3x3", "stride2"])
+def test_conv_generic_ring_form_is_bit_equal(case, dtype):
+    """round 5: the NST-stage ring form of the generic LDS-DMA kernel (JG_CONV_RING 2 = wherever it exists) against the double-buffered form
+    (JG_CONV_RING 0): same products, same K order -> bit-identical, with bias + residual; and against fp32 torch."""
+    from joligen_amd import _lib, ops  # noqa: F401
+
+    B, H, W, Cin, Cout, k, pad, stride = case
+    x = rnd((B, Cin, H, W), dtype, 31)
+    w = rnd((Cout, Cin, k, k), dtype, 32, 1.0 / math.sqrt(Cin * k * k))
+    bias = rnd((Cout,), torch.float32, 33)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = rnd((B, Cout, Ho, Wo), dtype, 34)
+    ref = 0.5 * F.conv2d(x.float(), w.float(), None, stride, pad) + bias.view(1, -1, 1, 1) + 0.7 * res.float()
+    d = dev()
+    args = (nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d), bias.to(d), nhwc(res).to(d), pad, stride, 0.5, 0.7)
+    ys = []
+    for ring in (2, 0, 1):
+        prev = _lib.set_tuning("JG_CONV_RING", ring)
+        try:
+            ys.append(torch.ops.jg355.conv2d_nt(*args))
+        finally:
+            _lib.set_tuning("JG_CONV_RING", prev)
+    torch.cuda.synchronize()
+    assert relerr(nchw(ys[0]), ref) < TOL[dtype], (case, dtype)
+    assert torch.equal(ys[0], ys[1]) and torch.equal(ys[2], ys[1])
+
+
 def _make_conv_module(Cin, Cout, k, pad, dtype, real_cin=None, real_cout=None, needs_dgrad=True):
     """A JGConv2d inside a tiny module finalised by a ParamArena (exercises padding + refresh)."""
     import torch.nn as nn
