@@ -362,6 +362,12 @@ int jg_gather_rows(int dtype, const void* src, int64_t ld, const int64_t* ids, f
                    jg_stream_t s);
 int jg_scatter_rows(int dtype, void* dsrc, int64_t ld, const int64_t* ids, const float* ddst, int B, int64_t HW, int C, int P,
                     jg_stream_t s);
+/* the same with G id sets ([G][P]): image b uses set (b / per) % G -- one launch for the concatenated batch of both contrastive terms of
+ * cut_model.py:708-909 ([translated | identity | source | target] x B images: G = 2, per = B) */
+int jg_gather_rows_grouped(int dtype, const void* src, int64_t ld, const int64_t* ids, float* dst, int B, int64_t HW, int C, int P, int G, int per,
+                           jg_stream_t s);
+int jg_scatter_rows_grouped(int dtype, void* dsrc, int64_t ld, const int64_t* ids, const float* ddst, int B, int64_t HW, int C, int P, int G,
+                            int per, jg_stream_t s);
 int jg_l2norm_fwd(const float* x, float* y, float* nrm, int64_t R, int D, float eps, jg_stream_t s);
 int jg_l2norm_bwd(const float* y, const float* nrm, const float* dy, float* dx, int64_t R, int D, float eps, jg_stream_t s);
 int jg_lsgan_loss(int dtype, const void* pred, float target, float* loss, void* dpred, int64_t Npix, int Cpad, float scale,
@@ -418,6 +424,10 @@ int jg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* 
                      jg_stream_t s);
 int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, void* dx, float* dgamma, float* dbeta,
                      int64_t R, int C, jg_stream_t s);
+/* the same with the residual branch's gradient added in the pass: dx = res + LayerNorm'(dy) -- the fan-in of a pre-norm block's input,
+ * x + drop_path(f(norm(x))) (models/modules/segformer/backbone.py:401-438); res may be NULL */
+int jg_layernorm_bwd_add(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, const void* res, void* dx, float* dgamma,
+                         float* dbeta, int64_t R, int C, jg_stream_t s);
 int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C, int gelu,
                      jg_stream_t s);
 int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw, float* dbias,

@@ -115,6 +115,8 @@ SIGNATURES = {
                                 c_f32, c_p],
     "jg_gather_rows": [c_i32, c_p, c_i64, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p],
     "jg_scatter_rows": [c_i32, c_p, c_i64, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_p],
+    "jg_gather_rows_grouped": [c_i32, c_p, c_i64, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_scatter_rows_grouped": [c_i32, c_p, c_i64, c_p, c_p, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_l2norm_fwd": [c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
     "jg_l2norm_bwd": [c_p, c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
     "jg_lsgan_loss": [c_i32, c_p, c_f32, c_p, c_p, c_i64, c_i32, c_f32, c_f32, c_p],
@@ -136,6 +138,7 @@ SIGNATURES = {
     "jg_unpatchify": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_transpose2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_p],
     "jg_layernorm_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p],
+    "jg_layernorm_bwd_add": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p],
     "jg_dwconv3x3_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dwconv3x3_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dwconv3x3_bwd_ws": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],

@@ -558,26 +558,28 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const T* __restrict__ 
 // ---- PatchSampleF / GAN-loss glue (cut_networks.py:6-73, loss.py:59-85) ------------------------------------------
 // dst[b*P + p][c] = src[b, ids[p], c] as fp32 (the SAME patch ids for every image of the batch, cut_networks.py:43-57);
 // scatter = its adjoint (ids come from randperm: unique, so plain stores into a zeroed gradient).
+// Grouped form (G id sets, round 5): image b reads ids[((b / per) % G) * P + p] -- consecutive runs of `per` images cycle through the G sets,
+// so ONE launch serves the concatenated batch [translated | identity | source | target] of the two contrastive terms (G = 2, per = B).
 template <typename T>
 __global__ void gather_rows_kernel(const T* __restrict__ src, long ld, const int64_t* __restrict__ ids, float* __restrict__ dst,
-                                   int B, long HW, int C, int P) {
+                                   int B, long HW, int C, int P, int G, int per) {
   const long total = (long)B * P * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = i % C;
     const long r = i / C;
     const int p = r % P, b = r / P;
-    dst[i] = to_f32(src[((long)b * HW + ids[p]) * ld + c]);
+    dst[i] = to_f32(src[((long)b * HW + ids[((b / per) % G) * P + p]) * ld + c]);
   }
 }
 template <typename T>
 __global__ void scatter_rows_kernel(T* __restrict__ dsrc, long ld, const int64_t* __restrict__ ids, const float* __restrict__ ddst,
-                                    int B, long HW, int C, int P) {
+                                    int B, long HW, int C, int P, int G, int per) {
   const long total = (long)B * P * C;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = i % C;
     const long r = i / C;
     const int p = r % P, b = r / P;
-    dsrc[((long)b * HW + ids[p]) * ld + c] = from_f32<T>(ddst[i]);
+    dsrc[((long)b * HW + ids[((b / per) % G) * P + p]) * ld + c] = from_f32<T>(ddst[i]);
   }
 }
 
@@ -1102,21 +1104,29 @@ extern "C" int jg_channel_sum(int dtype, const void* x, int64_t ldx, float* out,
   return JG_OK;
 }
 
-extern "C" int jg_gather_rows(int dtype, const void* src, int64_t ld, const int64_t* ids, float* dst, int B, int64_t HW, int C, int P,
-                              jg_stream_t s) {
-  if (!src || !ids || !dst || B < 1 || P < 1 || C < 1 || ld < C) return JG_ERR_BAD_ARG;
+extern "C" int jg_gather_rows_grouped(int dtype, const void* src, int64_t ld, const int64_t* ids, float* dst, int B, int64_t HW, int C, int P,
+                                      int G, int per, jg_stream_t s) {
+  if (!src || !ids || !dst || B < 1 || P < 1 || C < 1 || ld < C || G < 1 || per < 1) return JG_ERR_BAD_ARG;
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(grid_for((long)B * P * C)), dim3(256), 0, (hipStream_t)s,
-                                              (const T*)src, (long)ld, ids, dst, B, (long)HW, C, P););
+                                              (const T*)src, (long)ld, ids, dst, B, (long)HW, C, P, G, per););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
-extern "C" int jg_scatter_rows(int dtype, void* dsrc, int64_t ld, const int64_t* ids, const float* ddst, int B, int64_t HW, int C,
-                               int P, jg_stream_t s) {
-  if (!dsrc || !ids || !ddst || B < 1 || P < 1 || C < 1 || ld < C) return JG_ERR_BAD_ARG;
+extern "C" int jg_scatter_rows_grouped(int dtype, void* dsrc, int64_t ld, const int64_t* ids, const float* ddst, int B, int64_t HW, int C,
+                                       int P, int G, int per, jg_stream_t s) {
+  if (!dsrc || !ids || !ddst || B < 1 || P < 1 || C < 1 || ld < C || G < 1 || per < 1) return JG_ERR_BAD_ARG;
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((scatter_rows_kernel<T>), dim3(grid_for((long)B * P * C)), dim3(256), 0, (hipStream_t)s,
-                                              (T*)dsrc, (long)ld, ids, ddst, B, (long)HW, C, P););
+                                              (T*)dsrc, (long)ld, ids, ddst, B, (long)HW, C, P, G, per););
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+extern "C" int jg_gather_rows(int dtype, const void* src, int64_t ld, const int64_t* ids, float* dst, int B, int64_t HW, int C, int P,
+                              jg_stream_t s) {
+  return jg_gather_rows_grouped(dtype, src, ld, ids, dst, B, HW, C, P, 1, B > 0 ? B : 1, s);
+}
+extern "C" int jg_scatter_rows(int dtype, void* dsrc, int64_t ld, const int64_t* ids, const float* ddst, int B, int64_t HW, int C,
+                               int P, jg_stream_t s) {
+  return jg_scatter_rows_grouped(dtype, dsrc, ld, ids, ddst, B, HW, C, P, 1, B > 0 ? B : 1, s);
 }
 extern "C" int jg_l2norm_fwd(const float* x, float* y, float* nrm, int64_t R, int D, float eps, jg_stream_t s) {
   if (!x || !y || !nrm || R < 1 || D < 1) return JG_ERR_BAD_ARG;

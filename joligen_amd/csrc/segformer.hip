@@ -170,11 +170,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
   }
 }
 
-// dx = rstd (g - mean(g) - xh mean(g xh)),  g = dy gamma,  xh = (x - mean) rstd;  dgamma += sum dy xh;  dbeta += sum dy
+// dx = (res +) rstd (g - mean(g) - xh mean(g xh)),  g = dy gamma,  xh = (x - mean) rstd;  dgamma += sum dy xh;  dbeta += sum dy
+// res (optional): the gradient that reaches x through the residual connection around the normalised branch (pre-norm block:
+// x + f(LN(x))), added here instead of in a separate pass
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
-                                                            const float* __restrict__ mr, T* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, long R, int C, int lpr) {
+                                                            const float* __restrict__ mr, const T* __restrict__ res, T* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, long R, int C, int lpr) {
   __shared__ float s_red[2][512];
   const int lane = threadIdx.x & 63;
   const int sub = lane % lpr, rsub = lane / lpr, rpw = 64 / lpr;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
   for (long r0 = wave * rpw; r0 < R; r0 += 2 * nwaves * rpw) {
     long row[2];
     bool ok[2];
-    uint4 vx[2], vd[2];
+    uint4 vx[2], vd[2], vr[2];
     float mean[2], rstd[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       const int cc = act ? sub * 8 : 0;
       vx[u] = *reinterpret_cast<const uint4*>(x + rr * C + cc);
       vd[u] = *reinterpret_cast<const uint4*>(dy + rr * C + cc);
+      vr[u] = res ? *reinterpret_cast<const uint4*>(res + rr * C + cc) : make_uint4(0u, 0u, 0u, 0u);
       mean[u] = mr[rr * 2];
       rstd[u] = mr[rr * 2 + 1];
     }
@@ -228,9 +231,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
       }
       if (ok[u] && dx) {
         const float m1 = s1 * inv_c, m2 = s2 * inv_c;
-        float o8[8];
+        float o8[8], r8[8];
+        unpack8<T>(vr[u], r8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o8[j] = rstd[u] * (gy[j] - m1 - xh[j] * m2);
+        for (int j = 0; j < 8; ++j) o8[j] = r8[j] + rstd[u] * (gy[j] - m1 - xh[j] * m2);
         *reinterpret_cast<uint4*>(dx + row[u] * C + sub * 8) = pack8<T>(o8);
       }
     }
@@ -1346,17 +1350,21 @@ extern "C" int jg_layernorm_fwd(int dtype, const void* x, const float* gamma, co
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
-extern "C" int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, void* dx, float* dgamma,
-                                float* dbeta, int64_t R, int C, jg_stream_t s) {
-  if (!x || !dy || !gamma || !mr || R < 1 || C < 8 || C % 8 || C > 512 || (!dgamma != !dbeta)) return JG_ERR_BAD_ARG;
+extern "C" int jg_layernorm_bwd_add(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, const void* res, void* dx,
+                                    float* dgamma, float* dbeta, int64_t R, int C, jg_stream_t s) {
+  if (!x || !dy || !gamma || !mr || R < 1 || C < 8 || C % 8 || C > 512 || (!dgamma != !dbeta) || (res && !dx)) return JG_ERR_BAD_ARG;
   // (with the parameter gradients every block ends with 2 C global atomics onto the same addresses: 256 blocks instead of 1024 keep
   //  that chain short -- it, not the streaming, set the 20 us floor of this launch)
   const int lpr = lanes_per_row(C);
   const long waves = (R + 64 / lpr - 1) / (64 / lpr);
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, dgamma ? jg_tune(JG_TUNE_LN_BWD_CAP) : 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
-                                              (const T*)dy, gamma, mr, (T*)dx, dgamma, dbeta, (long)R, C, lpr););
+                                              (const T*)dy, gamma, mr, (const T*)res, (T*)dx, dgamma, dbeta, (long)R, C, lpr););
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+extern "C" int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, void* dx, float* dgamma,
+                                float* dbeta, int64_t R, int C, jg_stream_t s) {
+  return jg_layernorm_bwd_add(dtype, x, dy, gamma, mr, nullptr, dx, dgamma, dbeta, R, C, s);
 }
 extern "C" int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C,
                                 int gelu, jg_stream_t s) {

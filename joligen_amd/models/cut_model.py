@@ -246,7 +246,9 @@ class CUTModel(BaseModel):
         o = self.opt
         B = self.batch_size
         net, netF = self._net("G_A"), self._net("F")
-        feats = net.get_feats(torch.cat((self.fake_B, self.real_A, self.idt_B, self.real_B), dim=0), self.nce_layers)
+        # images in the order [translated | identity | source | target] = cat(G's output, G's input): no slice of either is needed, and the
+        # rows of every layer come out as [q of term 0 | q of term 1 | k of term 0 | k of term 1]
+        feats = net.get_feats(torch.cat((self.fake, self.real), dim=0), self.nce_layers)
         self._feat_calls += 2
         netF.arena.ensure_fresh()
         P = o.alg_cut_num_patches
@@ -254,17 +256,16 @@ class CUTModel(BaseModel):
         ids_all = [[netF.draw_ids(f, P) for f in feats] for _ in range(2)]         # term 0: NCE, term 1: identity NCE (reference draw order)
         for li, f in enumerate(feats):
             C = self.feat_channels[li]
-            # rows of a layer: [q0 (translated) | k0 (source) | q1 (identity) | k1 (target)], each B * P_l rows
-            r = torch.cat((ops.gather_patches(f[:2 * B], ids_all[0][li], C), ops.gather_patches(f[2 * B:], ids_all[1][li], C)), dim=0)
-            rows.append(netF.embed(r, li))
-            counts.append(ids_all[0][li].numel())
+            ids = torch.stack((ids_all[0][li], ids_all[1][li]))                      # [2, P_l]: images b use set (b // B) % 2
+            rows.append(netF.embed(ops.gather_patches(f, ids, C, per=B), li).split(2 * B * ids.shape[1]))     # (q rows, k rows): one cat in backward
+            counts.append(ids.shape[1])
         T, monce = o.alg_cut_nce_T, o.alg_cut_nce_loss == "monce"
         tot = [0.0, 0.0]
         for Pl in sorted(set(counts)):
             ls = [i for i, c in enumerate(counts) if c == Pl]
             n = B * Pl
-            q = torch.cat([rows[i][t * 2 * n:t * 2 * n + n] for i in ls for t in (0, 1)], dim=0)
-            k = torch.cat([rows[i][t * 2 * n + n:(t + 1) * 2 * n] for i in ls for t in (0, 1)], dim=0)
+            q = torch.cat([rows[i][0] for i in ls], dim=0)                           # [layer][term][B * P_l] problems
+            k = torch.cat([rows[i][1] for i in ls], dim=0)
             loss = ops.patch_nce_loss(q, k, 2 * len(ls) * B, T, P, monce).view(len(ls), 2, n)
             m = loss.mean(dim=2).sum(dim=0) * o.alg_cut_lambda_NCE
             tot = [tot[0] + m[0], tot[1] + m[1]]

@@ -164,8 +164,11 @@ class TransformerEncoderLayer(nn.Module):
         self.ffn = MixFFN(embed_dims, feedforward_channels, drop_path_rate, rand)
 
     def forward(self, x, hw):
-        x = self.attn(S.layer_norm(x, self.norm1.weight, self.norm1.bias, 1e-6), hw, identity=x)
-        return self.ffn(S.layer_norm(x, self.norm2.weight, self.norm2.bias, 1e-6), hw, identity=x)
+        # (identity, norm(x)) from one node: the identity path's gradient is added inside the LayerNorm backward pass
+        xi, h = S.layer_norm_id(x, self.norm1.weight, self.norm1.bias, 1e-6)
+        x = self.attn(h, hw, identity=xi)
+        xi, h = S.layer_norm_id(x, self.norm2.weight, self.norm2.bias, 1e-6)
+        return self.ffn(h, hw, identity=xi)
 
 
 class PatchEmbed(nn.Module):

@@ -967,15 +967,16 @@ def sgemm(A, B, C, M, N, K, sa, sb, sc, nbatch=1, bstr=(0, 0, 0), bias=None, E=N
 
 class _GatherPatchesFn(JGFunction):
     @staticmethod
-    def forward(ctx, feat, ids, C):
+    def forward(ctx, feat, ids, C, per):
         _require_cuda(feat, ids)
         B, H, W, ld = feat.shape
-        P = ids.numel()
+        G, P = (ids.shape[0], ids.shape[1]) if ids.dim() == 2 else (1, ids.numel())
+        per = per if G > 1 else B
         out = torch.empty((B * P, C), device=feat.device, dtype=torch.float32)
-        check(_lib.lib().jg_gather_rows(_dt(feat), feat.data_ptr(), ld, ids.data_ptr(), out.data_ptr(), B, H * W, C, P, _st()),
-              "jg_gather_rows")
+        check(_lib.lib().jg_gather_rows_grouped(_dt(feat), feat.data_ptr(), ld, ids.data_ptr(), out.data_ptr(), B, H * W, C, P, G, per, _st()),
+              "jg_gather_rows_grouped")
         ctx.save_for_backward(ids)
-        ctx.shape, ctx.dtype, ctx.C = feat.shape, feat.dtype, C
+        ctx.shape, ctx.dtype, ctx.C, ctx.geo = feat.shape, feat.dtype, C, (G, P, per)
         return out
 
     @staticmethod
@@ -983,19 +984,25 @@ class _GatherPatchesFn(JGFunction):
     def backward(ctx, dout):
         (ids,) = ctx.saved_tensors
         B, H, W, ld = ctx.shape
+        G, P, per = ctx.geo
         dfeat = torch.zeros(ctx.shape, device=dout.device, dtype=ctx.dtype)
         dout = dout.contiguous()
-        check(_lib.lib().jg_scatter_rows(_DT[ctx.dtype], dfeat.data_ptr(), ld, ids.data_ptr(), dout.data_ptr(), B, H * W, ctx.C,
-                                         ids.numel(), _st()), "jg_scatter_rows")
-        return dfeat, None, None
+        check(_lib.lib().jg_scatter_rows_grouped(_DT[ctx.dtype], dfeat.data_ptr(), ld, ids.data_ptr(), dout.data_ptr(), B, H * W, ctx.C, P, G, per,
+                                                 _st()), "jg_scatter_rows_grouped")
+        return dfeat, None, None, None
 
 
-def gather_patches(feat, ids, C):
+def gather_patches(feat, ids, C, per=0):
     """feat [B,H,W,ld] 16-bit NHWC -> [B*P, C] fp32 rows at the flattened positions `ids` (shared by the batch):
-    `feat.permute(0,2,3,1).flatten(1,2)[:, patch_id, :].flatten(0,1)` of cut_networks.py:45-57."""
+    `feat.permute(0,2,3,1).flatten(1,2)[:, patch_id, :].flatten(0,1)` of cut_networks.py:45-57.  `ids` [G, P] with `per` > 0: G id sets,
+    image b uses set (b // per) % G (one launch for the concatenated batches of several PatchSampleF calls)."""
+    if ids.dim() == 2 and ids.shape[0] > 1:
+        if per < 1 or TORCH_OPS_BOUNDARY:
+            raise ValueError("grouped gather_patches needs per >= 1 and the ctypes path")
+        return _GatherPatchesFn.apply(feat, ids.contiguous().long(), C, int(per))
     if TORCH_OPS_BOUNDARY:
         return torch.ops.jg355.gather_patches(feat, ids.contiguous().long(), C)
-    return _GatherPatchesFn.apply(feat, ids.contiguous().long(), C)
+    return _GatherPatchesFn.apply(feat, ids.reshape(-1).contiguous().long(), C, 0)
 
 
 class _L2NormFn(JGFunction):

@@ -56,6 +56,50 @@ def layer_norm(x, weight, bias, eps=1e-6):
     return _LayerNormFn.apply(x, weight, bias, float(eps))
 
 
+class _LayerNormIdFn(JGFunction):
+    """(x, LayerNorm(x)) for a pre-norm residual block `x + f(norm(x))`: the gradient that comes back through the identity output is added
+    inside the LayerNorm-backward pass (jg_layernorm_bwd_add) instead of by autograd's separate accumulation launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_cuda(x)
+        x = x.contiguous()
+        C = x.shape[-1]
+        R = x.numel() // C
+        y = torch.empty_like(x)
+        mr = torch.empty((R, 2), device=x.device, dtype=torch.float32)
+        check(_lib.lib().jg_layernorm_fwd(_dt(x), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), mr.data_ptr(), R, C, eps, _st()),
+              "jg_layernorm_fwd")
+        ctx.save_for_backward(x, mr, weight)
+        ctx.gw, ctx.gb = weight.grad, bias.grad
+        return x.view_as(x), y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, did, dy):
+        x, mr, weight = ctx.saved_tensors
+        if dy is None:
+            return did, None, None, None
+        dy = dy.contiguous()
+        C = x.shape[-1]
+        R = x.numel() // C
+        want_p = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        if want_p and (ctx.gw is None or ctx.gb is None):
+            raise RuntimeError("LayerNorm parameters have no arena-backed .grad")
+        need_x = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x) if need_x else None
+        res = did.contiguous() if (did is not None and need_x) else None
+        check(_lib.lib().jg_layernorm_bwd_add(_dt(x), x.data_ptr(), dy.data_ptr(), weight.data_ptr(), mr.data_ptr(), _p(res), _p(dx),
+                                              _p(ctx.gw) if want_p else None, _p(ctx.gb) if want_p else None, R, C, _st()), "jg_layernorm_bwd_add")
+        return dx, None, None, None
+
+
+def layer_norm_id(x, weight, bias, eps=1e-6):
+    """(x, nn.LayerNorm(C, eps)(x)): use the FIRST output as the residual branch's identity so that its gradient is summed into the
+    LayerNorm backward's pass."""
+    return _LayerNormIdFn.apply(x, weight, bias, float(eps))
+
+
 # ---- depth-wise 3x3 + GELU ---------------------------------------------------------------------------------------------------------
 class _DWConvGeluFn(JGFunction):
     @staticmethod

@@ -50,6 +50,35 @@ def test_layernorm(R, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("R,C", [(4096, 32), (77, 160), (3, 8)])
+def test_layernorm_with_identity_gradient(R, C, dtype):
+    """round 5: `layer_norm_id` = (x, LayerNorm(x)) of a pre-norm block x + f(norm(x)); the identity output's gradient is added inside the
+    LayerNorm-backward launch (jg_layernorm_bwd_add) -- against fp32 torch autograd on the same little block, and with either output unused."""
+    from joligen_amd import ops_segformer as S
+    x, gy = rnd((2, R, C), dtype, 1), rnd((2, R, C), dtype, 2)
+    w, b = 1 + 0.2 * rnd((C,), torch.float32, 3), 0.1 * rnd((C,), torch.float32, 4)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = 0.5 * xr + 2.0 * F.layer_norm(xr, (C,), wr, br, 1e-6)
+    yr.backward(gy.float())
+    xd, wd, bd = x.to(D0).requires_grad_(True), param(w), param(b)
+    xi, h = S.layer_norm_id(xd, wd, bd, 1e-6)
+    y = 0.5 * xi + 2.0 * h
+    y.backward(gy.to(D0))
+    torch.cuda.synchronize()
+    assert relerr(y, yr) < TOL[dtype] and relerr(xd.grad, xr.grad) < TOL[dtype], (relerr(y, yr), relerr(xd.grad, xr.grad))
+    assert relerr(wd.grad, wr.grad) < 1e-3 and relerr(bd.grad, br.grad) < 1e-3
+    # only the normalised branch used / only the identity used
+    x2 = x.to(D0).requires_grad_(True)
+    S.layer_norm_id(x2, param(w), param(b), 1e-6)[1].backward(gy.to(D0))
+    x3 = x.to(D0).requires_grad_(True)
+    S.layer_norm(x3, param(w), param(b), 1e-6).backward(gy.to(D0))
+    assert torch.equal(x2.grad, x3.grad)
+    x4 = x.to(D0).requires_grad_(True)
+    S.layer_norm_id(x4, param(w), param(b), 1e-6)[0].backward(gy.to(D0))
+    assert torch.equal(x4.grad, gy.to(D0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("two_phase", [True, False])
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 128), (1, 9, 7, 256), (2, 4, 4, 1024), (1, 32, 32, 64), (8, 64, 64, 128), (4, 16, 16, 640)])
 def test_dwconv3x3_gelu(B, H, W, C, dtype, two_phase, monkeypatch):

@@ -905,3 +905,29 @@ def test_cut_batched_nce_matches_the_four_pass_form(nce_loss, monkeypatch):
     for n in a["m1"]:
         e = float((b["m1"][n] - a["m1"][n]).norm() / a["m1"][n].norm())
         assert e <= 4 * floor_p + 2e-3, (n, e, floor_p)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_gather_patches_grouped(dtype):
+    """round 5: `gather_patches` with G id sets over runs of `per` images (one launch for the concatenated batch of both contrastive terms)
+    against one plain gather per run, values and the scattered gradient bit-equal."""
+    from joligen_amd import ops
+
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    B, H, W, ld, C, P = 3, 9, 7, 24, 20, 11
+    f = torch.randn(4 * B, H, W, ld, generator=g).to(dtype).to(d)
+    ids = torch.stack([torch.randperm(H * W, generator=g)[:P] for _ in range(2)]).to(d)
+    go = torch.randn(4 * B * P, C, generator=g).to(d)
+    fa = f.clone().requires_grad_(True)
+    out = ops.gather_patches(fa, ids, C, per=B)
+    out.backward(go)
+    fb = f.clone().requires_grad_(True)
+    parts = [ops.gather_patches(fb[i * B:(i + 1) * B], ids[i % 2], C) for i in range(4)]
+    ref = torch.cat(parts, 0)
+    ref.backward(go)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref) and torch.equal(fa.grad, fb.grad)
+    want = f.float().view(4 * B, H * W, ld)[:, :, :C]
+    for i in range(4 * B):
+        assert torch.equal(out[i * P:(i + 1) * P], want[i, ids[(i // B) % 2]])

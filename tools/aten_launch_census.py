@@ -13,7 +13,7 @@ import bench
 
 which = sys.argv[1] if len(sys.argv) > 1 else "palette"
 if which == "cut":      # BASELINE configs[2] shape
-    args = argparse.Namespace(model="cut", efficient=1, size=256, batch=16, dtype="bf16", netG="segformer_attn_conv", netDs="projected_d,basic", force_exchange=False)
+    args = argparse.Namespace(model="cut", efficient=1, size=256, batch=16, dtype="bf16", netG="segformer_attn_conv", netDs="projected_d,basic", force_exchange=False, proj="vitsmall")
     import warnings
     warnings.simplefilter("ignore")
     model, opt = bench.build_model(args, 0, 0, 1)
@@ -27,7 +27,7 @@ for _ in range(3):
     model.set_input(batch)
     model.optimize_parameters()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     model.set_input(batch)
     model.optimize_parameters()
     torch.cuda.synchronize()
@@ -49,3 +49,11 @@ for k, n in kern.most_common(25):
     print(f"   {n:5d} {k}")
 for (name, site), n in cnt.most_common(60):
     print(f"{n:5d} {name:28s} {site[:150]}")
+
+shp = Counter()
+for ev in prof.events():
+    if ev.name in ("aten::copy_", "aten::clone", "aten::add_", "aten::fill_", "aten::zeros", "aten::slice_backward", "aten::cat", "aten::mul", "aten::add", "aten::div", "aten::_to_copy"):
+        shp[(ev.name, str(ev.input_shapes)[:110])] += 1
+print("by input shapes:")
+for (name, sh), n in sorted(shp.items(), key=lambda kv: (kv[0][0], -kv[1])):
+    print(f"{n:5d} {name:24s} {sh}")
