@@ -132,6 +132,12 @@ int jg_conv1x1_gn_bwd_apply(int dtype, const jg_conv_args* a, const void* gn_x, 
  * 3x3 taps that land on tap (a, b) of output phase (py, px) of conv3x3(Upsample_nearest(x)) -- per axis {w0 | w1+w2} for phase 0,
  * {w0+w1 | w2} for phase 1 (fp32 sum, one rounding). */
 int jg_subpixel_fold(int dtype, const float* w32, void* out, int Cout, int Cin, jg_stream_t s);
+/* Four-phase (sub-pixel) form of a stride-2 TRANSPOSED convolution -- nn.ConvTranspose2d(k 3, stride 2, padding 1, output_padding 1) of the
+ * ResnetDecoder tail (models/modules/segformer/segformer_generator.py:135-140) and the input gradient of the discriminators' Conv2d(k 4,
+ * stride 2, padding 1) (models/modules/discriminators.py NLayerDiscriminator): wT = the flipped / transposed 16-bit working weights
+ * [N][R][S][C]; out [4][N][2][2][C] for jg_conv2d_nt with x_mode 2 (R = S = 3, pad 1 in the args; ldw = 4 C).  Replaces the zero-dilated
+ * copy of the input + a stride-1 convolution over it. */
+int jg_transposed_fold(int dtype, const void* wT, void* out, int N, int C, int R, int S, int pad, jg_stream_t s);
 
 /* Weight gradient / batched GEMM "TN" on MFMA:
  *   dw[z][co][(r,s,ci)] (+)= alpha * sum_p dy[z][p][co] * xcol[z][p][(r,s,ci)]

@@ -467,7 +467,38 @@ __global__ __launch_bounds__(256) void subpixel_fold_kernel(const float* __restr
   }
 }
 
+// The same four-phase form for a TRANSPOSED convolution of stride 2 (the input gradient of a stride-2 convolution / nn.ConvTranspose2d):
+// y[2h + py][2w + px][n] = sum over (a, b) of Wp[py][px][n][a][b] . x[h + a + py - 1][w + b + px - 1], where tap (a, b) of phase (py, px) is tap
+// r = pad + 2 - py - 2a, s = pad + 2 - px - 2b of the strided convolution's kernel (zero outside 0 .. R-1: a 3x3 kernel fills 9 of the 16 slots, a
+// 4x4 kernel all of them) -- no zero-dilated copy of x, a quarter (4x4) of the dilated form's MACs.  wT = the flipped / transposed working
+// weights [N][R][S][C] (wT[n][R-1-r][S-1-s][c] = w[c][r][s][n]), 16-bit; out [4][N][2][2][C]: a rearrangement, no arithmetic.
+template <typename T>
+__global__ __launch_bounds__(256) void transposed_fold_kernel(const T* __restrict__ wT, T* __restrict__ out, int N, int C, int R, int S, int pad) {
+  const long n = (long)N * C * 16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int tap = (int)(t & 3);
+    t >>= 2;
+    const int nn = (int)(t % N), ph = (int)(t / N);
+    const int py = ph >> 1, px = ph & 1, a = tap >> 1, b = tap & 1;
+    const int r = pad + 2 - py - 2 * a, sx = pad + 2 - px - 2 * b;
+    T v = from_f32<T>(0.f);
+    if (r >= 0 && r < R && sx >= 0 && sx < S) v = wT[(((long)nn * R + (R - 1 - r)) * S + (S - 1 - sx)) * C + c];
+    out[i] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" int jg_transposed_fold(int dtype, const void* wT, void* out, int N, int C, int R, int S, int pad, jg_stream_t s) {
+  if (!wT || !out || N < 1 || C < 1 || R < 1 || S < 1 || pad < 0) return JG_ERR_BAD_ARG;
+  const long n = (long)N * C * 16;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((transposed_fold_kernel<T>), dim3(blocks), dim3(256), 0, (hipStream_t)s, (const T*)wT, (T*)out, N, C, R, S, pad););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
 
 extern "C" int jg_subpixel_fold(int dtype, const float* w32, void* out, int Cout, int Cin, jg_stream_t s) {
   if (!w32 || !out || Cout < 1 || Cin < 1) return JG_ERR_BAD_ARG;

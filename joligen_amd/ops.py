@@ -326,6 +326,28 @@ def dilate2d(x, Ho, Wo, stride):
     return y
 
 
+# stride-2 transposed convolutions (input gradient of a stride-2 convolution, nn.ConvTranspose2d) in the four-phase form of the halo-resident
+# kernel (jg_transposed_fold + jg_conv2d_nt x_mode 2) instead of a zero-dilated copy + a stride-1 convolution over it; JG_PHASE_TCONV=0: off
+PHASE_TCONV = os.environ.get("JG_PHASE_TCONV", "1") != "0"
+
+
+def phase_tconv_ok(m: ConvMeta, Hout, Wout, C, N):
+    """shape limits of the phase form: kernel 3 or 4, stride 2, padding 1, output exactly twice the input, the halo kernel's channel / tile multiples"""
+    return (PHASE_TCONV and m.stride == 2 and m.R == m.S and m.R in (3, 4) and m.pad == 1 and C % 64 == 0 and N % 64 == 0 and Hout % 32 == 0
+            and Wout % 32 == 0)
+
+
+def phase_tconv(x, m: ConvMeta, y, bias=None, alpha=1.0):
+    """y [B, 2h, 2w, N] = transposed convolution of x [B, h, w, C] with the strided convolution's weights (m.w16T [N][R][S][C])"""
+    B, h, w, C = x.shape
+    N = y.shape[-1]
+    wf = torch.empty((4, N, 2, 2, C), device=x.device, dtype=x.dtype)
+    check(_lib.lib().jg_transposed_fold(_dt(x), m.w16T.data_ptr(), wf.data_ptr(), N, C, m.R, m.S, m.pad, _st()), "jg_transposed_fold")
+    conv_nt(x, wf, y, B=B, H=2 * h, W=2 * w, Cin=C, Cout=N, R=3, S=3, pad=1, stride=1, Ho=2 * h, Wo=2 * w, ldx=C, ldw=4 * C, ldy=N, bias=bias,
+            alpha=alpha, x_mode=2)
+    return y
+
+
 def conv2d_dgrad(dy, m: ConvMeta, x_shape, alpha=1.0):
     """dx = conv(dy, flipped/transposed weights).  Stride s > 1: the same stride-1 convolution over the zero-dilated
     dy (length H + 2p - k + 1 per axis) with pad k-1-p."""
@@ -333,6 +355,8 @@ def conv2d_dgrad(dy, m: ConvMeta, x_shape, alpha=1.0):
     _, Ho, Wo, Cout = dy.shape
     dx = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
     if m.stride != 1:
+        if H == 2 * Ho and W == 2 * Wo and phase_tconv_ok(m, H, W, Cout, Cin):
+            return phase_tconv(dy, m, dx, alpha=alpha)
         Hd, Wd = H + 2 * m.pad - m.R + 1, W + 2 * m.pad - m.S + 1
         dyd = dilate2d(dy, Hd, Wd, m.stride)
         conv_nt(dyd, m.w16T, dx, B=B, H=Hd, W=Wd, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,
@@ -567,9 +591,11 @@ def conv_transpose2d_forward(x, m: ConvMeta, output_padding=0):
     assert Cin_t == m.Cout, (Cin_t, m.Cout)
     Ho = (H - 1) * m.stride - 2 * m.pad + m.R + output_padding
     Wo = (W - 1) * m.stride - 2 * m.pad + m.S + output_padding
+    y = torch.empty((B, Ho, Wo, m.Cin), device=x.device, dtype=x.dtype)
+    if Ho == 2 * H and Wo == 2 * W and phase_tconv_ok(m, Ho, Wo, Cin_t, m.Cin):
+        return phase_tconv(x.contiguous(), m, y, bias=m.bias)
     Hd, Wd = Ho + 2 * m.pad - m.R + 1, Wo + 2 * m.pad - m.S + 1
     xd = dilate2d(x, Hd, Wd, m.stride)
-    y = torch.empty((B, Ho, Wo, m.Cin), device=x.device, dtype=x.dtype)
     conv_nt(xd, m.w16T, y, B=B, H=Hd, W=Wd, Cin=Cin_t, Cout=m.Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=Ho, Wo=Wo,
             ldx=Cin_t, ldw=m.R * m.S * Cin_t, ldy=m.Cin, bias=m.bias)
     return y

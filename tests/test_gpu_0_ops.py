@@ -1061,6 +1061,66 @@ def test_strided_and_transposed_conv(case, dtype):
     assert relerr(m.c.bias.grad, br.grad) < TOL[dtype]
 
 
+PHASE_TCONV_CASES = [
+    ("conv4 s2 p1 64->128 dgrad", dict(k=4, transposed=False, Cin=64, Cout=128, H=32, W=64)),     # NLayerDiscriminator layer 2: dx via the phase form
+    ("conv3 s2 p1 128->64 dgrad", dict(k=3, transposed=False, Cin=128, Cout=64, H=32, W=32)),
+    ("convT3 s2 p1 op1 128->64", dict(k=3, transposed=True, Cin=128, Cout=64, H=16, W=32)),        # ResnetDecoder tail
+    ("convT4 s2 p1 64->64", dict(k=4, transposed=True, Cin=64, Cout=64, H=16, W=16)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", PHASE_TCONV_CASES, ids=[c[0] for c in PHASE_TCONV_CASES])
+def test_stride2_transposed_conv_phase_form(case, dtype, monkeypatch):
+    """round 5: stride-2 transposed convolutions (nn.ConvTranspose2d forward; the input gradient of a stride-2 Conv2d) in the four-phase form
+    of the halo-resident kernel (jg_transposed_fold + x_mode 2) -- against torch autograd, and against the zero-dilated form (JG_PHASE_TCONV
+    off): same products, another summation order."""
+    import torch.nn as nn
+
+    from joligen_amd import _lib, ops
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.modules.layers import JGConv2d, JGConvTranspose2d
+
+    _, c = case
+    Cin, Cout, k = c["Cin"], c["Cout"], c["k"]
+    op = 1 if k == 3 else 0
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = (JGConvTranspose2d(Cin, Cout, k, stride=2, padding=1, output_padding=op) if c["transposed"]
+                      else JGConv2d(Cin, Cout, k, padding=1, stride=2))
+
+    m = M()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        m.c.weight.copy_((torch.randn(m.c.weight.shape, generator=g) / math.sqrt(m.c.weight[0].numel())).to(dtype).float())
+        m.c.bias.copy_(torch.randn(m.c.bias.shape, generator=g) * 0.1)
+    w0, b0 = m.c.weight.detach().clone(), m.c.bias.detach().clone()
+    arena = ParamArena(m, dev(), dtype, priority=())
+    arena.refresh()
+    x = rnd((2, Cin, c["H"], c["W"]), dtype, 83)
+    xr, wr, br = x.float().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = (F.conv_transpose2d(xr, wr, br, stride=2, padding=1, output_padding=op) if c["transposed"] else F.conv2d(xr, wr, br, stride=2, padding=1))
+    R = rnd(tuple(yr.shape), dtype, 84)
+    yr.backward(R.float())
+    outs = []
+    for phase in (True, False):
+        monkeypatch.setattr(ops, "PHASE_TCONV", phase)
+        xd = nhwc(x).to(dev()).requires_grad_(True)
+        y = m.c(xd)
+        name_f = _lib.lib().jg_last_kernel().decode()
+        y.backward(nhwc(R).to(dev()))
+        torch.cuda.synchronize()
+        outs.append((y.detach(), xd.grad, name_f))
+    y, dx, name_f = outs[0]
+    if c["transposed"]:
+        assert "subpixel" in name_f and "subpixel" not in outs[1][2], (name_f, outs[1][2])
+    assert relerr(nchw(y), yr.detach()) < TOL[dtype]
+    assert relerr(nchw(dx), xr.grad) < TOL[dtype]
+    assert relerr(y, outs[1][0]) < TOL[dtype] and relerr(dx, outs[1][1]) < TOL[dtype]
+
+
 REFLECT_CASES = [
     (2, 16, 16, 64, 64),      # one tile per image: every halo pixel of the border is mirrored
     (1, 64, 64, 256, 256),    # the ResnetBlock shape of the CUT generator at 256x256
