@@ -238,7 +238,7 @@ __device__ __forceinline__ int swz_tr(int row) { return (row & 3) | (((row >> 3)
 constexpr int TR_TILE = 64 * 16;  // uint4 chunks per operand tile (64 rows x 256 B)
 
 // the body of wgrad_tn_tr_kernel for tile `bx` (column tile fastest) and (batch, split) index `bz` of problem `p`
-template <typename T, int WAVES_M>
+template <typename T, int WAVES_M, bool DEEP>
 __device__ __forceinline__ void wgrad_tn_tr_body(const WgP& p, const int bx, const int bz, uint4 (*sm)[2 * TR_TILE]) {
   constexpr int BM = 64 * WAVES_M, BN = 128, BK = 64;
   constexpr int WAVES_N = 4 / WAVES_M;
@@ -277,13 +277,13 @@ __device__ __forceinline__ void wgrad_tn_tr_body(const WgP& p, const int bx, con
   const int fr = rs / p.S, fs = rs % p.S;
   const bool quad_row = (p.Wo & 3) == 0;
 
-  uint4 ra[4], rb[4];
+  uint4 ra0[4], rb0[4], ra1[4], rb1[4];     // two register stages: the loads of K-steps k + 1 AND k + 2 are in flight under the MFMAs of step k
   float bsum[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
   const bool do_bias = p.dbias != nullptr && (bx % tilesN) == 0;
 
-  auto load_tiles = [&](int kbase) {
+  auto load_tiles = [&](int kbase, uint4 (&ra)[4], uint4 (&rb)[4]) {
     const int p0 = kbase + prow;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -320,7 +320,7 @@ __device__ __forceinline__ void wgrad_tn_tr_body(const WgP& p, const int bx, con
       }
     }
   };
-  auto store_lds = [&](int buf) {
+  auto store_lds = [&](int buf, const uint4 (&ra)[4], const uint4 (&rb)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = prow + i;
@@ -376,16 +376,38 @@ __device__ __forceinline__ void wgrad_tn_tr_body(const WgP& p, const int bx, con
     }
   };
 
-  load_tiles(kbeg);
-  store_lds(0);
-  __syncthreads();
-  for (int ks = 0; ks < nk; ++ks) {
-    const int cur = ks & 1;
-    const bool more = ks + 1 < nk;
-    if (more) load_tiles(kbeg + (ks + 1) * BK);
-    compute(cur);
-    if (more) store_lds(cur ^ 1);
+  // Two K-steps of global loads in flight per thread (round 5; one before): with a single register stage a workgroup had 32 KB in flight
+  // for the ~4 us a loaded HBM round trip takes here (2 workgroups per CU: 4.0 TB/s).  The loads are unconditional -- past the end of the
+  // slice they are predicated to the base address -- so the compiler's vmcnt waits are exact counts (store_lds of stage k + 1 waits for ITS
+  // eight loads and leaves the eight of stage k + 2 in flight).
+  if constexpr (DEEP) {
+    load_tiles(kbeg, ra0, rb0);
+    load_tiles(kbeg + BK, ra1, rb1);
+    store_lds(0, ra0, rb0);
     __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+      load_tiles(kbeg + (ks + 2) * BK, ra0, rb0);
+      compute(0);
+      store_lds(1, ra1, rb1);
+      __syncthreads();
+      if (ks + 1 >= nk) break;
+      load_tiles(kbeg + (ks + 3) * BK, ra1, rb1);
+      compute(1);
+      store_lds(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    load_tiles(kbeg, ra0, rb0);
+    store_lds(0, ra0, rb0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+      const int cur = ks & 1;
+      const bool more = ks + 1 < nk;
+      if (more) load_tiles(kbeg + (ks + 1) * BK, ra0, rb0);
+      compute(cur);
+      if (more) store_lds(cur ^ 1, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   const long zoff = zb * p.sdwb + zh * p.sdwh;
@@ -432,10 +454,10 @@ __device__ __forceinline__ void wgrad_tn_tr_body(const WgP& p, const int bx, con
   }
 }
 
-template <typename T, int WAVES_M>
-__global__ __launch_bounds__(256) void wgrad_tn_tr_kernel(WgP p) {
+template <typename T, int WAVES_M, bool DEEP = false>
+__global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgP p) {
   __shared__ uint4 sm[2][2 * TR_TILE];
-  wgrad_tn_tr_body<T, WAVES_M>(p, blockIdx.x, blockIdx.z, sm);
+  wgrad_tn_tr_body<T, WAVES_M, DEEP>(p, blockIdx.x, blockIdx.z, sm);
 }
 
 // GROUPED launch (round 5): up to GROUP_MAX independent small weight-gradient problems in ONE grid.  The SegFormer generator's backward issues
@@ -450,8 +472,8 @@ struct WgGroup {
   int tiles[GROUP_MAX];         // output tiles of problem i (its workgroups = tiles x splitk)
   int n;
 };
-template <typename T, int WAVES_M>
-__global__ __launch_bounds__(256) void wgrad_tn_tr_group_kernel(const WgGroup g) {
+template <typename T, int WAVES_M, bool DEEP = false>
+__global__ __launch_bounds__(256, 2) void wgrad_tn_tr_group_kernel(const WgGroup g) {
   __shared__ uint4 sm[2][2 * TR_TILE];
   const int b = blockIdx.x;
   int i = 0;
@@ -459,7 +481,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_tr_group_kernel(const WgGroup g)
   for (int k = 1; k < GROUP_MAX; ++k) i += (k < g.n && b >= g.start[k]) ? 1 : 0;
   i = __builtin_amdgcn_readfirstlane(i);
   const int local = b - g.start[i];
-  wgrad_tn_tr_body<T, WAVES_M>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
+  wgrad_tn_tr_body<T, WAVES_M, DEEP>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
 }
 
 }  // namespace
@@ -516,10 +538,13 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
     auto flush = [&]() -> int {
       if (!g.n) return JG_OK;
       const dim3 grid(g.start[g.n]);
+      const int deep = jg_tune(JG_TUNE_WGRAD_DEEP);      // two register stages of global loads in flight: bit 0 = the 64-row tile, bit 1 = the 128-row tile
       if (wavesm == 1) {
-        JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, g););
+        if (deep & 1) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
+        else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
       } else {
-        JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, g););
+        if (deep & 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
+        else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
       }
       g.n = 0;
       return JG_OK;
@@ -564,10 +589,12 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p););
   } else if (p.Cout <= 64 && variant != 3) {
     dim3 grid(tilesN, 1, a->nbatch * a->splitk);
-    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p););
+    if (jg_tune(JG_TUNE_WGRAD_DEEP) & 1) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
+    else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
   } else {
     dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * a->splitk);
-    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, p););
+    if (jg_tune(JG_TUNE_WGRAD_DEEP) & 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
+    else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
   }
   JG_CHECK_LAUNCH();
   return JG_OK;

@@ -1995,3 +1995,43 @@ def test_wgrad_halo_narrow_output(dtype):
     for dw, db, name in outs:
         assert relerr(dw.permute(0, 3, 1, 2), wr.grad) < TOL[dtype], (name, relerr(dw.permute(0, 3, 1, 2), wr.grad))
         assert relerr(db, dy[..., :Cout].double().sum((0, 1, 2)).cpu()) < TOL[dtype], name
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [
+    (2, 20, 12, 64, 64, 1, 0, 1, 3),       # 64-row tile, 480 pixels over 3 slices: 160 = 2.5 K-steps per slice (odd / ragged step counts)
+    (1, 9, 7, 24, 40, 3, 1, 1, 1),         # 3x3, 63 pixels: ONE K-step, ragged channels
+    (2, 16, 16, 64, 192, 1, 0, 1, 2),      # 128-row tile
+    (2, 17, 17, 32, 160, 3, 1, 2, 4),      # stride 2 (9 x 9 outputs), 128-row tile, more slices than steps
+], ids=["1x1", "onestep", "tall", "stride2"])
+def test_wgrad_tn_two_register_stages(case, dtype):
+    """round 5: `wgrad_tn_tr_kernel` with two register stages of global loads in flight (JG_WGRAD_DEEP bit 0: 64-row tile, bit 1: 128-row tile)
+    against the single-stage loop: same products (the atomics' order differs) and against fp32 torch."""
+    from joligen_amd import _lib, ops
+    from joligen_amd.ops import JG_OUT_ATOMIC_F32
+
+    B, H, W, Cin, Cout, k, pad, stride, splitk = case
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    d = dev()
+    x = rnd((B, H, W, Cin), dtype, 61).to(d)
+    dy = rnd((B, Ho, Wo, Cout), dtype, 62).to(d)
+    outs = []
+    prev_v = _lib.set_tuning("JG_WGRAD_VARIANT", 2)
+    try:
+        for deep in (3, 0):
+            prev = _lib.set_tuning("JG_WGRAD_DEEP", deep)
+            try:
+                dw = torch.zeros(Cout, k, k, Cin, device=d)
+                db = torch.zeros(Cout, device=d)
+                ops.wgrad_tn(dy, x, dw, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=k, S=k, pad=pad, stride=stride, Ho=Ho, Wo=Wo, lddy=Cout, ldx=Cin,
+                             lddw=k * k * Cin, dbias=db, splitk=splitk, out_mode=JG_OUT_ATOMIC_F32)
+                torch.cuda.synchronize()
+                outs.append((dw, db))
+            finally:
+                _lib.set_tuning("JG_WGRAD_DEEP", prev)
+    finally:
+        _lib.set_tuning("JG_WGRAD_VARIANT", prev_v)
+    wr = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wr, None, stride, pad).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    assert relerr(outs[0][0].permute(0, 3, 1, 2), wr.grad) < TOL[dtype]
+    assert relerr(outs[0][0], outs[1][0]) < 1e-5 and relerr(outs[0][1], outs[1][1]) < 1e-5
