@@ -166,6 +166,11 @@ template <typename T>
 bool launch_kxk(const ConvP& p, hipStream_t st) {
   const int tw = (p.Wo + TS - 1) / TS, th = (p.Ho + TS - 1) / TS;
   const dim3 grid((unsigned)(p.B * tw * th));
+  if (p.R == 3) {      // 3x3 with at most 32 output channels (the UNet's 64 -> 3 (8) output convolution at 256 x 256): 68 KB, two workgroups per CU
+    if (p.N > 32 || p.Cin % 64) return false;
+    hipLaunchKernelGGL((conv_kxk_halo_kernel<T, 3, 64, 32, 2>), grid, dim3(256), 0, st, p, tw, th);
+    return true;
+  }
   const int mode = jg_tune(JG_TUNE_CONV_KXK);      // 1: two workgroups per CU wherever a configuration allows it; 2: the one-workgroup forms (A/B)
   if (p.N <= 32 && p.Cin % 64 == 0 && mode == 2) {
     hipLaunchKernelGGL((conv_kxk_halo_kernel<T, 7, 64, 32, 2>), grid, dim3(256), 0, st, p, tw, th);
@@ -185,13 +190,14 @@ bool launch_kxk(const ConvP& p, hipStream_t st) {
 
 bool jg_conv_kxk_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   if (!jg_tune(JG_TUNE_CONV_KXK)) return false;
-  if (nbatch != 1 || p.R != 7 || p.S != 7 || p.stride != 1 || p.out_f32 || p.res || p.stats || p.reflect || p.x_up || p.y_pool || p.res_up) return false;
+  if (nbatch != 1 || (p.R != 7 && p.R != 3) || p.S != p.R || p.stride != 1 || p.out_f32 || p.res || p.stats || p.reflect || p.x_up || p.y_pool || p.res_up) return false;
   if (p.N > 64 || (p.N & 7) || (p.Cin & 31) || (p.ldy & 7) || (p.ldx & 7) || (p.ldw & 7)) return false;
   if ((long)p.B * p.Ho * p.Wo < 16384) return false;          // tiny launches: the generic kernel's split-K forms serve them
+  if (p.R == 3 && (p.N > 32 || (long)p.B * p.Ho * p.Wo < 262144)) return false;   // 3x3: only the few-channel layers the 64-wide halo kernels do not serve
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.B * p.Ho * p.Wo * p.ldy >= (1L << 31)) return false;
   bool ok = false;
   if (dtype == JG_F16) ok = launch_kxk<f16_t>(p, st);
   else if (dtype == JG_BF16) ok = launch_kxk<bf16_t>(p, st);
-  if (ok) jg_note_kernel("conv_kxk_halo_kernel<7x7>");
+  if (ok) jg_note_kernel(p.R == 3 ? "conv_kxk_halo_kernel<3x3>" : "conv_kxk_halo_kernel<7x7>");
   return ok;
 }

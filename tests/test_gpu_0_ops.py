@@ -1966,6 +1966,33 @@ def test_conv7x7_halo_kernel(B, Hin, Cin, Cout, pad, bias, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv3x3_few_output_channels_halo_kernel(dtype):
+    """round 5: the UNet's output convolution (GroupNorm - SiLU - Conv2d(64, 3 (8), 3, padding 1) at 256 x 256) on the halo-resident few-channel kernel
+    (conv_kxk_halo_kernel at KS = 3) instead of the im2col kernel: against fp32 torch and against the im2col kernel."""
+    from joligen_amd import _lib, ops
+
+    d = dev()
+    B, H, Cin, Cout = 4, 256, 64, 8
+    x = rnd((B, H, H, Cin), dtype, 45).to(d)
+    w = (rnd((Cout, 3, 3, Cin), dtype, 46).float() / math.sqrt(9 * Cin)).to(dtype).to(d)
+    bv = rnd((Cout,), torch.float32, 47).to(d)
+    geo = dict(B=B, H=H, W=H, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=H, ldx=Cin, ldw=9 * Cin, ldy=Cout)
+    y = torch.empty(B, H, H, Cout, device=d, dtype=dtype)
+    ops.conv_nt(x, w, y, bias=bv, **geo)
+    assert _lib.lib().jg_last_kernel().decode() == "conv_kxk_halo_kernel<3x3>"
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float().cpu().permute(0, 3, 1, 2), bv.cpu(), 1, 1)
+    assert relerr(y.permute(0, 3, 1, 2), ref) < TOL[dtype], relerr(y.permute(0, 3, 1, 2), ref)
+    prev = _lib.set_tuning("JG_CONV_KXK", 0)
+    try:
+        y2 = torch.empty_like(y)
+        ops.conv_nt(x, w, y2, bias=bv, **geo)
+        assert "kxk" not in _lib.lib().jg_last_kernel().decode()
+    finally:
+        _lib.set_tuning("JG_CONV_KXK", prev)
+    assert relerr(y, y2) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_halo_narrow_output(dtype):
     """round 5: the halo-resident 3x3 weight gradient with FEWER than 64 output channels (the 64 -> 3 (8) head of the UNet at 256 x 256): the missing
     channel chunks of the dy tile come from the zero page, only the real rows are written -- against fp32 torch and against the im2col kernel."""
