@@ -377,6 +377,8 @@ void dispatch_wg(const WgP& p, hipStream_t st) {
   const bool big = cfg == 2 || (cfg == 0 && per1 >= 64);
   // mirrored borders (pad_mode 1) are compiled only into the 16x16 / 64-co configuration: the extra address arithmetic would push
   // the register-tight 8-row configurations into spilling
+  if (p.Cout < 64) jg_note_kernel("wgrad3x3_halo_kernel<16 rows,<64 co>");     // its own row in the kernel tables: 8 of 64 channel rows live, HBM-bound
+  else
   jg_note_kernel(p.reflect || !(big && p.Cout % 128 == 0) ? (cfg == 3 && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,64 co,4 waves>" :
                                                              (cfg == 4 || cfg == 5) && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,32 co,4 waves>" : "wgrad3x3_halo_kernel<16 rows,64 co>")
                                                           : "wgrad3x3_halo_kernel<8 rows,128 co>");
