@@ -885,7 +885,7 @@ def test_cut_step_through_torch_ops(dtype_name):
 
 @pytest.mark.parametrize("nce_loss", ["monce", "patchnce"])
 def test_cut_batched_nce_matches_the_four_pass_form(nce_loss, monkeypatch):
-    """`jg_batched_nce` (round 5: ONE encoder pass over cat(fake_B, real_A, idt_B, real_B), one PatchSampleF pass, one batched PatchNCE / MoNCE call
+    """`jg_batched_nce` (round 5: ONE encoder pass over cat(fake_B, idt_B, real_A, real_B), one grouped patch gather + PatchSampleF pass per layer, one batched PatchNCE / MoNCE call
     for both contrastive terms) against the reference's structure (four `get_feats` passes, four `netF` passes, 2 L loss calls; `JG_BATCHED_NCE=0`)
     on a resnet generator, where both forms draw the same patch ids from the same generator state (no DropPath): five iterations at learning rate
     zero, every logged loss and Adam's first moment of G / F / D agree to the run-to-run floor of the four-pass form."""
