@@ -40,6 +40,7 @@ import sys
 import time
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # before the HIP runtime initialises: see joligen_amd/__init__.py
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # multi-process GPU work on this stack needs dmabuf IPC (RCCL); exported on the boxes, kept here for ranks launched by hand
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "oracle")):
