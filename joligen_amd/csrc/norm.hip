@@ -12,6 +12,14 @@
 #include "common.h"
 #include <cstdlib>
 
+// register budget of the two backward passes (experiment: -DJG_GN_BWD_WAVES=8 caps them at 64 VGPRs so that two of their waves fit a SIMD
+// next to a resident weight-gradient workgroup of the side stream)
+#ifdef JG_GN_BWD_WAVES
+#define JG_GN_BWD_BOUNDS __launch_bounds__(256, JG_GN_BWD_WAVES)
+#else
+#define JG_GN_BWD_BOUNDS __launch_bounds__(256)
+#endif
+
 namespace {
 
 struct Map {
@@ -202,7 +210,7 @@ __global__ __launch_bounds__(256) void gn_apply_pool_kernel(const T* __restrict_
 // UP: dy is the gradient of a 2x2 average pool's OUTPUT ([B, H/2, W/2, C], W = full-resolution width): the pool's adjoint
 // (nearest upsample * dysc) is applied while reading, the full-resolution gradient is never materialised
 template <typename T, int ACT, bool UP = false>
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+__global__ JG_GN_BWD_BOUNDS void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                             long lddy, const float* __restrict__ ab,
                                                             float* __restrict__ red, int HW, int C, int mult, int W = 0,
                                                             float dysc = 1.f) {
@@ -343,7 +351,7 @@ struct GnFc {
 
 // UP: dy AND add1 are low-resolution ([B, H/2, W/2, C]) and read through the nearest-upsample index map (see gn_bwd_reduce_kernel)
 template <typename T, int ACT, bool UP = false, bool FC = false>
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
+__global__ JG_GN_BWD_BOUNDS void gn_bwd_apply_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                            long lddy, const float* __restrict__ ab,
                                                            const float* __restrict__ pqr, T* __restrict__ dx, long lddx,
                                                            const T* __restrict__ add1, long ldadd1, float sc1,

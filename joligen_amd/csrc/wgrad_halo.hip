@@ -227,6 +227,9 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
     return make_uint4(u0.x, u0.y, u1.x, u1.y);
   };
 
+#ifdef JG_WG_BLOAT
+  asm volatile("" ::: "v255");     // experiment: the register footprint of the sliding-window kernel on this one
+#endif
   f32x4 acc[9][CPW], accb[CPW];
 #pragma unroll
   for (int t9 = 0; t9 < 9; ++t9)
@@ -370,7 +373,7 @@ void launch_wg(const WgP& p, hipStream_t st) {
 
 template <typename T>
 void dispatch_wg(const WgP& p, hipStream_t st) {
-  const int cfg = jg_tune(JG_TUNE_WGRAD_HALO_CFG);   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co; 3: 8x16 x 64 co, 4 waves; 4: 8x16 x 32 co, 4 waves
+  const int cfg = jg_tune(JG_TUNE_WGRAD_HALO_CFG);   // 0: auto; 1: 16x16 tiles x 64 co; 2: 8x16 tiles x 128 co; 3: 8x16 x 64 co, 4 waves; 4: 8x16 x 32 co, 4 waves; 6: sliding-window form (wgrad_sw.hip) for every launch
   // the 128-channel x 8-row configuration halves the L2->LDS bytes per MFMA but doubles the atomic
   // volume: it pays once a block has >= 64 (16-row) tiles to walk
   const long per1 = (long)p.B * (p.H >> 4) * (p.W >> 4) * (p.Cout / 64) * (p.Cin / 64) / 256;
@@ -382,6 +385,19 @@ void dispatch_wg(const WgP& p, hipStream_t st) {
   jg_note_kernel(p.reflect || !(big && p.Cout % 128 == 0) ? (cfg == 3 && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,64 co,4 waves>" :
                                                              (cfg == 4 || cfg == 5) && !p.reflect && !p.x_up ? "wgrad3x3_halo_kernel<8 rows,32 co,4 waves>" : "wgrad3x3_halo_kernel<16 rows,64 co>")
                                                           : "wgrad3x3_halo_kernel<8 rows,128 co>");
+  // round 6: the sliding-window form (wgrad_sw.hip), OFF by default.  Alone it beats both tiles it could replace (10.94 vs 11.49 ms over
+  // the 3x3 layers of the step); inside the step it loses: in place of the 16-row tile by 1.0 - 1.4 ms (243 VGPRs x 8 waves against 192: the
+  // waves of the main stream find no room beside it -- the same +1.3 ms appear when the round-5 tile is merely COMPILED to 256 VGPRs), in
+  // place of the 8-row x 128-co tile by 0.1 - 0.3 ms (the same footprint, but twice the L2 -> LDS bytes per MFMA).  profiles/r06_wgrad_sw_ab.txt.
+  // JG_WGRAD_SW 1: in place of the 8-row x 128-co tile; 2: wherever the shape allows; JG_WGRAD_HALO_CFG 6: every launch (tests, tools).
+  const int swm = jg_tune(JG_TUNE_WGRAD_SW);
+  const bool bigt = big && p.Cout % 128 == 0;
+  const bool sw = p.Cout >= 64 && (cfg == 6 || (cfg == 0 && ((swm == 1 && bigt && !p.reflect) || swm == 2)));
+  if (sw) {
+    jg_note_kernel("wgrad3x3_sw_kernel<16 rows,64 co>");
+    jg_wgrad_sw_launch(std::is_same<T, bf16_t>::value ? JG_BF16 : JG_F16, p, st);
+    return;
+  }
   if (p.reflect) launch_wg<T, 16, 2, 2, 1>(p, st);
   else if (p.x_up && big && p.Cout % 128 == 0) launch_wg<T, 8, 4, 2, 2>(p, st);   // upsample-on-read: the two shapes the UNet up-blocks use
   else if (p.x_up) launch_wg<T, 16, 2, 2, 2>(p, st);

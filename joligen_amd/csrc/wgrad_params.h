@@ -22,3 +22,5 @@ struct WgP {
 bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st);
 // wgrad_kxk.hip: returns true when the shape was handled by the halo-resident large-kernel (7x7) weight-gradient kernel.
 bool jg_wgrad_kxk_try(int dtype, const WgP& p, int nbatch, hipStream_t st);
+// wgrad_sw.hip: sliding-window form of the 16-row x 64-co tile (v_mfma_f32_32x32x16, one pixel row per K step); the caller has validated the shape.
+void jg_wgrad_sw_launch(int dtype, const WgP& p, hipStream_t st);

@@ -190,7 +190,10 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.alpha, a.out_mode, a.dbias_scale = alpha, out_mode, dbias_scale
     a.pad_mode = pad_mode
     a.x_mode = x_mode
-    if WGRAD_DEFER is not None and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32 and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None:
+    # never under the torch.ops boundary: jg355::conv2d_wgrad hands a TEMPORARY dw / dbias back to autograd, which accumulates it into .grad at
+    # once -- a launch deferred to the flush would write into a tensor nobody reads any more (silently zero gradients)
+    if (WGRAD_DEFER is not None and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32 and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None
+            and not TORCH_OPS_BOUNDARY and not _IN_OP):
         WGRAD_DEFER.append((_dt(dy), a, (dy, x, dw, dbias)))       # launched with its peers by flush_deferred_wgrads(); operands kept alive
         if _WGRAD_SIDE is not None and len(WGRAD_DEFER) >= _WGRAD_SIDE[1]:
             flush_deferred_wgrads()

@@ -396,6 +396,10 @@ WGRAD_FORCED = [
     (3, "wgrad3x3_halo_kernel<8,4,1>", (2, 32, 32, 128, 64)),
     (4, "wgrad3x3_halo_kernel<8,2,1> (round 5: 32 co, two independent workgroups per CU)", (2, 32, 32, 128, 64)),
     (4, "wgrad3x3_halo_kernel<8,2,1>", (3, 16, 48, 64, 96 + 32)),
+    (6, "wgrad3x3_sw_kernel (round 6: sliding window, 32x32x16 MFMA, two row halves summed through LDS)", (2, 32, 32, 64, 128)),
+    (6, "wgrad3x3_sw_kernel, ragged split-K (9 tiles), three input chunks", (3, 16, 48, 192, 64)),
+    (6, "wgrad3x3_sw_kernel, one tile per workgroup", (1, 16, 16, 128, 192)),
+    (1, "wgrad3x3_halo_kernel<16,2,2> (round-5 tile, kept selectable)", (3, 16, 48, 192, 64)),
 ]
 
 
@@ -420,6 +424,39 @@ def test_wgrad_halo_forced_configs(cfg, inst, shape, dtype):
         _lib.set_tuning("JG_WGRAD_HALO_CFG", prev)
     assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype], (inst, relerr(m.c.weight.grad, wr.grad))
     assert relerr(m.c.bias.grad, br.grad) < TOL[dtype], (inst, relerr(m.c.bias.grad, br.grad))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mode", ["zero", "reflect", "up"])
+def test_wgrad_sliding_window_modes_match_the_round5_tile(mode, dtype):
+    """wgrad_sw.hip (JG_WGRAD_HALO_CFG 6: 32x32x16 MFMA, one pixel row per K step, x fragments shared by the three tap rows) against
+    wgrad3x3_halo_kernel<16,2,2> (cfg 1) on the same operands, in its three halo forms: zero padding, mirrored borders (pad_mode 1, the CUT
+    ResnetBlocks) and upsample-on-read (x_mode 1, the UNet up-blocks).  Same products, other summation order: 3e-6 on the fp32 gradient;
+    with the bias gradient (a VALU sum of the dy fragments here, an MFMA against ones there)."""
+    from joligen_amd import _lib, ops
+
+    B, H, W, Cin, Cout = 3, 32, 48, 128, 192
+    d = dev()
+    xs = (B, H // 2, W // 2, Cin) if mode == "up" else (B, H, W, Cin)
+    x = rnd(xs, dtype, 41).to(d)
+    dy = rnd((B, H, W, Cout), dtype, 42).to(d)
+    out = {}
+    for cfg in (1, 6):
+        prev = _lib.set_tuning("JG_WGRAD_HALO_CFG", cfg)
+        try:
+            dw = torch.zeros(Cout, 3, 3, Cin, device=d)
+            db = torch.zeros(Cout, device=d)
+            ops.wgrad_tn(dy, x, dw, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, lddy=Cout, ldx=Cin, lddw=9 * Cin,
+                         dbias=db, dbias_scale=1.0, pad_mode=1 if mode == "reflect" else 0, x_mode=1 if mode == "up" else 0)
+            name = _lib.lib().jg_last_kernel().decode()
+            torch.cuda.synchronize()
+        finally:
+            _lib.set_tuning("JG_WGRAD_HALO_CFG", prev)
+        assert ("sw_kernel" in name) == (cfg == 6), name
+        out[cfg] = (dw, db)
+    assert float(out[1][0].norm()) > 0
+    assert relerr(out[6][0], out[1][0]) < 3e-6, relerr(out[6][0], out[1][0])
+    assert relerr(out[6][1], out[1][1]) < 3e-6, relerr(out[6][1], out[1][1])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

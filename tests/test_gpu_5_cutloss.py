@@ -820,14 +820,17 @@ def test_cut_step_drivers_agree_c3_shape(monkeypatch):
         assert e <= 4 * floor_p + 2e-3, (n, e, floor_p)
 
 
+@pytest.mark.parametrize("driver", ["sequential", "default"])
 @pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
-def test_cut_step_through_torch_ops(dtype_name):
+def test_cut_step_through_torch_ops(dtype_name, driver):
     """The op boundary for the CUT family (VERDICT r4 missing #2 / weak #9): ONE cut_model iteration -- resnet generator (reflect-pad convolutions,
     InstanceNorm, stride-2 and transposed convolutions, tanh), PatchGAN discriminator (4x4 stride-2 convolutions, LeakyReLU), PatchSampleF
     (gather, MLP, L2 normalisation), PatchNCE / MoNCE, lsgan -- with every op a `torch.ops.jg355.*` call (`ops.torch_ops_boundary()`: autograd
     assembles the backward from the registered formulas, parameter gradients arrive through autograd on the fp32 master weights) against the same
     iteration on the ctypes autograd nodes: same kernels behind both, so the losses and every parameter gradient agree to the run-to-run floor of
-    the ctypes graph itself (two ctypes runs are compared the same way)."""
+    the ctypes graph itself (two ctypes runs are compared the same way).  `driver` "default" = the early-D driver that cut_model selects by itself,
+    whose generator backward runs inside `ops.deferred_wgrads()`: under the boundary the weight gradients must NOT be deferred (the op
+    returns a temporary dw that autograd consumes at once -- deferred, every plain convolution of the generator got a zero gradient)."""
     import contextlib
     import warnings
 
@@ -845,7 +848,10 @@ def test_cut_step_through_torch_ops(dtype_name):
         torch.manual_seed(4)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            m = create_model(opt_from_json(cfg, overrides={"jg_act_dtype": dtype_name, "gpu_ids": "0", "jg_early_D": False}), 0)
+            ov = {"jg_act_dtype": dtype_name, "gpu_ids": "0"}
+            if driver == "sequential":
+                ov["jg_early_D"] = False
+            m = create_model(opt_from_json(cfg, overrides=ov), 0)
         m.data_dependent_initialize(data)
         m.setup(m.opt)
         m.single_gpu()
@@ -854,7 +860,7 @@ def test_cut_step_through_torch_ops(dtype_name):
         with (ops.torch_ops_boundary() if boundary else contextlib.nullcontext()):
             m.optimize_parameters()
         torch.cuda.synchronize()
-        assert m.step_driver == "sequential"
+        assert (m.step_driver == "sequential") == (driver == "sequential"), m.step_driver
         losses = {k: float(getattr(m, "loss_" + k)) for k in ("G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_basic", "D_tot")}
         m1 = {f"{n}.{k}": v.detach().double().cpu() for n in m.model_names for k, v in m._net(n).arena.named_views(m._net(n).arena.m).items()}
         return losses, m1                          # Adam's first moment after one step = (1 - beta1) x the gradient of every parameter
@@ -877,7 +883,7 @@ def test_cut_step_through_torch_ops(dtype_name):
     zero = [k for k in ga if (float(ga[k].norm()) == 0) != (float(go[k].norm()) == 0)]
     assert not zero, zero
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/torch_ops_cut_step_{dtype_name}.txt", "w") as f:
+    with open(f"gpurun_out/torch_ops_cut_step_{dtype_name}_{driver}.txt", "w") as f:
         f.write(f"losses ctypes {la} ctypes again {la2} torch.ops {lo}\nworst gradient tensor torch.ops vs ctypes {worst}\n"
                 f"run-to-run floor of the ctypes graph: losses {floor_l:.3e} worst tensor {floor_g:.3e} whole vector {floor_w:.3e}\n"
                 f"all gradients as one vector: torch.ops vs ctypes {rel(cat(go), cat(ga)):.3e}\n")
