@@ -128,15 +128,19 @@ def usable_cores():
     return max(1, n)
 
 
-def _reference_ratio_note():
+def _reference_ratio(model):
     """the port-vs-reference ratio measured once in the build container (oracle/measure_reference_cpu.py; /root/reference does not
-    exist on the GPU box, so the timed CPU leg is the oracle PORT of the reference step)"""
+    exist on the GPU box, so the timed CPU leg is the oracle PORT of the reference step): palette (round 2), cut / cm (round 6, the
+    configs[2] / configs[4] shapes the legs time).  Returns (note for `sample`, port speed / reference speed)."""
     try:
-        r = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_reference_vs_port.json")))
+        if model == "palette":
+            r = json.load(open(os.path.join(ROOT, "profiles", "r02_cpu_reference_vs_port.json")))
+        else:
+            r = json.load(open(os.path.join(ROOT, "profiles", "r06_cpu_reference_vs_port.json")))[model]
         return (f"; kind=port: the unmodified reference itself measured {r['reference_img_per_s']} images/s against {r['port_img_per_s']} for this "
-                f"port on the build container's {r['cores']} cores (port / reference = {r['port_over_reference']}x)")
+                f"port on the build container's {r['cores']} cores (port / reference = {r['port_over_reference']}x)"), r["port_over_reference"]
     except Exception:
-        return ""
+        return "", None
 
 
 def cpu_baseline_subprocess(args, timeout_s=240):
@@ -151,8 +155,9 @@ def cpu_baseline_subprocess(args, timeout_s=240):
         for line in out.stdout.splitlines():
             if line.startswith("{"):
                 res = json.loads(line)
-                if args.model == "palette":
-                    res["sample"] += _reference_ratio_note()
+                note, ratio = _reference_ratio(args.model)
+                res["sample"] += note
+                res["port_over_reference"] = ratio
                 return res
         return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
                 "sample": "cpu leg failed: " + out.stderr[-300:]}
@@ -399,7 +404,7 @@ def cut_leg(local_rank, no_cpu, proj="vitsmall"):
             "roofline": roof, "cpu_baseline": cpu}
 
 
-def unet_leg(local_rank, model_kind, size, batch, efficient, steps=20, warmup=5):
+def unet_leg(local_rank, model_kind, size, batch, efficient, steps=20, warmup=5, no_cpu=True):
     """One more single-GPU configuration of BASELINE.json on the default line: `c4_512` = configs[3] (palette_model DDPM, UNet with mid-block
     self-attention, 512x512, batch 8 per GPU) and `cm` = configs[4] (cm_model consistency step, 256x256, batch 64 per GPU, fused AdamW):
     value, ms per step, the step's algorithmic FLOPs as a fraction of the bf16 MFMA peak.  Same step definition as the palette leg
@@ -418,7 +423,8 @@ def unet_leg(local_rank, model_kind, size, batch, efficient, steps=20, warmup=5)
     mult = 3 if model_kind == "palette" else 4          # cm = student forward + teacher forward + backward
     tflop = mult * FWD_GFLOP_PER_IMG[(size, bool(efficient))] * batch / 1e3
     loss = float(model.get_current_losses()["G_tot"].detach())
-    return {"metric": f"train images/sec at {size}x{size} ({'DDPM UNet' if model_kind == 'palette' else 'CM UNet'} step)",
+    cpu = None if no_cpu else cpu_baseline_subprocess(ns, timeout_s=180)
+    return {"cpu_baseline": cpu, "metric": f"train images/sec at {size}x{size} ({'DDPM UNet' if model_kind == 'palette' else 'CM UNet'} step)",
             "value": round(batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(ms, 3),
             "ms_per_step_median": round(sorted(per_step)[len(per_step) // 2], 3), "steps": steps, "warmup": warmup, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{'palette_model DDPM' if model_kind == 'palette' else 'cm_model consistency'}, {'efficient ' if efficient else ''}UNet unet_mha "
@@ -445,8 +451,8 @@ def compact_cpu(c):
         return c
     out = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
     out["sample"] = str(c.get("sample", ""))[:200]
-    if "reference_over_port" in c:
-        out["reference_over_port"] = c["reference_over_port"]
+    if "port_over_reference" in c:
+        out["port_over_reference"] = c["port_over_reference"]
     return out
 
 
@@ -460,7 +466,7 @@ def compact_leg(leg):
         out["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us")}
     c = leg.get("cpu_baseline")
     if c:
-        out["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind")}
+        out["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "kind", "port_over_reference")}
     w = (leg.get("config") or {}).get("workload")
     if w:
         out["config"] = {"workload": w[:120]}
@@ -547,7 +553,7 @@ def main():
     if args.leg:
         torch.cuda.set_device(0)
         obj = (cut_leg(0, args.no_cpu_baseline) if args.leg == "cut" else cut_leg(0, True, proj="efficientnet") if args.leg == "cut_effnet"
-               else unet_leg(0, **EXTRA_LEGS[args.leg]))
+               else unet_leg(0, **EXTRA_LEGS[args.leg], no_cpu=args.no_cpu_baseline or args.leg != "cm"))
         print(json.dumps(obj), flush=True)
         return
 
@@ -714,7 +720,7 @@ def main():
         cut = leg_subprocess("cut", args.no_cpu_baseline)
         for key in list(EXTRA_LEGS) + ["cut_effnet"]:
             print(f"[bench] {key} leg", file=sys.stderr, flush=True)
-            extra[key] = leg_subprocess(key, True)
+            extra[key] = leg_subprocess(key, args.no_cpu_baseline or key != "cm")      # CPU leg: cut (above) and cm; c4_512 / cut_effnet share their families' ratios
 
     if rank == 0:
         line = {

@@ -837,9 +837,24 @@ def test_cut_step_drivers_agree_c3_shape(monkeypatch, proj):
         assert e <= 4 * floor_p + 2e-3, (n, e, floor_p)
 
 
-@pytest.mark.parametrize("driver", ["sequential", "default"])
-@pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
-def test_cut_step_through_torch_ops(dtype_name, driver):
+_OPS_CFGS = {
+    "resnet_patchgan": ({"model_type": "cut", "G": {"netG": "resnet", "ngf": 64, "nblocks": 2}, "D": {"netDs": ["basic"], "ndf": 32},
+                         "alg": {"cut": {"nce_layers": "0,4,8", "nce_loss": "monce"}}, "data": {"crop_size": 64, "load_size": 64},
+                         "train": {"batch_size": 2, "G_ema": False, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0}}, 64,
+                        ("G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_basic", "D_tot")),
+    # BASELINE configs[2] (what bench.py's `cut` leg times): SegFormer-attn generator + [projected_d with the ViT projector at proj_interp 256, basic]
+    "c3": ({"model_type": "cut", "G": {"netG": "segformer_attn_conv", "ngf": 64, "nblocks": 9},
+            "D": {"netDs": ["projected_d", "basic"], "ndf": 64, "proj_interp": 256, "proj_network_type": "vitsmall"},
+            "alg": {"cut": {"nce_loss": "monce"}}, "data": {"crop_size": 256, "load_size": 256},
+            "train": {"batch_size": 2, "G_ema": False, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0}}, 256,
+           ("G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_basic", "G_GAN_D_B_projected_d", "D_tot")),
+}
+
+
+@pytest.mark.parametrize("which,driver,dtype_name", [("resnet_patchgan", "sequential", "bf16"), ("resnet_patchgan", "sequential", "fp16"),
+                                                     ("resnet_patchgan", "default", "bf16"), ("resnet_patchgan", "default", "fp16"),
+                                                     ("c3", "sequential", "bf16"), ("c3", "default", "bf16")])
+def test_cut_step_through_torch_ops(dtype_name, driver, which):
     """The op boundary for the CUT family (VERDICT r4 missing #2 / weak #9): ONE cut_model iteration -- resnet generator (reflect-pad convolutions,
     InstanceNorm, stride-2 and transposed convolutions, tanh), PatchGAN discriminator (4x4 stride-2 convolutions, LeakyReLU), PatchSampleF
     (gather, MLP, L2 normalisation), PatchNCE / MoNCE, lsgan -- with every op a `torch.ops.jg355.*` call (`ops.torch_ops_boundary()`: autograd
@@ -847,7 +862,10 @@ def test_cut_step_through_torch_ops(dtype_name, driver):
     iteration on the ctypes autograd nodes: same kernels behind both, so the losses and every parameter gradient agree to the run-to-run floor of
     the ctypes graph itself (two ctypes runs are compared the same way).  `driver` "default" = the early-D driver that cut_model selects by itself,
     whose generator backward runs inside `ops.deferred_wgrads()`: under the boundary the weight gradients must NOT be deferred (the op
-    returns a temporary dw that autograd consumes at once -- deferred, every plain convolution of the generator got a zero gradient)."""
+    returns a temporary dw that autograd consumes at once -- deferred, every plain convolution of the generator got a zero gradient).
+    `which` "c3" (VERDICT r5 next #6): the same at the BASELINE configs[2] selection that is benchmarked -- SegFormer blocks (LayerNorm, spatially
+    reduced attention, MixFFN depth-wise convolution + GELU), the ViT projector (frozen: LayerNorm, attention, GELU MLP, Conv1d CCM / CSM, MLP
+    heads) and the hinge objective, every one a `torch.ops.jg355.*` call."""
     import contextlib
     import warnings
 
@@ -855,11 +873,9 @@ def test_cut_step_through_torch_ops(dtype_name, driver):
     from joligen_amd.models import create_model
     from joligen_amd.options import opt_from_json
 
+    cfg, S, loss_keys = _OPS_CFGS[which]
     gen = torch.Generator().manual_seed(21)
-    data = {"A": torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1, "B": torch.rand(2, 3, 64, 64, generator=gen) * 2 - 1}
-    cfg = {"model_type": "cut", "G": {"netG": "resnet", "ngf": 64, "nblocks": 2}, "D": {"netDs": ["basic"], "ndf": 32},
-           "alg": {"cut": {"nce_layers": "0,4,8", "nce_loss": "monce"}}, "data": {"crop_size": 64, "load_size": 64},
-           "train": {"batch_size": 2, "G_ema": False, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0}}
+    data = {"A": torch.rand(2, 3, S, S, generator=gen) * 2 - 1, "B": torch.rand(2, 3, S, S, generator=gen) * 2 - 1}
 
     def run(boundary):
         torch.manual_seed(4)
@@ -868,17 +884,19 @@ def test_cut_step_through_torch_ops(dtype_name, driver):
             ov = {"jg_act_dtype": dtype_name, "gpu_ids": "0"}
             if driver == "sequential":
                 ov["jg_early_D"] = False
+            if which == "c3":
+                ov["jg_batched_nce"] = False       # the boundary runs the reference's four encoder passes; the batched form draws other DropPath masks
             m = create_model(opt_from_json(cfg, overrides=ov), 0)
         m.data_dependent_initialize(data)
         m.setup(m.opt)
         m.single_gpu()
-        torch.manual_seed(9)                       # patch ids
+        torch.manual_seed(9)                       # patch ids, DropPath / Dropout2d draws
         m.set_input(data)
         with (ops.torch_ops_boundary() if boundary else contextlib.nullcontext()):
             m.optimize_parameters()
         torch.cuda.synchronize()
         assert (m.step_driver == "sequential") == (driver == "sequential"), m.step_driver
-        losses = {k: float(getattr(m, "loss_" + k)) for k in ("G_tot", "G_NCE", "G_NCE_Y", "G_GAN_D_B_basic", "D_tot")}
+        losses = {k: float(getattr(m, "loss_" + k)) for k in loss_keys}
         m1 = {f"{n}.{k}": v.detach().double().cpu() for n in m.model_names for k, v in m._net(n).arena.named_views(m._net(n).arena.m).items()}
         return losses, m1                          # Adam's first moment after one step = (1 - beta1) x the gradient of every parameter
 
@@ -893,14 +911,15 @@ def test_cut_step_through_torch_ops(dtype_name, driver):
     floor_w = rel(cat(ga2), cat(ga))
     print("run-to-run floor of the ctypes graph: losses %.2e worst tensor %.2e whole vector %.2e" % (floor_l, floor_g, floor_w))
     for k in la:
-        assert abs(lo[k] - la[k]) <= (3 * floor_l + 2e-3) * abs(la[k]), (k, lo[k], la[k], la2[k])
+        # + 5e-5 absolute: the projected hinge term of the generator is -mean(logits), ~4e-3 at random weights -- a mean of cancelling values
+        assert abs(lo[k] - la[k]) <= (3 * floor_l + 2e-3) * abs(la[k]) + 5e-5, (k, lo[k], la[k], la2[k])
     worst = max((rel(go[k], ga[k]), k) for k in keys)
     assert worst[0] <= 3 * floor_g + 5e-3, (worst, floor_g)
     assert rel(cat(go), cat(ga)) <= 3 * floor_w + 2e-3, (rel(cat(go), cat(ga)), floor_w)
     zero = [k for k in ga if (float(ga[k].norm()) == 0) != (float(go[k].norm()) == 0)]
     assert not zero, zero
     os.makedirs("gpurun_out", exist_ok=True)
-    with open(f"gpurun_out/torch_ops_cut_step_{dtype_name}_{driver}.txt", "w") as f:
+    with open(f"gpurun_out/torch_ops_cut_step_{which}_{dtype_name}_{driver}.txt", "w") as f:
         f.write(f"losses ctypes {la} ctypes again {la2} torch.ops {lo}\nworst gradient tensor torch.ops vs ctypes {worst}\n"
                 f"run-to-run floor of the ctypes graph: losses {floor_l:.3e} worst tensor {floor_g:.3e} whole vector {floor_w:.3e}\n"
                 f"all gradients as one vector: torch.ops vs ctypes {rel(cat(go), cat(ga)):.3e}\n")
