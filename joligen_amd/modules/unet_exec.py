@@ -20,6 +20,8 @@ from __future__ import annotations
 import contextlib
 import math
 import os
+import weakref
+from typing import Tuple
 
 import torch
 import torch.nn as nn
@@ -419,6 +421,10 @@ class UNetExecutor:
         self.tape = None
         self._pool_need = {}
         self._side = None          # HIP stream of the weight-gradient launches (created with the first backward)
+        self.handle = None         # torch.ops handle (fused_unet)
+
+    def arena_g(self):
+        return self.u._jg_arena_ref.g
 
     # ---- weight gradients off the critical chain -----------------------------------------------------
     def wgrad(self, dy, x, m, **kw):
@@ -804,8 +810,89 @@ class _FusedUNetFn(JGFunction):
         return dx, demb, None
 
 
+# ---- the fused node as a pair of torch.ops (round 6; VERDICT r5 missing #3 / next #6) ---------------------------------------------------------
+# north_star: the kernels are "exposed to the Python host as torch.ops"; precedent in the reference: models/modules/op/upfirdn2d.py:19-167 (a
+# custom op whose backward is a second custom op).  `jg355::unet_fused` is the forward of the whole UNet on the fused schedule (what bench.py
+# times), `jg355::unet_fused_bwd` its backward; both are torch.library custom ops with fake kernels, the pair is tied by register_autograd, and
+# this is what `UNet.forward` -- i.e. `optimize_parameters()` -- calls by default (JG_FUSED_TORCH_OPS=0: the autograd.Function of rounds 1-5,
+# same executor behind it).
+#   * the executor (module tree, launch schedule) is addressed by an integer HANDLE; the weights it reads are passed as the arena's 16-bit
+#     working copies (`w16`, `w16T`: the data dependence is visible to the dispatcher), the fp32 gradient arena it accumulates into is an
+#     argument of the backward op declared in `mutates_args`;
+#   * the tape (saved activations, statistics, the pool of GroupNorm sums) stays with the executor under an integer id that the forward
+#     returns as a 1-element int64 tensor; the backward op consumes it, a finalizer on that tensor drops an unused tape.
+FUSED_TORCH_OPS = os.environ.get("JG_FUSED_TORCH_OPS", "1") != "0"
+_EXES, _TAPES, _NEXT = {}, {}, [1]
+
+
+@torch.library.custom_op("jg355::unet_fused", mutates_args=())
+def _op_unet_fused(xin: torch.Tensor, emb: torch.Tensor, w16: torch.Tensor, w16T: torch.Tensor, handle: int, keep: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """UNet forward on the fused schedule: (xin [B,H,W,Cpad] 16-bit NHWC, emb = stacked FiLM projections) -> (out [B,H,W,8], tape id)"""
+    exe = _EXES[handle]
+    out, state = exe.forward(xin, emb)
+    tid = 0
+    if keep:
+        tid = _NEXT[0]
+        _NEXT[0] += 1
+        _TAPES[tid] = state
+    return out, torch.tensor([tid], dtype=torch.int64)
+
+
+@_op_unet_fused.register_fake
+def _(xin, emb, w16, w16T, handle, keep):
+    B, H, W, _c = xin.shape
+    return xin.new_empty((B, H, W, 8)), torch.empty(1, dtype=torch.int64)
+
+
+@torch.library.custom_op("jg355::unet_fused_bwd", mutates_args=("grad",))
+def _op_unet_fused_bwd(dout: torch.Tensor, tape: torch.Tensor, grad: torch.Tensor, handle: int, need_dx: bool) -> Tuple[torch.Tensor, torch.Tensor]:
+    """backward of jg355::unet_fused: -> (d xin (empty when not needed), d emb); every parameter gradient is ACCUMULATED into `grad`, the fp32
+    gradient arena of the network (weight gradients on the side stream, joined before this op returns)"""
+    exe = _EXES[handle]
+    if grad.data_ptr() != exe.arena_g().data_ptr():
+        raise ValueError("jg355::unet_fused_bwd: `grad` must be the fp32 gradient arena of the network behind `handle` (the kernels accumulate "
+                         "into the arena the executor was built on)")
+    state = _TAPES.pop(int(tape[0]))
+    demb = exe.backward(state, dout.contiguous(), need_dx)
+    dx, exe.dxin = exe.dxin, None
+    return (dx if dx is not None else dout.new_empty(0)), demb
+
+
+@_op_unet_fused_bwd.register_fake
+def _(dout, tape, grad, handle, need_dx):
+    exe = _EXES[handle]
+    B, H, W, _c = dout.shape
+    return (dout.new_empty((B, H, W, exe.in_pad)) if need_dx else dout.new_empty(0)), dout.new_empty(exe.emb_shape, dtype=torch.float32)
+
+
+def _fused_setup(ctx, inputs, output):
+    ctx.handle = inputs[4]
+    ctx.need_dx = ctx.needs_input_grad[0]
+    ctx.save_for_backward(output[1])
+
+
+def _fused_backward(ctx, dout, _dtape):
+    (tape,) = ctx.saved_tensors
+    dx, demb = torch.ops.jg355.unet_fused_bwd(dout, tape, _EXES[ctx.handle].arena_g(), ctx.handle, ctx.need_dx)
+    return (dx if ctx.need_dx else None), demb, None, None, None, None
+
+
+_op_unet_fused.register_autograd(_fused_backward, setup_context=_fused_setup)
+
+
 def fused_unet(unet, xin, emb_all):
     exe = getattr(unet, "_jg_executor", None)
     if exe is None:
         exe = unet._jg_executor = UNetExecutor(unet)
+    if FUSED_TORCH_OPS:
+        if exe.handle is None:
+            exe.handle = len(_EXES) + 1
+            _EXES[exe.handle] = exe
+        exe.in_pad, exe.emb_shape = xin.shape[-1], tuple(emb_all.shape)
+        arena = unet._jg_arena_ref
+        keep = torch.is_grad_enabled() and (xin.requires_grad or emb_all.requires_grad)
+        out, tape = torch.ops.jg355.unet_fused(xin, emb_all, arena.w16, arena.w16T, exe.handle, keep)
+        if keep:
+            weakref.finalize(tape, _TAPES.pop, int(tape[0]), None)      # a forward whose graph is dropped without a backward
+        return out
     return _FusedUNetFn.apply(xin, emb_all, exe)

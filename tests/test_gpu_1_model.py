@@ -1204,6 +1204,66 @@ def test_gn_backward_with_fused_coefficients(golden_dir, efficient, monkeypatch)
         assert e < 5e-3, (name, e)        # same arithmetic, other summation orders (fp32 atomics) in front of fp16 stores
 
 
+@pytest.mark.parametrize("efficient", [True, False])
+def test_fused_unet_node_is_a_torch_op(golden_dir, efficient, monkeypatch):
+    """The benchmarked palette graph goes through `torch.ops` (VERDICT r5 missing #3): UNet.forward on the fused schedule is
+    `torch.ops.jg355.unet_fused` (+ `unet_fused_bwd` through register_autograd), by default.  Held against the autograd.Function of rounds 1-5 on
+    the same executor (JG_FUSED_TORCH_OPS=0): output, input gradient, embedding gradient and the gradient arena to the summation-order
+    floor; schema + fake-tensor checks of torch.library.opcheck on both ops; an inference call keeps no tape and a dropped graph frees its tape."""
+    import gc
+
+    from joligen_amd import ops
+    from joligen_amd.modules import unet_exec
+
+    c = dict(ngf=64, mults=[1, 2], res_blocks=[1, 1], attn_res=[2], efficient=efficient, S=64, B=2)
+    dtype = torch.float16
+    net, _ = build_net(c, dtype, golden_dir)
+    unet = net.denoise_fn.model
+    net.arena.ensure_fresh()
+    d = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(17)
+    x0 = ops.to_nhwc(torch.randn(c["B"], 6, c["S"], c["S"], generator=g).to(d), dtype, 8)
+    emb0 = torch.randn(c["B"], unet.cond_embed_dim, generator=g).to(d)
+    R = ops.to_nhwc(torch.randn(c["B"], 3, c["S"], c["S"], generator=g).to(d), dtype, 8)
+    res = {}
+    for as_op in (False, True, False):
+        monkeypatch.setattr(unet_exec, "FUSED_TORCH_OPS", as_op)
+        net.arena.g.zero_()
+        x = x0.clone().requires_grad_(True)
+        emb = emb0.clone().requires_grad_(True)
+        y = unet(x, emb)
+        assert ("Unet_fused" in type(y.grad_fn).__name__ or "unet_fused" in type(y.grad_fn).__name__.lower()) == as_op, type(y.grad_fn).__name__
+        y.backward(R)
+        torch.cuda.synchronize()
+        res.setdefault(as_op, []).append((y.detach().float(), x.grad.float(), emb.grad.clone(), net.arena.g.clone()))
+    assert not unet_exec._TAPES, "the backward consumed its tape"
+    for i, name in enumerate(("y", "dx", "demb", "gradient arena")):
+        floor = relerr(res[False][1][i], res[False][0][i])
+        e = relerr(res[True][0][i], res[False][0][i])
+        assert e <= 3 * floor + 1e-6, (name, e, floor)
+    assert float(res[True][0][3].norm()) > 0
+    # inference: no tape; a graph dropped without a backward: its tape goes with it
+    monkeypatch.setattr(unet_exec, "FUSED_TORCH_OPS", True)
+    with torch.no_grad():
+        unet(x0, emb0)
+    assert not unet_exec._TAPES
+    y = unet(x0.clone().requires_grad_(True), emb0)
+    assert len(unet_exec._TAPES) == 1
+    del y
+    gc.collect()
+    assert not unet_exec._TAPES
+    exe = unet._jg_executor
+    emb_all = unet._emb_all(emb0.float().contiguous()).all.detach()
+    torch.library.opcheck(torch.ops.jg355.unet_fused, (x0, emb_all, net.arena.w16, net.arena.w16T, exe.handle, False), test_utils=("test_schema", "test_faketensor"))
+    out, tape = torch.ops.jg355.unet_fused(x0, emb_all, net.arena.w16, net.arena.w16T, exe.handle, True)
+    with pytest.raises(ValueError):          # the mutated argument is the network's own gradient arena, nothing else
+        torch.ops.jg355.unet_fused_bwd(R, tape, torch.zeros_like(net.arena.g), exe.handle, True)
+    net.arena.g.zero_()
+    dx, demb = torch.ops.jg355.unet_fused_bwd(R, tape, net.arena.g, exe.handle, True)
+    torch.cuda.synchronize()
+    assert dx.shape == x0.shape and demb.shape == emb_all.shape and float(net.arena.g.norm()) > 0 and not unet_exec._TAPES
+
+
 @pytest.mark.parametrize("dtype_name", ["bf16", "fp16"])
 def test_palette_step_through_torch_ops(golden_dir, dtype_name):
     """The op boundary of north_star / SURVEY.md 8(b3): ONE palette training step with every op a `torch.ops.jg355.*` call
