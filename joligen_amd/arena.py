@@ -118,6 +118,12 @@ class ParamArena:
                     break
                 off, n = self.slices[name]
                 self.frozen_end = (off + n + ALIGN - 1) // ALIGN * ALIGN
+        # frozen parameters OUTSIDE the leading block would still be stepped by the fused optimizer (weight decay moves them) while their 16-bit
+        # working copies are no longer refreshed: refuse the layout instead of drifting silently
+        if frozen_prefixes:
+            stray = [name for name, _ in ordered if name.startswith(tuple(frozen_prefixes)) and self.slices[name][0] >= self.frozen_end]
+            if stray:
+                raise ValueError(f"ParamArena: frozen parameters must form the leading block of the arena; behind trained ones: {stray[:4]}")
         self._bias_pads = []
         for (name, conv), d in zip(convs, desc):
             _, dst, dstT, cout, rs, cin, coutp, cinp = d

@@ -814,6 +814,10 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   }
 }
 
+// loss reductions (one atomicAdd of a workgroup partial per workgroup): JG_DETERMINISTIC 1 -> ONE workgroup walks everything in its
+// grid-stride loop, the wave partials are summed in a fixed order: a reproducible loss
+inline int grid_for(long total, int block, int cap);
+inline int loss_grid(long total, int block, int cap) { return jg_tune(JG_TUNE_DETERMINISTIC) != 0 ? 1 : grid_for(total, block, cap); }
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
   long g = (total + block - 1) / block;
   if (g < 1) g = 1;
@@ -932,7 +936,7 @@ extern "C" int jg_ddpm_mse_loss(int dtype, const float* noise, const void* noise
                                 float grad_scale, jg_stream_t s) {
   if (!noise || !noise_hat || !loss || Cpad < C || Cpad % 8) return JG_ERR_BAD_ARG;
   const long total = (long)B * H * W;
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ddpm_mse_loss_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0,
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ddpm_mse_loss_kernel<T>), dim3(loss_grid(total, 256, 1024)), dim3(256), 0,
                                               (hipStream_t)s, noise, (const T*)noise_hat, mask, w, loss, (T*)dnh, B, C,
                                               H * W, Cpad, lambda, grad_scale););
   JG_CHECK_LAUNCH();
@@ -981,7 +985,7 @@ extern "C" int jg_cm_loss(int dtype, const void* Fn, const void* Fc, const float
   if (!Fn || !Fc || !noisy_n || !noisy_c || !cs_n || !co_n || !cs_c || !co_c || !w || !loss || Cpad < C || Cpad % 8)
     return JG_ERR_BAD_ARG;
   const long total = (long)B * H * W;
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cm_loss_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, (hipStream_t)s,
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cm_loss_kernel<T>), dim3(loss_grid(total, 256, 1024)), dim3(256), 0, (hipStream_t)s,
                                               (const T*)Fn, (const T*)Fc, noisy_n, noisy_c, cs_n, co_n, cs_c, co_c, mask, w, loss,
                                               (T*)dFn, B, C, H * W, Cpad, c_huber, lambda, grad_scale););
   JG_CHECK_LAUNCH();
@@ -1171,11 +1175,11 @@ extern "C" int jg_ddpm_multiscale_loss(int dtype, const float* noise, const void
   const long total = (long)B * H * W;
   hipStream_t st = (hipStream_t)s;
   if (nlevels > 1) {
-    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ms_loss_down_kernel<T>), dim3(grid_for((long)B * C * (H / 2) * (W / 2), 256, 512), nlevels - 1),
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ms_loss_down_kernel<T>), dim3(loss_grid((long)B * C * (H / 2) * (W / 2), 256, 512), nlevels - 1),
                                                 dim3(256), 0, st, noise, (const T*)noise_hat, mask, w, ws, losses, B, C, H, W, Cpad, nlevels,
                                                 l1, lambda););
   }
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ms_loss_grad_kernel<T>), dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, noise,
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((ms_loss_grad_kernel<T>), dim3(loss_grid(total, 256, 1024)), dim3(256), 0, st, noise,
                                               (const T*)noise_hat, mask, w, ws, losses, (T*)dnh, B, C, H, W, Cpad, nlevels, l1, multiscale,
                                               lambda, grad_scale););
   JG_CHECK_LAUNCH();

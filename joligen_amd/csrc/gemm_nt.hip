@@ -605,6 +605,18 @@ extern "C" int jg_conv2d_nt(int dtype, const jg_conv_args* a, jg_stream_t stream
   ConvP p;
   const int rc = conv_args_to_params(a, p);
   if (rc != JG_OK) return rc;
+  if (p.stats && jg_tune(JG_TUNE_DETERMINISTIC) != 0) {
+    // JG_DETERMINISTIC 1: the fused GroupNorm statistics are fp32 atomics from every tile (and ds_add_f32 chains inside a tile), summed in
+    // whatever order the tiles retire.  The convolution runs without them and the ordered statistics pass (norm.hip) reads its output:
+    // replica 0 of the caller's [B][slots][ldstats][2] rows (the others stay zero; jg_gn_coef_ld sums the replicas in order).
+    if (p.stats_mode != 0) return JG_ERR_UNSUPPORTED;      // the GroupNorm-backward reductions of stats_mode 1 have no ordered form
+    float* st = p.stats;
+    p.stats = nullptr;
+    int r2;
+    JG_DISPATCH_DTYPE(dtype, r2 = launch_conv<T>(p, a->nbatch, (hipStream_t)stream, a->ws ? (long)a->ws_bytes : 0););
+    if (r2 != JG_OK) return r2;
+    return jg_gn_stats_ld(dtype, a->y, a->ldy, st, (int64_t)p.nslots * p.ldstats, a->B, a->Ho * a->Wo, a->Cout, stream);
+  }
   JG_DISPATCH_DTYPE(dtype, return launch_conv<T>(p, a->nbatch, (hipStream_t)stream, a->ws ? (long)a->ws_bytes : 0););
 }
 

@@ -14,6 +14,7 @@
 // ds_read_b128 groups and the 16-lane ds_write_b64 groups.
 #include "common.h"
 #include "wgrad_params.h"
+#include <vector>
 #include <cstdlib>
 
 namespace {
@@ -503,6 +504,9 @@ static int make_wgp(const jg_wgrad_args* a, WgP& p) {
   p.Cout_out = a->Cout_out > 0 ? a->Cout_out : a->Cout;
   p.lddy = a->lddy; p.ldx = a->ldx; p.lddw = a->lddw;
   p.nh = a->nh; p.splitk = a->splitk;
+  // JG_DETERMINISTIC 1: no split over the pixels -- every element of dw (and of dbias) is then produced by ONE thread of ONE workgroup, its
+  // atomicAdd a single add onto a reproducible value (the halo-resident kernels choose their own split: pick_split there)
+  if (jg_tune(JG_TUNE_DETERMINISTIC) != 0 && a->out_mode == JG_OUT_ATOMIC_F32) p.splitk = 1;
   p.sdyb = a->sdyb; p.sdyh = a->sdyh; p.sxb = a->sxb; p.sxh = a->sxh; p.sdwb = a->sdwb; p.sdwh = a->sdwh;
   p.alpha = a->alpha; p.out_mode = a->out_mode; p.B = a->B;
   p.dbias_scale = a->dbias_scale != 0.f ? a->dbias_scale : 1.f;
@@ -521,16 +525,22 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
   if (!a || n < 1 || n > 4096) return JG_ERR_BAD_ARG;
   // problems that one of the halo-resident kernels serves (3x3 / 7x7 stride 1 at their channel multiples) are launched by it, singly: those
   // fill the chip by themselves; everything else is the im2col TN kernel and goes into the groups
-  bool special[4096];
+  // Every descriptor is validated BEFORE anything is launched (a bad descriptor in the middle used to leave part of the group
+  // accumulated into the gradient arena).  The grouped kernel is the transposing-read TN kernel of JG_WGRAD_VARIANT >= 2; variant 1 (register
+  // transpose) has no grouped form and is refused rather than silently replaced, so that an A/B of the variants measures what it names.
   const int variant = jg_tune(JG_TUNE_WGRAD_VARIANT);
+  if (variant < 2) return JG_ERR_UNSUPPORTED;
+  std::vector<WgP> ps((size_t)n);
+  std::vector<char> special((size_t)n, 0);
   for (int i = 0; i < n; ++i) {
-    WgP p;
-    const int rc = make_wgp(a + i, p);
+    const int rc = make_wgp(a + i, ps[i]);
     if (rc != JG_OK) return rc;
-    if (a[i].nbatch != 1 || a[i].out_mode != JG_OUT_ATOMIC_F32 || p.reflect || p.x_up) return JG_ERR_UNSUPPORTED;
+    if (a[i].nbatch != 1 || a[i].out_mode != JG_OUT_ATOMIC_F32 || ps[i].reflect || ps[i].x_up) return JG_ERR_UNSUPPORTED;
     special[i] = variant >= 4 && (a[i].R > 1 || a[i].S > 1) &&
-                 (jg_wgrad_halo_try(dtype, p, 1, (hipStream_t)stream) || jg_wgrad_kxk_try(dtype, p, 1, (hipStream_t)stream));
+                 (jg_wgrad_halo_try(dtype, ps[i], 1, (hipStream_t)stream, true) || jg_wgrad_kxk_try(dtype, ps[i], 1, (hipStream_t)stream, true));
   }
+  for (int i = 0; i < n; ++i)
+    if (special[i] && !jg_wgrad_halo_try(dtype, ps[i], 1, (hipStream_t)stream)) jg_wgrad_kxk_try(dtype, ps[i], 1, (hipStream_t)stream);
   for (int wavesm = 1; wavesm <= 2; ++wavesm) {
     WgGroup g;
     g.n = 0;
@@ -550,9 +560,7 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
       return JG_OK;
     };
     for (int i = 0; i < n; ++i) {
-      WgP p;
-      const int rc = make_wgp(a + i, p);
-      if (rc != JG_OK) return rc;
+      const WgP& p = ps[i];
       if (special[i] || (p.Cout <= 64 ? 1 : 2) != wavesm) continue;
       const int tiles = ((p.Cout + 64 * wavesm - 1) / (64 * wavesm)) * ((p.Ktot + 127) / 128);
       g.p[g.n] = p;
@@ -585,14 +593,14 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
   if (p.reflect || p.x_up) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read exist only in the halo-resident kernel
   const int tilesN = (p.Ktot + 127) / 128;
   if (variant == 1) {
-    dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * a->splitk);
+    dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * p.splitk);
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_kernel<T>), grid, dim3(256), 0, (hipStream_t)stream, p););
   } else if (p.Cout <= 64 && variant != 3) {
-    dim3 grid(tilesN, 1, a->nbatch * a->splitk);
+    dim3 grid(tilesN, 1, a->nbatch * p.splitk);
     if (jg_tune(JG_TUNE_WGRAD_DEEP) & 1) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
     else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
   } else {
-    dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * a->splitk);
+    dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * p.splitk);
     if (jg_tune(JG_TUNE_WGRAD_DEEP) & 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
     else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);); }
   }

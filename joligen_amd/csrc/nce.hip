@@ -612,7 +612,7 @@ extern "C" int jg_sgemm(const float* A, const float* B, float* C, const float* b
   // accumulating GEMMs with a long reduction and a small output (the nn.Linear weight gradient: 16 tiles, K = rows of the batch)
   // are split along K so that the launch fills the chip; partial tiles land with atomics
   const int tiles = ((M + 63) / 64) * ((N + 63) / 64);
-  if (nbatch == 1 && beta == 1.0f && !bias && !E && tiles < 128 && K >= 256) {
+  if (nbatch == 1 && beta == 1.0f && !bias && !E && tiles < 128 && K >= 256 && jg_tune(JG_TUNE_DETERMINISTIC) == 0) {     // (deterministic mode: no K split, no atomics)
     int ks = 256 / tiles;
     while (ks > 1 && K / ks < 64) ks >>= 1;
     p.ksplit = ks;

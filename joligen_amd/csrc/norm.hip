@@ -48,21 +48,43 @@ inline int red_mult(int B, int HW, int C) {
   return 16;
 }
 
+// Deterministic forms (JG_DETERMINISTIC 1, `det`): ONE workgroup per image walks all its pixels (no cross-workgroup atomics), and the
+// threads that share a channel octet are combined by an ORDERED sum over their LDS slots instead of ds_add_f32 chains: the result does not
+// depend on the order in which waves and workgroups happen to run.  s_part: 256 threads x 16 partial sums behind the [C][2] row.
+__device__ __forceinline__ void ordered_octet_sum(float* s_acc, const float (&s1)[8], const float (&s2)[8], const Map& mp, int C, bool active) {
+  float* s_part = s_acc + 2 * C;
+  const int tid = threadIdx.x;
+  if (active) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      s_part[tid * 16 + q * 2] = s1[q];
+      s_part[tid * 16 + q * 2 + 1] = s2[q];
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * C; i += 256) {
+    const int c = i >> 1, k = i & 1, co = c >> 3, q = c & 7;
+    float s = 0.f;
+    for (int pl = 0; pl < mp.pl; ++pl) s += s_part[(pl * mp.noct + co) * 16 + q * 2 + k];
+    s_acc[i] = s;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, long ldx, float* __restrict__ sums, long ldsums,
-                                                       int HW, int C) {
-  extern __shared__ float s_acc[];  // [C][2]
+                                                       int HW, int C, int det) {
+  extern __shared__ float s_acc[];  // [C][2] (+ [256][16] in the deterministic form)
   const Map mp = make_map(C);
   const int tid = threadIdx.x, b = blockIdx.y;
   for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.f;
   __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s1[q] = s2[q] = 0.f;
   if (tid < mp.active) {
     const int co = tid % mp.noct, pl = tid / mp.noct;
-    float s1[8], s2[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) s1[q] = s2[q] = 0.f;
-    const int pbeg = blockIdx.x * mp.chunk;
-    const int pend = min(HW, pbeg + mp.chunk);
+    const int pbeg = det ? 0 : blockIdx.x * mp.chunk;
+    const int pend = det ? HW : min(HW, pbeg + mp.chunk);
     const T* xb = x + ((long)b * HW) * ldx + co * 8;
     for (int p = pbeg + pl; p < pend; p += mp.pl) {
       const uint4 v = *reinterpret_cast<const uint4*>(xb + (long)p * ldx);
@@ -74,13 +96,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         s2[q] += f[q] * f[q];
       }
     }
+    if (!det) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
-      atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
+      for (int q = 0; q < 8; ++q) {
+        atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
+        atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
+      }
     }
   }
+  if (det) ordered_octet_sum(s_acc, s1, s2, mp, C, tid < mp.active);      // every thread of the workgroup: it holds a barrier
   __syncthreads();
+  // (deterministic form: one workgroup per image, so ONE add per address onto a value that is itself reproducible)
   for (int i = tid; i < 2 * C; i += 256) atomicAdd(&sums[(long)b * 2 * ldsums + i], s_acc[i]);
 }
 
@@ -213,23 +239,25 @@ template <typename T, int ACT, bool UP = false>
 __global__ JG_GN_BWD_BOUNDS void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                             long lddy, const float* __restrict__ ab,
                                                             float* __restrict__ red, int HW, int C, int mult, int W = 0,
-                                                            float dysc = 1.f) {
-  extern __shared__ float s_acc[];  // [C][2]
+                                                            float dysc = 1.f, int det = 0) {
+  extern __shared__ float s_acc[];  // [C][2] (+ [256][16] in the deterministic form, see gn_stats_kernel)
   const Map mp = make_map_red(C, mult);
   const int tid = threadIdx.x, b = blockIdx.y;
   for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.f;
   __syncthreads();
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s1[q] = s2[q] = 0.f;
   if (tid < mp.active) {
     const int co = tid % mp.noct, pl = tid / mp.noct;
-    float a[8], bb[8], s1[8], s2[8];
+    float a[8], bb[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       a[q] = ab[((long)b * C + co * 8 + q) * 2];
       bb[q] = ab[((long)b * C + co * 8 + q) * 2 + 1];
-      s1[q] = s2[q] = 0.f;
     }
-    const int pbeg = blockIdx.x * mp.chunk;
-    const int pend = min(HW, pbeg + mp.chunk);
+    const int pbeg = det ? 0 : blockIdx.x * mp.chunk;
+    const int pend = det ? HW : min(HW, pbeg + mp.chunk);
     const long row0 = (long)b * HW;
     auto dy_row = [&](int p) -> long {
       return UP ? ((long)b * (HW >> 2) + (long)((p / W) >> 1) * (W >> 1) + ((p % W) >> 1)) : row0 + p;
@@ -268,23 +296,26 @@ __global__ JG_GN_BWD_BOUNDS void gn_bwd_reduce_kernel(const T* __restrict__ x, l
     // lanes of a wave that share the channel octet (tid % noct, noct a power of two < 64) combine by xor-shuffle
     // first: one LDS atomic per wave and channel instead of up to 32 colliding ones
     const bool p2 = (mp.noct & (mp.noct - 1)) == 0 && mp.noct < 64;
-    if (p2) {
+    if (!det) {
+      if (p2) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        for (int o = mp.noct; o < 64; o <<= 1) {
-          s1[q] += __shfl_xor(s1[q], o);
-          s2[q] += __shfl_xor(s2[q], o);
+        for (int q = 0; q < 8; ++q) {
+          for (int o = mp.noct; o < 64; o <<= 1) {
+            s1[q] += __shfl_xor(s1[q], o);
+            s2[q] += __shfl_xor(s2[q], o);
+          }
+        }
+      }
+      if (!p2 || (tid & 63) < mp.noct) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
+          atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
         }
       }
     }
-    if (!p2 || (tid & 63) < mp.noct) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        atomicAdd(&s_acc[(co * 8 + q) * 2], s1[q]);
-        atomicAdd(&s_acc[(co * 8 + q) * 2 + 1], s2[q]);
-      }
-    }
   }
+  if (det) ordered_octet_sum(s_acc, s1, s2, mp, C, tid < mp.active);
   __syncthreads();
   for (int i = tid; i < 2 * C; i += 256) atomicAdd(&red[(long)b * 2 * C + i], s_acc[i]);
 }
@@ -330,6 +361,25 @@ __global__ void gn_bwd_coef_kernel(const float* __restrict__ red, int nslots, co
     dfilm[(long)b * lddfilm + c] = a0 * A2 + b0 * A1;
     dfilm[(long)b * lddfilm + C + c] = A1;
   }
+}
+
+// Deterministic form of the parameter gradients (JG_DETERMINISTIC 1): one thread per channel adds the images' terms IN ORDER and writes its
+// sum once (gn_bwd_coef_kernel is then launched without dgamma / dbeta: its per-(image, channel) atomics come in any order).
+__global__ void gn_bwd_param_det_kernel(const float* __restrict__ red, int nslots, const float* __restrict__ film, long ldfilm,
+                                        const float* __restrict__ mr, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C, int G) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int cpg = C / G, g = c / cpg;
+  float dg = 0.f, db = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float mean = mr[((long)b * G + g) * 2], rstd = mr[((long)b * G + g) * 2 + 1];
+    const float f = film ? 1.f + film[(long)b * ldfilm + c] : 1.f;
+    const float A1 = red_sum(red, nslots, b, C, c, 0), A2 = red_sum(red, nslots, b, C, c, 1);
+    dg += f * rstd * (A2 - mean * A1);
+    db += f * A1;
+  }
+  if (dgamma) dgamma[c] += dg;
+  if (dbeta) dbeta[c] += db;
 }
 
 // FC ("fused coefficients"): the pass derives its own (P, Q, R) from the reductions instead of reading them from a coefficient kernel's
@@ -475,9 +525,10 @@ extern "C" int jg_gn_stats_ld(int dtype, const void* x, int64_t ldx, float* sums
                               jg_stream_t s) {
   if (!x || !sums || bad_shape(B, HW, C) || ldx < C || (ldx % 8) || ldsums < C) return JG_ERR_BAD_ARG;
   const Map mp = make_map(C);
-  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), 2 * C * sizeof(float), (hipStream_t)s,
-                                              (const T*)x, (long)ldx, sums, (long)ldsums, HW, C););
+  const int det = jg_tune(JG_TUNE_DETERMINISTIC) != 0;
+  dim3 grid(det ? 1 : (HW + mp.chunk - 1) / mp.chunk, B);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), (2 * C + (det ? 4096 : 0)) * sizeof(float), (hipStream_t)s,
+                                              (const T*)x, (long)ldx, sums, (long)ldsums, HW, C, det););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -539,10 +590,11 @@ static int gn_bwd_reduce_ld_impl(int dtype, const void* x, int64_t ldx, const vo
   if (zero && hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
   const int mult = red_mult(B, HW, C);
   const Map mp = make_map_red(C, mult);
-  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  const size_t shm = 2 * C * sizeof(float);
+  const int det = jg_tune(JG_TUNE_DETERMINISTIC) != 0;
+  dim3 grid(det ? 1 : (HW + mp.chunk - 1) / mp.chunk, B);
+  const size_t shm = (2 * C + (det ? 4096 : 0)) * sizeof(float);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, ACT>), grid, dim3(256), shm, st, (const T*)x,
-                                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult);););
+                                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult, 0, 1.f, det);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -565,10 +617,11 @@ static int gn_bwd_reduce_up_impl(int dtype, const void* x, int64_t ldx, const vo
   if (zero && hipMemsetAsync(red, 0, sizeof(float) * 2 * B * C, st) != hipSuccess) return JG_ERR_LAUNCH;
   const int mult = red_mult(B, HW, C);
   const Map mp = make_map_red(C, mult);
-  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  const size_t shm = 2 * C * sizeof(float);
+  const int det = jg_tune(JG_TUNE_DETERMINISTIC) != 0;
+  dim3 grid(det ? 1 : (HW + mp.chunk - 1) / mp.chunk, B);
+  const size_t shm = (2 * C + (det ? 4096 : 0)) * sizeof(float);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, ACT, true>), grid, dim3(256), shm, st, (const T*)x,
-                                                            (long)ldx, (const T*)dy_low, (long)lddy, ab, red, HW, C, mult, W, dy_scale);););
+                                                            (long)ldx, (const T*)dy_low, (long)lddy, ab, red, HW, C, mult, W, dy_scale, det);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -641,8 +694,12 @@ extern "C" int jg_gn_bwd_coef_slots(const float* red, int nslots, const float* g
                                     int64_t ldfilm, const float* mr, float* pqr, float* dgamma, float* dbeta, float* dfilm,
                                     int64_t lddfilm, int B, int HW, int C, int G, jg_stream_t s) {
   if (!red || !mr || !pqr || G < 1 || C % G || nslots < 1) return JG_ERR_BAD_ARG;
+  const bool det = jg_tune(JG_TUNE_DETERMINISTIC) != 0 && (dgamma || dbeta);
   hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)s, red, nslots, gamma, beta, film,
-                     (long)ldfilm, mr, pqr, dgamma, dbeta, dfilm, (long)lddfilm, B, HW, C, G);
+                     (long)ldfilm, mr, pqr, det ? nullptr : dgamma, det ? nullptr : dbeta, dfilm, (long)lddfilm, B, HW, C, G);
+  if (det)
+    hipLaunchKernelGGL(gn_bwd_param_det_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, red, nslots, film, (long)ldfilm, mr, dgamma, dbeta,
+                       B, C, G);
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -343,6 +343,10 @@ __global__ __launch_bounds__(WMR * 256, 3 - WMR) void wgrad3x3_halo_kernel(WgP p
 static void pick_split(int npairs, int ntiles, int ovh, int slots, int* per_out, int* splitk_out) {
   long best = -1;
   int bper = ntiles, bsk = 1;
+  if (jg_tune(JG_TUNE_DETERMINISTIC) != 0) {     // no split over the tiles: one workgroup, one thread per element of dw -- a reproducible sum
+    *per_out = ntiles; *splitk_out = 1;
+    return;
+  }
   const int skmax = ntiles < 2048 / npairs + 1 ? ntiles : 2048 / npairs + 1;
   for (int sk = 1; sk <= skmax; ++sk) {
     const int per = (ntiles + sk - 1) / sk;
@@ -410,13 +414,14 @@ void dispatch_wg(const WgP& p, hipStream_t st) {
 
 }  // namespace
 
-bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st) {
+bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st, bool dry_run) {
   if (nbatch != 1 || p.R != 3 || p.S != 3 || p.pad != 1 || p.stride != 1 || p.out_mode != JG_OUT_ATOMIC_F32) return false;
   // Cout: a multiple of 64, or fewer than 64 (one partly filled channel tile: the 3 -> 8-channel head of the UNet at 256 x 256 x 32 images, whose
   // im2col weight gradient fetched the input once per tap pair: 582 us for 60 us of bytes)
   if (p.Cin % 64 || (p.Cout % 64 && (p.Cout > 64 || (p.Cout & 7))) || (p.H & 15) || (p.W & 15) || p.H != p.Ho || p.W != p.Wo) return false;
   if (p.Cout < 64 && ((long)p.B * p.H * p.W < 262144 || p.reflect || p.x_up)) return false;      // small launches stay on the im2col kernel
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.B * p.H * p.W * p.lddy >= (1L << 31)) return false;
+  if (dry_run) return dtype == JG_F16 || dtype == JG_BF16;
   if (dtype == JG_F16) dispatch_wg<f16_t>(p, st);
   else if (dtype == JG_BF16) dispatch_wg<bf16_t>(p, st);
   else return false;

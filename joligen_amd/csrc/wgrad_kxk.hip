@@ -225,11 +225,12 @@ void launch_kxk(const WgP& p, hipStream_t st) {
 
 }  // namespace
 
-bool jg_wgrad_kxk_try(int dtype, const WgP& p, int nbatch, hipStream_t st) {
+bool jg_wgrad_kxk_try(int dtype, const WgP& p, int nbatch, hipStream_t st, bool dry_run) {
   if (nbatch != 1 || p.R != 7 || p.S != 7 || p.stride != 1 || p.out_mode != JG_OUT_ATOMIC_F32 || p.reflect || p.x_up) return false;
   if (p.Cin % 64 || p.Cout % 8 || (p.Ho & 7) || (p.Wo & 15) || p.Ho != p.H + 2 * p.pad - 6 || p.Wo != p.W + 2 * p.pad - 6) return false;
   if ((long)p.B * p.Ho * p.Wo < 65536) return false;        // small maps: the generic kernel's split over pixels fills the chip better
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.B * p.Ho * p.Wo * p.lddy >= (1L << 31)) return false;
+  if (dry_run) return dtype == JG_F16 || dtype == JG_BF16;
   if (dtype == JG_F16) launch_kxk<f16_t, 7, 2>(p, st);
   else if (dtype == JG_BF16) launch_kxk<bf16_t, 7, 2>(p, st);
   else return false;

@@ -19,8 +19,9 @@ struct WgP {
 };
 
 // wgrad_halo.hip: returns true when the shape was handled by the halo-resident 3x3 kernel.
-bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st);
+// dry_run: only answer whether the kernel WOULD take the problem (the grouped entry validates every descriptor before it launches anything)
+bool jg_wgrad_halo_try(int dtype, const WgP& p, int nbatch, hipStream_t st, bool dry_run = false);
 // wgrad_kxk.hip: returns true when the shape was handled by the halo-resident large-kernel (7x7) weight-gradient kernel.
-bool jg_wgrad_kxk_try(int dtype, const WgP& p, int nbatch, hipStream_t st);
+bool jg_wgrad_kxk_try(int dtype, const WgP& p, int nbatch, hipStream_t st, bool dry_run = false);
 // wgrad_sw.hip: sliding-window form of the 16-row x 64-co tile (v_mfma_f32_32x32x16, one pixel row per K step); the caller has validated the shape.
 void jg_wgrad_sw_launch(int dtype, const WgP& p, hipStream_t st);

@@ -301,6 +301,10 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_sw_kernel(WgP p, int ntiles, 
 static void pick_split(int npairs, int ntiles, int ovh, int slots, int* per_out, int* splitk_out) {
   long best = -1;
   int bper = ntiles, bsk = 1;
+  if (jg_tune(JG_TUNE_DETERMINISTIC) != 0) {     // no split over the tiles: one workgroup, one thread per element of dw -- a reproducible sum
+    *per_out = ntiles; *splitk_out = 1;
+    return;
+  }
   const int skmax = ntiles < 2048 / npairs + 1 ? ntiles : 2048 / npairs + 1;
   for (int sk = 1; sk <= skmax; ++sk) {
     const int per = (ntiles + sk - 1) / sk;

@@ -387,19 +387,21 @@ class CUTModel(BaseModel):
             for fn in gG.backward_functions:
                 getattr(self, fn)()
         self._drawn_fakes = self._draw_pool_fakes(side)
-        self.real_B.record_stream(side)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            self._group_flags(gD)
-            if self._d_half_from_graph(side, its):
-                self.step_driver = "graph"
-            else:
-                self.step_driver = "early"
-                for fn in gD.backward_functions:
-                    getattr(self, fn)()
-                for loss in gD.loss_backward:
-                    (getattr(self, loss) / its).backward()
-        self._drawn_fakes = None
+        try:                               # whatever happens below, a later compute_D_loss must query the pool again, not reuse these
+            self.real_B.record_stream(side)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._group_flags(gD)
+                if self._d_half_from_graph(side, its):
+                    self.step_driver = "graph"
+                else:
+                    self.step_driver = "early"
+                    for fn in gD.backward_functions:
+                        getattr(self, fn)()
+                    for loss in gD.loss_backward:
+                        (getattr(self, loss) / its).backward()
+        finally:
+            self._drawn_fakes = None
         if os.environ.get("JG_DBG_EARLY_D_SYNC"):      # dev (tools/dbg_graph_d.py): the two halves one after the other
             torch.cuda.synchronize()
         self._group_flags(gG)
@@ -472,6 +474,8 @@ class CUTModel(BaseModel):
         st["real_B"].copy_(self.real_B)
         self.real_A, self.real_B = st["real_A"], st["real_B"]
         st["fwd"].replay()
+        for n in nets:                     # graph F has just refreshed every trained working copy on the device: the host-side flag follows,
+            n.arena._dirty = False         # or the discriminator half would refresh D's copies again on the side stream while graph B reads them
         for k, v in st["outs"].items():
             setattr(self, k, v)
         if self.fake_B_pool.pool_size > 0:        # the pool keeps views of what it is handed: not of a buffer the next replay overwrites
@@ -581,6 +585,14 @@ class CUTModel(BaseModel):
         if self.act_dtype == torch.float16 or self.niter <= 2 or ops.KERNEL_TIMING is not None:
             return False
         nets = [self._net(dn) for dn in self.discriminators_names]
+        from .. import parallel
+
+        if parallel.world_size() > 1 and any(getattr(m, "jg_forward_collective", False) or isinstance(m, torch.nn.SyncBatchNorm)
+                                             for n in nets for m in n.modules()):
+            # the side stream (and a captured graph) must never carry a collective: none of today's discriminators has one in its forward --
+            # BatchNorm statistics are per rank, as in the reference's DDP default -- a module that adds one marks itself and gets the eager path
+            self.step_driver_note = "a discriminator module issues a collective in its forward: discriminator half not captured"
+            return False
         key = (tuple(self.real_B.shape), self.real_B.dtype, tuple(self.fake_B.shape), its, float(self.loss_scale),
                tuple(n.arena.p.data_ptr() for n in nets), tuple(n.training for n in nets))
         graphs = self.__dict__.setdefault("_dg_graphs", {})      # one graph per operand shape (a last, smaller batch of an epoch): at most three

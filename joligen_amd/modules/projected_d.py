@@ -797,6 +797,7 @@ class ProjectedDiscriminator(nn.Module):
         if self.projector_model == "vitsmall":       # timm VisionTransformer keys are the module's own
             res = self.freeze_feature_network.pretrained.load_state_dict(sd, strict=True)
             self.backbone_pretrained = True
+            self._backbone_loaded()
             return res
         remap = {}
         for k, v in sd.items():
@@ -811,7 +812,14 @@ class ProjectedDiscriminator(nn.Module):
                 remap[f"{stage}.{idx}.{rest}"] = v
         res = self.freeze_feature_network.pretrained.load_state_dict(remap, strict=True)
         self.backbone_pretrained = True
+        self._backbone_loaded()
         return res
+
+    def _backbone_loaded(self):
+        """a load_state_dict on a SUB-module does not reach the top-level post hook of the arena: the frozen 16-bit working copies are stale now"""
+        arena = getattr(self, "arena", None)
+        if arena is not None:
+            arena.dirty = True
 
     def check_loaded_backbone(self, incompatible, source=""):
         """after a non-strict load_state_dict of a discriminator checkpoint: a checkpoint that does not carry the frozen backbone
