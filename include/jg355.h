@@ -339,6 +339,17 @@ int jg_act_fwd(int dtype, const void* x, void* y, int64_t n, int act, jg_stream_
 int jg_act_bwd(int dtype, const void* y, const void* dy, void* dx, int64_t n, int act, jg_stream_t s);
 int jg_reflect_pad2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int pad, jg_stream_t s);
 int jg_reflect_pad2d_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int pad, jg_stream_t s);
+/* Input gradient of ReflectionPad2d(1) -> Conv2d(3x3, padding 0) (the ResnetBlocks of the CUT generators,
+ * models/modules/resnet_architecture/resnet_generator.py:247-275; autograd of F.pad(mode="reflect") + F.conv2d in the reference):
+ * dx holds the zero-padded ("same") input gradient on the H x W domain (jg_conv2d_nt on the flipped / transposed weight copy wT
+ * [Cin][3][3][Cout] with pad 1 -- the halo-resident kernel's shape); this adds alpha x the one-pixel ring of the padded-domain gradient,
+ * folded by the reflection's adjoint, into rows 1 / H - 2 and columns 1 / W - 2 of dx (csrc/reflect_border.hip).  Together: what
+ * jg_conv2d_nt over the (H + 2) x (W + 2) domain followed by jg_reflect_pad2d_bwd computes.  Cout % 32 == 0, Cin % 8 == 0,
+ * H, W <= 272; no atomics (every target pixel is increased once, by one thread). */
+int jg_reflect_dgrad_border(int dtype, const void* dy, int64_t lddy, const void* wT, void* dx, int64_t lddx, float* ws, int B, int H, int W,
+                            int Cout, int Cin, float alpha, jg_stream_t s);
+/* fp32 scratch of jg_reflect_dgrad_border ([B][4 lines][max(H, W) + 2][Cin]) */
+int64_t jg_reflect_dgrad_border_ws_floats(int B, int H, int W, int Cin);
 /* window crop (adjoint = 0: y[B,Ho,Wo,C] = x[B,H,W,C][:, top:top+Ho, left:left+Wo]) and its adjoint (1: y[B,H,W,C] = x[B,Ho,Wo,C] placed
  * at (top, left), zeros elsewhere): reflect-padded depth-wise conv of SeparableConv2d (mobile_modules.py:4-40) = pad -> dwconv -> crop */
 int jg_crop2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int top, int left, int Ho, int Wo, int adjoint, jg_stream_t s);

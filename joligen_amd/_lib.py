@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libjg355.so")
-SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "conv_kxk.hip", "conv_p64.hip", "conv1x1.hip", "gemm_tn.hip", "wgrad_halo.hip", "wgrad_sw.hip", "wgrad_kxk.hip", "nce.hip", "segformer.hip", "vit.hip", "projected_d.hip", "effnet.hip", "norm.hip", "gn_fused.hip", "elementwise.hip", "optim.hip", "capi.hip"]
+SOURCES = ["attention.hip", "gemm_nt.hip", "conv_halo.hip", "conv_kxk.hip", "reflect_border.hip", "conv_p64.hip", "conv1x1.hip", "gemm_tn.hip", "wgrad_halo.hip", "wgrad_sw.hip", "wgrad_kxk.hip", "nce.hip", "segformer.hip", "vit.hip", "projected_d.hip", "effnet.hip", "norm.hip", "gn_fused.hip", "elementwise.hip", "optim.hip", "capi.hip"]
 # -fno-slp-vectorize: the SLP vectoriser packs independent fp32 chains into v_pk_* pairs (register tuples: gn_fused.hip went from 150 spilled
 # registers to none without it) -- "an anti-lever beside MFMAs" in the MI355X guide; same-box A/B of the whole step: 52.2 -> 52.0 ms
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics", "-fno-slp-vectorize"]
@@ -109,6 +109,8 @@ SIGNATURES = {
     "jg_reflect_pad2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_crop2d": [c_i32, c_p, c_p] + [c_i32] * 9 + [c_p],
     "jg_reflect_pad2d_bwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_reflect_dgrad_border": [c_i32, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
+    "jg_reflect_dgrad_border_ws_floats": [c_i32, c_i32, c_i32, c_i32],
     "jg_dilate2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_subsample2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_channel_sum": [c_i32, c_p, c_i64, c_p, c_i64, c_i32, c_f32, c_p],

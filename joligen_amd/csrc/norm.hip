@@ -493,7 +493,11 @@ __global__ JG_GN_BWD_BOUNDS void gn_bwd_apply_kernel(const T* __restrict__ x, lo
   };
   // NB pixels per trip: their 2 NB to 4 NB loads are issued together (see gn_bwd_reduce_kernel).  NB = 4 (137 VGPRs, an occupancy step
   // down) measured 0.5 ms/step SLOWER than 2 on the palette step (profiles/r04_gn_load_batching_ab.log)
+#ifdef JG_GN_APPLY_NB
+  constexpr int NB = JG_GN_APPLY_NB;
+#else
   constexpr int NB = 2;
+#endif
   int p = pbeg + pl;
   for (; p + (NB - 1) * mp.pl < pend; p += NB * mp.pl) {
     uint4 vx[NB], vg[NB], va1[NB], va2[NB];

@@ -448,6 +448,11 @@ def conv2d(x, meta: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
     return _Conv2dFn.apply(x, meta.weight, meta.bias, res, meta, res_scale, alpha)
 
 
+# input gradient of the reflect-padded 3x3 convolutions on the halo-resident kernel + a ring kernel (1, round 6) or as a full convolution over
+# the padded domain on the im2col kernel + reflect_pad_bwd (0: rounds 1-5)
+REFLECT_DGRAD_HALO = os.environ.get("JG_REFLECT_DGRAD_HALO", "1") != "0"
+
+
 def reflect_conv_ok(x, m: ConvMeta):
     """shape limits of pad_mode = 1 (halo-resident kernels): ReflectionPad2d(1) + 3x3 / stride 1 / pad 0 convolution"""
     B, H, W, Cin = x.shape
@@ -482,9 +487,19 @@ class _ReflectConv2dFn(JGFunction):
         B, H, W, Cin = x.shape
         dx = None
         if ctx.needs_input_grad[0]:
-            dxp = conv2d_dgrad(dy, m, (B, H + 2, W + 2, Cin))
-            dx = torch.empty_like(x)
-            check(_lib.lib().jg_reflect_pad2d_bwd(_dt(dy), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cin, 1, _st()), "jg_reflect_pad2d_bwd")
+            if REFLECT_DGRAD_HALO and m.Cout % 64 == 0 and Cin % 64 == 0:
+                # round 6: the interior of the padded-domain gradient IS the zero-padded input gradient on H x W (halo-resident kernel); the
+                # one-pixel ring of the reflection's adjoint is added by jg_reflect_dgrad_border (csrc/reflect_border.hip)
+                dx = torch.empty_like(x)
+                conv_nt(dy, m.w16T, dx, B=B, H=H, W=W, Cin=m.Cout, Cout=Cin, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=m.Cout, ldw=9 * m.Cout,
+                        ldy=Cin)
+                ws = torch.empty(_lib.lib().jg_reflect_dgrad_border_ws_floats(B, H, W, Cin), device=x.device, dtype=torch.float32)
+                check(_lib.lib().jg_reflect_dgrad_border(_dt(dy), dy.data_ptr(), m.Cout, m.w16T.data_ptr(), dx.data_ptr(), Cin, ws.data_ptr(), B, H, W,
+                                                         m.Cout, Cin, 1.0, _st()), "jg_reflect_dgrad_border")
+            else:
+                dxp = conv2d_dgrad(dy, m, (B, H + 2, W + 2, Cin))
+                dx = torch.empty_like(x)
+                check(_lib.lib().jg_reflect_pad2d_bwd(_dt(dy), dxp.data_ptr(), dx.data_ptr(), B, H, W, Cin, 1, _st()), "jg_reflect_pad2d_bwd")
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             wg = m.weight.grad
             if wg is None:

@@ -1196,6 +1196,39 @@ def test_reflect_conv_fused(case, dtype):
     assert relerr(m.c.bias.grad, br.grad) < TOL[dtype], ("db", relerr(m.c.bias.grad, br.grad))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", REFLECT_CASES + [(2, 48, 16, 192, 128)])
+def test_reflect_conv_input_gradient_ring(case, dtype, monkeypatch):
+    """Round 6: the input gradient of ReflectionPad2d(1) + conv3x3 as the zero-padded gradient on the H x W domain (halo-resident kernel) plus
+    the one-pixel ring of the reflection's adjoint (csrc/reflect_border.hip: rows 1 / H - 2, columns 1 / W - 2, corners folded twice) against
+    fp32 autograd of F.pad(mode="reflect") + F.conv2d -- on the four border lines and the corner pixels separately, where a wrong fold would
+    hide inside a whole-tensor norm -- and against the form of rounds 1-5 (full convolution over the padded domain + reflect_pad_bwd)."""
+    from joligen_amd import _lib, ops
+
+    B, H, W, Cin, Cout = case
+    m, arena, w_ref, b_ref = _make_conv_module(Cin, Cout, 3, 0, dtype)
+    x = rnd((B, Cin, H, W), dtype, 23)
+    gy = rnd((B, Cout, H, W), dtype, 24)
+    xr = x.float().requires_grad_(True)
+    F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), w_ref, b_ref).backward(gy.float())
+    ref = xr.grad
+    got = {}
+    for halo in (True, False):
+        monkeypatch.setattr(ops, "REFLECT_DGRAD_HALO", halo)
+        xd = nhwc(x).to(dev()).requires_grad_(True)
+        ops.reflect_conv2d(xd, m.c.meta).backward(nhwc(gy).to(dev()))
+        torch.cuda.synchronize()
+        got[halo] = nchw(xd.grad).float().cpu()
+    g = got[True]
+    assert relerr(g, ref) < TOL[dtype], relerr(g, ref)
+    for name, sl in (("row 1", (slice(None), slice(None), 1)), ("row H-2", (slice(None), slice(None), H - 2)), ("col 1", (slice(None), slice(None), slice(None), 1)),
+                     ("col W-2", (slice(None), slice(None), slice(None), W - 2)), ("row 0", (slice(None), slice(None), 0)), ("col 0", (slice(None), slice(None), slice(None), 0)),
+                     ("corner (1, 1)", (slice(None), slice(None), 1, 1)), ("corner (H-2, W-2)", (slice(None), slice(None), H - 2, W - 2)),
+                     ("corner (1, W-2)", (slice(None), slice(None), 1, W - 2))):
+        assert relerr(g[sl], ref[sl]) < 1.5 * TOL[dtype], (name, relerr(g[sl], ref[sl]))
+    assert relerr(g, got[False]) < (2e-3 if dtype == torch.float16 else 1.6e-2), relerr(g, got[False])
+
+
 def test_reflect_conv_unsupported_shape_is_refused():
     from joligen_amd import ops
 
