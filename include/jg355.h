@@ -454,6 +454,13 @@ int jg_dwconv3x3_bwd(int dtype, const void* x, const void* pre, const void* dy, 
 int jg_dwconv3x3_bwd_ws(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
                         float* dbias, float* ws, int64_t ws_floats, int B, int H, int W, int C, int gelu, jg_stream_t s);
 int64_t jg_dwconv3x3_bwd_ws_floats(int B, int H, int W, int C);
+/* pad_mode 1: padding_mode = 'reflect' (nn.Conv2d(C, C, 3, padding=1, padding_mode='reflect', groups=C): the depth-wise convolution of
+ * SeparableConv2d in the mobile ResNet blocks, models/modules/mobile_modules.py:4-40) -- out-of-image taps read the mirrored pixel, the
+ * input gradient collects the mirror images' terms; pad_mode 0 = the entry points above (zero padding). */
+int jg_dwconv3x3_fwd_pad(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C, int gelu,
+                         int pad_mode, jg_stream_t s);
+int jg_dwconv3x3_bwd_ws_pad(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
+                            float* dbias, float* ws, int64_t ws_floats, int B, int H, int W, int C, int gelu, int pad_mode, jg_stream_t s);
 int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, const void* v, void* o, float* lse, int B, int Tq, int Tkv, int heads,
                         int64_t ldq, int64_t ldkv, int64_t ldo, float scale, jg_stream_t s);
 int jg_attn_smallkv_bwd(int dtype, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, void* dq,

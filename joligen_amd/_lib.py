@@ -146,6 +146,8 @@ SIGNATURES = {
     "jg_dwconv3x3_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dwconv3x3_bwd_ws": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dwconv3x3_bwd_ws_floats": [c_i32, c_i32, c_i32, c_i32],
+    "jg_dwconv3x3_fwd_pad": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_dwconv3x3_bwd_ws_pad": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_attn_smallkv_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_f32, c_p],
     "jg_attn_smallkv_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_i64,
                             c_f32, c_p],

@@ -106,14 +106,21 @@ struct DwWalk {
   }
 };
 // window of pixel (py, px) of an [H, W, C] image row-major at `base` (pointer to the centre pixel's chunk): pointers + validity of the 9 taps
+// reflect (round 6: padding_mode = 'reflect' of the depth-wise convolutions of the mobile ResNet blocks, mobile_modules.py:4-40): an
+// out-of-image tap reads the mirrored pixel (-1 -> 1, H -> H - 2) instead of a zero -- no padded copy of x, no crop of the result
 template <typename T, bool FLIP>
-__device__ __forceinline__ void dw_window(const T* centre, int px, int py, int H, int W, int C, const void* (&ptr)[9], bool (&ok)[9]) {
+__device__ __forceinline__ void dw_window(const T* centre, int px, int py, int H, int W, int C, const void* (&ptr)[9], bool (&ok)[9], int reflect = 0) {
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int sx = 0; sx < 3; ++sx) {
-      const int dy = FLIP ? 1 - r : r - 1, dx = FLIP ? 1 - sx : sx - 1;
-      const bool in = (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W;
+      int dy = FLIP ? 1 - r : r - 1, dx = FLIP ? 1 - sx : sx - 1;
+      bool in = (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W;
+      if (reflect && !in) {
+        dy = (py + dy < 0 || py + dy >= H) ? -dy : dy;
+        dx = (px + dx < 0 || px + dx >= W) ? -dx : dx;
+        in = true;
+      }
       ok[r * 3 + sx] = in;
       ptr[r * 3 + sx] = in ? centre + ((long)dy * W + dx) * C : centre;
     }
@@ -268,12 +275,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // over pixels; a block covers all chunks of 256 / (C/8) pixels at a time, so a wave reads contiguous channel rows
 template <typename T, bool FLIP>
 __device__ __forceinline__ void dw_apply(const T* __restrict__ x, const float (&wr)[8][9], const float* bs, long p, int px, int py, int H, int W,
-                                         int C, int c8, float* acc) {
+                                         int C, int c8, float* acc, int reflect = 0) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = bs ? bs[j] : 0.f;
   const void* ptr[9];
   bool ok[9];
-  dw_window<T, FLIP>(x + p * C + c8 * 8, px, py, H, W, C, ptr, ok);
+  dw_window<T, FLIP>(x + p * C + c8 * 8, px, py, H, W, C, ptr, ok, reflect);
   uint4 v[9];
   dw_load9(v, ptr);
 #pragma unroll
@@ -287,7 +294,7 @@ __device__ __forceinline__ void dw_apply(const T* __restrict__ x, const float (&
 }
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                            T* __restrict__ pre, T* __restrict__ y, int B, int H, int W, int C, int gelu) {
+                                                            T* __restrict__ pre, T* __restrict__ y, int B, int H, int W, int C, int gelu, int reflect) {
   const int c8n = C >> 3;
   const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;
   const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
@@ -304,7 +311,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
   for (long p = blockIdx.x * (long)tpb + pl; p < npix; p += (long)gridDim.x * tpb, wk.step()) {
     const int px = wk.px, py = wk.py;
     float acc[8];
-    dw_apply<T, false>(x, wr, bs, p, px, py, H, W, C, c8, acc);
+    dw_apply<T, false>(x, wr, bs, p, px, py, H, W, C, c8, acc, reflect);
     if (pre) *reinterpret_cast<uint4*>(pre + p * C + c8 * 8) = pack8<T>(acc);
     if (gelu) {
 #pragma unroll
@@ -319,7 +326,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_fwd_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restrict__ x, const T* __restrict__ pre, const T* __restrict__ dy,
                                                               T* __restrict__ du, float* __restrict__ dw, float* __restrict__ dbias,
-                                                              float* __restrict__ ws, int B, int H, int W, int C, int gelu) {
+                                                              float* __restrict__ ws, int B, int H, int W, int C, int gelu, int reflect) {
   __shared__ float s_acc[40 * 257];
   const int c8n = C >> 3;
   const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;          // pixel lanes per block (c8n <= 256)
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_w_kernel(const T* __restric
       const int px = wk.px, py = wk.py;
       const void* ptr9[9];
       bool ok[9];
-      dw_window<T, false>(x + p * C + c8 * 8, px, py, H, W, C, ptr9, ok);
+      dw_window<T, false>(x + p * C + c8 * 8, px, py, H, W, C, ptr9, ok, reflect);
       const void* ptr[11];
       ptr[0] = dy + p * C + c8 * 8;
       ptr[1] = gelu ? pre + p * C + c8 * 8 : dy + p * C + c8 * 8;
@@ -447,9 +454,36 @@ __global__ __launch_bounds__(256) void dw_partials_sum_kernel(const float* __res
 }
 
 // dx[p][c] = sum_taps du[p - tap][c] w[c][tap]   (same thread layout as the forward)
+// reflect: x was read through the mirror, so pixel q also collects what the padded-domain gradient holds at its mirror images -- row -1 for
+// q in row 1, row H for row H - 2, likewise the columns (up to four windows in the corners): dx[q] = sum_{q' -> q} sum_taps du[q' - tap] w[tap],
+// du zero outside the image.  The extra windows are centred OUTSIDE the image; their taps are addressed from the image origin.
+template <typename T>
+__device__ __forceinline__ void dw_apply_flip_at(const T* __restrict__ img, const float (&wr)[8][9], int yc, int xc, int H, int W, int C, int c8, float* acc) {
+  const void* ptr[9];
+  bool ok[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      const int yy = yc + 1 - r, xx = xc + 1 - sx;
+      const bool in = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+      ok[r * 3 + sx] = in;
+      ptr[r * 3 + sx] = img + (in ? ((long)yy * W + xx) * C : 0) + c8 * 8;
+    }
+  uint4 v[9];
+  dw_load9(v, ptr);
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    float f[8];
+    unpack8<T>(v[t], f);
+    const float m = ok[t] ? 1.f : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += f[j] * m * wr[j][t];
+  }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3x3_bwd_x_kernel(const T* __restrict__ du, const float* __restrict__ w, T* __restrict__ dx, int B,
-                                                              int H, int W, int C) {
+                                                              int H, int W, int C, int reflect) {
   const int c8n = C >> 3;
   const int tpb = 256 / c8n > 0 ? 256 / c8n : 1;
   const int c8 = threadIdx.x % c8n, pl = threadIdx.x / c8n;
@@ -465,6 +499,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_bwd_x_kernel(const T* __restric
     const int px = wk.px, py = wk.py;
     float acc[8];
     dw_apply<T, true>(du, wr, nullptr, p, px, py, H, W, C, c8, acc);
+    if (reflect) {
+      const int ym = py == 1 ? -1 : -2, yM = py == H - 2 ? H : -2;      // mirror rows of this pixel's row (-2: none)
+      const int xm = px == 1 ? -1 : -2, xM = px == W - 2 ? W : -2;
+      if (ym != -2 || yM != -2 || xm != -2 || xM != -2) {              // the ring next to the border only
+        const T* img = du + (p - ((long)py * W + px)) * C;
+        const int ys[3] = {py, ym, yM}, xs[3] = {px, xm, xM};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2)
+            if ((a | b2) && ys[a] != -2 && xs[b2] != -2) dw_apply_flip_at<T>(img, wr, ys[a], xs[b2], H, W, C, c8, acc);
+      }
+    }
     *reinterpret_cast<uint4*>(dx + p * C + c8 * 8) = pack8<T>(acc);
   }
 }
@@ -1366,15 +1413,21 @@ extern "C" int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const 
                                 float* dbeta, int64_t R, int C, jg_stream_t s) {
   return jg_layernorm_bwd_add(dtype, x, dy, gamma, mr, nullptr, dx, dgamma, dbeta, R, C, s);
 }
-extern "C" int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C,
-                                int gelu, jg_stream_t s) {
+extern "C" int jg_dwconv3x3_fwd_pad(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C,
+                                    int gelu, int pad_mode, jg_stream_t s) {
   if (!x || !w || !y || B < 1 || H < 1 || W < 1 || C < 8 || C % 8) return JG_ERR_BAD_ARG;
   if (C > 2048) return JG_ERR_UNSUPPORTED;
   const int tpb_f = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
+  if (pad_mode != 0 && pad_mode != 1) return JG_ERR_BAD_ARG;
+  if (pad_mode == 1 && (H < 2 || W < 2)) return JG_ERR_BAD_ARG;
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_fwd_kernel<T>), dim3(grid_for((long)B * H * W, tpb_f * 4, 4096)), dim3(256), 0, (hipStream_t)s,
-                                              (const T*)x, w, bias, (T*)pre, (T*)y, B, H, W, C, gelu););
+                                              (const T*)x, w, bias, (T*)pre, (T*)y, B, H, W, C, gelu, pad_mode););
   JG_CHECK_LAUNCH();
   return JG_OK;
+}
+extern "C" int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C,
+                                int gelu, jg_stream_t s) {
+  return jg_dwconv3x3_fwd_pad(dtype, x, w, bias, pre, y, B, H, W, C, gelu, 0, s);
 }
 static int dw_bwd_blocks(long npix, int C) {
   const int c8n = C / 8;
@@ -1388,7 +1441,12 @@ extern "C" int64_t jg_dwconv3x3_bwd_ws_floats(int B, int H, int W, int C) {
 }
 extern "C" int jg_dwconv3x3_bwd_ws(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
                                    float* dbias, float* ws, int64_t ws_floats, int B, int H, int W, int C, int gelu, jg_stream_t s) {
+  return jg_dwconv3x3_bwd_ws_pad(dtype, x, pre, dy, w, du, dx, dw, dbias, ws, ws_floats, B, H, W, C, gelu, 0, s);
+}
+extern "C" int jg_dwconv3x3_bwd_ws_pad(int dtype, const void* x, const void* pre, const void* dy, const float* w, void* du, void* dx, float* dw,
+                                       float* dbias, float* ws, int64_t ws_floats, int B, int H, int W, int C, int gelu, int pad_mode, jg_stream_t s) {
   if (!x || !dy || !w || !du || B < 1 || H < 1 || W < 1 || C < 8 || C % 8 || (gelu && !pre)) return JG_ERR_BAD_ARG;
+  if ((pad_mode != 0 && pad_mode != 1) || (pad_mode == 1 && (H < 4 || W < 4))) return JG_ERR_BAD_ARG;
   if (C > 2048) return JG_ERR_UNSUPPORTED;   // one 8-channel chunk per thread of a 256-thread block
   hipStream_t st = (hipStream_t)s;
   const int c8n = C / 8;
@@ -1398,13 +1456,13 @@ extern "C" int jg_dwconv3x3_bwd_ws(int dtype, const void* x, const void* pre, co
   if (ws && ws_floats < (int64_t)G * C * 10) return JG_ERR_BAD_ARG;
   if (!dw && !dbias) ws = nullptr;   // nothing to reduce: the kernel only writes du
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_w_kernel<T>), dim3(G), dim3(256), 0, st,
-                                              (const T*)x, (const T*)pre, (const T*)dy, (T*)du, dw, dbias, ws, B, H, W, C, gelu););
+                                              (const T*)x, (const T*)pre, (const T*)dy, (T*)du, dw, dbias, ws, B, H, W, C, gelu, pad_mode););
   if (ws) {
     hipLaunchKernelGGL(dw_partials_sum_kernel, dim3((C * 10 + 63) / 64, (G + 63) / 64), dim3(256), 0, st, (const float*)ws, G, C * 10, c8n, dw, dbias);
   }
   if (dx) {
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((dwconv3x3_bwd_x_kernel<T>), dim3(grid_for(npix, tpb * 4, 4096)), dim3(256), 0, st, (const T*)du, w,
-                                                (T*)dx, B, H, W, C););
+                                                (T*)dx, B, H, W, C, pad_mode););
   }
   JG_CHECK_LAUNCH();
   return JG_OK;

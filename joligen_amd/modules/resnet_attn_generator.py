@@ -53,8 +53,7 @@ class SeparableConv2d(nn.Module):
     def forward(self, x):
         B, H, W, C = x.shape
         dw = self.conv[0]
-        h = S.dwconv3x3(ops.reflect_pad2d(x, 1), dw.weight, dw.bias, gelu=False)
-        h = ops.crop2d(h, 1, 1, H, W)
+        h = S.dwconv3x3(x, dw.weight, dw.bias, gelu=False, reflect=True)      # mirrored taps inside the kernel: no padded copy, no crop
         return self.conv[2](_in_act(h, self.conv[1], JG_ACT_NONE))
 
 

@@ -103,16 +103,16 @@ def layer_norm_id(x, weight, bias, eps=1e-6):
 # ---- depth-wise 3x3 + GELU ---------------------------------------------------------------------------------------------------------
 class _DWConvGeluFn(JGFunction):
     @staticmethod
-    def forward(ctx, x, weight, bias, gelu):
+    def forward(ctx, x, weight, bias, gelu, reflect=False):
         _require_cuda(x)
         x = x.contiguous()
         B, H, W, C = x.shape
         y = torch.empty_like(x)
         pre = torch.empty_like(x) if gelu else None
-        check(_lib.lib().jg_dwconv3x3_fwd(_dt(x), x.data_ptr(), weight.data_ptr(), _p(bias), _p(pre), y.data_ptr(), B, H, W, C, int(gelu), _st()),
-              "jg_dwconv3x3_fwd")
+        check(_lib.lib().jg_dwconv3x3_fwd_pad(_dt(x), x.data_ptr(), weight.data_ptr(), _p(bias), _p(pre), y.data_ptr(), B, H, W, C, int(gelu),
+                                              int(reflect), _st()), "jg_dwconv3x3_fwd_pad")
         ctx.save_for_backward(x, pre, weight)
-        ctx.gelu, ctx.gw, ctx.gb = gelu, weight.grad, None if bias is None else bias.grad
+        ctx.gelu, ctx.gw, ctx.gb, ctx.reflect = gelu, weight.grad, None if bias is None else bias.grad, bool(reflect)
         return y
 
     @staticmethod
@@ -132,15 +132,25 @@ class _DWConvGeluFn(JGFunction):
         if want_w and DW_TWO_PHASE:
             nws = int(_lib.lib().jg_dwconv3x3_bwd_ws_floats(B, H, W, C))
             ws = torch.empty(nws, device=x.device, dtype=torch.float32)
-        check(_lib.lib().jg_dwconv3x3_bwd_ws(_dt(x), x.data_ptr(), _p(pre), dy.data_ptr(), weight.data_ptr(), du.data_ptr(), _p(dx),
-                                             _p(ctx.gw) if want_w else None, _p(ctx.gb) if (want_w and ctx.gb is not None) else None, _p(ws), nws,
-                                             B, H, W, C, int(ctx.gelu), _st()), "jg_dwconv3x3_bwd_ws")
-        return dx, None, None, None
+        check(_lib.lib().jg_dwconv3x3_bwd_ws_pad(_dt(x), x.data_ptr(), _p(pre), dy.data_ptr(), weight.data_ptr(), du.data_ptr(), _p(dx),
+                                                 _p(ctx.gw) if want_w else None, _p(ctx.gb) if (want_w and ctx.gb is not None) else None, _p(ws), nws,
+                                                 B, H, W, C, int(ctx.gelu), int(ctx.reflect), _st()), "jg_dwconv3x3_bwd_ws_pad")
+        return dx, None, None, None, None
 
 
-def dwconv3x3(x, weight, bias, gelu=True):
-    """nn.Conv2d(C, C, 3, padding=1, groups=C) (+ nn.GELU()) on an NHWC map; weight is the arena view of [C, 1, 3, 3]."""
-    return _DWConvGeluFn.apply(x, weight, bias, bool(gelu))
+DW_REFLECT = os.environ.get("JG_DW_REFLECT", "1") != "0"
+
+
+def dwconv3x3(x, weight, bias, gelu=True, reflect=False):
+    """nn.Conv2d(C, C, 3, padding=1, groups=C) (+ nn.GELU()) on an NHWC map; weight is the arena view of [C, 1, 3, 3].
+    reflect: padding_mode='reflect' -- one launch with mirrored taps (round 6), or (JG_DW_REFLECT=0 / under the torch.ops boundary, whose op
+    schema knows zero padding only) reflect-pad -> zero-padded depth-wise kernel -> crop as in rounds 3-5."""
+    from . import ops
+
+    if reflect and (not DW_REFLECT or ops.TORCH_OPS_BOUNDARY or x.shape[1] < 4 or x.shape[2] < 4):
+        B, H, W, C = x.shape
+        return ops.crop2d(_DWConvGeluFn.apply(ops.reflect_pad2d(x, 1), weight, bias, bool(gelu), False), 1, 1, H, W)
+    return _DWConvGeluFn.apply(x, weight, bias, bool(gelu), bool(reflect))
 
 
 # ---- attention with a spatially reduced key / value set ---------------------------------------------------------------------------------

@@ -102,6 +102,41 @@ def test_dwconv3x3_gelu(B, H, W, C, dtype, two_phase, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 128), (1, 9, 7, 256), (2, 4, 5, 64), (4, 64, 64, 256)])
+def test_dwconv3x3_reflect_padding_in_one_launch(B, H, W, C, dtype, monkeypatch):
+    """Round 6: nn.Conv2d(C, C, 3, padding=1, padding_mode='reflect', groups=C) -- the depth-wise convolution of SeparableConv2d in the mobile
+    ResNet blocks (mobile_modules.py:4-40) -- with the mirror inside the kernels (jg_dwconv3x3_fwd_pad / _bwd_ws_pad, pad_mode 1): forward,
+    input gradient (the border-adjacent rows / columns collect their mirror images' terms; the corners four windows), weight and bias gradient
+    against fp32 autograd of F.pad(mode='reflect') + F.conv2d; the border ring of the input gradient separately; and against the
+    reflect-pad -> zero-padded kernel -> crop composition of rounds 3-5 (JG_DW_REFLECT=0)."""
+    from joligen_amd import ops_segformer as S
+    x, gy = rnd((B, C, H, W), dtype, 15), rnd((B, C, H, W), dtype, 16)
+    w, b = rnd((C, 1, 3, 3), torch.float32, 17, 0.4), rnd((C,), torch.float32, 18, 0.1)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(F.pad(xr, (1, 1, 1, 1), mode="reflect"), wr, br, groups=C)
+    yr.backward(gy.float())
+    nchw = lambda t: t.permute(0, 3, 1, 2)
+    got = {}
+    for one in (True, False):
+        monkeypatch.setattr(S, "DW_REFLECT", one)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True)
+        wd, bd = param(w), param(b)
+        y = S.dwconv3x3(xd, wd, bd, gelu=False, reflect=True)
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().to(D0))
+        torch.cuda.synchronize()
+        got[one] = (nchw(y).float().cpu(), nchw(xd.grad).float().cpu(), wd.grad.float().cpu(), bd.grad.float().cpu())
+    y, dx, dw, db = got[True]
+    assert relerr(y, yr) < TOL[dtype] and relerr(dx, xr.grad) < 2 * TOL[dtype], (relerr(y, yr), relerr(dx, xr.grad))
+    assert relerr(dw, wr.grad) < 2 * TOL[dtype] and relerr(db, br.grad) < 2 * TOL[dtype]
+    ring = torch.zeros(H, W, dtype=torch.bool)
+    ring[[0, 1, H - 2, H - 1], :] = True
+    ring[:, [0, 1, W - 2, W - 1]] = True
+    assert relerr(dx[:, :, ring], xr.grad[:, :, ring]) < 2 * TOL[dtype], relerr(dx[:, :, ring], xr.grad[:, :, ring])
+    for a, c in zip(got[True], got[False]):
+        assert relerr(a, c) < 2 * TOL[dtype], relerr(a, c)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,Tq,Tkv,heads", [(2, 4096, 64, 1), (2, 1024, 64, 2), (1, 100, 16, 5), (2, 64, 64, 8), (1, 256, 256, 2), (1, 70, 130, 1)])
 def test_attention_smallkv(B, Tq, Tkv, heads, dtype):
     from joligen_amd import ops_segformer as S
