@@ -86,7 +86,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     const int pbeg = det ? 0 : blockIdx.x * mp.chunk;
     const int pend = det ? HW : min(HW, pbeg + mp.chunk);
     const T* xb = x + ((long)b * HW) * ldx + co * 8;
-    for (int p = pbeg + pl; p < pend; p += mp.pl) {
+    // four pixels per trip, their loads issued together (round 6; as in gn_bwd_reduce_kernel: one 16-byte load in flight per wave left the
+    // InstanceNorm statistics passes of the CUT generators at 40 us for 8 us of bytes)
+    int p = pbeg + pl;
+    for (; p + 3 * mp.pl < pend; p += 4 * mp.pl) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(xb + (long)(p + u * mp.pl) * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack8<T>(v[u], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          s1[q] += f[q];
+          s2[q] += f[q] * f[q];
+        }
+      }
+    }
+    for (; p < pend; p += mp.pl) {
       const uint4 v = *reinterpret_cast<const uint4*>(xb + (long)p * ldx);
       float f[8];
       unpack8<T>(v, f);
