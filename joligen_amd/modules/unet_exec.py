@@ -422,6 +422,7 @@ class UNetExecutor:
         self._pool_need = {}
         self._side = None          # HIP stream of the weight-gradient launches (created with the first backward)
         self.handle = None         # torch.ops handle (fused_unet)
+        self._g1x1 = []            # collected 1x1 weight gradients (GROUP_1X1_WGRAD)
 
     def arena_g(self):
         return self.u._jg_arena_ref.g
@@ -431,6 +432,13 @@ class UNetExecutor:
         """conv_wgrad on the side stream: it starts once everything launched so far on the compute stream (the producers of dy and
         x) is done.  Both operands are marked as in use by the side stream, so the caching allocator does not hand their memory to a
         later allocation of the compute stream while the kernel may still be reading it."""
+        if GROUP_1X1_WGRAD and m.R == 1 and m.S == 1 and not kw.get("x_up"):
+            # experiment (VERDICT r5 next #1c, JG_GROUP_1X1_WGRAD=1): the 1x1 weight gradients of the backward are collected and leave as grouped
+            # launches (jg_conv2d_wgrad_tn_group) every GROUP_1X1_EVERY problems and at the end of the backward
+            self._g1x1.append((dy, x, m, kw))
+            if len(self._g1x1) >= GROUP_1X1_EVERY:
+                self.flush_1x1()
+            return
         if not WGRAD_STREAM:
             return conv_wgrad(dy, x, m, **kw)
         main = torch.cuda.current_stream()
@@ -449,6 +457,22 @@ class UNetExecutor:
             conv_wgrad(dy, x, m, **kw)
         dy.record_stream(self._side)
         x.record_stream(self._side)
+
+    def flush_1x1(self):
+        if not self._g1x1:
+            return
+        items, self._g1x1 = self._g1x1, []
+        main = torch.cuda.current_stream()
+        side = self._side if (WGRAD_STREAM and self._side is not None) else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side), ops.deferred_wgrads():
+            for dy, x, m, kw in items:
+                conv_wgrad(dy, x, m, **kw)
+        for dy, x, m, kw in items:
+            if side is not main:
+                dy.record_stream(side)
+                x.record_stream(side)
 
     @contextlib.contextmanager
     def exchange_context(self):
@@ -664,6 +688,7 @@ class UNetExecutor:
             else:
                 dacts[rec["in_id"]] = dX
         assert not dacts and not dhs, (list(dacts), list(dhs))
+        self.flush_1x1()
         self.wgrad_join()
         self._pool_need[bkey] = max(self.bpool.off, 64)
         self.bpool = None
@@ -822,6 +847,8 @@ class _FusedUNetFn(JGFunction):
 #   * the tape (saved activations, statistics, the pool of GroupNorm sums) stays with the executor under an integer id that the forward
 #     returns as a 1-element int64 tensor; the backward op consumes it, a finalizer on that tensor drops an unused tape.
 FUSED_TORCH_OPS = os.environ.get("JG_FUSED_TORCH_OPS", "1") != "0"
+GROUP_1X1_WGRAD = os.environ.get("JG_GROUP_1X1_WGRAD", "0") != "0"
+GROUP_1X1_EVERY = int(os.environ.get("JG_GROUP_1X1_EVERY", "64"))
 _EXES, _TAPES, _NEXT = {}, {}, [1]
 
 
