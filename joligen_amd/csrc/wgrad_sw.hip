@@ -225,26 +225,25 @@ __global__ __launch_bounds__(512, 1) void wgrad3x3_sw_kernel(WgP p, int ntiles, 
     }
     // halo rows hl = 0..9 of this wave's row half (tile rows y = 0..7): step hl multiplies the x fragments (hl, s) with the dy rows
     // hl - r; the fragments of step hl + 1 are requested before the MFMAs of step hl issue
-    uint4 xf[2][3], dyf[4];
+    // Single-buffered x fragments (round 6b: every register this kernel gives back is room for the waves of the other stream): the
+    // MFMAs of a step go column by column -- (r = 2, 1, 0; s) for s = 0, 1, 2 -- and xf[s] is reloaded for the next halo row right behind its
+    // column, a whole step (9 MFMAs) ahead of its next use; the dy rows sit in a ring of four, row hl + 1 requested at the top of step hl.
+    uint4 xf[3], dyf[4];
 #pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) xf[0][s3] = tr_frag(boff + bbase[s3][0], boff + bbase[s3][1]);
+    for (int s3 = 0; s3 < 3; ++s3) xf[s3] = tr_frag(boff + bbase[s3][0], boff + bbase[s3][1]);
     dyf[0] = tr_frag(boff + abase[0], boff + abase[1]);
 #pragma unroll
     for (int hl = 0; hl < RH + 2; ++hl) {
-      if (hl + 1 < RH + 2) {
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
-          xf[(hl + 1) & 1][s3] = tr_frag(boff + bbase[s3][0] + (hl + 1) * HROW, boff + bbase[s3][1] + (hl + 1) * HROW);
-        if (hl + 1 < RH) dyf[(hl + 1) & 3] = tr_frag(boff + abase[0] + (hl + 1) * DROW, boff + abase[1] + (hl + 1) * DROW);
-      }
+      if (hl + 1 < RH) dyf[(hl + 1) & 3] = tr_frag(boff + abase[0] + (hl + 1) * DROW, boff + abase[1] + (hl + 1) * DROW);
       if (hl < RH && do_bias) bsum += sum8<T>(dyf[hl & 3]);
 #pragma unroll
-      for (int r = 2; r >= 0; --r) {
-        const int y = hl - r;
-        if (y >= 0 && y < RH) {
+      for (int s3 = 0; s3 < 3; ++s3) {
 #pragma unroll
-          for (int s3 = 0; s3 < 3; ++s3) mfma32_pinned<T>(acc[r * 3 + s3], dyf[y & 3], xf[hl & 1][s3]);
+        for (int r = 2; r >= 0; --r) {
+          const int y = hl - r;
+          if (y >= 0 && y < RH) mfma32_pinned<T>(acc[r * 3 + s3], dyf[y & 3], xf[s3]);
         }
+        if (hl + 1 < RH + 2) xf[s3] = tr_frag(boff + bbase[s3][0] + (hl + 1) * HROW, boff + bbase[s3][1] + (hl + 1) * HROW);
       }
     }
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");     // the compiler does not see the MFMAs: keep its next VALU access off their results
