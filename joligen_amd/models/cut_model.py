@@ -48,6 +48,9 @@ class _ScaleGradFn(JGFunction):
         return g * ctx.s, None
 
 
+FORK_GAN_DEFAULT = True
+
+
 class CUTModel(BaseModel):
     def __init__(self, opt, rank):
         for k, v in CUT_DEFAULTS.items():
@@ -211,10 +214,41 @@ class CUTModel(BaseModel):
         self._feat_calls = 0
 
     # ---- generator losses ---------------------------------------------------------------------------------------------
+    def _fork_gan(self):
+        """`JG_FORK_GAN` / option `jg_fork_gan` (round 6): the two branches of the generator loss hang off `fake_B` independently -- the GAN terms
+        (every discriminator's forward on the translated image, ViT projector included) and the contrastive terms (encoder passes, PatchSampleF,
+        NCE) -- and each is a string of 5 - 30 us launches that fills a fraction of the chip.  The GAN branch is enqueued on a forked stream;
+        autograd runs a node's backward on the stream of its forward, so the two branches overlap in the backward as well, and both forks are
+        captured into the generator graphs (a fork that joins before the capture ends is a legal capture)."""
+        want = os.environ.get("JG_FORK_GAN", "")
+        return ((getattr(self.opt, "jg_fork_gan", FORK_GAN_DEFAULT) or want == "1") and want != "0" and self.device.type == "cuda"
+                and not ops.TORCH_OPS_BOUNDARY and ops.KERNEL_TIMING is None
+                and "compute_G_loss_GAN" in self.loss_functions_G and len(self.loss_functions_G) > 1)
+
     def compute_G_loss(self):
         self.loss_G_tot = 0
-        for f in self.loss_functions_G:
-            getattr(self, f)()
+        if self._fork_gan():
+            main = torch.cuda.current_stream(self.device)
+            side = self.__dict__.get("_gan_stream")
+            if side is None:
+                side = self._gan_stream = torch.cuda.Stream(device=self.device)
+            side.wait_stream(main)
+            for t in (self.fake_B, self.real_B):
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                self.compute_G_loss_GAN()
+                gan_tot, self.loss_G_tot = self.loss_G_tot, 0
+            for f in self.loss_functions_G:
+                if f != "compute_G_loss_GAN":
+                    getattr(self, f)()
+            main.wait_stream(side)
+            gan_tot.record_stream(main)
+            for dn in self.discriminators_names:
+                getattr(self, "loss_G_GAN_" + dn).record_stream(main)
+            self.loss_G_tot = self.loss_G_tot + gan_tot
+        else:
+            for f in self.loss_functions_G:
+                getattr(self, f)()
         self.loss_G_tot = _ScaleGradFn.apply(self.loss_G_tot, self.loss_scale)
 
     def compute_G_loss_GAN(self):

@@ -803,6 +803,34 @@ def test_cut_graph_canary_failure_falls_back_to_eager(monkeypatch):
     assert float(((e["losses"] - b["losses"]).abs() / b["losses"].abs()).max()) <= 2e-2
 
 
+def test_cut_forked_gan_branch_agrees_c3_shape(monkeypatch):
+    """Round 6 (`jg_fork_gan`, default on): the GAN terms of the generator loss -- every discriminator's forward on the translated image -- are
+    enqueued on a forked stream next to the contrastive terms, and autograd runs their backward there too.  Same kernels on the same operands:
+    against the one-stream form (`JG_FORK_GAN=0`) losses and Adam first moments of all four networks agree to the run-to-run floor, on the
+    sequential driver (eager, two streams inside compute_G_loss only) and on the benchmarked `graph+graphG` driver (both forks captured), at the
+    BASELINE configs[2] selection (ViT projector, 256 x 256, batch 4), 5 calls."""
+    gen = torch.Generator().manual_seed(13)
+    data = {"A": torch.rand(4, 3, 256, 256, generator=gen) * 2 - 1, "B": torch.rand(4, 3, 256, 256, generator=gen) * 2 - 1}
+    cfg = {"model_type": "cut", "G": {"netG": "segformer_attn_conv", "ngf": 64, "nblocks": 9},
+           "D": {"netDs": ["projected_d", "basic"], "ndf": 64, "proj_interp": 256, "proj_network_type": "vitsmall"}, "data": {"crop_size": 256, "load_size": 256},
+           "train": {"batch_size": 4, "G_ema": True, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0}}
+    monkeypatch.setenv("JG_FORK_GAN", "0")
+    b = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
+    b2 = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
+    monkeypatch.setenv("JG_FORK_GAN", "1")
+    f_seq = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
+    f_gr = _run_cut_driver(cfg, data, monkeypatch, True, True, calls=5)
+    _assert_graph_ran(f_gr)
+    floor_l = float(((b["losses"] - b2["losses"]).abs() / b["losses"].abs()).max())
+    floor_p = max(float((b["m1"][n] - b2["m1"][n]).norm() / b["m1"][n].norm()) for n in b["m1"])
+    for name, r in (("sequential + fork", f_seq), ("graph+graphG + fork", f_gr)):
+        assert torch.isfinite(r["losses"]).all()
+        assert float(((r["losses"] - b["losses"]).abs() / b["losses"].abs()).max()) <= 4 * floor_l + 2e-3, name
+        for n in b["m1"]:
+            e = float((r["m1"][n] - b["m1"][n]).norm() / b["m1"][n].norm())
+            assert e <= 4 * floor_p + 2e-3, (name, n, e, floor_p)
+
+
 @pytest.mark.parametrize("proj", ["efficientnet", "vitsmall"])
 def test_cut_step_drivers_agree_c3_shape(monkeypatch, proj):
     """The same comparison at the BASELINE configs[2] shape bench.py times (segformer_attn_conv generator, [projected_d, basic], 256 x 256, batch 4
