@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -72,6 +74,9 @@ class NoiseLevelEmbedding(nn.Module):
         return ops.linear(h, l2.weight, l2.bias, JG_ACT_SILU)
 
 
+CM_FORK = os.environ.get("JG_CM_FORK", "1") != "0"
+
+
 class CMGenerator(nn.Module):
     def __init__(self, cm_model, sampling_method, image_size, G_ngf, opt=None):
         super().__init__()
@@ -129,10 +134,29 @@ class CMGenerator(nn.Module):
         current_sigmas, next_sigmas = sigmas[timesteps], sigmas[timesteps + 1]
         cpad = (x.shape[1] + (0 if x_cond is None else x_cond.shape[1]) + 7) // 8 * 8
         next_noisy_x, xin_next = ops.cm_noisy(x, noise, next_sigmas, mask, x_cond, self.act_dtype, cpad)
-        F_next = self._unet(xin_next, next_sigmas)
-        with torch.no_grad():
-            current_noisy_x, xin_cur = ops.cm_noisy(x, noise, current_sigmas, mask, x_cond, self.act_dtype, cpad)
-            F_cur = self._unet(xin_cur, current_sigmas)
+        if CM_FORK and x.is_cuda:
+            # round 6 (JG_CM_FORK, default 1; 121.3 -> 120.4 ms at batch 64): the no-grad pass on the current noise level is independent of the student pass -- enqueued on a
+            # forked stream, joined before the loss
+            main = torch.cuda.current_stream(dev)
+            side = self.__dict__.get("_fork_stream")
+            if side is None:
+                side = self.__dict__["_fork_stream"] = torch.cuda.Stream(device=dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side), torch.no_grad():
+                current_noisy_x, xin_cur = ops.cm_noisy(x, noise, current_sigmas, mask, x_cond, self.act_dtype, cpad)
+                F_cur = self._unet(xin_cur, current_sigmas)
+            for t in (x, noise, current_sigmas, mask, x_cond):
+                if t is not None and t.is_cuda:
+                    t.record_stream(side)
+            F_next = self._unet(xin_next, next_sigmas)
+            main.wait_stream(side)
+            F_cur.record_stream(main)
+            current_noisy_x.record_stream(main)
+        else:
+            F_next = self._unet(xin_next, next_sigmas)
+            with torch.no_grad():
+                current_noisy_x, xin_cur = ops.cm_noisy(x, noise, current_sigmas, mask, x_cond, self.act_dtype, cpad)
+                F_cur = self._unet(xin_cur, current_sigmas)
         self.current_t += x.shape[0]
         return dict(F_next=F_next, F_cur=F_cur, next_noisy_x=next_noisy_x, current_noisy_x=current_noisy_x,
                     cs_n=skip_scaling(next_sigmas, self.sigma_data, self.sigma_min),
