@@ -204,10 +204,25 @@ class CUTModel(BaseModel):
             self.real_B_pool.query(self.real_B)
         self._forward_core()
 
+    def _reuse_feats(self):
+        """`jg_nce_reuse_feats` (round 6, default on): the key-side features of both contrastive terms -- `netG.get_feats` of the source image
+        (NCE term) and of the target image (identity term), cut_model.py:848-887 -- are the encoder activations the generator's forward has
+        just computed on cat(real_A, real_B): for an encoder that is a deterministic function of its input in training mode (the ResNet
+        families: InstanceNorm, no dropout) a second pass recomputes the same values from the same weights, and its backward adds the same
+        gradients to them.  The forward hands the tapped activations out (`forward_with_feats`) and the encoder pass of the loss runs over the
+        2 B translated / identity images only.  NOT for the SegFormer encoder: its DropPath masks are drawn per pass in the reference."""
+        net = self._net("G_A")
+        return (getattr(self.opt, "jg_nce_reuse_feats", True) and os.environ.get("JG_NCE_REUSE_FEATS", "1") != "0" and self.opt.isTrain
+                and getattr(net, "deterministic_encoder", False) and net.training and self._batched_nce())
+
     def _forward_core(self):
         B = self.batch_size
         self.real = torch.cat((self.real_A, self.real_B), dim=0) if self.opt.alg_cut_nce_idt else self.real_A
-        self.fake = self._net("G_A")(self.real)
+        self._real_feats = None
+        if self._reuse_feats():
+            self.fake, self._real_feats = self._net("G_A").forward_with_feats(self.real, self.nce_layers)
+        else:
+            self.fake = self._net("G_A")(self.real)
         self.fake_B = self.fake[:B]
         if self.opt.alg_cut_nce_idt:
             self.idt_B = self.fake[B:]
@@ -282,7 +297,13 @@ class CUTModel(BaseModel):
         net, netF = self._net("G_A"), self._net("F")
         # images in the order [translated | identity | source | target] = cat(G's output, G's input): no slice of either is needed, and the
         # rows of every layer come out as [q of term 0 | q of term 1 | k of term 0 | k of term 1]
-        feats = net.get_feats(torch.cat((self.fake, self.real), dim=0), self.nce_layers)
+        reuse = self.__dict__.get("_real_feats")
+        if reuse is not None:         # `jg_nce_reuse_feats`: the source / target features are the forward's own activations
+            feats = net.get_feats(self.fake, self.nce_layers)
+            feats_k, self._real_feats = reuse, None
+        else:
+            feats = net.get_feats(torch.cat((self.fake, self.real), dim=0), self.nce_layers)
+            feats_k = None
         self._feat_calls += 2
         netF.arena.ensure_fresh()
         P = o.alg_cut_num_patches
@@ -291,7 +312,11 @@ class CUTModel(BaseModel):
         for li, f in enumerate(feats):
             C = self.feat_channels[li]
             ids = torch.stack((ids_all[0][li], ids_all[1][li]))                      # [2, P_l]: images b use set (b // B) % 2
-            rows.append(netF.embed(ops.gather_patches(f, ids, C, per=B), li).split(2 * B * ids.shape[1]))     # (q rows, k rows): one cat in backward
+            if feats_k is not None:
+                g = torch.cat((ops.gather_patches(f, ids, C, per=B), ops.gather_patches(feats_k[li], ids, C, per=B)), dim=0)
+            else:
+                g = ops.gather_patches(f, ids, C, per=B)
+            rows.append(netF.embed(g, li).split(2 * B * ids.shape[1]))     # (q rows, k rows): one cat in backward
             counts.append(ids.shape[1])
         T, monce = o.alg_cut_nce_T, o.alg_cut_nce_loss == "monce"
         tot = [0.0, 0.0]

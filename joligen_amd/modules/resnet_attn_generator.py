@@ -168,6 +168,15 @@ class ResnetGenerator_attn(nn.Module):
         logits = self.deconv3_attention(a)
         return logits, image
 
+    deterministic_encoder = True       # InstanceNorm, no dropout: see ResnetGenerator.forward_with_feats
+
+    def forward_with_feats(self, input, extract_layer_ids):
+        if self.arena is not None:
+            self.arena.ensure_fresh()
+        feat, feats = self.compute_feats(input, self.tapped_layers(extract_layer_ids))
+        logits, image = self.compute_attention_content(feat)
+        return S.attention_compose(image, logits, input, self.nb_mask_attn, self.nb_mask_attn - self.nb_mask_input, min(self.output_nc, 3)), feats
+
     def forward(self, input):
         if self.arena is not None:
             self.arena.ensure_fresh()

@@ -174,3 +174,14 @@ class ResnetGenerator(nn.Module):
         if self.arena is not None:
             self.arena.ensure_fresh()
         return self.decoder(self.encoder(input))
+
+    # the encoder is a deterministic function of its input in training mode as well (InstanceNorm without running statistics, no dropout):
+    # the features `get_feats(x)` returns are the activations `forward(x)` has already computed (cut_model `jg_nce_reuse_feats`)
+    deterministic_encoder = True
+
+    def forward_with_feats(self, input, extract_layer_ids):
+        """(forward(input), get_feats(input, extract_layer_ids)) from ONE encoder pass"""
+        if self.arena is not None:
+            self.arena.ensure_fresh()
+        feat, feats = self.encoder.compute_feats(input, extract_layer_ids)
+        return self.decoder(feat), feats

@@ -803,6 +803,36 @@ def test_cut_graph_canary_failure_falls_back_to_eager(monkeypatch):
     assert float(((e["losses"] - b["losses"]).abs() / b["losses"].abs()).max()) <= 2e-2
 
 
+@pytest.mark.parametrize("netG", ["resnet", "mobile_resnet_attn"])
+def test_cut_nce_key_features_reused_from_the_forward(monkeypatch, netG):
+    """Round 6 (`jg_nce_reuse_feats`, default on for deterministic encoders): the key-side features of the NCE and identity-NCE terms --
+    `netG.get_feats(real_A)` / `get_feats(real_B)`, cut_model.py:848-887 -- taken from the generator forward's own encoder pass over
+    cat(real_A, real_B) instead of a second pass.  InstanceNorm encoders without dropout compute the same values either way and the backward
+    adds the same gradients to the same weights: losses and the Adam first moments of G, F and D agree with the two-pass form
+    (`JG_NCE_REUSE_FEATS=0`) to the run-to-run floor, on the BASELINE configs[0] selection (resnet_9blocks + basic, 128 x 128) and on the
+    attention generator of example_gan_horse2zebra.json; the patch ids are the same draws (same RNG consumption)."""
+    gen = torch.Generator().manual_seed(19)
+    data = {"A": torch.rand(2, 3, 128, 128, generator=gen) * 2 - 1, "B": torch.rand(2, 3, 128, 128, generator=gen) * 2 - 1}
+    cfg = {"model_type": "cut", "G": {"netG": netG, "ngf": 64, "nblocks": 9}, "D": {"netDs": ["basic"], "ndf": 64},
+           "alg": {"cut": {"nce_loss": "monce"}}, "data": {"crop_size": 128, "load_size": 128},
+           "train": {"batch_size": 2, "G_ema": True, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0}}
+    monkeypatch.setenv("JG_NCE_REUSE_FEATS", "0")
+    b = _run_cut_driver(cfg, data, monkeypatch, True, True, calls=5)
+    b2 = _run_cut_driver(cfg, data, monkeypatch, True, True, calls=5)
+    monkeypatch.setenv("JG_NCE_REUSE_FEATS", "1")
+    r = _run_cut_driver(cfg, data, monkeypatch, True, True, calls=5)
+    rs = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
+    _assert_graph_ran(r)
+    floor_l = float(((b["losses"] - b2["losses"]).abs() / b["losses"].abs()).max())
+    floor_p = max(float((b["m1"][n] - b2["m1"][n]).norm() / b["m1"][n].norm()) for n in b["m1"])
+    for name, x in (("graph+graphG", r), ("sequential", rs)):
+        assert torch.isfinite(x["losses"]).all()
+        assert float(((x["losses"] - b["losses"]).abs() / b["losses"].abs()).max()) <= 4 * floor_l + 2e-3, name
+        for n in b["m1"]:
+            e = float((x["m1"][n] - b["m1"][n]).norm() / b["m1"][n].norm())
+            assert e <= 4 * floor_p + 3e-3, (name, n, e, floor_p)
+
+
 def test_cut_forked_gan_branch_agrees_c3_shape(monkeypatch):
     """Round 6 (`jg_fork_gan`, default on): the GAN terms of the generator loss -- every discriminator's forward on the translated image -- are
     enqueued on a forked stream next to the contrastive terms, and autograd runs their backward there too.  Same kernels on the same operands:
