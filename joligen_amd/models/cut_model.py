@@ -49,7 +49,6 @@ class _ScaleGradFn(JGFunction):
 
 
 FORK_GAN_DEFAULT = True
-SPLIT_KEYS_DEFAULT = 1
 
 
 class CUTModel(BaseModel):
@@ -216,36 +215,10 @@ class CUTModel(BaseModel):
         return (getattr(self.opt, "jg_nce_reuse_feats", True) and os.environ.get("JG_NCE_REUSE_FEATS", "1") != "0" and self.opt.isTrain
                 and getattr(net, "deterministic_encoder", False) and net.training and self._batched_nce())
 
-    def _split_keys(self):
-        """`jg_nce_split_keys` (round 6): in the batched contrastive pass the key-side images (source / target) go through the encoder in their
-        OWN pass under `no_grad` instead of riding along with the query-side images -- the reference detaches the keys inside the loss
-        (`patchnce.py`: `feat_k = feat_k.detach()`), so the one 4 B-image pass of round 5 ran its whole BACKWARD over 4 B images of which 2 B carried
-        zero gradients.  Value 2 (`JG_NCE_SPLIT_KEYS=2`): that pass is enqueued on a forked stream before the generator's forward (it needs the
-        real images and the weights only) and joined where the loss reads it."""
-        want = os.environ.get("JG_NCE_SPLIT_KEYS", "")
-        v = int(want) if want else int(getattr(self.opt, "jg_nce_split_keys", SPLIT_KEYS_DEFAULT))
-        if not v or not self.opt.isTrain or not self._batched_nce() or self._reuse_feats():
-            return 0
-        if v == 2 and (self.device.type != "cuda" or ops.TORCH_OPS_BOUNDARY or ops.KERNEL_TIMING is not None):
-            return 1
-        return v
-
     def _forward_core(self):
         B = self.batch_size
         self.real = torch.cat((self.real_A, self.real_B), dim=0) if self.opt.alg_cut_nce_idt else self.real_A
         self._real_feats = None
-        self._key_feats = None
-        if self._split_keys() == 2:
-            net = self._net("G_A")
-            net.arena.ensure_fresh()                    # the refresh of the working copies stays on the main stream, ahead of both readers
-            main = torch.cuda.current_stream(self.device)
-            ks = self.__dict__.get("_key_stream")
-            if ks is None:
-                ks = self._key_stream = torch.cuda.Stream(device=self.device)
-            ks.wait_stream(main)
-            self.real.record_stream(ks)
-            with torch.cuda.stream(ks), torch.no_grad():
-                self._key_feats = net.get_feats(self.real, self.nce_layers)
         if self._reuse_feats():
             self.fake, self._real_feats = self._net("G_A").forward_with_feats(self.real, self.nce_layers)
         else:
@@ -328,17 +301,6 @@ class CUTModel(BaseModel):
         if reuse is not None:         # `jg_nce_reuse_feats`: the source / target features are the forward's own activations
             feats = net.get_feats(self.fake, self.nce_layers)
             feats_k, self._real_feats = reuse, None
-        elif self._split_keys():       # `jg_nce_split_keys`: the keys in their own pass without a tape (forked earlier, or here)
-            feats = net.get_feats(self.fake, self.nce_layers)
-            feats_k, self._key_feats = self.__dict__.get("_key_feats"), None
-            if feats_k is None:
-                with torch.no_grad():
-                    feats_k = net.get_feats(self.real, self.nce_layers)
-            else:
-                main = torch.cuda.current_stream(self.device)
-                main.wait_stream(self._key_stream)
-                for f in feats_k:
-                    f.record_stream(main)
         else:
             feats = net.get_feats(torch.cat((self.fake, self.real), dim=0), self.nce_layers)
             feats_k = None

@@ -833,35 +833,6 @@ def test_cut_nce_key_features_reused_from_the_forward(monkeypatch, netG):
             assert e <= 4 * floor_p + 3e-3, (name, n, e, floor_p)
 
 
-def test_cut_nce_keys_in_their_own_pass(monkeypatch):
-    """Round 6 (`jg_nce_split_keys`, default on): the key-side images of the batched contrastive pass go through the encoder in their own pass
-    under `no_grad` -- the loss detaches the keys (`patchnce.py`), so nothing flows back through them and the encoder's backward covers the 2 B
-    query images instead of 4 B.  On a resnet generator (no DropPath: both forms compute the same features and draw the same patch ids; the
-    forward's own features are switched off with `JG_NCE_REUSE_FEATS=0` so that the pass under test runs) losses and Adam's first moments of
-    G / F / D agree with the one-pass form to its run-to-run floor, on the sequential and on the `graph+graphG` driver."""
-    gen = torch.Generator().manual_seed(23)
-    data = {"A": torch.rand(2, 3, 128, 128, generator=gen) * 2 - 1, "B": torch.rand(2, 3, 128, 128, generator=gen) * 2 - 1}
-    cfg = {"model_type": "cut", "G": {"netG": "resnet", "ngf": 64, "nblocks": 9}, "D": {"netDs": ["basic"], "ndf": 64},
-           "alg": {"cut": {"nce_loss": "monce"}}, "data": {"crop_size": 128, "load_size": 128},
-           "train": {"batch_size": 2, "G_ema": True, "iter_size": 1, "pool_size": 0, "G_lr": 0.0, "D_lr": 0.0}}
-    monkeypatch.setenv("JG_NCE_REUSE_FEATS", "0")
-    monkeypatch.setenv("JG_NCE_SPLIT_KEYS", "0")
-    b = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
-    b2 = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
-    monkeypatch.setenv("JG_NCE_SPLIT_KEYS", "1")
-    rs = _run_cut_driver(cfg, data, monkeypatch, False, False, calls=5)
-    rg = _run_cut_driver(cfg, data, monkeypatch, True, True, calls=5)
-    _assert_graph_ran(rg)
-    floor_l = float(((b["losses"] - b2["losses"]).abs() / b["losses"].abs()).max())
-    floor_p = max(float((b["m1"][n] - b2["m1"][n]).norm() / b["m1"][n].norm()) for n in b["m1"])
-    for name, x in (("sequential", rs), ("graph+graphG", rg)):
-        assert torch.isfinite(x["losses"]).all()
-        assert float(((x["losses"] - b["losses"]).abs() / b["losses"].abs()).max()) <= 4 * floor_l + 2e-3, name
-        for n in b["m1"]:
-            e = float((x["m1"][n] - b["m1"][n]).norm() / b["m1"][n].norm())
-            assert e <= 4 * floor_p + 3e-3, (name, n, e, floor_p)
-
-
 def test_cut_forked_gan_branch_agrees_c3_shape(monkeypatch):
     """Round 6 (`jg_fork_gan`, default on): the GAN terms of the generator loss -- every discriminator's forward on the translated image -- are
     enqueued on a forked stream next to the contrastive terms, and autograd runs their backward there too.  Same kernels on the same operands:
