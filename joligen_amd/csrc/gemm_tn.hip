@@ -541,12 +541,27 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
   }
   for (int i = 0; i < n; ++i)
     if (special[i] && !jg_wgrad_halo_try(dtype, ps[i], 1, (hipStream_t)stream)) jg_wgrad_kxk_try(dtype, ps[i], 1, (hipStream_t)stream);
+  const int group_blocks = jg_tune(JG_TUNE_WGRAD_GROUP_BLOCKS);
   for (int wavesm = 1; wavesm <= 2; ++wavesm) {
     WgGroup g;
     g.n = 0;
     g.start[0] = 0;
     auto flush = [&]() -> int {
       if (!g.n) return JG_OK;
+      // Round 6: the callers' split-K factors are chosen for a launch that has the chip to itself (JG_WGRAD_TARGET_BLOCKS workgroups PER PROBLEM:
+      // up to 512 slices of four K-steps each, every one ending in a 32 - 64 KB burst of fp32 atomics).  Side by side the problems of a group
+      // fill the chip together: the K-steps of the whole group are dealt out over `group_blocks` workgroups of equal length, a problem is never
+      // split further than its caller asked.
+      if (group_blocks > 0) {
+        long total = 0;
+        for (int i = 0; i < g.n; ++i) total += (long)g.tiles[i] * ((g.p[i].Mpix + 63) / 64);
+        const long len = std::max<long>(4, (total + group_blocks - 1) / group_blocks);      // K-steps per workgroup
+        for (int i = 0; i < g.n; ++i) {
+          const long ks = (g.p[i].Mpix + 63) / 64;
+          g.p[i].splitk = (int)std::max<long>(1, std::min<long>(g.p[i].splitk, (ks + len - 1) / len));
+          g.start[i + 1] = g.start[i] + g.tiles[i] * g.p[i].splitk;
+        }
+      }
       const dim3 grid(g.start[g.n]);
       const int deep = jg_tune(JG_TUNE_WGRAD_DEEP);      // two register stages of global loads in flight: bit 0 = the 64-row tile, bit 1 = the 128-row tile
       if (wavesm == 1) {

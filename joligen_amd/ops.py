@@ -231,6 +231,11 @@ def flush_deferred_wgrads():
     by_dt = {}
     for dt, a, keep in todo:
         by_dt.setdefault(dt, []).append(a)
+    if os.environ.get("JG_WGRAD_DUMP"):        # dev: the problems of one flush (tools/wgrad_group_model.py reads this)
+        with open(os.environ["JG_WGRAD_DUMP"], "a") as f:
+            f.write("flush %d\n" % len(todo))
+            for dt, a, keep in todo:
+                f.write("%d %d %d %d %d %d %d %d %d %d %d %d %d\n" % (a.B, a.H, a.W, a.Cin, a.Cout, a.R, a.S, a.pad, a.stride, a.Ho, a.Wo, a.splitk, int(bool(a.dbias))))
     side = _WGRAD_SIDE[0] if _WGRAD_SIDE is not None else None
     if side is not None:
         side.wait_stream(torch.cuda.current_stream())

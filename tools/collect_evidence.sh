@@ -56,6 +56,7 @@ cutprof)
   cd $R
   python tools/rocpd_stats.py $(db ckt) 4 > $O/${TAG}_cut_kernel_stats.md 2>> $O/${TAG}_evidence.log
   python tools/rocpd_overlap.py $(db ckt) > $O/${TAG}_cut_overlap.txt 2>> $O/${TAG}_evidence.log
+  python tools/rocpd_stats.py $(db ckt) 4 --by-queue > $O/${TAG}_cut_kernel_stats_by_queue.md 2>> $O/${TAG}_evidence.log
   rm -rf $O/${TAG}_ckt
   head -14 $O/${TAG}_cut_kernel_stats.md ;;
 cutpmc)

@@ -30,6 +30,16 @@ def main():
     if len(marks) >= 2:
         where = f" where start > {marks[0]} and start < {marks[-1]} and name not like '%spin_kernel%'"
         note = f"steady-state window between the two marker kernels ({(marks[-1] - marks[0]) / 1e6:.2f} ms of wall time = {(marks[-1] - marks[0]) / 1e6 / steps:.2f} ms/step)"
+    if "--by-queue" in sys.argv:        # one table per (queue, stream): which kernels a forked branch / side stream carries
+        qs = db.execute("select queue_id, stream_id, count(*), sum(duration) from kernels" + where + " group by queue_id, stream_id order by sum(duration) desc").fetchall()
+        for q, st, n, tot in qs:
+            print(f"\n### queue {q} stream {st}: {n / steps:.0f} launches, {tot / 1e6 / steps:.3f} ms of kernel time per step\n")
+            print("| kernel | calls/step | ms/step | avg us |")
+            print("|---|---|---|---|")
+            cond = (where + " and " if where else " where ") + f"queue_id = {q} and stream_id = {st}"
+            for name, k, t, avg in db.execute("select name, count(*), sum(duration), avg(duration) from kernels" + cond + " group by name order by sum(duration) desc limit 40").fetchall():
+                print(f"| `{short(name)}` | {k / steps:.1f} | {t / 1e6 / steps:.3f} | {avg / 1e3:.1f} |")
+        return
     rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels" + where +
                       " group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows)
