@@ -354,6 +354,12 @@ int64_t jg_reflect_dgrad_border_ws_floats(int B, int H, int W, int Cin);
  * at (top, left), zeros elsewhere): reflect-padded depth-wise conv of SeparableConv2d (mobile_modules.py:4-40) = pad -> dwconv -> crop */
 int jg_crop2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int top, int left, int Ho, int Wo, int adjoint, jg_stream_t s);
 int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s);
+/* Round 6: autograd's grad_input of a STRIDED nn.Conv2d whose input is an image (<= 4 real channels in an 8-channel NHWC pixel) -- the first
+ * convolution of the MiT encoder (segformer/backbone.py PatchEmbed: 7x7 stride 4) and of NLayerDiscriminator (discriminators.py:53-60: 4x4
+ * stride 2) -- in gather form: every input pixel sums the ceil(R/s) x ceil(S/s) taps that reach it.  dy [B,Ho,Wo,Cout], w16 [Cout][R][S][8]
+ * (forward layout), dx [B,H,W,8] (channels 4..7 written as zero).  JG_ERR_UNSUPPORTED when R*S*Cout*16 bytes exceed 64 KB of LDS. */
+int jg_conv_dgrad_gather(int dtype, const void* dy, const void* w16, void* dx, int B, int H, int W, int Ho, int Wo, int Cout, int R, int S,
+                         int stride, int pad, float alpha, jg_stream_t s);
 
 /* Frozen tf_efficientnet_lite0 feature network of the projected discriminator (models/modules/projected_d/projector.py:51-59,251-255; timm
  * MBConv blocks; the feature network stays in eval mode, discriminator.py:267-270, so BatchNorm is the per-channel affine scale / shift):

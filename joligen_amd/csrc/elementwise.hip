@@ -1081,6 +1081,71 @@ extern "C" int jg_crop2d(int dtype, const void* x, void* y, int B, int H, int W,
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
+namespace {
+// Input gradient of a STRIDED convolution onto an image-like input (<= 4 real channels in an 8-channel pixel), gather form (round 6): the
+// first convolutions of the SegFormer encoder (7x7 stride 4, 3 -> 32: segformer/backbone.py PatchEmbed) and of the PatchGAN (4x4 stride 2,
+// 3 -> 64: discriminators.py:53-60).  One thread per input pixel collects the ceil(R / s) x ceil(S / s) taps that reach it:
+//     dx[b][y][x][ci] = sum_{ky = (y + p) mod s, step s} sum_{kx likewise} sum_co dy[b][(y + p - ky) / s][(x + p - kx) / s][co] w[co][ky][kx][ci].
+// Rounds 1-5 ran this as a stride-1 R x S convolution over the zero-dilated dy on the MFMA kernels: s^2 x the useful multiply-adds over an
+// output of 3 channels padded to 8 (7x7 stride 4 at 256^2, batch 32: 180 us for 0.8 G useful multiply-adds).  Weights: fp32 in LDS,
+// [ky][kx][co][4].
+template <typename T>
+__global__ __launch_bounds__(256) void conv_dgrad_gather_kernel(const T* __restrict__ dy, const T* __restrict__ w16, T* __restrict__ dx, int B, int H, int W,
+                                                                int Ho, int Wo, int Cout, int R, int S, int stride, int pad, float alpha) {
+  extern __shared__ float sw[];
+  for (int i = threadIdx.x; i < R * S * Cout; i += 256) {
+    const int rs = i / Cout, co = i % Cout;
+    const T* src = w16 + ((long)co * R * S + rs) * 8;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sw[i * 4 + c] = to_f32(src[c]);
+  }
+  __syncthreads();
+  const long total = (long)B * H * W;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int x = (int)(i % W);
+    const long t = i / W;
+    const int y = (int)(t % H), b = (int)(t / H);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int ky = (y + pad) % stride; ky < R; ky += stride) {
+      const int ny = y + pad - ky;
+      if (ny < 0) break;
+      const int oy = ny / stride;
+      if (oy >= Ho) continue;
+      for (int kx = (x + pad) % stride; kx < S; kx += stride) {
+        const int nx = x + pad - kx;
+        if (nx < 0) break;
+        const int ox = nx / stride;
+        if (ox >= Wo) continue;
+        const uint4* p = reinterpret_cast<const uint4*>(dy + (((long)b * Ho + oy) * Wo + ox) * Cout);
+        const float4* wp = reinterpret_cast<const float4*>(sw) + (ky * S + kx) * Cout;
+        for (int c8 = 0; c8 < Cout / 8; ++c8) {
+          float f[8];
+          unpack8<T>(p[c8], f);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const float4 w4 = wp[c8 * 8 + q];
+            a0 += f[q] * w4.x; a1 += f[q] * w4.y; a2 += f[q] * w4.z; a3 += f[q] * w4.w;
+          }
+        }
+      }
+    }
+    float o[8] = {alpha * a0, alpha * a1, alpha * a2, alpha * a3, 0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<uint4*>(dx + i * 8) = pack8<T>(o);
+  }
+}
+}  // namespace
+// dy [B, Ho, Wo, Cout] 16-bit, w16 [Cout][R][S][8] (the arena's forward copy; input channels 4 .. 7 are padding), dx [B, H, W, 8].
+extern "C" int jg_conv_dgrad_gather(int dtype, const void* dy, const void* w16, void* dx, int B, int H, int W, int Ho, int Wo, int Cout, int R, int S,
+                                    int stride, int pad, float alpha, jg_stream_t s) {
+  if (!dy || !w16 || !dx || B < 1 || H < 1 || W < 1 || Ho < 1 || Wo < 1 || Cout < 8 || (Cout % 8) || R < 1 || S < 1 || stride < 1 || pad < 0) return JG_ERR_BAD_ARG;
+  const size_t lds = (size_t)R * S * Cout * 4 * sizeof(float);
+  if (lds > 64 * 1024) return JG_ERR_UNSUPPORTED;
+  const long total = (long)B * H * W;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((conv_dgrad_gather_kernel<T>), dim3(grid_for(total)), dim3(256), lds, (hipStream_t)s, (const T*)dy, (const T*)w16,
+                                              (T*)dx, B, H, W, Ho, Wo, Cout, R, S, stride, pad, alpha););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
 extern "C" int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s) {
   if (!x || !y || C % 8 || stride < 1 || Ho < (H - 1) * stride + 1 || Wo < (W - 1) * stride + 1) return JG_ERR_BAD_ARG;
   const long total = (long)B * Ho * Wo * (C / 8);

@@ -337,6 +337,7 @@ def dilate2d(x, Ho, Wo, stride):
 # stride-2 transposed convolutions (input gradient of a stride-2 convolution, nn.ConvTranspose2d) in the four-phase form of the halo-resident
 # kernel (jg_transposed_fold + jg_conv2d_nt x_mode 2) instead of a zero-dilated copy + a stride-1 convolution over it; JG_PHASE_TCONV=0: off
 PHASE_TCONV = os.environ.get("JG_PHASE_TCONV", "1") != "0"
+PATCH_DGRAD = os.environ.get("JG_PATCH_DGRAD", "1") != "0"      # round 6: input gradient of kernel == stride convolutions as one GEMM (conv2d_dgrad)
 
 
 def phase_tconv_ok(m: ConvMeta, Hout, Wout, C, N):
@@ -365,6 +366,22 @@ def conv2d_dgrad(dy, m: ConvMeta, x_shape, alpha=1.0):
     if m.stride != 1:
         if H == 2 * Ho and W == 2 * Wo and phase_tconv_ok(m, H, W, Cout, Cin):
             return phase_tconv(dy, m, dx, alpha=alpha)
+        if (PATCH_DGRAD and Cin == 8 and m.Cin_real <= 4 and Cout % 8 == 0 and m.R * m.S * Cout * 16 <= 65536
+                and Ho == (H + 2 * m.pad - m.R) // m.stride + 1 and Wo == (W + 2 * m.pad - m.S) // m.stride + 1):
+            # onto an image (<= 4 real channels): gather form, s^2 x fewer multiply-adds than the dilated convolution and no MFMA padding of 3 -> 8
+            check(_lib.lib().jg_conv_dgrad_gather(_dt(dy), dy.contiguous().data_ptr(), m.w16.data_ptr(), dx.data_ptr(), B, H, W, Ho, Wo, Cout, m.R, m.S,
+                                                  m.stride, m.pad, alpha, _st()), "jg_conv_dgrad_gather")
+            return dx
+        if PATCH_DGRAD and m.stride == m.R == m.S and m.pad == 0 and H == Ho * m.R and W == Wo * m.S:
+            # kernel == stride (the spatial-reduction convolutions of the MiT attention, segformer/backbone.py): the patches do not overlap, the
+            # input gradient of a patch is dy . W -- ONE GEMM with R S Cin output columns per output pixel + a depth-to-space copy.  (The dilated
+            # form below runs an R x S convolution over a tensor of which one tap in R S is non-zero: 64 x the MFMA work at sr_ratio 8.)
+            N = m.R * m.S * Cin
+            wt = m.w16.view(Cout, N).t().contiguous()                          # [(ky, kx, ci)][co]
+            tmp = torch.empty((B, Ho, Wo, N), device=dy.device, dtype=dy.dtype)
+            conv_nt(dy, wt, tmp, B=B, H=Ho, W=Wo, Cin=Cout, Cout=N, R=1, S=1, pad=0, stride=1, Ho=Ho, Wo=Wo, ldx=Cout, ldw=Cout, ldy=N, alpha=alpha)
+            dx.view(B, Ho, m.R, Wo, m.S, Cin).copy_(tmp.view(B, Ho, Wo, m.R, m.S, Cin).permute(0, 1, 3, 2, 4, 5))
+            return dx
         Hd, Wd = H + 2 * m.pad - m.R + 1, W + 2 * m.pad - m.S + 1
         dyd = dilate2d(dy, Hd, Wd, m.stride)
         conv_nt(dyd, m.w16T, dx, B=B, H=Hd, W=Wd, Cin=Cout, Cout=Cin, R=m.R, S=m.S, pad=m.R - 1 - m.pad, stride=1, Ho=H, Wo=W,

@@ -1052,6 +1052,8 @@ STRIDED_CASES = [
     ("conv4 s2 p1", dict(k=4, stride=2, padding=1, transposed=False)),
     ("conv7 p0", dict(k=7, stride=1, padding=0, transposed=False)),
     ("convT3 s2 p1 op1", dict(k=3, stride=2, padding=1, transposed=True)),
+    ("conv4 s4 p0 (sr)", dict(k=4, stride=4, padding=0, transposed=False)),        # kernel == stride: input gradient as one GEMM + depth-to-space
+    ("conv2 s2 p0 (sr)", dict(k=2, stride=2, padding=0, transposed=False)),
 ]
 
 
@@ -1096,6 +1098,59 @@ def test_strided_and_transposed_conv(case, dtype):
     assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype]
     assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype]
     assert relerr(m.c.bias.grad, br.grad) < TOL[dtype]
+
+
+IMAGE_DGRAD_CASES = [
+    ("MiT patch embed 7x7 s4 p3, 3 -> 32", dict(k=7, stride=4, padding=3, Cout=32, H=32, W=48)),
+    ("PatchGAN 4x4 s2 p1, 3 -> 64", dict(k=4, stride=2, padding=1, Cout=64, H=16, W=24)),
+    ("EfficientNet stem 3x3 s2 p1, 3 -> 32", dict(k=3, stride=2, padding=1, Cout=32, H=18, W=14)),
+    ("ragged: 7x7 s4 p3 on 30 x 26", dict(k=7, stride=4, padding=3, Cout=32, H=30, W=26)),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", IMAGE_DGRAD_CASES, ids=[c[0] for c in IMAGE_DGRAD_CASES])
+def test_strided_conv_input_gradient_onto_an_image(case, dtype, monkeypatch):
+    """Round 6 (`jg_conv_dgrad_gather`): grad_input of the strided first convolutions (3 real channels in an 8-channel pixel) in gather form
+    against torch autograd, and against the dilated-convolution form of rounds 1-5 (`JG_PATCH_DGRAD=0`); the padding channels come out zero."""
+    import torch.nn as nn
+
+    from joligen_amd import ops
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.modules.layers import JGConv2d
+
+    _, c = case
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = JGConv2d(3, c["Cout"], c["k"], padding=c["padding"], stride=c["stride"])
+
+    m = M()
+    g = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        m.c.weight.copy_((torch.randn(m.c.weight.shape, generator=g) / math.sqrt(m.c.weight[0].numel())).to(dtype).float())
+    w0 = m.c.weight.detach().clone()
+    arena = ParamArena(m, dev(), dtype, priority=())
+    arena.refresh()
+    x = rnd((2, 3, c["H"], c["W"]), dtype, 83)
+    xr, wr = x.float().requires_grad_(True), w0.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride=c["stride"], padding=c["padding"])
+    R = rnd(tuple(yr.shape), dtype, 84)
+    yr.backward(R.float())
+    x8 = torch.zeros(2, c["H"], c["W"], 8, dtype=dtype)
+    x8[..., :3] = nhwc(x)
+    grads = {}
+    for mode in (True, False):
+        monkeypatch.setattr(ops, "PATCH_DGRAD", mode)
+        xd = x8.to(dev()).requires_grad_(True)
+        y = m.c(xd)
+        y.backward(nhwc(R).to(dev()))
+        torch.cuda.synchronize()
+        grads[mode] = xd.grad.float().cpu()
+    assert relerr(grads[True][..., :3].permute(0, 3, 1, 2), xr.grad) < TOL[dtype]
+    assert float(grads[True][..., 3:].abs().max()) == 0.0
+    assert relerr(grads[True][..., :3], grads[False][..., :3]) < TOL[dtype]
 
 
 PHASE_TCONV_CASES = [
