@@ -482,6 +482,12 @@ int jg_bilinear2_fwd(int dtype, const void* x, void* y, int B, int H, int W, int
 int jg_bilinear2_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, int align_corners, jg_stream_t s);
 int jg_bilinear_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int64_t ldy, jg_stream_t s);
 int jg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, jg_stream_t s);
+/* Round 6: y[B,Ho,Wo,C] = act(x0 + sum_i F.interpolate(x_i, (Ho, Wo), "bilinear", align_corners=False)) for up to three lower-resolution maps
+ * x_i [B,H_i,W_i,C] (NULL = absent); act JG_ACT_NONE / JG_ACT_RELU.  SegformerHead.forward (mmseg decode head used by
+ * models/modules/segformer/segformer_generator.py): `fusion_conv(cat([resize(conv_i(f_i))]))` evaluated as
+ * relu(sum_i resize(W_i conv_i(f_i)) + b) -- the 1x1 fusion convolution and the bilinear resize commute. */
+int jg_resize_sum(int dtype, const void* x0, const void* x1, int H1, int W1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
+                  void* y, int B, int Ho, int Wo, int C, int act, jg_stream_t s);
 int jg_bn_coef(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* ab, float* mr, int B,
                int HW, int C, float eps, float momentum, int training, jg_stream_t s);
 int jg_bn_bwd_coef(const float* red, const float* gamma, const float* mr, float* pqr, float* dgamma, float* dbeta, int B, int HW, int C,

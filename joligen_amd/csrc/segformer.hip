@@ -731,6 +731,51 @@ __global__ void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, 
     *reinterpret_cast<uint4*>(y + (((long)b * Ho + oy) * Wo + ox) * ldy + c8 * 8) = pack8<T>(o8);
   }
 }
+// y = act(x0 + sum_i bilinear(x_i -> Ho x Wo)), up to three resized terms (round 6): the SegFormer head with its fusion convolution applied
+// BEFORE the resize (SegformerHead.forward, modules/segformer.py) sums four 256-channel maps instead of concatenating them
+struct ResizeSumP {
+  const void* x[3];
+  int H[3], W[3];
+  int n;
+};
+template <typename T>
+__global__ void resize_sum_kernel(const T* __restrict__ x0, ResizeSumP rp, T* __restrict__ y, int B, int C, int Ho, int Wo, int act) {
+  const int c8n = C >> 3;
+  const long total = (long)B * Ho * Wo * c8n;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c8 = i % c8n;
+    long p = i / c8n;
+    const int ox = p % Wo;
+    p /= Wo;
+    const int oy = p % Ho, b = p / Ho;
+    float o8[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(x0 + i * 8), o8);
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      if (t >= rp.n) break;
+      const int H = rp.H[t], W = rp.W[t];
+      int y0, y1, x0i, x1i;
+      float wy, wx;
+      bil_coord<false>(oy, H, Ho, y0, y1, wy);
+      bil_coord<false>(ox, W, Wo, x0i, x1i, wx);
+      float a[8], bq[8], c[8], d[8];
+      const T* xb = (const T*)rp.x[t] + (long)b * H * W * C + c8 * 8;
+      unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y0 * W + x0i) * C), a);
+      unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y0 * W + x1i) * C), bq);
+      unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y1 * W + x0i) * C), c);
+      unpack8<T>(*reinterpret_cast<const uint4*>(xb + ((long)y1 * W + x1i) * C), d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o8[j] += (1.f - wy) * ((1.f - wx) * a[j] + wx * bq[j]) + wy * ((1.f - wx) * c[j] + wx * d[j]);
+      }
+    }
+    if (act == JG_ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = fmaxf(o8[j], 0.f);
+    }
+    *reinterpret_cast<uint4*>(y + i * 8) = pack8<T>(o8);
+  }
+}
 // adjoint as a gather: an input pixel collects from the output pixels whose two source rows / columns include it
 template <typename T, bool ALIGN = false>
 __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo, long lddy) {
@@ -1558,6 +1603,27 @@ extern "C" int jg_bilinear2_bwd(int dtype, const void* dy, void* dx, int B, int 
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bilinear_bwd_kernel<T, false>), dim3(grid_for((long)B * H * W * (C / 8))), dim3(256), 0,
                                                 (hipStream_t)s, (const T*)dy, (T*)dx, B, H, W, C, Ho, Wo, (long)lddy););
   }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_resize_sum(int dtype, const void* x0, const void* x1, int H1, int W1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
+                             void* y, int B, int Ho, int Wo, int C, int act, jg_stream_t s) {
+  if (!x0 || !y || B < 1 || Ho < 1 || Wo < 1 || C < 8 || C % 8 || (act != JG_ACT_NONE && act != JG_ACT_RELU)) return JG_ERR_BAD_ARG;
+  ResizeSumP rp;
+  const void* xs[3] = {x1, x2, x3};
+  const int Hs[3] = {H1, H2, H3}, Ws[3] = {W1, W2, W3};
+  rp.n = 0;
+  for (int t = 0; t < 3; ++t) {
+    rp.x[t] = nullptr; rp.H[t] = 1; rp.W[t] = 1;
+  }
+  for (int t = 0; t < 3; ++t) {
+    if (!xs[t]) continue;
+    if (Hs[t] < 1 || Ws[t] < 1) return JG_ERR_BAD_ARG;
+    rp.x[rp.n] = xs[t]; rp.H[rp.n] = Hs[t]; rp.W[rp.n] = Ws[t];
+    ++rp.n;
+  }
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(grid_for((long)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)s, (const T*)x0, rp,
+                                              (T*)y, B, C, Ho, Wo, act););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -226,6 +226,9 @@ class MixVisionTransformer(nn.Module):
         return outs, feats
 
 
+HEAD_COMMUTE = os.environ.get("JG_HEAD_COMMUTE", "1") != "0"     # SegformerHead: fusion convolution before the resize (below)
+
+
 class SegformerHead(nn.Module):
     def __init__(self, rand, in_channels, in_index, channels, dropout_ratio=0.1, num_classes=10, align_corners=False, **unused):
         super().__init__()
@@ -244,7 +247,19 @@ class SegformerHead(nn.Module):
         inputs = [inputs[i] for i in self.in_index]
         Ho, Wo = inputs[0].shape[1:3]
         outs = [ops.activation(self.convs[i].conv(x), JG_ACT_RELU) for i, x in enumerate(inputs)]
-        h = ops.activation(self.fusion_conv.conv(S.resize_concat(outs, Ho, Wo)), JG_ACT_RELU)
+        fm = self.fusion_conv.conv.meta
+        C = outs[0].shape[-1]
+        if (HEAD_COMMUTE and not ops.TORCH_OPS_BOUNDARY and 1 < len(outs) <= 4 and fm is not None and fm.Cin == fm.Cin_real == C * len(outs)
+                and C % 8 == 0 and all(o.shape[-1] == C for o in outs) and tuple(outs[0].shape[1:3]) == (Ho, Wo)):
+            # Round 6: the 1x1 fusion convolution and the bilinear resize are both linear and act on different axes, so
+            #   fusion(cat_i resize(o_i)) = sum_i resize(W_i o_i) + b,   W_i = the i-th block of input channels of the fusion weight:
+            # each term is convolved on its OWN map (64^2, 32^2, 16^2, 8^2 tokens per image instead of four times 64^2) and the four C-channel
+            # results are resized and summed in one pass -- no 4 C-channel concatenation (268 MB per direction at batch 32), a quarter of the
+            # GEMM work.  Same function; the 16-bit rounding points move from the resized maps to the convolved ones.
+            ts = [S.sliced_in_conv(o, fm, i * C, with_bias=(i == 0)) for i, o in enumerate(outs)]
+            h = S.resize_sum(ts[0], ts[1:], JG_ACT_RELU)
+        else:
+            h = ops.activation(self.fusion_conv.conv(S.resize_concat(outs, Ho, Wo)), JG_ACT_RELU)
         if self.dropout is not None and self.training:        # nn.Dropout2d: whole channels, scaled by 1 / (1 - p)
             u = self._rand[0]((h.shape[0], h.shape[-1]), h.device)
             h = S.scale_add(h, (u >= self.dropout_ratio).float() / (1.0 - self.dropout_ratio), None, per_channel=True)

@@ -459,5 +459,101 @@ class _SlicedLinearFn(JGFunction):
         return dx, None, None, None, None, None
 
 
+class _SlicedInConvFn(JGFunction):
+    """y = x W[:, col0 : col0 + k]^T (+ b) for a 1x1 ConvMeta whose weight is [Cout, Cin_total]: one term of a convolution over a channel
+    concatenation, taken on the term's own (smaller) map.  Weight and bias gradients go into the arena rows / columns of the slice."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, meta, col0, with_bias):
+        from .ops import conv_nt
+
+        _require_cuda(x)
+        x = x.contiguous()
+        B, H, W, k = x.shape
+        m = meta
+        y = torch.empty((B, H, W, m.Cout), device=x.device, dtype=x.dtype)
+        conv_nt(x, m.w16, y, B=B, H=H, W=W, Cin=k, Cout=m.Cout, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=k, ldw=m.Cin, ldy=m.Cout,
+                bias=(m.bias_pad if m.bias_pad is not None else m.bias) if with_bias else None, w_off=col0)
+        ctx.save_for_backward(x)
+        ctx.cfg = (m, col0, with_bias)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        from .ops import _wgrad_splitk, conv_nt, wgrad_tn
+
+        (x,) = ctx.saved_tensors
+        m, col0, with_bias = ctx.cfg
+        dy = dy.contiguous()
+        B, H, W, k = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            conv_nt(dy, m.w16T, dx, B=B, H=H, W=W, Cin=m.Cout, Cout=k, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, ldx=m.Cout, ldw=m.Cout, ldy=k,
+                    w_off=col0 * m.Cout)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            wg = m.weight.grad
+            if wg is None:
+                raise RuntimeError("convolution weight has no arena-backed .grad")
+            dbias = m.bias.grad if (with_bias and m.bias is not None and ctx.needs_input_grad[2]) else None
+            tiles = ((m.Cout + 127) // 128) * ((k + 127) // 128)
+            wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=k, Cout=m.Cout, R=1, S=1, pad=0, stride=1, Ho=H, Wo=W, lddy=m.Cout, ldx=k, lddw=m.Cin_real,
+                     dbias=dbias, Cin_out=k, Cout_out=m.Cout_real, splitk=_wgrad_splitk(tiles, B * H * W), dw_off=col0)
+        return dx, None, None, None, None, None
+
+
+def sliced_in_conv(x, meta, col0, with_bias=False):
+    """1x1 convolution of x [B,H,W,k] with input-channel slice [col0, col0 + k) of `meta`'s weight."""
+    if meta.R != 1 or meta.S != 1 or meta.Cin != meta.Cin_real or col0 % 8 or x.shape[-1] % 8:
+        raise ValueError("sliced_in_conv: 1x1 convolution with unpadded input channels, slices on multiples of 8")
+    return _SlicedInConvFn.apply(x, meta.weight, meta.bias, meta, col0, with_bias)
+
+
+class _ResizeSumFn(JGFunction):
+    """act(x0 + sum_i bilinear(x_i -> size of x0)) (jg_resize_sum); backward: act' once, then the bilinear adjoint per resized term."""
+
+    @staticmethod
+    def forward(ctx, act, x0, *xs):
+        _require_cuda(x0, *xs)
+        x0 = x0.contiguous()
+        xs = [x.contiguous() for x in xs]
+        if len(xs) > 3:
+            raise ValueError("resize_sum: at most three resized terms")
+        B, Ho, Wo, C = x0.shape
+        y = torch.empty_like(x0)
+        a = []
+        for i in range(3):
+            a += [xs[i].data_ptr(), xs[i].shape[1], xs[i].shape[2]] if i < len(xs) else [None, 1, 1]
+        check(_lib.lib().jg_resize_sum(_dt(x0), x0.data_ptr(), *a, y.data_ptr(), B, Ho, Wo, C, act, _st()), "jg_resize_sum")
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, [tuple(x.shape) for x in xs])
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        act, shapes = ctx.cfg
+        dy = dy.contiguous()
+        B, Ho, Wo, C = y.shape
+        g = dy
+        if act != JG_ACT_NONE:
+            g = torch.empty_like(y)
+            check(_lib.lib().jg_act_bwd(_dt(y), y.data_ptr(), dy.data_ptr(), g.data_ptr(), y.numel(), act, _st()), "jg_act_bwd")
+        outs = []
+        for i, (_, H, W, _c) in enumerate(shapes):
+            dx = None
+            if ctx.needs_input_grad[2 + i]:
+                dx = torch.empty((B, H, W, C), device=dy.device, dtype=dy.dtype)
+                check(_lib.lib().jg_bilinear_bwd(_dt(g), g.data_ptr(), dx.data_ptr(), B, H, W, C, Ho, Wo, C, _st()), "jg_bilinear_bwd")
+            outs.append(dx)
+        return (None, g if ctx.needs_input_grad[1] else None) + tuple(outs)
+
+
+def resize_sum(x0, xs, act=JG_ACT_NONE):
+    return _ResizeSumFn.apply(act, x0, *xs)
+
+
 def sliced_linear(x, meta, row0, n):
     return _SlicedLinearFn.apply(x, meta.weight, meta.bias, meta, row0, n)

@@ -176,6 +176,76 @@ def test_resize_concat(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [0, 2])
+def test_resize_sum(dtype, act):
+    """round 6 (`jg_resize_sum`): act(x0 + sum_i F.interpolate(x_i)) and its adjoint against torch, 1 .. 3 resized terms, ragged sizes"""
+    from joligen_amd import ops_segformer as S
+    B, Ho, Wo, C = 2, 16, 24, 40
+    for sizes in ([(8, 12)], [(8, 12), (4, 6), (2, 3)], [(5, 7), (16, 24)]):
+        x0 = rnd((B, C, Ho, Wo), dtype, 40)
+        xs = [rnd((B, C, h, w), dtype, 41 + i) for i, (h, w) in enumerate(sizes)]
+        gy = rnd((B, C, Ho, Wo), dtype, 50)
+        r0, rs = x0.float().requires_grad_(True), [x.float().requires_grad_(True) for x in xs]
+        yr = r0 + sum(F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False) for x in rs)
+        yr = torch.relu(yr) if act == 2 else yr
+        yr.backward(gy.float())
+        d0 = x0.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True)
+        ds = [x.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True) for x in xs]
+        y = S.resize_sum(d0, ds, act)
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().to(D0))
+        torch.cuda.synchronize()
+        assert relerr(y.permute(0, 3, 1, 2), yr) < TOL[dtype]
+        for a, b in zip([d0] + ds, [r0] + rs):
+            assert relerr(a.grad.permute(0, 3, 1, 2), b.grad) < TOL[dtype], (sizes, relerr(a.grad.permute(0, 3, 1, 2), b.grad))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_segformer_head_fusion_before_resize(dtype, monkeypatch):
+    """round 6 (`JG_HEAD_COMMUTE`, default on): SegformerHead with its 1x1 fusion convolution applied to every stage's map BEFORE the bilinear
+    resize (sum of four resized C-channel maps) against the reference's structure in fp32 torch -- resize, concatenate, convolve (mmseg
+    SegformerHead.forward as used by segformer_generator.py) -- output, input gradients and the gradients of every weight and bias; and against
+    the concatenating path of rounds 3-5 (`HEAD_COMMUTE = False`)."""
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.modules import segformer as M
+
+    torch.manual_seed(11)
+    in_ch, ch, ncls, B, Ho = [32, 64, 160, 256], 64, 16, 2, 16
+    head = M.SegformerHead(None, in_ch, [0, 1, 2, 3], ch, dropout_ratio=0.0, num_classes=ncls)
+    with torch.no_grad():
+        for p_ in head.parameters():
+            p_.copy_(p_.to(dtype).float())
+    ref = {k: v.detach().clone().requires_grad_(True) for k, v in head.named_parameters()}
+    ParamArena(head, torch.device(D0), dtype, priority=()).refresh()
+    xs = [rnd((B, c, Ho >> i, Ho >> i), dtype, 60 + i) for i, c in enumerate(in_ch)]
+    xr = [x.float().requires_grad_(True) for x in xs]
+    outs = [F.interpolate(torch.relu(F.conv2d(x, ref["convs.%d.conv.weight" % i], ref["convs.%d.conv.bias" % i])), size=(Ho, Ho), mode="bilinear",
+                          align_corners=False) for i, x in enumerate(xr)]
+    hr = torch.relu(F.conv2d(torch.cat(outs, 1), ref["fusion_conv.conv.weight"], ref["fusion_conv.conv.bias"]))
+    yr = F.conv2d(hr, ref["conv_seg.weight"], ref["conv_seg.bias"])
+    gy = rnd(tuple(yr.shape), dtype, 70)
+    yr.backward(gy.float())
+    res = {}
+    for mode in (True, False):
+        monkeypatch.setattr(M, "HEAD_COMMUTE", mode)
+        for p_ in head.parameters():
+            p_.grad.zero_()
+        xd = [x.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True) for x in xs]
+        y = head(xd)
+        y.backward(gy.permute(0, 2, 3, 1).contiguous().to(D0)[..., :y.shape[-1]] if y.shape[-1] == ncls else
+                   F.pad(gy.permute(0, 2, 3, 1), (0, y.shape[-1] - ncls)).contiguous().to(D0))
+        torch.cuda.synchronize()
+        res[mode] = (y[..., :ncls].permute(0, 3, 1, 2).float().cpu(), [x.grad.permute(0, 3, 1, 2).float().cpu() for x in xd],
+                     {k: v.grad.detach().float().cpu().clone() for k, v in head.named_parameters()})
+    for mode in (True, False):
+        y, gx, gp = res[mode]
+        assert relerr(y, yr) < TOL[dtype], (mode, relerr(y, yr))
+        for a, b in zip(gx, xr):
+            assert relerr(a, b.grad) < 2 * TOL[dtype], (mode, relerr(a, b.grad))
+        for k in ref:
+            assert relerr(gp[k], ref[k].grad) < 3 * TOL[dtype], (mode, k, relerr(gp[k], ref[k].grad))      # (bias gradients: sums with cancellation)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("training", [True, False])
 def test_batch_norm_relu(training, dtype):
     from joligen_amd import ops_segformer as S
