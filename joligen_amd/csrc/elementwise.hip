@@ -1100,11 +1100,20 @@ __global__ __launch_bounds__(256) void conv_dgrad_gather_kernel(const T* __restr
     for (int c = 0; c < 4; ++c) sw[i * 4 + c] = to_f32(src[c]);
   }
   __syncthreads();
-  const long total = (long)B * H * W;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int x = (int)(i % W);
-    const long t = i / W;
-    const int y = (int)(t % H), b = (int)(t / H);
+  // phase-major pixel order: the lanes of a wave share (y mod s, x mod s), hence the taps -- the weight reads are LDS broadcasts and the dy reads
+  // of consecutive lanes are consecutive output pixels (x-major order: 4 distinct weight addresses per read, 230 us instead of 70 at 7x7 s4)
+  const int Hs = (H + stride - 1) / stride, Ws = (W + stride - 1) / stride;
+  const long total = (long)B * stride * stride * Hs * Ws;
+  for (long ii = (long)blockIdx.x * 256 + threadIdx.x; ii < total; ii += (long)gridDim.x * 256) {
+    long t = ii;
+    const int X = (int)(t % Ws); t /= Ws;
+    const int Y = (int)(t % Hs); t /= Hs;
+    const int px = (int)(t % stride); t /= stride;
+    const int py = (int)(t % stride);
+    const int b = (int)(t / stride);
+    const int x = X * stride + px, y = Y * stride + py;
+    if (x >= W || y >= H) continue;
+    const long i = ((long)b * H + y) * W + x;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     for (int ky = (y + pad) % stride; ky < R; ky += stride) {
       const int ny = y + pad - ky;

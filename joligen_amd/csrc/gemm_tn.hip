@@ -542,6 +542,7 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
   for (int i = 0; i < n; ++i)
     if (special[i] && !jg_wgrad_halo_try(dtype, ps[i], 1, (hipStream_t)stream)) jg_wgrad_kxk_try(dtype, ps[i], 1, (hipStream_t)stream);
   const int group_blocks = jg_tune(JG_TUNE_WGRAD_GROUP_BLOCKS);
+  const size_t gpad = (size_t)jg_tune(JG_TUNE_WGRAD_LDS_PAD);      // A/B: unused dynamic LDS = one workgroup per CU instead of two
   for (int wavesm = 1; wavesm <= 2; ++wavesm) {
     WgGroup g;
     g.n = 0;
@@ -565,11 +566,11 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
       const dim3 grid(g.start[g.n]);
       const int deep = jg_tune(JG_TUNE_WGRAD_DEEP);      // two register stages of global loads in flight: bit 0 = the 64-row tile, bit 1 = the 128-row tile
       if (wavesm == 1) {
-        if (deep & 1) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
-        else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
+        if (deep & 1) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1, true>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
+        else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
       } else {
-        if (deep & 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2, true>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
-        else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, g);); }
+        if (deep & 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2, true>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
+        else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 2>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
       }
       g.n = 0;
       return JG_OK;

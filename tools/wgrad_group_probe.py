@@ -57,3 +57,27 @@ def grouped():
 for gb in (0, 512, 1024, 2048):
     _lib.set_tuning("JG_WGRAD_GROUP_BLOCKS", gb)
     print("grouped, JG_WGRAD_GROUP_BLOCKS=%d: %.1f us" % (gb, time_fn(grouped)))
+
+# per group of the C side's grouping (problems of one tile class in arrival order, 16 per launch; halo-served 3x3 / 7x7 problems leave singly)
+_lib.set_tuning("JG_WGRAD_GROUP_BLOCKS", 1024)
+special = lambda kw: kw["R"] > 1 and kw["stride"] == 1 and kw["R"] in (3, 7)
+for cls in (1, 2):
+    sel = [o for o in ops_ if not special(o[4]) and (1 if o[4]["Cout"] <= 64 else 2) == cls]
+    for g0 in range(0, len(sel), 16):
+        grp = sel[g0:g0 + 16]
+
+        def run():
+            with ops.deferred_wgrads():
+                for dy, x, dw, db, kw in grp:
+                    ops.wgrad_tn(dy, x, dw, dbias=db, **kw)
+
+        t = time_fn(run)
+        byts = sum(2.0 * (dy.numel() + x.numel()) for dy, x, dw, db, kw in grp)
+        flops = sum(2.0 * kw["B"] * kw["Ho"] * kw["Wo"] * kw["Cout"] * kw["Cin"] * kw["R"] * kw["S"] for dy, x, dw, db, kw in grp)
+        print("class %d group %d: %7.1f us, %6.1f MB operands (%.2f TB/s), %.1f GFLOP (%.0f TFLOP/s)" % (cls, g0 // 16, t, byts / 1e6, byts / t / 1e6, flops / 1e9, flops / t / 1e6))
+        for dy, x, dw, db, kw in grp:
+            print("      B %d H %d Cin %d Cout %d R %d stride %d" % (kw["B"], kw["H"], kw["Cin"], kw["Cout"], kw["R"], kw["stride"]))
+for o in ops_:
+    if special(o[4]):
+        dy, x, dw, db, kw = o
+        print("special: %.1f us  B %d H %d Cin %d Cout %d R %d" % (time_fn(lambda: ops.wgrad_tn(dy, x, dw, dbias=db, **kw)), kw["B"], kw["H"], kw["Cin"], kw["Cout"], kw["R"]))
