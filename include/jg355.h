@@ -353,6 +353,15 @@ int64_t jg_reflect_dgrad_border_ws_floats(int B, int H, int W, int Cin);
 /* window crop (adjoint = 0: y[B,Ho,Wo,C] = x[B,H,W,C][:, top:top+Ho, left:left+Wo]) and its adjoint (1: y[B,H,W,C] = x[B,Ho,Wo,C] placed
  * at (top, left), zeros elsewhere): reflect-padded depth-wise conv of SeparableConv2d (mobile_modules.py:4-40) = pad -> dwconv -> crop */
 int jg_crop2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int top, int left, int Ho, int Wo, int adjoint, jg_stream_t s);
+/* Round 6, row-packed 7x7 head: nn.ReflectionPad2d(3) + nn.Conv2d(64, 3, 7) (+ nn.Tanh), the last layer of the CUT generators
+ * (resnet_generator.py:247-263, segformer_generator.py:135-140), as a 1 x 7 convolution onto 7 x 4 packed channels (jg_conv2d_nt, R = 1, S = 7:
+ * z[B][H+6][W][32], column ky * 4 + c = tap row ky of output channel c) followed by the sum over the tap rows:
+ *   jg_tapsum7:    out[b][y][x][c] = act(bias[c] + sum_ky z[b][y + ky][x][ky * 4 + c]),  out [B][H][W][8], act JG_ACT_NONE / JG_ACT_TANH
+ *   jg_tapspread7: its adjoint -- dz[b][y'][x][ky * 4 + c] = dout[b][y' - ky][x][c] * act'(out), written as dz [B][Hz][W][32] (Hz >= H + 6, a
+ *                  multiple of 8: operand of jg_conv2d_wgrad_tn with R = 1, S = 7) and as dzm [B][H+6][W+12][32] with six zero columns on
+ *                  either side (operand of the 1 x 7 input-gradient convolution, pad 0). */
+int jg_tapsum7(int dtype, const void* z, const float* bias, void* out, int B, int H, int W, int act, jg_stream_t s);
+int jg_tapspread7(int dtype, const void* dout, const void* out, void* dz, void* dzm, int B, int H, int W, int Hz, int act, jg_stream_t s);
 int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s);
 /* Round 6: autograd's grad_input of a STRIDED nn.Conv2d whose input is an image (<= 4 real channels in an 8-channel NHWC pixel) -- the first
  * convolution of the MiT encoder (segformer/backbone.py PatchEmbed: 7x7 stride 4) and of NLayerDiscriminator (discriminators.py:53-60: 4x4

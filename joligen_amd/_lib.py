@@ -112,6 +112,8 @@ SIGNATURES = {
     "jg_reflect_dgrad_border": [c_i32, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_reflect_dgrad_border_ws_floats": [c_i32, c_i32, c_i32, c_i32],
     "jg_dilate2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_tapsum7": [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_tapspread7": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_conv_dgrad_gather": [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_subsample2d": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_channel_sum": [c_i32, c_p, c_i64, c_p, c_i64, c_i32, c_f32, c_p],

@@ -25,16 +25,18 @@ template <int NCH> __device__ __forceinline__ int kx_swz(int row) { return NCH =
 
 // WBUF 2: the next tap row's weights are written into the other LDS buffer while this one is read; WBUF 1: one buffer (two barriers per tap row) --
 // for the configurations that fit TWO workgroups per CU that way, where the other workgroup's MFMAs cover the exposed weight staging
-template <typename T, int KS, int CK, int BN, int WBUF>
-__global__ __launch_bounds__(256, ((TS + KS - 1) * (TS + KS) * (CK / 8) + WBUF * KS * BN * (CK / 8)) * 16 * 2 <= 163840 ? 2 : 1) void conv_kxk_halo_kernel(ConvP p, int tw, int th) {
+// KR (round 6): tap ROWS; KR = 1 with KS = 7 is the 1 x 7 convolution of the row-packed few-channel heads (ops.py head7x7): one weight stage per
+// channel chunk; launched with pad 0 only (the callers hand over tensors that carry their margins)
+template <typename T, int KS, int CK, int BN, int WBUF, int KR = KS>
+__global__ __launch_bounds__(256, ((TS + KR - 1) * (TS + KS) * (CK / 8) + WBUF * KS * BN * (CK / 8)) * 16 * 2 <= 163840 ? 2 : 1) void conv_kxk_halo_kernel(ConvP p, int tw, int th) {
   constexpr int NCH = CK / 8;                       // 16-byte chunks per pixel of a channel chunk
-  constexpr int HR = TS + KS - 1, HP = HR + 1;      // halo rows / cols; row pitch in pixels (odd)
+  constexpr int HR = TS + KR - 1, HC = TS + KS - 1, HP = HC + 1;      // halo rows, cols; row pitch in pixels (odd)
   static_assert((HP & 1) == 1 && (NCH == 8 || NCH == 4), "layout");
   constexpr int HALO16 = HR * HP * NCH;             // halo image in 16-byte chunks
   constexpr int WROW16 = KS * BN * NCH;             // one tap row of weights
   constexpr int NT = BN / 16, KSTEPS = CK / 32;
   constexpr int NCOLF = 4 + KS - 1;                 // column fragments per wave and tap row
-  constexpr int HLOADS = (HR * HR * NCH + 255) / 256, WLOADS = (WROW16 + 255) / 256;
+  constexpr int HLOADS = (HR * HC * NCH + 255) / 256, WLOADS = (WROW16 + 255) / 256;
   static_assert((HALO16 + WBUF * WROW16) * 16 <= 163840 && TS * TS * BN * 2 <= (HALO16 + WBUF * WROW16) * 16, "LDS");
   __shared__ uint4 sm[HALO16 + WBUF * WROW16];
   uint4* sH = sm;
@@ -63,17 +65,17 @@ __global__ __launch_bounds__(256, ((TS + KS - 1) * (TS + KS) * (CK / 8) + WBUF *
       for (int i = 0; i < HLOADS; ++i) {
         const int pos = i * 256 + tid;
         const int px = pos / NCH, c = pos % NCH;
-        const int hy = px / HR, hx = px % HR;
+        const int hy = px / HC, hx = px % HC;
         const int ih = oh0 + hy - p.pad, iw = ow0 + hx - p.pad;
-        const bool ok = pos < HR * HR * NCH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        const bool ok = pos < HR * HC * NCH && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         hv[i] = ldg16(xb + (ok ? ((long)ih * p.W + iw) * p.ldx + ci0 + c * 8 : 0), ok);
       }
 #pragma unroll
       for (int i = 0; i < HLOADS; ++i) {
         const int pos = i * 256 + tid;
-        if (pos < HR * HR * NCH) {
+        if (pos < HR * HC * NCH) {
           const int px = pos / NCH, c = pos % NCH;
-          const int hy = px / HR, hx = px % HR;
+          const int hy = px / HC, hx = px % HC;
           sH[(hy * HP + hx) * NCH + (c ^ kx_swz<NCH>(hy))] = hv[i];
         }
       }
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(256, ((TS + KS - 1) * (TS + KS) * (CK / 8) + WBUF *
     wstore(0);
     __syncthreads();
 
-    for (int r = 0; r < KS; ++r) {
-      const bool more = r + 1 < KS;
+    for (int r = 0; r < KR; ++r) {
+      const bool more = r + 1 < KR;
       if (more) wload(r + 1);
       // column fragments of halo rows r .. r + 15: lane (pixel row l15, channel group g)
       uint4 fa[NCOLF][KSTEPS];
@@ -166,6 +168,13 @@ template <typename T>
 bool launch_kxk(const ConvP& p, hipStream_t st) {
   const int tw = (p.Wo + TS - 1) / TS, th = (p.Ho + TS - 1) / TS;
   const dim3 grid((unsigned)(p.B * tw * th));
+  if (p.R == 1) {      // 1 x 7 stages of the row-packed heads: forward (64 -> 28 (32) packed channels), input gradient (28 (32) packed -> 64)
+    if (p.N <= 32 && p.Cin % 32 == 0 && jg_tune(JG_TUNE_CONV_KXK) != 2) hipLaunchKernelGGL((conv_kxk_halo_kernel<T, 7, 32, 32, 1, 1>), grid, dim3(256), 0, st, p, tw, th);
+    else if (p.N <= 32 && p.Cin % 64 == 0) hipLaunchKernelGGL((conv_kxk_halo_kernel<T, 7, 64, 32, 1, 1>), grid, dim3(256), 0, st, p, tw, th);
+    else if (p.N <= 64 && p.Cin % 32 == 0) hipLaunchKernelGGL((conv_kxk_halo_kernel<T, 7, 32, 64, 1, 1>), grid, dim3(256), 0, st, p, tw, th);
+    else return false;
+    return true;
+  }
   if (p.R == 3) {      // 3x3 with at most 32 output channels (the UNet's 64 -> 3 (8) output convolution at 256 x 256): 68 KB, two workgroups per CU
     if (p.N > 32 || p.Cin % 64) return false;
     hipLaunchKernelGGL((conv_kxk_halo_kernel<T, 3, 64, 32, 2>), grid, dim3(256), 0, st, p, tw, th);
@@ -190,7 +199,8 @@ bool launch_kxk(const ConvP& p, hipStream_t st) {
 
 bool jg_conv_kxk_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   if (!jg_tune(JG_TUNE_CONV_KXK)) return false;
-  if (nbatch != 1 || (p.R != 7 && p.R != 3) || p.S != p.R || p.stride != 1 || p.out_f32 || p.res || p.stats || p.reflect || p.x_up || p.y_pool || p.res_up) return false;
+  const bool row1 = p.R == 1 && p.S == 7 && p.pad == 0;
+  if (nbatch != 1 || (!row1 && ((p.R != 7 && p.R != 3) || p.S != p.R)) || p.stride != 1 || p.out_f32 || p.res || p.stats || p.reflect || p.x_up || p.y_pool || p.res_up) return false;
   if (p.N > 64 || (p.N & 7) || (p.Cin & 31) || (p.ldy & 7) || (p.ldx & 7) || (p.ldw & 7)) return false;
   if ((long)p.B * p.Ho * p.Wo < 16384) return false;          // tiny launches: the generic kernel's split-K forms serve them
   if (p.R == 3 && (p.N > 32 || (long)p.B * p.Ho * p.Wo < 262144)) return false;   // 3x3: only the few-channel layers the 64-wide halo kernels do not serve
@@ -198,6 +208,6 @@ bool jg_conv_kxk_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   bool ok = false;
   if (dtype == JG_F16) ok = launch_kxk<f16_t>(p, st);
   else if (dtype == JG_BF16) ok = launch_kxk<bf16_t>(p, st);
-  if (ok) jg_note_kernel(p.R == 3 ? "conv_kxk_halo_kernel<3x3>" : "conv_kxk_halo_kernel<7x7>");
+  if (ok) jg_note_kernel(p.R == 3 ? "conv_kxk_halo_kernel<3x3>" : p.R == 1 ? "conv_kxk_halo_kernel<1x7>" : "conv_kxk_halo_kernel<7x7>");
   return ok;
 }

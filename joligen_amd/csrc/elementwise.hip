@@ -1155,6 +1155,150 @@ extern "C" int jg_conv_dgrad_gather(int dtype, const void* dy, const void* w16, 
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
+namespace {
+// ---- row-packed 7x7 head with <= 4 output channels (round 6; ops.py head_conv7) ------------------------------------------------------------
+// A 7x7 convolution onto 3 image channels (ReflectionPad2d(3) + Conv2d(64, 3, 7) + Tanh, the last layer of every CUT generator:
+// resnet_generator.py:247-263, segformer_generator.py:135-140) pads its 3 output channels to an MFMA tile of 32: 10.7 x the useful work.
+// Packed: the 7 tap ROWS become output channels of a 1 x 7 convolution, Z[y'][x][ky * 4 + c] = sum_{kx, ci} xpad[y'][x + kx][ci] w[c][ky][kx][ci]
+// (28 of 32 columns live, 7 x fewer multiply-adds), and the rows are summed here: out[y][x][c] = act(b[c] + sum_ky Z[y + ky][x][ky * 4 + c]).
+// One thread walks a strip of RY output rows of one column: every z pixel (64 bytes, consecutive lanes = consecutive pixels) is read ONCE and
+// feeds the seven output rows it belongs to, held in a ring of accumulators whose slots are compile-time constants (rows in chunks of seven).
+// (A first version read z[y + ky][x][ky * 4 ..] per output pixel: seven 8-byte reads at a 64-byte lane stride, 7 x the L2 -> L1 traffic, 160 us.)
+template <typename T>
+__global__ __launch_bounds__(256) void tapsum7_kernel(const T* __restrict__ z, const float* __restrict__ bias, T* __restrict__ out, int B, int H, int W, int act) {
+  constexpr int RY = 32;
+  const int nstrip = (H + RY - 1) / RY;
+  const long total = (long)B * nstrip * W;
+  float bv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) bv[c] = bias ? bias[c] : 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W);
+    const long t = i / W;
+    const int st = (int)(t % nstrip), b = (int)(t / nstrip);
+    const int y0 = st * RY, ny = min(H, y0 + RY) - y0;      // output rows y0 .. y0 + ny - 1 <- z rows y0 .. y0 + ny + 5
+    float acc[7][4];
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[k][c] = bv[c];
+    const T* zp = z + (((long)b * (H + 6) + y0) * W + x) * 32;
+    T* op = out + (((long)b * H + y0) * W + x) * 8;
+    for (int base = 0; base < ny + 6; base += 7) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int r = base + j;                               // z row (relative to y0); slot of output row r - ky = (j - ky) mod 7
+        if (r < ny + 6) {
+          const uint4* q = reinterpret_cast<const uint4*>(zp + (long)r * W * 32);
+          const uint4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+          const uint2 taps[7] = {make_uint2(v0.x, v0.y), make_uint2(v0.z, v0.w), make_uint2(v1.x, v1.y), make_uint2(v1.z, v1.w),
+                                 make_uint2(v2.x, v2.y), make_uint2(v2.z, v2.w), make_uint2(v3.x, v3.y)};
+#pragma unroll
+          for (int ky = 0; ky < 7; ++ky) {
+            const int yo = r - ky;
+            if (yo >= 0 && yo < ny) {
+              float f[4];
+              unpack4<T>(taps[ky], f);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[(j - ky + 7) % 7][c] += f[c];
+            }
+          }
+          const int yd = r - 6;                               // this output row has all seven terms
+          if (yd >= 0 && yd < ny) {
+            float o[8] = {acc[(j + 1) % 7][0], acc[(j + 1) % 7][1], acc[(j + 1) % 7][2], acc[(j + 1) % 7][3], 0.f, 0.f, 0.f, 0.f};
+            if (act == JG_ACT_TANH) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) o[c] = tanhf(o[c]);
+            }
+            *reinterpret_cast<uint4*>(op + (long)yd * W * 8) = pack8<T>(o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[(j + 1) % 7][c] = bv[c];
+          }
+        }
+      }
+    }
+  }
+}
+// adjoint: dpre = dout * act'(out); dZ[y'][x][ky * 4 + c] = dpre[y' - ky][x][c] (zero outside), written twice: dz [B][Hz][W][32] (rows >= H + 6
+// zero; the weight-gradient kernel's operand, Hz a multiple of its 8-row tile) and dzm [B][H + 6][W + 12][32] with six zero columns on either
+// side (the 1 x 7 input-gradient convolution runs over it without padding).  Same walk: a thread owns a column and a strip of RY z rows, reads
+// every (dout, out) pixel once into a ring of seven and writes one 64-byte z pixel per row to each destination.
+template <typename T>
+__global__ __launch_bounds__(256) void tapspread7_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ dz, T* __restrict__ dzm, int B, int H,
+                                                         int W, int Hz, int act) {
+  constexpr int RY = 8;       // short strips: the launch is a store stream (128 bytes per row and thread), it needs the threads
+  const int Wm = W + 12, nstrip = (Hz + RY - 1) / RY;
+  const long total = (long)B * nstrip * Wm;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xm = (int)(i % Wm);
+    const long t = i / Wm;
+    const int st = (int)(t % nstrip), b = (int)(t / nstrip);
+    const int s0 = st * RY, nz = min(Hz, s0 + RY) - s0;     // z rows s0 .. s0 + nz - 1 <- dpre rows s0 - 6 .. s0 + nz - 1
+    const int x = xm - 6;
+    const bool xin = x >= 0 && x < W;
+    uint2 ring[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) ring[k] = make_uint2(0u, 0u);
+    for (int base = 0; base < nz + 6; base += 7) {
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        const int r = base + j;
+        if (r < nz + 6) {
+          const int yy = s0 - 6 + r;                         // dpre row loaded into slot j; z row yy is complete with it
+          uint2 pv = make_uint2(0u, 0u);
+          if (xin && yy >= 0 && yy < H) {
+            const long o = (((long)b * H + yy) * W + x) * 8;
+            float d[4];
+            unpack4<T>(*reinterpret_cast<const uint2*>(dout + o), d);
+            if (act == JG_ACT_TANH) {
+              float v[4];
+              unpack4<T>(*reinterpret_cast<const uint2*>(out + o), v);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) d[c] *= 1.f - v[c] * v[c];
+            }
+            pv.x = (uint32_t)to_bits<T>(from_f32<T>(d[0])) | ((uint32_t)to_bits<T>(from_f32<T>(d[1])) << 16);
+            pv.y = (uint32_t)to_bits<T>(from_f32<T>(d[2])) | ((uint32_t)to_bits<T>(from_f32<T>(d[3])) << 16);
+          }
+          ring[j] = pv;
+          if (r >= 6) {
+            // z pixel of row yy: column ky * 4 + c = dpre[yy - ky][c] = ring slot (j - ky) mod 7
+            const uint4 q0 = make_uint4(ring[j].x, ring[j].y, ring[(j + 6) % 7].x, ring[(j + 6) % 7].y);
+            const uint4 q1 = make_uint4(ring[(j + 5) % 7].x, ring[(j + 5) % 7].y, ring[(j + 4) % 7].x, ring[(j + 4) % 7].y);
+            const uint4 q2 = make_uint4(ring[(j + 3) % 7].x, ring[(j + 3) % 7].y, ring[(j + 2) % 7].x, ring[(j + 2) % 7].y);
+            const uint4 q3 = make_uint4(ring[(j + 1) % 7].x, ring[(j + 1) % 7].y, 0u, 0u);
+            if (yy < H + 6) {
+              uint4* pm = reinterpret_cast<uint4*>(dzm + (((long)b * (H + 6) + yy) * Wm + xm) * 32);
+              pm[0] = q0; pm[1] = q1; pm[2] = q2; pm[3] = q3;
+            }
+            if (xin) {
+              uint4* pz = reinterpret_cast<uint4*>(dz + (((long)b * Hz + yy) * W + x) * 32);
+              pz[0] = q0; pz[1] = q1; pz[2] = q2; pz[3] = q3;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+}  // namespace
+// z [B][H + 6][W][32] (column ky * 4 + c = tap row ky of output channel c), bias fp32 [>= 4] or NULL, out [B][H][W][8] (channels 4 .. 7 zero);
+// act JG_ACT_NONE / JG_ACT_TANH
+extern "C" int jg_tapsum7(int dtype, const void* z, const float* bias, void* out, int B, int H, int W, int act, jg_stream_t s) {
+  if (!z || !out || B < 1 || H < 1 || W < 1 || (act != JG_ACT_NONE && act != JG_ACT_TANH)) return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tapsum7_kernel<T>), dim3(grid_for((long)B * ((H + 31) / 32) * W)), dim3(256), 0, (hipStream_t)s, (const T*)z, bias, (T*)out, B, H,
+                                              W, act););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+// dout, out [B][H][W][8]; dz [B][Hz][W][32], dzm [B][H + 6][W + 12][32], both fully written; Hz >= H + 6
+extern "C" int jg_tapspread7(int dtype, const void* dout, const void* out, void* dz, void* dzm, int B, int H, int W, int Hz, int act, jg_stream_t s) {
+  if (!dout || !dz || !dzm || B < 1 || H < 1 || W < 1 || Hz < H + 6 || (act != JG_ACT_NONE && act != JG_ACT_TANH) || (act == JG_ACT_TANH && !out))
+    return JG_ERR_BAD_ARG;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((tapspread7_kernel<T>), dim3(grid_for((long)B * ((Hz + 7) / 8) * (W + 12))), dim3(256), 0, (hipStream_t)s, (const T*)dout,
+                                              (const T*)out, (T*)dz, (T*)dzm, B, H, W, Hz, act););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
 extern "C" int jg_dilate2d(int dtype, const void* x, void* y, int B, int H, int W, int C, int Ho, int Wo, int stride, jg_stream_t s) {
   if (!x || !y || C % 8 || stride < 1 || Ho < (H - 1) * stride + 1 || Wo < (W - 1) * stride + 1) return JG_ERR_BAD_ARG;
   const long total = (long)B * Ho * Wo * (C / 8);

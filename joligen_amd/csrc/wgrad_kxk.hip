@@ -216,7 +216,8 @@ void pick_split(int nwork, int ntiles, int ovh, int slots, int* per_out, int* sp
 template <typename T, int KS, int RT>
 void launch_kxk(const WgP& p, hipStream_t st) {
   constexpr int TH = 8, CPW = 2, BCO = 32;
-  const int ncot = (p.Cout + BCO - 1) / BCO, npairs = ncot * (p.Cin / 64), ngroups = (KS + RT - 1) / RT;
+  // (p.R == 1: the 1 x KS convolution of the row-packed heads -- one tap row, one group)
+  const int ncot = (p.Cout + BCO - 1) / BCO, npairs = ncot * (p.Cin / 64), ngroups = p.R == 1 ? 1 : (KS + RT - 1) / RT;
   const int ntiles = p.B * (p.Ho / TH) * (p.Wo >> 4);
   int per, splitk;
   pick_split(npairs * ngroups, ntiles, 12, 512, &per, &splitk);
@@ -226,11 +227,20 @@ void launch_kxk(const WgP& p, hipStream_t st) {
 }  // namespace
 
 bool jg_wgrad_kxk_try(int dtype, const WgP& p, int nbatch, hipStream_t st, bool dry_run) {
-  if (nbatch != 1 || p.R != 7 || p.S != 7 || p.stride != 1 || p.out_mode != JG_OUT_ATOMIC_F32 || p.reflect || p.x_up) return false;
-  if (p.Cin % 64 || p.Cout % 8 || (p.Ho & 7) || (p.Wo & 15) || p.Ho != p.H + 2 * p.pad - 6 || p.Wo != p.W + 2 * p.pad - 6) return false;
+  // 1 x 7 (round 6, the row-packed heads): pad 0; dy may carry zero rows below the image (Ho >= H: its row count is a multiple of the 8-row tile)
+  const bool row1 = p.R == 1 && p.S == 7 && p.pad == 0 && p.Ho >= p.H;
+  if (nbatch != 1 || (!row1 && (p.R != 7 || p.S != 7)) || p.stride != 1 || p.out_mode != JG_OUT_ATOMIC_F32 || p.reflect || p.x_up) return false;
+  if (p.Cin % 64 || p.Cout % 8 || (p.Ho & 7) || (p.Wo & 15) || (!row1 && p.Ho != p.H + 2 * p.pad - 6) || p.Wo != p.W + 2 * p.pad - 6) return false;
   if ((long)p.B * p.Ho * p.Wo < 65536) return false;        // small maps: the generic kernel's split over pixels fills the chip better
   if ((long)p.B * p.H * p.W * p.ldx >= (1L << 31) || (long)p.B * p.Ho * p.Wo * p.lddy >= (1L << 31)) return false;
   if (dry_run) return dtype == JG_F16 || dtype == JG_BF16;
+  if (row1) {
+    if (dtype == JG_F16) launch_kxk<f16_t, 7, 1>(p, st);
+    else if (dtype == JG_BF16) launch_kxk<bf16_t, 7, 1>(p, st);
+    else return false;
+    jg_note_kernel("wgrad_kxk_halo_kernel<1x7>");
+    return true;
+  }
   if (dtype == JG_F16) launch_kxk<f16_t, 7, 2>(p, st);
   else if (dtype == JG_BF16) launch_kxk<bf16_t, 7, 2>(p, st);
   else return false;

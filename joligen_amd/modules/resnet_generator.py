@@ -41,6 +41,10 @@ def _run(seq, x, taps=None, feats=None, upto=None):
                 i += 1
             else:
                 x = ops.reflect_pad2d(x, m.padding[0])
+        elif (isinstance(m, JGConv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.Tanh) and not (taps and (i in taps or i + 1 in taps))
+              and (upto is None or i + 1 <= upto) and ops.head7_ok(x, m.meta)):
+            x = ops.head_conv7(x, m.meta, JG_ACT_TANH)      # 7x7 onto <= 4 channels + Tanh, row-packed (round 6)
+            i += 1
         elif isinstance(m, (JGConv2d, JGConvTranspose2d, ResnetBlock)):
             x = m(x)
         elif isinstance(m, nn.InstanceNorm2d):

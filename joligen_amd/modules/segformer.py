@@ -296,8 +296,10 @@ class ResnetDecoderBN(nn.Module):
         m = self.model
         x = S.batch_norm(m[0](x), m[1], JG_ACT_RELU)
         x = S.batch_norm(m[3](x), m[4], JG_ACT_RELU)
-        x = m[7](ops.reflect_pad2d(x, 3))
-        return ops.activation(x, JG_ACT_TANH)
+        x = ops.reflect_pad2d(x, 3)
+        if ops.head7_ok(x, m[7].meta):
+            return ops.head_conv7(x, m[7].meta, JG_ACT_TANH)      # 7x7 onto 3 channels + Tanh, row-packed (round 6)
+        return ops.activation(m[7](x), JG_ACT_TANH)
 
 
 class SegformerGenerator_attn(nn.Module):

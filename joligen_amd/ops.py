@@ -174,7 +174,7 @@ def conv_nt(x, w, y, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, ldx, ldw,
 
 def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, ldx, lddw, dbias=None, Cin_out=0,
              Cout_out=0, splitk=1, nbatch=1, nh=1, sdy=(0, 0), sx=(0, 0), sdw=(0, 0), alpha=1.0,
-             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0, dbias_scale=0.0, pad_mode=0, x_mode=0):
+             out_mode=JG_OUT_ATOMIC_F32, dy_off=0, x_off=0, dw_off=0, dbias_scale=0.0, pad_mode=0, x_mode=0, defer=True):
     a = WgradArgs()
     a.dy = dy.data_ptr() + dy_off * 2
     a.x = x.data_ptr() + x_off * 2
@@ -192,7 +192,7 @@ def wgrad_tn(dy, x, dw, *, B, H, W, Cin, Cout, R, S, pad, stride, Ho, Wo, lddy, 
     a.x_mode = x_mode
     # never under the torch.ops boundary: jg355::conv2d_wgrad hands a TEMPORARY dw / dbias back to autograd, which accumulates it into .grad at
     # once -- a launch deferred to the flush would write into a tensor nobody reads any more (silently zero gradients)
-    if (WGRAD_DEFER is not None and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32 and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None
+    if (defer and WGRAD_DEFER is not None and nbatch == 1 and out_mode == JG_OUT_ATOMIC_F32 and pad_mode == 0 and x_mode == 0 and KERNEL_TIMING is None
             and not TORCH_OPS_BOUNDARY and not _IN_OP):
         WGRAD_DEFER.append((_dt(dy), a, (dy, x, dw, dbias)))       # launched with its peers by flush_deferred_wgrads(); operands kept alive
         if _WGRAD_SIDE is not None and len(WGRAD_DEFER) >= _WGRAD_SIDE[1]:
@@ -405,6 +405,92 @@ def conv2d_wgrad(dy, x, m: ConvMeta, alpha=1.0, want_w=True, want_b=True):
     wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
              lddy=Cout, ldx=Cin, lddw=m.R * m.S * m.Cin_real, dbias=dbias, Cin_out=m.Cin_real, Cout_out=m.Cout_real,
              splitk=splitk, alpha=alpha)
+
+
+# ---- row-packed 7x7 head (round 6) -----------------------------------------------------------------------------------------------------------
+HEAD7_PACKED = os.environ.get("JG_HEAD7_PACKED", "1") != "0"
+_HEAD7_BUFS = {}      # per convolution (keyed by its 16-bit weight copy): the packed weight buffers of _Head7x7Fn
+
+
+def head7_ok(x_pad, m: ConvMeta):
+    """shapes the row-packed form serves: 7x7, stride 1, no padding of its own (the caller has reflect-padded), 64 k input channels, <= 4 real
+    output channels, a map the halo-resident kernels tile (W a multiple of 16)"""
+    if not HEAD7_PACKED or TORCH_OPS_BOUNDARY or KERNEL_TIMING is not None or not x_pad.is_cuda:
+        return False
+    B, Hp, Wp, Cin = x_pad.shape
+    return (m.R == 7 and m.S == 7 and m.stride == 1 and m.pad == 0 and Cin == m.Cin and Cin % 64 == 0 and m.Cout_real <= 4 and (Wp - 6) % 16 == 0
+            and Hp > 6 and B * (Hp - 6) * (Wp - 6) >= 65536 and x_pad.dtype in (torch.float16, torch.bfloat16))
+
+
+class _Head7x7Fn(JGFunction):
+    """act(conv7x7(x_pad) + b) for <= 4 output channels, row-packed (csrc/elementwise.hip tapsum7): a 1 x 7 convolution onto 7 x 4 packed
+    channels on the halo-resident kernel, then the sum over the tap rows -- 7 x fewer multiply-adds than the 7x7 convolution whose 3 output
+    channels are padded to an MFMA tile of 32; the backward is the same two steps transposed."""
+
+    @staticmethod
+    def forward(ctx, x_pad, weight, bias, meta, act):
+        m = meta
+        x_pad = x_pad.contiguous()
+        B, Hp, Wp, Cin = x_pad.shape
+        H, W = Hp - 6, Wp - 6
+        dev, dt = x_pad.device, x_pad.dtype
+        # packed weight copies, rebuilt from the arena's 16-bit copy on every forward (two small launches; the buffers persist with the module so
+        # that a captured graph replays into the same addresses): wz [32 = (ky, c)][1][7][Cin] for the forward stage and the weight
+        # gradient's layout, wzT [Cin][1][7 flipped][32] for the input-gradient stage
+        key = (m.w16.data_ptr(), dt, Cin)
+        bufs = _HEAD7_BUFS.get(key)
+        if bufs is None:
+            bufs = _HEAD7_BUFS[key] = (torch.zeros((8, 4, 7, Cin), device=dev, dtype=dt), torch.zeros((Cin, 7, 8, 4), device=dev, dtype=dt))
+        wz, wzT = bufs
+        wz[:7].copy_(m.w16[:4].permute(1, 0, 2, 3))
+        wzT[:, :, :7].copy_(m.w16[:4].permute(3, 2, 1, 0).flip(1))              # [ci][6 - kx][ky][c]
+        z = torch.empty((B, Hp, W, 32), device=dev, dtype=dt)
+        conv_nt(x_pad, wz, z, B=B, H=Hp, W=Wp, Cin=Cin, Cout=32, R=1, S=7, pad=0, stride=1, Ho=Hp, Wo=W, ldx=Cin, ldw=7 * Cin, ldy=32)
+        out = torch.empty((B, H, W, 8), device=dev, dtype=dt)
+        b4 = m.bias_pad                                                        # fp32, padded to the 8-channel pixel (None: no bias)
+        if b4 is None and m.bias is not None:
+            b4 = torch.zeros(4, device=dev, dtype=torch.float32)
+            b4[:m.Cout_real].copy_(m.bias.detach()[:m.Cout_real])
+        check(_lib.lib().jg_tapsum7(_dt(x_pad), z.data_ptr(), _p(b4), out.data_ptr(), B, H, W, act, _st()), "jg_tapsum7")
+        ctx.save_for_backward(x_pad, out, wzT)
+        ctx.cfg = (m, act)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        x_pad, out, wzT = ctx.saved_tensors
+        m, act = ctx.cfg
+        dout = dout.contiguous()
+        B, Hp, Wp, Cin = x_pad.shape
+        H, W = Hp - 6, Wp - 6
+        dev, dt = x_pad.device, x_pad.dtype
+        Hz = (Hp + 7) // 8 * 8
+        dz = torch.empty((B, Hz, W, 32), device=dev, dtype=dt)
+        dzm = torch.empty((B, Hp, W + 12, 32), device=dev, dtype=dt)
+        check(_lib.lib().jg_tapspread7(_dt(dout), dout.data_ptr(), out.data_ptr(), dz.data_ptr(), dzm.data_ptr(), B, H, W, Hz, act, _st()), "jg_tapspread7")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x_pad)
+            conv_nt(dzm, wzT, dx, B=B, H=Hp, W=W + 12, Cin=32, Cout=Cin, R=1, S=7, pad=0, stride=1, Ho=Hp, Wo=Wp, ldx=32, ldw=7 * 32, ldy=Cin)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            wg = m.weight.grad
+            if wg is None:
+                raise RuntimeError("conv weight has no arena-backed .grad (module not finalised by ParamArena)")
+            acc = torch.zeros(32 * 7 * Cin + 32, device=dev, dtype=torch.float32)          # packed weight gradient + bias sums, one clear
+            dwz, db = acc[:32 * 7 * Cin].view(8, 4, 7, Cin), acc[32 * 7 * Cin:]
+            wgrad_tn(dz, x_pad, dwz, B=B, H=Hp, W=Wp, Cin=Cin, Cout=32, R=1, S=7, pad=0, stride=1, Ho=Hz, Wo=W, lddy=32, ldx=Cin, lddw=7 * Cin, dbias=db,
+                     Cin_out=Cin, Cout_out=32, splitk=1, defer=False)
+            cr = m.Cout_real
+            wg.permute(0, 2, 3, 1)[:cr].add_(dwz[:7, :cr].permute(1, 0, 2, 3)[..., :m.Cin_real])      # physical [Cout][R][S][Cin]
+            if m.bias is not None and ctx.needs_input_grad[2]:
+                m.bias.grad[:cr].add_(db[:cr])
+        return dx, None, None, None, None
+
+
+def head_conv7(x_pad, m: ConvMeta, act=0):
+    """ReflectionPad2d(3)'s output -> act(Conv2d(Cin, <= 4, 7)(x_pad)) [B, H, W, 8]; callers check head7_ok first"""
+    return _Head7x7Fn.apply(x_pad, m.weight, m.bias, m, act)
 
 
 class _Conv2dFn(JGFunction):

