@@ -200,8 +200,8 @@ class CUTModel(BaseModel):
 
     def forward(self):
         if self.opt.isTrain:
-            self.real_A_pool.query(self.real_A)
-            self.real_B_pool.query(self.real_B)
+            self.real_A_pool.store(self.real_A)
+            self.real_B_pool.store(self.real_B)
         self._forward_core()
 
     def _reuse_feats(self):
@@ -527,8 +527,8 @@ class CUTModel(BaseModel):
                 return None
             graphs[key] = st
         if self.opt.isTrain:               # the metric pools of forward(): host draws in the reference's order, outside the graph
-            self.real_A_pool.query(self.real_A)
-            self.real_B_pool.query(self.real_B)
+            self.real_A_pool.store(self.real_A)
+            self.real_B_pool.store(self.real_B)
         st["real_A"].copy_(self.real_A)
         st["real_B"].copy_(self.real_B)
         self.real_A, self.real_B = st["real_A"], st["real_B"]

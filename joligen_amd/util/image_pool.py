@@ -37,6 +37,19 @@ class ImagePool:
                 out.append(image)
         return torch.cat(out, 0)
 
+    def store(self, images):
+        """`query` for a caller that discards the result (cut_model.forward's real-image pools, base_gan_model.py:172-173 of the reference): the same
+        pool update from the same host draws, without the device copies of the returned batch (round 6: ~18 launches per step)."""
+        if self.pool_size == 0:
+            return
+        for image in images:
+            image = image.detach().unsqueeze(0)
+            if self.num_imgs < self.pool_size:
+                self.num_imgs += 1
+                self.images.append(image)
+            elif self.rng.uniform(0, 1) > 0.5:
+                self.images[self.rng.randint(0, self.pool_size - 1)] = image
+
     def get_all(self):
         return self.images
 
