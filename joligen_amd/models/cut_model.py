@@ -607,7 +607,10 @@ class CUTModel(BaseModel):
             vals.append(val)
             tot = tot + val
         tot = _ScaleGradFn.apply(tot, self.loss_scale)
-        (tot / its).backward()
+        # round 6: the discriminators' weight gradients leave as grouped launches too (34 split-K launches of 37 - 69 us, each sized to fill
+        # the chip by itself, next to the generator's backward); the spectral-norm fix of a discriminator flushes the ones it reads first
+        with ops.deferred_wgrads():
+            (tot / its).backward()
         return vals, tot
 
     def _d_half_from_graph(self, side, its):

@@ -188,6 +188,8 @@ class _SnPass:
         if self.flushed or not self.mask:
             return
         g = self.g
+        if ops.WGRAD_DEFER:         # inside ops.deferred_wgrads(): the dWsn this fix reads are still queued -- issue them (grouped) first
+            ops.flush_deferred_wgrads()
         check(_lib.lib().jg_spectral_group_wgrad_fix(g.table.data_ptr(), g.L, self.fbuf.data_ptr(), self.dbuf.data_ptr(),
                                                      self.dbuf.data_ptr() + 4 * g.dots_off, self.mask, g.max_n, _st()), "jg_spectral_group_wgrad_fix")
         self.flushed = True
@@ -279,7 +281,8 @@ class _SpectralConvFn(JGFunction):
             ktot = m.R * m.S * Cin
             splitk = ops._wgrad_splitk(((Cout + 127) // 128) * ((ktot + 127) // 128), B * Ho * Wo)
             wgrad_tn(dy, x, dwsn, B=B, H=H, W=W_, Cin=Cin, Cout=Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo, lddy=Cout, ldx=Cin,
-                     lddw=K, dbias=mod.bias.grad if mod.bias is not None else None, Cin_out=m.Cin_real, Cout_out=m.Cout_real, splitk=splitk)
+                     lddw=K, dbias=mod.bias.grad if mod.bias is not None else None, Cin_out=m.Cin_real, Cout_out=m.Cout_real, splitk=splitk,
+                     defer=ctx.sn is not None)      # (the per-layer fix below reads dwsn at once)
             if ctx.sn is not None:             # the sigma-gradient fix of all layers runs once, when the last one has delivered its dWsn
                 ctx.sn[0].delivered(ctx.sn[1])
                 return dx, None, None, None
