@@ -151,9 +151,130 @@ __global__ __launch_bounds__(256) void sgemm_kernel(SgemmP p) {
   }
 }
 
+// ---- the same GEMM on the 16-bit matrix cores with SPLIT fp32 operands (round 6) ---------------------------------------------------------
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits per operand, and a . b ~ hi_a hi_b + hi_a lo_b + lo_a hi_b (the lo lo
+// term is 2^-16 of the product) in fp32 accumulators: relative error ~ 2^-16 per product against 2^-24 of v_mfma_f32_32x32x2_f32 -- and three
+// v_mfma_f32_16x16x32_bf16 per 32-deep step instead of sixteen fp32 MFMAs at 1/16 of the rate: 5 x the MFMA throughput.  The PatchSampleF
+// GEMMs and the q k^T products of the contrastive losses (16 K rows x 256 x 256) took 26 - 35 us each at 125 TFLOP/s, the fp32 roofline; their
+// inputs are features of a 16-bit encoder.  MEASURED: 35.7 -> 24.3 us alone (16384 x 256 x 256), the CUT steps unchanged (20.90 vs 20.86 ms,
+// 34.36 vs 34.26 ms: profiles/r06_sgemm_split_ab.txt) -- these launches are not what the main queue waits for; opt-in (JG_SGEMM_SPLIT=1), since it
+// moves results by 1e-5 for nothing.  Same tile (64 x 64, K steps of 32), same operand loaders and epilogue as sgemm_kernel; LDS holds
+// the two halves row-major [row][k] (80-byte rows: the 16-byte fragment reads of 16 rows fall into distinct bank groups).
+constexpr int SG3_LD = 40;      // bf16 elements per LDS row (32 + 8 of padding)
+__device__ __forceinline__ void sg_split(float x, uint16_t& hi, uint16_t& lo) {
+  const bf16_t h = from_f32<bf16_t>(x);
+  hi = to_bits<bf16_t>(h);
+  lo = to_bits<bf16_t>(from_f32<bf16_t>(x - to_f32(h)));
+}
+template <bool KC>
+__device__ __forceinline__ void sg3_put(const float (&v)[8], int act, uint16_t (*Sh)[SG3_LD], uint16_t (*Sl)[SG3_LD], int t) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (KC) {
+      const int r = t >> 2, kk = (t & 3) * 8 + h * 4;
+      uint16_t hi[4], lo[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sg_split(act_rt(v[h * 4 + i], act), hi[i], lo[i]);
+      *reinterpret_cast<uint2*>(&Sh[r][kk]) = make_uint2((uint32_t)hi[0] | ((uint32_t)hi[1] << 16), (uint32_t)hi[2] | ((uint32_t)hi[3] << 16));
+      *reinterpret_cast<uint2*>(&Sl[r][kk]) = make_uint2((uint32_t)lo[0] | ((uint32_t)lo[1] << 16), (uint32_t)lo[2] | ((uint32_t)lo[3] << 16));
+    } else {
+      const int r = (t & 15) * 4, kk = (t >> 4) + h * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        uint16_t hi, lo;
+        sg_split(act_rt(v[h * 4 + i], act), hi, lo);
+        Sh[r + i][kk] = hi;
+        Sl[r + i][kk] = lo;
+      }
+    }
+  }
+}
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256) void sgemm3_kernel(SgemmP p) {
+  __shared__ __attribute__((aligned(16))) uint16_t Ah[64][SG3_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Al[64][SG3_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Bh[64][SG3_LD];
+  __shared__ __attribute__((aligned(16))) uint16_t Bl[64][SG3_LD];
+  const int z = p.ksplit > 1 ? 0 : blockIdx.z;
+  const int kchunk = p.ksplit > 1 ? ((p.K + p.ksplit - 1) / p.ksplit + SG_BK - 1) / SG_BK * SG_BK : p.K;
+  const int kbeg = p.ksplit > 1 ? blockIdx.z * kchunk : 0;
+  const int kend = min(p.K, kbeg + kchunk);
+  const float* A = p.A + z * p.ba;
+  const float* B = p.B + z * p.bb;
+  float* C = p.C + z * p.bc;
+  const float* E = p.E ? p.E + z * p.bc : nullptr;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int qm = (wave >> 1) * 32, qn = (wave & 1) * 32;
+  const int l16 = lane & 15, kg = lane >> 4;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float ra[8], rb[8];
+  sg_fetch<AKC>(A, p.sam, p.sak, p.M, m0, kbeg, kend, t, ra);
+  sg_fetch<BKC>(B, p.sbn, p.sbk, p.N, n0, kbeg, kend, t, rb);
+  for (int k0 = kbeg; k0 < kend; k0 += SG_BK) {
+    sg3_put<AKC>(ra, p.act_a, Ah, Al, t);
+    sg3_put<BKC>(rb, p.act_b, Bh, Bl, t);
+    __syncthreads();
+    if (k0 + SG_BK < kend) {
+      sg_fetch<AKC>(A, p.sam, p.sak, p.M, m0, k0 + SG_BK, kend, t, ra);
+      sg_fetch<BKC>(B, p.sbn, p.sbk, p.N, n0, k0 + SG_BK, kend, t, rb);
+    }
+    uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ah[i] = *reinterpret_cast<const uint4*>(&Ah[qm + i * 16 + l16][kg * 8]);
+      al[i] = *reinterpret_cast<const uint4*>(&Al[qm + i * 16 + l16][kg * 8]);
+      bh[i] = *reinterpret_cast<const uint4*>(&Bh[qn + i * 16 + l16][kg * 8]);
+      bl[i] = *reinterpret_cast<const uint4*>(&Bl[qn + i * 16 + l16][kg * 8]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = Mfma<bf16_t>::run(al[i], bh[j], acc[i][j]);      // the small terms first
+        acc[i][j] = Mfma<bf16_t>::run(ah[i], bl[j], acc[i][j]);
+        acc[i][j] = Mfma<bf16_t>::run(ah[i], bh[j], acc[i][j]);
+      }
+    __syncthreads();
+  }
+  // D of a 16 x 16 tile: row = 4 * (lane / 16) + q, column = lane % 16
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + qm + i * 16 + kg * 4 + q;
+        const int n = n0 + qn + j * 16 + l16;
+        if (m >= p.M || n >= p.N) continue;
+        const long o = (long)m * p.scm + (long)n * p.scn;
+        float c = p.alpha * acc[i][j][q];
+        if (p.ksplit > 1) {
+          atomicAdd(&C[o], c);
+          continue;
+        }
+        if (p.bias) c += p.bias[n];
+        if (E) c *= act_grad_rt2(E[o], p.act_e);
+        if (p.beta != 0.f) c += p.beta * C[o];
+        C[o] = c;
+      }
+}
+
 int sgemm_launch(const SgemmP& p, int nbatch, hipStream_t st) {
   const dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, p.ksplit > 1 ? p.ksplit : nbatch);
   const bool akc = p.sak == 1, bkc = p.sbk == 1;
+  if (jg_tune(JG_TUNE_SGEMM_SPLIT) != 0) {        // opt-in: split-bf16 operands on the 16-bit matrix cores (above); default: v_mfma_f32_32x32x2_f32
+    if (akc && bkc) hipLaunchKernelGGL((sgemm3_kernel<true, true>), grid, dim3(256), 0, st, p);
+    else if (akc) hipLaunchKernelGGL((sgemm3_kernel<true, false>), grid, dim3(256), 0, st, p);
+    else if (bkc) hipLaunchKernelGGL((sgemm3_kernel<false, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((sgemm3_kernel<false, false>), grid, dim3(256), 0, st, p);
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   if (akc && bkc) hipLaunchKernelGGL((sgemm_kernel<true, true>), grid, dim3(256), 0, st, p);
   else if (akc) hipLaunchKernelGGL((sgemm_kernel<true, false>), grid, dim3(256), 0, st, p);
   else if (bkc) hipLaunchKernelGGL((sgemm_kernel<false, true>), grid, dim3(256), 0, st, p);
