@@ -401,6 +401,10 @@ bool jg_conv1x1_try(int dtype, const ConvP& p, int nbatch, hipStream_t st) {
   if (p.ldx % 8 || p.ldy % 8 || p.ldw % 8 || (p.res && p.ldres % 8)) return false;
   // only where the layer is memory-bound: few hundred FLOP per byte; deep / low-resolution layers stay on the MFMA-tiled GEMM
   if ((long)p.M < 65536) return false;
+  // round 6: 256 -> >= 256 channels is GEMM-shaped (128 FLOP per byte): the LDS-tiled kernel is faster there (the point-wise convolutions of the
+  // mobile ResNet blocks at 64 x 64: 66 -> ~45 us, mobile_resnet_attn + [projected_d, basic] 347.5 -> 354.2 images/s); the fused GroupNorm forms
+  // exist only here and stay
+  if (!p.aab && !p.bgx && p.Cin >= 256 && p.N >= 256 && jg_tune(JG_TUNE_CONV1X1) < 2) return false;
   if (dtype == JG_F16) return dispatch_1x1<f16_t>(p, st);
   if (dtype == JG_BF16) return dispatch_1x1<bf16_t>(p, st);
   return false;
