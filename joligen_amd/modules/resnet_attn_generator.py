@@ -25,8 +25,19 @@ from .layers import JGConv2d, JGConvTranspose2d
 from .resnet_generator import _AddFn
 
 
-def _in_act(x, norm, act):
-    return ops.group_norm(x, x.shape[-1], None, None, None, act, norm.eps)
+def _in_act(x, norm, act, sums=None):
+    return ops.group_norm(x, x.shape[-1], None, None, None, act, norm.eps, sums=sums)
+
+
+def _conv_in_act(conv, x, norm, act):
+    """InstanceNorm2d(conv(x)) + act with the statistics taken in the convolution's epilogue where that form exists (ops.conv2d_stats)"""
+    if isinstance(conv, SeparableConv2d):
+        y, sums = conv(x, want_stats=True)
+    elif isinstance(conv, JGConv2d) and conv.meta is not None:
+        y, sums = ops.conv2d_stats(x, conv.meta)
+    else:
+        y, sums = conv(x), None
+    return _in_act(y, norm, act, sums)
 
 
 def _reflect_conv3(x, conv):
@@ -50,11 +61,14 @@ class SeparableConv2d(nn.Module):
         self.conv = nn.Sequential(_DWConv(in_channels, in_channels, 3, stride=1, padding=1, padding_mode="reflect", groups=in_channels),
                                   nn.InstanceNorm2d(in_channels), JGConv2d(in_channels, out_channels, 1))
 
-    def forward(self, x):
+    def forward(self, x, want_stats=False):
         B, H, W, C = x.shape
         dw = self.conv[0]
         h = S.dwconv3x3(x, dw.weight, dw.bias, gelu=False, reflect=True)      # mirrored taps inside the kernel: no padded copy, no crop
-        return self.conv[2](_in_act(h, self.conv[1], JG_ACT_NONE))
+        h = _in_act(h, self.conv[1], JG_ACT_NONE)
+        if want_stats:              # (y, statistics of y for the InstanceNorm the caller applies next)
+            return ops.conv2d_stats(h, self.conv[2].meta)
+        return self.conv[2](h)
 
 
 class resnet_block_attn(nn.Module):
@@ -82,8 +96,12 @@ class resnet_block_attn(nn.Module):
         return conv(x) if self.mobile else _reflect_conv3(x, conv)
 
     def forward(self, x):
-        h = _in_act(self._conv(self.conv1, x), self.conv1_norm, JG_ACT_RELU)
-        h = _in_act(self._conv(self.conv2, h), self.conv2_norm, JG_ACT_NONE)
+        if self.mobile:             # the point-wise convolution's epilogue takes the statistics of the InstanceNorm behind it
+            h = _conv_in_act(self.conv1, x, self.conv1_norm, JG_ACT_RELU)
+            h = _conv_in_act(self.conv2, h, self.conv2_norm, JG_ACT_NONE)
+        else:
+            h = _in_act(self._conv(self.conv1, x), self.conv1_norm, JG_ACT_RELU)
+            h = _in_act(self._conv(self.conv2, h), self.conv2_norm, JG_ACT_NONE)
         return _AddFn.apply(x, h)
 
 

@@ -314,7 +314,7 @@ def _wgrad_splitk(tiles, mpix, nbatch=1):
     return max(1, min(want, cap, WGRAD_MAX_SPLITK, 65535 // max(1, nbatch)))
 
 
-def conv2d_forward(x, m: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
+def conv2d_forward(x, m: ConvMeta, res=None, res_scale=1.0, alpha=1.0, stats=None):
     _require_cuda(x)
     B, H, W, Cin = x.shape
     assert Cin == m.Cin, (Cin, m.Cin)
@@ -322,7 +322,7 @@ def conv2d_forward(x, m: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
     y = torch.empty((B, Ho, Wo, m.Cout), device=x.device, dtype=x.dtype)
     conv_nt(x, m.w16, y, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=m.R, S=m.S, pad=m.pad, stride=m.stride, Ho=Ho, Wo=Wo,
             ldx=Cin, ldw=m.R * m.S * Cin, ldy=m.Cout, bias=m.bias_pad if m.bias_pad is not None else m.bias, res=res,
-            ldres=m.Cout, alpha=alpha, res_scale=res_scale)
+            ldres=m.Cout, alpha=alpha, res_scale=res_scale, stats=stats)
     return y
 
 
@@ -495,8 +495,10 @@ def head_conv7(x_pad, m: ConvMeta, act=0):
 
 class _Conv2dFn(JGFunction):
     @staticmethod
-    def forward(ctx, x, weight, bias, res, meta, res_scale, alpha):
-        y = conv2d_forward(x, meta, res, res_scale, alpha)
+    def forward(ctx, x, weight, bias, res, meta, res_scale, alpha, stats=None):
+        # stats (round 6, conv2d_stats): a zeroed fp32 [B, Cout, 2] buffer the launch's epilogue fills with the per-(image, channel) sum and sum
+        # of squares of its output -- the statistics pass of the InstanceNorm / GroupNorm that follows (not a differentiable input)
+        y = conv2d_forward(x, meta, res, res_scale, alpha, stats)
         ctx.save_for_backward(x)
         ctx.meta, ctx.res_scale, ctx.alpha, ctx.has_res = meta, res_scale, alpha, res is not None
         return y
@@ -514,7 +516,7 @@ class _Conv2dFn(JGFunction):
             conv2d_wgrad(dy, x, m, ctx.alpha, ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         if ctx.has_res and ctx.needs_input_grad[3]:
             dres = dy if ctx.res_scale == 1.0 else axpby(dy, ctx.res_scale)
-        return dx, None, None, dres, None, None, None
+        return dx, None, None, dres, None, None, None, None
 
 
 # torch.ops boundary mode: inside `with torch_ops_boundary():` every op of the palette step -- convolutions, norms,
@@ -547,6 +549,25 @@ def _conv2d_via_torch_ops(x, m: ConvMeta, res, res_scale, alpha):
         if b is not None:
             b = F.pad(b, (0, m.Cout - m.Cout_real))
     return torch.ops.jg355.conv2d_nt(x, w, b, res, m.pad, m.stride, alpha, res_scale if res is not None else 0.0)
+
+
+# round 6, A/B: InstanceNorm statistics of the mobile ResNet blocks in the epilogue of the point-wise convolution in front (jg_conv_args.stats, as the
+# fused UNet schedule does for its 3x3 layers).  MEASURED SLOWER: mobile_resnet_attn + [projected_d, basic] 45.0 -> 49.3 ms -- on a 45 us GEMM-shaped
+# launch the LDS-transposed reduction + 256 fp32 atomics per tile cost more than the 27 us statistics pass they replace.  Off.
+CONV_STATS = os.environ.get("JG_CONV_STATS", "0") != "0"
+
+
+def conv2d_stats(x, meta: ConvMeta):
+    """(conv2d(x), sums): sums fp32 [B, Cout, 2] = per-(image, channel) sum / sum of squares of the output, accumulated by the convolution's
+    epilogue (jg_conv_args.stats) -- hand it to group_norm(..., sums=sums) and the norm skips its statistics pass; None where the epilogue form
+    does not exist (shape limits of jg_conv2d_nt's stats: whole 256-pixel tiles inside an image, 64-channel multiples; op boundary; timing runs)"""
+    B, H, W, _ = x.shape
+    Ho, Wo = meta.out_hw(H, W)
+    if (not CONV_STATS or TORCH_OPS_BOUNDARY or KERNEL_TIMING is not None or (Ho * Wo) % 256 or meta.Cout % 64 or meta.R != meta.S or meta.R not in (1, 3)
+            or meta.stride != 1 or _lib.lib().jg_get_tuning(b"JG_DETERMINISTIC") != 0):
+        return conv2d(x, meta), None
+    sums = torch.zeros((B, meta.Cout, 2), device=x.device, dtype=torch.float32)
+    return _Conv2dFn.apply(x, meta.weight, meta.bias, None, meta, 1.0, 1.0, sums), sums
 
 
 def conv2d(x, meta: ConvMeta, res=None, res_scale=1.0, alpha=1.0):
@@ -631,18 +652,19 @@ def reflect_conv2d(x, meta: ConvMeta):
 # ======================================================================================
 class _GroupNormFn(JGFunction):
     @staticmethod
-    def forward(ctx, x, gamma, beta, film, G, act, eps):
+    def forward(ctx, x, gamma, beta, film, G, act, eps, sums=None):
         _require_cuda(x)
         L = _lib.lib()
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         dev, st, dt = x.device, _st(), _dt(x)
-        sums = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
         ab = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
         mr = torch.empty((B, G, 2), device=dev, dtype=torch.float32)
         y = torch.empty_like(x)
         ldfilm = film.stride(0) if film is not None else 0
-        check(L.jg_gn_stats(dt, x.data_ptr(), sums.data_ptr(), B, HW, C, st), "jg_gn_stats")
+        if sums is None:            # (given: the producing convolution's epilogue has accumulated them, ops.conv2d_stats)
+            sums = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+            check(L.jg_gn_stats(dt, x.data_ptr(), sums.data_ptr(), B, HW, C, st), "jg_gn_stats")
         check(L.jg_gn_coef(sums.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, ab.data_ptr(), mr.data_ptr(), B, HW, C,
                            G, eps, st), "jg_gn_coef")
         check(L.jg_gn_apply(dt, x.data_ptr(), ab.data_ptr(), y.data_ptr(), B, HW, C, act, st), "jg_gn_apply")
@@ -677,7 +699,7 @@ class _GroupNormFn(JGFunction):
             dx = torch.empty_like(x)
             check(L.jg_gn_bwd_apply(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), pqr.data_ptr(), dx.data_ptr(), B, HW,
                                     C, ctx.act, st), "jg_gn_bwd_apply")
-        return dx, None, None, dfilm, None, None, None
+        return dx, None, None, dfilm, None, None, None, None
 
 
 _GN_STATUS = {}
@@ -699,11 +721,12 @@ def check_gn_status():
             raise RuntimeError(f"jg_gn_bwd_fused: an inter-workgroup wait expired on cuda:{k} (results of that launch are invalid)")
 
 
-def group_norm(x, G, gamma=None, beta=None, film=None, act=JG_ACT_NONE, eps=1e-5):
-    """act(GroupNorm_G(x) * gamma + beta [* (1 + scale) + shift]); statistics in fp32."""
+def group_norm(x, G, gamma=None, beta=None, film=None, act=JG_ACT_NONE, eps=1e-5, sums=None):
+    """act(GroupNorm_G(x) * gamma + beta [* (1 + scale) + shift]); statistics in fp32.  sums: the [B, C, 2] statistics of x where a
+    convolution's epilogue has already taken them (conv2d_stats)."""
     if TORCH_OPS_BOUNDARY:
         return torch.ops.jg355.group_norm_act(x, gamma, beta, film, G, act, eps)
-    return _GroupNormFn.apply(x, gamma, beta, film, G, act, eps)
+    return _GroupNormFn.apply(x, gamma, beta, film, G, act, eps, sums)
 
 
 # ======================================================================================
