@@ -461,6 +461,184 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgP p) {
   wgrad_tn_tr_body<T, WAVES_M, DEEP>(p, blockIdx.x, blockIdx.z, sm);
 }
 
+// ---------------------------------------------------------------------------------------------
+// BIG tile (round 6): 256 (co) x 256 (r, s, ci) per workgroup of 8 waves (2 x 4 of 128 x 64), K steps of 64 pixels.  The 128 x 128 tile reads
+// every operand row once per tile COLUMN / ROW it takes part in: a 256 -> 256 point-wise layer (the mobile ResNet blocks: 36 of them per CUT
+// step at 131 K pixels) crosses L2 -> LDS twice per operand and runs at 300 TFLOP/s, bound by that traffic.  Here the whole 256 x 256 weight
+// gradient is ONE tile: dy and x are read once (268 MB per layer = its HBM time), the fragment reads per MFMA drop from 0.5 to 0.375.  Same
+// LDS layout as above with 512-byte pixel rows (32 chunks), one register stage of global loads, two LDS buffers of 64 KB.
+constexpr int BIG_CH = 32;                  // 16-byte chunks per 256-channel pixel row
+constexpr int BIG_TILE = 64 * BIG_CH;       // chunks per operand tile (64 pixel rows)
+template <typename T>
+__device__ __forceinline__ void wgrad_tn_big_body(const WgP& p, const int bx, const int bz, uint4 (*sm)[2 * BIG_TILE]) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves of 128 (co) x 64 (columns)
+
+  const int tilesN = (p.Ktot + BN - 1) / BN;
+  const int n0 = (bx % tilesN) * BN;
+  const int m0 = (bx / tilesN) * BM;
+  const int batch = bz / p.splitk, split = bz % p.splitk;
+  const int zb = batch / p.nh, zh = batch % p.nh;
+  const T* __restrict__ dy = (const T*)p.dy + zb * p.sdyb + zh * p.sdyh;
+  const T* __restrict__ x = (const T*)p.x + zb * p.sxb + zh * p.sxh;
+
+  int per = (p.Mpix + p.splitk - 1) / p.splitk;
+  per = (per + BK - 1) / BK * BK;
+  const int kbeg = split * per;
+  const int kend = min(p.Mpix, kbeg + per);
+  if (kbeg >= kend) return;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  const int cidx = tid & 31;          // 16-byte chunk (8 channels) of the 256-channel row
+  const int prow = (tid >> 5) * 4;    // 4 consecutive pixel rows per thread
+  const int cm = m0 + cidx * 8;
+  const bool a_ok = cm < p.Cout;
+  const int nn = n0 + cidx * 8;
+  const bool b_ok = nn < p.Ktot;
+  const int rs = nn / p.Cin, ci = nn % p.Cin;
+  const int fr = rs / p.S, fs = rs % p.S;
+
+  uint4 ra[4], rb[4];
+  float bsum[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) bsum[q] = 0.f;
+  const bool do_bias = p.dbias != nullptr && (bx % tilesN) == 0;
+
+  auto load_tiles = [&](int kbase) {
+    const int p0 = kbase + prow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = p0 + i;
+      const bool ok = a_ok && pp < kend;
+      ra[i] = ldg16(dy + (ok ? (long)pp * p.lddy + cm : 0), ok);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pp = p0 + i;
+      const int ow = pp % p.Wo;
+      const int t = pp / p.Wo;
+      const int oh = t % p.Ho;
+      const int b = t / p.Ho;
+      const int ih = oh * p.stride + fr - p.pad;
+      const int iw = ow * p.stride + fs - p.pad;
+      const bool ok = b_ok && pp < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      rb[i] = ldg16(x + (ok ? ((long)(b * p.H + ih) * p.W + iw) * p.ldx + ci : 0), ok);
+    }
+  };
+  auto store_lds = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = prow + i;
+      const int pos = row * BIG_CH + ((((cidx >> 1) ^ swz_tr(row)) << 1) | (cidx & 1));
+      sm[buf][pos] = ra[i];
+      sm[buf][BIG_TILE + pos] = rb[i];
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack8<T>(ra[i], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bsum[q] += f[q];
+      }
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int i16 = lane & 15, g = lane >> 4;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+  auto frag = [&](int buf, int tile, int cb, int sub) -> uint4 {
+    const char* base = reinterpret_cast<const char*>(&sm[buf][tile]);
+    uint32_t w[4];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int row = sub * 32 + g * 8 + rd * 4 + (i16 >> 2);
+      const int off = (row * BIG_CH + ((cb ^ swz_tr(row)) << 1)) * 16 + (i16 & 3) * 8;
+      const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + off));
+      const uint2 u = __builtin_bit_cast(uint2, v);
+      w[2 * rd] = u.x;
+      w[2 * rd + 1] = u.y;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      uint4 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag(buf, BIG_TILE, wn * 4 + j, sub);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint4 fa = frag(buf, 0, wm * 8 + i, sub);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa, fb[j], acc[i][j]);
+      }
+    }
+  };
+
+  load_tiles(kbeg);
+  store_lds(0);
+  __syncthreads();
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    const bool more = ks + 1 < nk;
+    if (more) load_tiles(kbeg + (ks + 1) * BK);
+    compute(cur);
+    if (more) store_lds(cur ^ 1);
+    __syncthreads();
+  }
+
+  const long zoff = zb * p.sdwb + zh * p.sdwh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+    if (n >= p.Ktot) continue;
+    const int ors = n / p.Cin, oci = n % p.Cin;
+    if (oci >= p.Cin_out) continue;
+    const long ocol = (long)ors * p.Cin_out + oci;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 128 + i * 16 + (lane >> 4) * 4 + q;
+        if (m >= p.Cout_out) continue;
+        atomicAdd((float*)p.dw + zoff + (long)m * p.lddw + ocol, p.alpha * acc[i][j][q]);
+      }
+    }
+  }
+  if (do_bias) {
+    // lanes l, l + 32 of a wave share a channel octet (tid & 31); then across the 8 waves through LDS: one atomic per channel and workgroup
+    float* s_b = reinterpret_cast<float*>(&sm[0][0]);      // all waves are past the last barrier of the K loop
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = bsum[q];
+      v += __shfl_xor(v, 32);
+      if (lane < 32) s_b[wave * 256 + cidx * 8 + q] = v;
+    }
+    __syncthreads();
+    if (tid < BM && (m0 + tid) < p.Cout_out) {
+      float v = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < 8; ++w8) v += s_b[w8 * 256 + tid];
+      atomicAdd(p.dbias + m0 + tid, p.dbias_scale * v);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void wgrad_tn_big_kernel(WgP p) {
+  __shared__ uint4 sm[2][2 * BIG_TILE];
+  wgrad_tn_big_body<T>(p, blockIdx.x, blockIdx.z, sm);
+}
+
 // GROUPED launch (round 5): up to GROUP_MAX independent small weight-gradient problems in ONE grid.  The SegFormer generator's backward issues
 // ~190 of these per step (linear layers / 1x1 convolutions of four stages at 8 ... 64 workgroups each, 10 - 40 us apiece because their
 // reduction over 10^4 - 10^5 tokens is a serial K loop per workgroup); side by side they fill the chip and the group costs what its
@@ -483,6 +661,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_group_kernel(const WgGroup
   i = __builtin_amdgcn_readfirstlane(i);
   const int local = b - g.start[i];
   wgrad_tn_tr_body<T, WAVES_M, DEEP>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
+}
+
+template <typename T>
+__global__ __launch_bounds__(512, 1) void wgrad_tn_big_group_kernel(const WgGroup g) {
+  __shared__ uint4 sm[2][2 * BIG_TILE];
+  const int b = blockIdx.x;
+  int i = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k) i += (k < g.n && b >= g.start[k]) ? 1 : 0;
+  i = __builtin_amdgcn_readfirstlane(i);
+  const int local = b - g.start[i];
+  wgrad_tn_big_body<T>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
+}
+
+// the big tile pays where a 128 x 128 tiling would re-read: at least 256 output channels and 256 columns, and a long reduction
+static inline bool wg_big_ok(const WgP& p) {
+  return jg_tune(JG_TUNE_WGRAD_BIG) != 0 && p.Cout >= 256 && p.Ktot >= 256 && p.Mpix >= 8192;
 }
 
 }  // namespace
@@ -543,7 +738,7 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
     if (special[i] && !jg_wgrad_halo_try(dtype, ps[i], 1, (hipStream_t)stream)) jg_wgrad_kxk_try(dtype, ps[i], 1, (hipStream_t)stream);
   const int group_blocks = jg_tune(JG_TUNE_WGRAD_GROUP_BLOCKS);
   const size_t gpad = (size_t)jg_tune(JG_TUNE_WGRAD_LDS_PAD);      // A/B: unused dynamic LDS = one workgroup per CU instead of two
-  for (int wavesm = 1; wavesm <= 2; ++wavesm) {
+  for (int wavesm = 1; wavesm <= 3; ++wavesm) {      // 1: 64-row tile, 2: 128-row tile, 3: the 256 x 256 tile
     WgGroup g;
     g.n = 0;
     g.start[0] = 0;
@@ -565,7 +760,9 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
       }
       const dim3 grid(g.start[g.n]);
       const int deep = jg_tune(JG_TUNE_WGRAD_DEEP);      // two register stages of global loads in flight: bit 0 = the 64-row tile, bit 1 = the 128-row tile
-      if (wavesm == 1) {
+      if (wavesm == 3) {
+        JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_group_kernel<T>), grid, dim3(512), 0, (hipStream_t)stream, g););
+      } else if (wavesm == 1) {
         if (deep & 1) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1, true>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
         else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
       } else {
@@ -577,8 +774,8 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
     };
     for (int i = 0; i < n; ++i) {
       const WgP& p = ps[i];
-      if (special[i] || (p.Cout <= 64 ? 1 : 2) != wavesm) continue;
-      const int tiles = ((p.Cout + 64 * wavesm - 1) / (64 * wavesm)) * ((p.Ktot + 127) / 128);
+      if (special[i] || (wg_big_ok(p) ? 3 : p.Cout <= 64 ? 1 : 2) != wavesm) continue;
+      const int tiles = wavesm == 3 ? ((p.Cout + 255) / 256) * ((p.Ktot + 255) / 256) : ((p.Cout + 64 * wavesm - 1) / (64 * wavesm)) * ((p.Ktot + 127) / 128);
       g.p[g.n] = p;
       g.tiles[g.n] = tiles;
       g.start[g.n + 1] = g.start[g.n] + tiles * p.splitk;
@@ -607,6 +804,15 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
     return JG_OK;
   }
   if (p.reflect || p.x_up) return JG_ERR_UNSUPPORTED;   // mirrored borders / upsample-on-read exist only in the halo-resident kernel
+  if (variant >= 2 && wg_big_ok(p)) {
+    const int tiles = ((p.Cout + 255) / 256) * ((p.Ktot + 255) / 256);
+    // the caller's split-K is sized for 128 x 128 tiles: a quarter of the workgroups per slice here, so keep the slice count
+    dim3 grid(tiles, 1, a->nbatch * p.splitk);
+    jg_note_kernel("wgrad_tn_big_kernel");
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T>), grid, dim3(512), 0, (hipStream_t)stream, p););
+    JG_CHECK_LAUNCH();
+    return JG_OK;
+  }
   const int tilesN = (p.Ktot + 127) / 128;
   if (variant == 1) {
     dim3 grid(((p.Cout + 127) / 128) * tilesN, 1, a->nbatch * p.splitk);

@@ -2173,6 +2173,58 @@ def test_conv3x3_few_output_channels_halo_kernel(dtype):
     assert relerr(y, y2) < TOL[dtype]
 
 
+BIG_WGRAD_CASES = [
+    # B, H, W, Cin, Cout, k, pad, stride, real_cout
+    (2, 64, 64, 256, 256, 1, 0, 1, 256),       # the point-wise layers of the mobile ResNet blocks: ONE 256 x 256 tile, split over pixels
+    (3, 64, 48, 256, 320, 1, 0, 1, 316),       # ragged: two tile rows, the second with 64 live rows of which 60 are stored; bias
+    (2, 128, 128, 128, 256, 3, 1, 2, 256),     # 3x3 stride 2 (decoder tails): 1152 columns = 4.5 tile columns, im2col gathers
+    (2, 128, 128, 512, 512, 4, 1, 2, 512),     # 4x4 stride 2 (PatchGAN / DownBlock): long rows of columns
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", BIG_WGRAD_CASES, ids=["1x1 256", "1x1 ragged", "3x3 s2", "4x4 s2"])
+def test_wgrad_big_tile(case, dtype):
+    """round 6: `wgrad_tn_big_kernel` (256 x 256 tile, 8 waves; JG_WGRAD_BIG, default on for >= 256 output channels and >= 256 columns) -- alone
+    and inside a grouped launch -- against autograd of F.conv2d in fp32 and against the 128 x 128 tile of rounds 2-5 on the same operands."""
+    import contextlib
+
+    from joligen_amd import _lib, ops
+
+    B, H, W, Cin, Cout, k, pad, stride, real = case
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = rnd((B, Cin, H, W), dtype, 91)
+    gy = rnd((B, Cout, Ho, Wo), dtype, 92)
+    gy[:, real:] = 0
+    wr = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    br = torch.zeros(Cout, requires_grad=True)
+    F.conv2d(x.float(), wr, br, stride=stride, padding=pad).backward(gy.float())
+    xd, gyd = nhwc(x).to(dev()), nhwc(gy).to(dev())
+    outs = {}
+    for big in (1, 0):
+        prev = _lib.set_tuning("JG_WGRAD_BIG", big)
+        try:
+            for grouped in (False, True):
+                dw = torch.zeros(real, k * k * Cin, device=dev())
+                db = torch.zeros(real, device=dev())
+                tiles = ((Cout + 127) // 128) * ((k * k * Cin + 127) // 128)
+                with (ops.deferred_wgrads() if grouped else contextlib.nullcontext()):
+                    ops.wgrad_tn(gyd, xd, dw, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=k, S=k, pad=pad, stride=stride, Ho=Ho, Wo=Wo, lddy=Cout, ldx=Cin,
+                                 lddw=k * k * Cin, dbias=db, Cin_out=Cin, Cout_out=real, splitk=ops._wgrad_splitk(tiles, B * Ho * Wo))
+                    if not grouped:
+                        name = _lib.lib().jg_last_kernel().decode()
+                        assert (name == "wgrad_tn_big_kernel") == (big == 1), name
+                torch.cuda.synchronize()
+                outs[(big, grouped)] = (dw.cpu(), db.cpu())
+        finally:
+            _lib.set_tuning("JG_WGRAD_BIG", prev)
+    ref_w = wr.grad[:real].permute(0, 2, 3, 1).reshape(real, -1)
+    for key, (dw, db) in outs.items():
+        assert relerr(dw, ref_w) < TOL[dtype], (key, relerr(dw, ref_w))
+        assert relerr(db, br.grad[:real]) < TOL[dtype], (key, relerr(db, br.grad[:real]))
+    assert relerr(outs[(1, False)][0], outs[(0, False)][0]) < 1e-4 and relerr(outs[(1, True)][0], outs[(1, False)][0]) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_wgrad_halo_narrow_output(dtype):
     """round 5: the halo-resident 3x3 weight gradient with FEWER than 64 output channels (the 64 -> 3 (8) head of the UNet at 256 x 256): the missing
