@@ -633,10 +633,170 @@ __device__ __forceinline__ void wgrad_tn_big_body(const WgP& p, const int bx, co
   }
 }
 
+// ---- the same tile with LDS-DMA staging (round 6, second form) --------------------------------------------------------------------------
+// The register-staged body above spends a K step on four things one after the other -- global loads into registers, ds_write of 64 KB,
+// fragment reads, 64 MFMAs per wave -- behind two barriers: 2.9 us per step where the MFMAs alone need 0.85 (tools/wgrad_big_probe.py).
+// The LDS tiles ARE the global layout (512-byte pixel rows), so a `global_load_lds_dwordx4` per 16-byte chunk puts them there without
+// registers: the XOR swizzle moves to the SOURCE side (the lane that fills slot p of a row fetches chunk p ^ swizzle), the loads of step k + 1
+// are in flight under the MFMAs of step k, and the loop has ONE barrier per step (the wait for this wave's loads, then the barrier, tell
+// every wave both that buffer `cur` is complete and that nobody reads `cur ^ 1` any more).  The bias gradient comes from the dy fragments
+// through an MFMA with a ones operand (wgrad_kxk.hip).
+__device__ uint4 jg_wt_zero_page = {0u, 0u, 0u, 0u};
+__device__ __forceinline__ void glds16_tn(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
 template <typename T>
+__device__ __forceinline__ void wgrad_tn_dma_body(const WgP& p, const int bx, const int bz, uint4 (*sm)[2 * BIG_TILE]) {
+  constexpr int BM = 256, BN = 256, BK = 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tilesN = (p.Ktot + BN - 1) / BN;
+  const int n0 = (bx % tilesN) * BN;
+  const int m0 = (bx / tilesN) * BM;
+  const int batch = bz / p.splitk, split = bz % p.splitk;
+  const int zb = batch / p.nh, zh = batch % p.nh;
+  const T* __restrict__ dy = (const T*)p.dy + zb * p.sdyb + zh * p.sdyh;
+  const T* __restrict__ x = (const T*)p.x + zb * p.sxb + zh * p.sxh;
+  const T* zp = reinterpret_cast<const T*>(&jg_wt_zero_page);
+
+  int per = (p.Mpix + p.splitk - 1) / p.splitk;
+  per = (per + BK - 1) / BK * BK;
+  const int kbeg = split * per;
+  const int kend = min(p.Mpix, kbeg + per);
+  if (kbeg >= kend) return;
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  typedef __attribute__((address_space(3))) char* lds_cptr;
+  const unsigned lds0 = (unsigned)(size_t)(lds_cptr)(char*)&sm[0][0];
+
+  // slot q = rd * 512 + tid of a tile (rd = 0 .. 3): pixel row q / 32, slot p = q % 32 of the row <- source chunk c = p ^ swizzle(row)
+  int a_col[4], b_ci[4], b_fr[4], b_fs[4];
+  bool a_ok[4], b_ok[4];
+#pragma unroll
+  for (int rd = 0; rd < 4; ++rd) {
+    const int q = rd * 512 + tid;
+    const int row = q >> 5, ps = q & 31;
+    const int c = (((ps >> 1) ^ swz_tr(row)) << 1) | (ps & 1);
+    a_col[rd] = m0 + c * 8;
+    a_ok[rd] = a_col[rd] < p.Cout;
+    const int nn = n0 + c * 8;
+    b_ok[rd] = nn < p.Ktot;
+    const int rs = nn / p.Cin;
+    b_ci[rd] = nn % p.Cin;
+    b_fr[rd] = rs / p.S;
+    b_fs[rd] = rs % p.S;
+  }
+  auto issue = [&](int kbase, int buf) {
+    const unsigned l0 = lds0 + (unsigned)((buf * 2 * BIG_TILE + wave * 64) * 16);
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const int pp = kbase + ((rd * 512 + tid) >> 5);
+      const bool ok = a_ok[rd] && pp < kend;
+      glds16_tn(ok ? dy + (long)pp * p.lddy + a_col[rd] : zp, l0 + rd * 512 * 16);
+    }
+#pragma unroll
+    for (int rd = 0; rd < 4; ++rd) {
+      const int pp = kbase + ((rd * 512 + tid) >> 5);
+      const int ow = pp % p.Wo;
+      const int t = pp / p.Wo;
+      const int oh = t % p.Ho;
+      const int b = t / p.Ho;
+      const int ih = oh * p.stride + b_fr[rd] - p.pad;
+      const int iw = ow * p.stride + b_fs[rd] - p.pad;
+      const bool ok = b_ok[rd] && pp < kend && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+      glds16_tn(ok ? x + ((long)(b * p.H + ih) * p.W + iw) * p.ldx + b_ci[rd] : zp, l0 + (BIG_TILE + rd * 512) * 16);
+    }
+  };
+
+  f32x4 acc[8][4], accb[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool do_bias = p.dbias != nullptr && (bx % tilesN) == 0 && wn == 0;
+  const uint32_t one1 = to_bits<T>(from_f32<T>(1.0f));
+  const uint32_t one2 = one1 | (one1 << 16);
+  const uint4 ones = make_uint4(one2, one2, one2, one2);
+
+  const int i16 = lane & 15, g = lane >> 4;
+  typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+  auto frag = [&](int buf, int tile, int cb, int sub) -> uint4 {
+    const char* base = reinterpret_cast<const char*>(&sm[buf][tile]);
+    uint32_t w[4];
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int row = sub * 32 + g * 8 + rd * 4 + (i16 >> 2);
+      const int off = (row * BIG_CH + ((cb ^ swz_tr(row)) << 1)) * 16 + (i16 & 3) * 8;
+      const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(base + off));
+      const uint2 u = __builtin_bit_cast(uint2, v);
+      w[2 * rd] = u.x;
+      w[2 * rd + 1] = u.y;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+  };
+
+  issue(kbeg, 0);
+  for (int ks = 0; ks < nk; ++ks) {
+    const int cur = ks & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of buffer `cur` has landed
+    __builtin_amdgcn_s_barrier();                           // everybody's has, and everybody is past the MFMAs that read `cur ^ 1`
+    if (ks + 1 < nk) issue(kbeg + (ks + 1) * BK, cur ^ 1);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      uint4 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = frag(cur, BIG_TILE, wn * 4 + j, sub);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint4 fa = frag(cur, 0, wm * 8 + i, sub);
+        if (do_bias) accb[i] = Mfma<T>::run(fa, ones, accb[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa, fb[j], acc[i][j]);
+      }
+    }
+  }
+
+  const long zoff = zb * p.sdwb + zh * p.sdwh;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+    if (n >= p.Ktot) continue;
+    const int ors = n / p.Cin, oci = n % p.Cin;
+    if (oci >= p.Cin_out) continue;
+    const long ocol = (long)ors * p.Cin_out + oci;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 128 + i * 16 + (lane >> 4) * 4 + q;
+        if (m >= p.Cout_out) continue;
+        atomicAdd((float*)p.dw + zoff + (long)m * p.lddw + ocol, p.alpha * acc[i][j][q]);
+      }
+    }
+  }
+  if (do_bias && (lane & 15) == 0) {      // the columns of accb are all equal (B = ones): column 0
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int m = m0 + wm * 128 + i * 16 + (lane >> 4) * 4 + q;
+        if (m < p.Cout_out) atomicAdd(p.dbias + m, p.dbias_scale * accb[i][q]);
+      }
+  }
+}
+
+template <typename T, bool DMA = true>
 __global__ __launch_bounds__(512, 1) void wgrad_tn_big_kernel(WgP p) {
   __shared__ uint4 sm[2][2 * BIG_TILE];
-  wgrad_tn_big_body<T>(p, blockIdx.x, blockIdx.z, sm);
+  if constexpr (DMA) wgrad_tn_dma_body<T>(p, blockIdx.x, blockIdx.z, sm);
+  else wgrad_tn_big_body<T>(p, blockIdx.x, blockIdx.z, sm);
 }
 
 // GROUPED launch (round 5): up to GROUP_MAX independent small weight-gradient problems in ONE grid.  The SegFormer generator's backward issues
@@ -663,7 +823,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_group_kernel(const WgGroup
   wgrad_tn_tr_body<T, WAVES_M, DEEP>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
 }
 
-template <typename T>
+template <typename T, bool DMA = true>
 __global__ __launch_bounds__(512, 1) void wgrad_tn_big_group_kernel(const WgGroup g) {
   __shared__ uint4 sm[2][2 * BIG_TILE];
   const int b = blockIdx.x;
@@ -672,7 +832,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_big_group_kernel(const WgGrou
   for (int k = 1; k < GROUP_MAX; ++k) i += (k < g.n && b >= g.start[k]) ? 1 : 0;
   i = __builtin_amdgcn_readfirstlane(i);
   const int local = b - g.start[i];
-  wgrad_tn_big_body<T>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
+  if constexpr (DMA) wgrad_tn_dma_body<T>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
+  else wgrad_tn_big_body<T>(g.p[i], local % g.tiles[i], local / g.tiles[i], sm);
 }
 
 // the big tile pays where a 128 x 128 tiling would re-read: at least 256 output channels and 256 columns, and a long reduction
@@ -761,7 +922,8 @@ extern "C" int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n
       const dim3 grid(g.start[g.n]);
       const int deep = jg_tune(JG_TUNE_WGRAD_DEEP);      // two register stages of global loads in flight: bit 0 = the 64-row tile, bit 1 = the 128-row tile
       if (wavesm == 3) {
-        JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_group_kernel<T>), grid, dim3(512), 0, (hipStream_t)stream, g););
+        if (jg_tune(JG_TUNE_WGRAD_BIG) == 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_group_kernel<T, false>), grid, dim3(512), 0, (hipStream_t)stream, g);); }
+        else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_group_kernel<T, true>), grid, dim3(512), 0, (hipStream_t)stream, g);); }
       } else if (wavesm == 1) {
         if (deep & 1) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1, true>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
         else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_tr_group_kernel<T, 1>), grid, dim3(256), gpad, (hipStream_t)stream, g);); }
@@ -809,7 +971,8 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
     // the caller's split-K is sized for 128 x 128 tiles: a quarter of the workgroups per slice here, so keep the slice count
     dim3 grid(tiles, 1, a->nbatch * p.splitk);
     jg_note_kernel("wgrad_tn_big_kernel");
-    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T>), grid, dim3(512), 0, (hipStream_t)stream, p););
+    if (jg_tune(JG_TUNE_WGRAD_BIG) == 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, false>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
+    else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, true>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
     JG_CHECK_LAUNCH();
     return JG_OK;
   }
