@@ -24,7 +24,7 @@ struct TuneDef { const char* env; int dflt; };
 const TuneDef kTune[JG_TUNE_COUNT] = {
     {"JG_HALO_CFG", 0}, {"JG_WGRAD_HALO_CFG", 0}, {"JG_CONV_VARIANT", 6}, {"JG_WGRAD_VARIANT", 4}, {"JG_SINKHORN_GENERIC", 0},
     {"JG_CONV1X1", 1}, {"JG_GN_REVERSE", 1}, {"JG_HALO_DBG", 0}, {"JG_PERSIST64", 1}, {"JG_HALO_PIPE", 1}, {"JG_WGRAD_PIPE", 1}, {"JG_CONV_SPLITK", 1}, {"JG_CONV_SMALL_TILE", 1}, {"JG_GN_FUSED", 1}, {"JG_GN_FUSED_CAP", 256}, {"JG_GN_FUSED_DBG", 0}, {"JG_GN_FUSED_SLEEP", 4}, {"JG_WGRAD_LDS_PAD", 0},
-    {"JG_LN_BWD_CAP", 256}, {"JG_DW_BWD_CAP", 512}, {"JG_DW_BWD_PPT", 8}, {"JG_CONV_KXK", 1}, {"JG_CONV_RING", 1}, {"JG_WGRAD_DEEP", 1}, {"JG_WGRAD_SW", 0}, {"JG_DETERMINISTIC", 0}, {"JG_WGRAD_GROUP_BLOCKS", 1024}, {"JG_SGEMM_SPLIT", 0}, {"JG_WGRAD_BIG", 1}};
+    {"JG_LN_BWD_CAP", 256}, {"JG_DW_BWD_CAP", 512}, {"JG_DW_BWD_PPT", 8}, {"JG_CONV_KXK", 1}, {"JG_CONV_RING", 1}, {"JG_WGRAD_DEEP", 1}, {"JG_WGRAD_SW", 0}, {"JG_DETERMINISTIC", 0}, {"JG_WGRAD_GROUP_BLOCKS", 1024}, {"JG_SGEMM_SPLIT", 0}, {"JG_WGRAD_BIG", 1}, {"JG_DW_RUN", 1}};
 std::atomic<int> g_tune[JG_TUNE_COUNT];
 std::once_flag g_tune_once;
 void tune_init() {

@@ -18,7 +18,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // not pick at test-sized shapes.  No per-launch getenv().
 enum JgTune { JG_TUNE_HALO_CFG = 0, JG_TUNE_WGRAD_HALO_CFG, JG_TUNE_CONV_VARIANT, JG_TUNE_WGRAD_VARIANT, JG_TUNE_SINKHORN_GENERIC,
               JG_TUNE_CONV1X1, JG_TUNE_GN_REVERSE, JG_TUNE_HALO_DBG, JG_TUNE_PERSIST64, JG_TUNE_HALO_PIPE, JG_TUNE_WGRAD_PIPE, JG_TUNE_CONV_SPLITK, JG_TUNE_CONV_SMALL_TILE, JG_TUNE_GN_FUSED, JG_TUNE_GN_FUSED_CAP, JG_TUNE_GN_FUSED_DBG, JG_TUNE_GN_FUSED_SLEEP, JG_TUNE_WGRAD_LDS_PAD,
-              JG_TUNE_LN_BWD_CAP, JG_TUNE_DW_BWD_CAP, JG_TUNE_DW_BWD_PPT, JG_TUNE_CONV_KXK, JG_TUNE_CONV_RING, JG_TUNE_WGRAD_DEEP, JG_TUNE_WGRAD_SW, JG_TUNE_DETERMINISTIC, JG_TUNE_WGRAD_GROUP_BLOCKS, JG_TUNE_SGEMM_SPLIT, JG_TUNE_WGRAD_BIG, JG_TUNE_COUNT };
+              JG_TUNE_LN_BWD_CAP, JG_TUNE_DW_BWD_CAP, JG_TUNE_DW_BWD_PPT, JG_TUNE_CONV_KXK, JG_TUNE_CONV_RING, JG_TUNE_WGRAD_DEEP, JG_TUNE_WGRAD_SW, JG_TUNE_DETERMINISTIC, JG_TUNE_WGRAD_GROUP_BLOCKS, JG_TUNE_SGEMM_SPLIT, JG_TUNE_WGRAD_BIG, JG_TUNE_DW_RUN, JG_TUNE_COUNT };
 int jg_tune(int which);
 // dispatch sites record which kernel instance handled the launch (read back through jg_last_kernel(): bench.py / tools name the
 // roofline rows by what actually ran, not by a host-side guess of the dispatch)
