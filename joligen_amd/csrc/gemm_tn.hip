@@ -648,7 +648,7 @@ __device__ __forceinline__ void glds16_tn(const void* gsrc, unsigned lds_dst) {
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 // SPREAD: one DMA per 8 MFMAs instead of the burst after the barrier -- measured equal (292.9 vs 292.2 us at 128 K steps per workgroup): off
-template <typename T, bool SPREAD = false>
+template <typename T, bool SPREAD = false, int ABL = 0>      // ABL (timing only, wrong results): 1 = no MFMAs, 2 = no fragment reads, 3 = no DMA
 __device__ __forceinline__ void wgrad_tn_dma_body(const WgP& p, const int bx, const int bz, uint4 (*sm)[2 * BIG_TILE]) {
   constexpr int BM = 256, BN = 256, BK = 64;
   const int tid = threadIdx.x;
@@ -731,6 +731,7 @@ __device__ __forceinline__ void wgrad_tn_dma_body(const WgP& p, const int bx, co
   const int i16 = lane & 15, g = lane >> 4;
   typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
   auto frag = [&](int buf, int tile, int cb, int sub) -> uint4 {
+    if constexpr (ABL == 2) return make_uint4((unsigned)(buf + tile), (unsigned)cb, (unsigned)sub, (unsigned)lane);
     const char* base = reinterpret_cast<const char*>(&sm[buf][tile]);
     uint32_t w[4];
 #pragma unroll
@@ -745,13 +746,16 @@ __device__ __forceinline__ void wgrad_tn_dma_body(const WgP& p, const int bx, co
     return make_uint4(w[0], w[1], w[2], w[3]);
   };
 
-  issue(kbeg, 0);
+  if constexpr (ABL != 3) issue(kbeg, 0);
   for (int ks = 0; ks < nk; ++ks) {
     const int cur = ks & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of buffer `cur` has landed
     __builtin_amdgcn_s_barrier();                           // everybody's has, and everybody is past the MFMAs that read `cur ^ 1`
     const bool more = ks + 1 < nk;
-    if (more && !SPREAD) issue(kbeg + (ks + 1) * BK, cur ^ 1);
+    if (more && !SPREAD && ABL != 3) issue(kbeg + (ks + 1) * BK, cur ^ 1);
+    // the dy fragment of row block i + 1 is requested before the four MFMAs of row block i are issued (the compiler otherwise reads, waits,
+    // multiplies, reads ... and both waves of a SIMD wait in step)
+    uint4 fa_n = frag(cur, 0, wm * 8, 0);
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
       uint4 fb[4];
@@ -759,11 +763,20 @@ __device__ __forceinline__ void wgrad_tn_dma_body(const WgP& p, const int bx, co
       for (int j = 0; j < 4; ++j) fb[j] = frag(cur, BIG_TILE, wn * 4 + j, sub);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const uint4 fa = frag(cur, 0, wm * 8 + i, sub);
-        if (SPREAD && more && (i & 1) == 0) issue_one(kbeg + (ks + 1) * BK, cur ^ 1, sub * 4 + (i >> 1));      // one DMA per 8 MFMAs
+        const uint4 fa = fa_n;
+        if (i < 7) fa_n = frag(cur, 0, wm * 8 + i + 1, sub);
+        else if (sub == 0) fa_n = frag(cur, 0, wm * 8, 1);
+        if (SPREAD && more && (i & 1) == 0) {      // one DMA per 8 MFMAs, fenced: the scheduler otherwise gathers the eight into one burst
+          __builtin_amdgcn_sched_barrier(0);
+          issue_one(kbeg + (ks + 1) * BK, cur ^ 1, sub * 4 + (i >> 1));
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (do_bias) accb[i] = Mfma<T>::run(fa, ones, accb[i]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = Mfma<T>::run(fa, fb[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (ABL == 1) { acc[i][j][0] += __builtin_bit_cast(float, fa.x ^ fb[j].y); acc[i][j][1] += __builtin_bit_cast(float, fa.z ^ fb[j].w); }
+          else acc[i][j] = Mfma<T>::run(fa, fb[j], acc[i][j]);
+        }
       }
     }
   }
@@ -797,10 +810,10 @@ __device__ __forceinline__ void wgrad_tn_dma_body(const WgP& p, const int bx, co
   }
 }
 
-template <typename T, bool DMA = true>
+template <typename T, bool DMA = true, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void wgrad_tn_big_kernel(WgP p) {
   __shared__ uint4 sm[2][2 * BIG_TILE];
-  if constexpr (DMA) wgrad_tn_dma_body<T>(p, blockIdx.x, blockIdx.z, sm);
+  if constexpr (DMA) wgrad_tn_dma_body<T, ABL == 4, ABL == 4 ? 0 : ABL>(p, blockIdx.x, blockIdx.z, sm);      // ABL 4: the SPREAD form (A/B)
   else wgrad_tn_big_body<T>(p, blockIdx.x, blockIdx.z, sm);
 }
 
@@ -976,7 +989,12 @@ extern "C" int jg_conv2d_wgrad_tn(int dtype, const jg_wgrad_args* a, jg_stream_t
     // the caller's split-K is sized for 128 x 128 tiles: a quarter of the workgroups per slice here, so keep the slice count
     dim3 grid(tiles, 1, a->nbatch * p.splitk);
     jg_note_kernel("wgrad_tn_big_kernel");
-    if (jg_tune(JG_TUNE_WGRAD_BIG) == 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, false>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
+    const int bigmode = jg_tune(JG_TUNE_WGRAD_BIG);      // 11 / 12 / 13: timing-only ablations of the DMA form (tools/wgrad_big_probe.py)
+    if (bigmode == 11) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, true, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
+    else if (bigmode == 12) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, true, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
+    else if (bigmode == 14) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, true, 4>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
+    else if (bigmode == 13) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, true, 3>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
+    else if (bigmode == 2) { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, false>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
     else { JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((wgrad_tn_big_kernel<T, true>), grid, dim3(512), 0, (hipStream_t)stream, p);); }
     JG_CHECK_LAUNCH();
     return JG_OK;
