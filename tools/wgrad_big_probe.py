@@ -27,6 +27,6 @@ def t(fn, n=10):
 
 for big in (1, 0, 2, 11, 12, 13, 14):      # 1 DMA form, 0 the 128 x 128 tile, 2 register-staged form, 11 / 12 / 13 timing-only: no MFMAs / no fragment reads / no DMA, 14 the DMA instructions spread over the MFMA loop
     _lib.set_tuning("JG_WGRAD_BIG", big)
-    for sk in ((16, 32, 64, 128, 256, 384, 512) if big < 2 else (16, 128)):
+    for sk in ((16, 32, 64, 128, 256, 384, 512) if big in (0, 1) else (16, 128)):
         us = t(lambda: ops.wgrad_tn(dy, x, dw, B=B, H=H, W=H, Cin=C, Cout=C, R=1, S=1, pad=0, stride=1, Ho=H, Wo=H, lddy=C, ldx=C, lddw=C, splitk=sk))
         print("big %d splitk %3d: %6.1f us  %5.0f TFLOP/s  %.2f TB/s" % (big, sk, us, 2.0 * B * H * H * C * C / us / 1e6, 4.0 * B * H * H * C / us / 1e6))
