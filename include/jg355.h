@@ -458,6 +458,11 @@ int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamm
                      int64_t R, int C, jg_stream_t s);
 /* the same with the residual branch's gradient added in the pass: dx = res + LayerNorm'(dy) -- the fan-in of a pre-norm block's input,
  * x + drop_path(f(norm(x))) (models/modules/segformer/backbone.py:401-438); res may be NULL */
+/* Round 6: nn.LayerNorm of `identity + drop_path(branch)` -- the residual sum in front of every LayerNorm of a pre-norm MiT block
+ * (segformer/backbone.py:401-438; DropPath :700-726) -- in one pass: xsum = x + add * scale[row / rows_per_image] (scale NULL: 1), y = LN(xsum)
+ * of the ROUNDED sum, mr = (mean, rstd) per row.  Replaces jg_scale (with a residual) + jg_layernorm_fwd. */
+int jg_layernorm_fwd_add(int dtype, const void* x, const void* add, const float* scale, int64_t rows_per_image, void* xsum, const float* gamma,
+                         const float* beta, void* y, float* mr, int64_t R, int C, float eps, jg_stream_t s);
 int jg_layernorm_bwd_add(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, const void* res, void* dx, float* dgamma,
                          float* dbeta, int64_t R, int C, jg_stream_t s);
 int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C, int gelu,

@@ -130,7 +130,11 @@ __device__ __forceinline__ void dw_window(const T* centre, int px, int py, int H
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y, float* __restrict__ mr,
-                                                            long R, int C, int lpr, float eps) {
+                                                            long R, int C, int lpr, float eps, const T* __restrict__ add = nullptr,
+                                                            const float* __restrict__ scale = nullptr, long rows_per_image = 1, T* __restrict__ xsum = nullptr) {
+  // add / scale / xsum (round 6, jg_layernorm_fwd_add): the row that is normalised is x + add * scale[image] -- the residual sum with its
+  // DropPath scale, `identity + drop_path(branch)` of a pre-norm transformer block (segformer/backbone.py:401-438) -- written to xsum as well:
+  // the sum kernel in front of every LayerNorm (jg_scale with a residual) folded into this pass
   const int lane = threadIdx.x & 63;
   const int sub = lane % lpr, rsub = lane / lpr, rpw = 64 / lpr;
   const long wave = blockIdx.x * 4L + (threadIdx.x >> 6), nwaves = gridDim.x * 4L;
@@ -150,6 +154,16 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     float s = 0.f, ss = 0.f;
     if (ok) {
       unpack8<T>(*reinterpret_cast<const uint4*>(x + row * C + sub * 8), f);
+      if (add) {
+        float a8[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(add + row * C + sub * 8), a8);
+        const float sc = scale ? scale[row / rows_per_image] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += a8[j] * sc;
+        const uint4 packed = pack8<T>(f);
+        *reinterpret_cast<uint4*>(xsum + row * C + sub * 8) = packed;
+        unpack8<T>(packed, f);          // normalise the ROUNDED sum: what a separate sum kernel would have stored and this pass read
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += f[j];
     }
@@ -1534,6 +1548,16 @@ extern "C" int jg_layernorm_fwd(int dtype, const void* x, const float* gamma, co
   const long waves = (R + 64 / lpr - 1) / (64 / lpr);
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(grid_for(waves, 4, 8192)), dim3(256), 0, (hipStream_t)s, (const T*)x,
                                               gamma, beta, (T*)y, mr, (long)R, C, lpr, eps););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_layernorm_fwd_add(int dtype, const void* x, const void* add, const float* scale, int64_t rows_per_image, void* xsum,
+                                    const float* gamma, const float* beta, void* y, float* mr, int64_t R, int C, float eps, jg_stream_t s) {
+  if (!x || !add || !xsum || !gamma || !beta || !y || R < 1 || C < 8 || C % 8 || C > 512 || rows_per_image < 1) return JG_ERR_BAD_ARG;
+  const int lpr = lanes_per_row(C);
+  const long waves = (R + 64 / lpr - 1) / (64 / lpr);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(grid_for(waves, 4, 8192)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                              gamma, beta, (T*)y, mr, (long)R, C, lpr, eps, (const T*)add, scale, (long)rows_per_image, (T*)xsum););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -58,6 +58,28 @@ class _Rand:
         return torch.rand((len(probs), batch), device=device).add_(keep).floor_().div_(keep)
 
 
+FUSE_ADD_LN = os.environ.get("JG_FUSE_ADD_LN", "1") != "0"      # round 6: residual sum (+ DropPath scale) inside the LayerNorm pass that reads it
+
+
+class _Pending:
+    """identity + branch * scale[b], not yet formed"""
+
+    __slots__ = ("identity", "branch", "scale")
+
+    def __init__(self, identity, branch, scale):
+        self.identity, self.branch, self.scale = identity, branch, scale
+
+    def materialize(self):
+        return _add(self.identity, self.branch) if self.scale is None else S.scale_add(self.branch, self.scale, self.identity)
+
+
+def _ln_id(x, norm):
+    """(residual input, LayerNorm(it)) for a tensor or a pending sum"""
+    if isinstance(x, _Pending):
+        return S.add_layer_norm_id(x.identity, x.branch, x.scale, norm.weight, norm.bias, 1e-6)
+    return S.layer_norm_id(x, norm.weight, norm.bias, 1e-6)
+
+
 class DropPath(nn.Module):
     """backbone.py:700-726; here fused with the residual add: identity + x * floor(keep + U) / keep."""
 
@@ -65,6 +87,19 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
         self._rand = [rand]
+
+    def pending(self, identity, x):
+        """(identity, branch, scale or None) of `add` WITHOUT the launch: the LayerNorm that consumes the sum forms it in its own pass
+        (S.add_layer_norm_id, round 6); consumes this pass's scale row exactly as `add` does"""
+        if self.drop_prob == 0.0 or not self.training:
+            return _Pending(identity, x, None)
+        pre = getattr(self, "_scale_row", None)
+        if pre is not None:
+            self._scale_row = None
+            return _Pending(identity, x, pre)
+        keep = 1.0 - self.drop_prob
+        u = self._rand[0]((x.shape[0],), x.device)
+        return _Pending(identity, x, (keep + u).floor() / keep)
 
     def add(self, identity, x):
         if self.drop_prob == 0.0 or not self.training:
@@ -125,12 +160,14 @@ class EfficientMultiheadAttention(nn.Module):
             self.sr = JGConv2d(embed_dims, embed_dims, sr_ratio, padding=0, stride=sr_ratio)
             self.norm = nn.LayerNorm(embed_dims, eps=1e-6)
 
-    def forward(self, x, hw, identity):
+    def forward(self, x, hw, identity, defer=False):
         B, N, C = x.shape
         kv = x
         if self.sr_ratio > 1:
             kv = self.sr(x.view(B, hw[0], hw[1], C))
             kv = S.layer_norm(kv.view(B, -1, C), self.norm.weight, self.norm.bias, self.norm.eps)
+        if defer:
+            return self.dropout_layer.pending(identity, self.attn(x, kv))
         return self.dropout_layer.add(identity, self.attn(x, kv))
 
 
@@ -147,11 +184,13 @@ class MixFFN(nn.Module):
         self.layers = nn.Sequential(fc1, pe, nn.GELU(), nn.Dropout(0.0), fc2, nn.Dropout(0.0))
         self.dropout_layer = DropPath(drop_path, rand)
 
-    def forward(self, x, hw, identity):
+    def forward(self, x, hw, identity, defer=False):
         B, N, C = x.shape
         h = self.layers[0](x.view(B, hw[0], hw[1], C))
         h = S.dwconv3x3(h, self.layers[1].weight, self.layers[1].bias, gelu=True)
         h = self.layers[4](h)
+        if defer:
+            return self.dropout_layer.pending(identity, h.view(B, N, C))
         return self.dropout_layer.add(identity, h.view(B, N, C))
 
 
@@ -164,11 +203,14 @@ class TransformerEncoderLayer(nn.Module):
         self.ffn = MixFFN(embed_dims, feedforward_channels, drop_path_rate, rand)
 
     def forward(self, x, hw):
-        # (identity, norm(x)) from one node: the identity path's gradient is added inside the LayerNorm backward pass
-        xi, h = S.layer_norm_id(x, self.norm1.weight, self.norm1.bias, 1e-6)
-        x = self.attn(h, hw, identity=xi)
-        xi, h = S.layer_norm_id(x, self.norm2.weight, self.norm2.bias, 1e-6)
-        return self.ffn(h, hw, identity=xi)
+        # (identity, norm(x)) from one node: the identity path's gradient is added inside the LayerNorm backward pass.  Round 6: the two residual
+        # sums of the block are not launched: each is handed on as a pending (identity, branch, DropPath scale) and formed inside the LayerNorm
+        # pass that reads it -- norm2 here, norm1 of the next block or the stage's final norm for the block's output
+        defer = FUSE_ADD_LN and not ops.TORCH_OPS_BOUNDARY
+        xi, h = _ln_id(x, self.norm1)
+        x = self.attn(h, hw, identity=xi, defer=defer)
+        xi, h = _ln_id(x, self.norm2)
+        return self.ffn(h, hw, identity=xi, defer=defer)
 
 
 class PatchEmbed(nn.Module):
@@ -217,7 +259,10 @@ class MixVisionTransformer(nn.Module):
             x, hw = layer[0](x)
             for block in layer[1]:
                 x = block(x, hw)
-            x = S.layer_norm(x, layer[2].weight, layer[2].bias, 1e-6)
+            if isinstance(x, _Pending):         # the last block's output sum is formed inside the stage's final LayerNorm pass
+                x = S.add_layer_norm_id(x.identity, x.branch, x.scale, layer[2].weight, layer[2].bias, 1e-6)[1]
+            else:
+                x = S.layer_norm(x, layer[2].weight, layer[2].bias, 1e-6)
             x = x.view(x.shape[0], hw[0], hw[1], x.shape[-1])
             if i in self.out_indices:
                 outs.append(x)

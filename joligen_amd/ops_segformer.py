@@ -94,6 +94,61 @@ class _LayerNormIdFn(JGFunction):
         return dx, None, None, None
 
 
+class _AddLayerNormIdFn(JGFunction):
+    """(y, LayerNorm(y)) with y = identity + branch * scale[image]: the DropPath-scaled residual sum and the LayerNorm behind it in one pass
+    (jg_layernorm_fwd_add).  Backward: the LayerNorm backward with the identity output's gradient added in its pass, as _LayerNormIdFn; the
+    result is the gradient of `identity` and, times the scale, of `branch`."""
+
+    @staticmethod
+    def forward(ctx, identity, branch, scale, weight, bias, eps):
+        _require_cuda(identity, branch)
+        identity, branch = identity.contiguous(), branch.contiguous()
+        C = identity.shape[-1]
+        R = identity.numel() // C
+        B = identity.shape[0]
+        y = torch.empty_like(identity)
+        h = torch.empty_like(identity)
+        mr = torch.empty((R, 2), device=identity.device, dtype=torch.float32)
+        sc = None if scale is None else scale.contiguous().float()
+        check(_lib.lib().jg_layernorm_fwd_add(_dt(identity), identity.data_ptr(), branch.data_ptr(), _p(sc), R // B, y.data_ptr(), weight.data_ptr(),
+                                              bias.data_ptr(), h.data_ptr(), mr.data_ptr(), R, C, eps, _st()), "jg_layernorm_fwd_add")
+        ctx.save_for_backward(y, mr, weight, sc)
+        ctx.gw, ctx.gb = weight.grad, bias.grad
+        return y, h
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, did, dh):
+        y, mr, weight, sc = ctx.saved_tensors
+        C = y.shape[-1]
+        R = y.numel() // C
+        B = y.shape[0]
+        if dh is None:
+            dtot = did
+        else:
+            dh = dh.contiguous()
+            want_p = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+            if want_p and (ctx.gw is None or ctx.gb is None):
+                raise RuntimeError("LayerNorm parameters have no arena-backed .grad")
+            dtot = torch.empty_like(y)
+            res = did.contiguous() if did is not None else None
+            check(_lib.lib().jg_layernorm_bwd_add(_dt(y), y.data_ptr(), dh.data_ptr(), weight.data_ptr(), mr.data_ptr(), _p(res), dtot.data_ptr(),
+                                                  _p(ctx.gw) if want_p else None, _p(ctx.gb) if want_p else None, R, C, _st()), "jg_layernorm_bwd_add")
+        dbranch = None
+        if ctx.needs_input_grad[1] and dtot is not None:
+            if sc is None:
+                dbranch = dtot
+            else:
+                dbranch = torch.empty_like(dtot)
+                check(_lib.lib().jg_scale(_dt(dtot), dtot.data_ptr(), sc.data_ptr(), None, dbranch.data_ptr(), B, R // B, C, 0, _st()), "jg_scale")
+        return (dtot if ctx.needs_input_grad[0] else None), dbranch, None, None, None, None
+
+
+def add_layer_norm_id(identity, branch, scale, weight, bias, eps=1e-6):
+    """(y, nn.LayerNorm(C, eps)(y)) for y = identity + branch * scale[b] (scale None: plain sum): one launch for the residual sum and the norm"""
+    return _AddLayerNormIdFn.apply(identity, branch, scale, weight, bias, float(eps))
+
+
 def layer_norm_id(x, weight, bias, eps=1e-6):
     """(x, nn.LayerNorm(C, eps)(x)): use the FIRST output as the residual branch's identity so that its gradient is summed into the
     LayerNorm backward's pass."""

@@ -79,6 +79,32 @@ def test_layernorm_with_identity_gradient(R, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,N,C,scaled", [(4, 1024, 32, True), (3, 77, 160, True), (2, 64, 256, False), (5, 3, 8, True)])
+def test_add_layer_norm_id(B, N, C, scaled, dtype):
+    """round 6 (`jg_layernorm_fwd_add`): y = identity + branch * scale[image] and LayerNorm(y) in one pass, both outputs and every gradient
+    (identity, branch, gamma, beta) against torch autograd of the same expression on the 16-bit-rounded sum."""
+    from joligen_amd import ops_segformer as S
+    ident, br = rnd((B, N, C), dtype, 90), rnd((B, N, C), dtype, 91)
+    sc = (torch.rand(B, generator=torch.Generator().manual_seed(3)) > 0.3).float() / 0.7 if scaled else None
+    g_, b_ = rnd((C,), torch.float32, 92) * 0.3 + 1.0, rnd((C,), torch.float32, 93) * 0.1
+    gy, gh = rnd((B, N, C), dtype, 94), rnd((B, N, C), dtype, 95)
+    ir, brr = ident.float().requires_grad_(True), br.float().requires_grad_(True)
+    gr, btr = g_.clone().requires_grad_(True), b_.clone().requires_grad_(True)
+    yr = ir + brr * (sc.view(B, 1, 1) if scaled else 1.0)
+    hr = F.layer_norm(yr, (C,), gr, btr, 1e-6)
+    (yr * gy.float()).sum().backward(retain_graph=True)
+    (hr * gh.float()).sum().backward()
+    idv, bd = ident.to(D0).requires_grad_(True), br.to(D0).requires_grad_(True)
+    gp, bp = param(g_), param(b_)
+    y, h = S.add_layer_norm_id(idv, bd, None if sc is None else sc.to(D0), gp, bp, 1e-6)
+    torch.autograd.backward([y, h], [gy.to(D0), gh.to(D0)])
+    torch.cuda.synchronize()
+    assert relerr(y, yr) < TOL[dtype] and relerr(h, hr) < TOL[dtype]
+    assert relerr(idv.grad, ir.grad) < TOL[dtype] and relerr(bd.grad, brr.grad) < TOL[dtype]
+    assert relerr(gp.grad, gr.grad) < 2 * TOL[dtype] and relerr(bp.grad, btr.grad) < 2 * TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("two_phase", [True, False])
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 128), (1, 9, 7, 256), (2, 4, 4, 1024), (1, 32, 32, 64), (8, 64, 64, 128), (4, 16, 16, 640)])
 def test_dwconv3x3_gelu(B, H, W, C, dtype, two_phase, monkeypatch):
