@@ -463,6 +463,10 @@ int jg_layernorm_bwd(int dtype, const void* x, const void* dy, const float* gamm
  * of the ROUNDED sum, mr = (mean, rstd) per row.  Replaces jg_scale (with a residual) + jg_layernorm_fwd. */
 int jg_layernorm_fwd_add(int dtype, const void* x, const void* add, const float* scale, int64_t rows_per_image, void* xsum, const float* gamma,
                          const float* beta, void* y, float* mr, int64_t R, int C, float eps, jg_stream_t s);
+/* jg_layernorm_bwd_add with a second output dx2 = dx * scale[row / rows_per_image] (scale NULL: a copy): the gradient of the DropPath-scaled
+ * branch of the residual sum jg_layernorm_fwd_add formed (round 6; replaces the jg_scale launch over dx). */
+int jg_layernorm_bwd_add2(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, const void* res, void* dx,
+                          const float* scale, int64_t rows_per_image, void* dx2, float* dgamma, float* dbeta, int64_t R, int C, jg_stream_t s);
 int jg_layernorm_bwd_add(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, const void* res, void* dx, float* dgamma,
                          float* dbeta, int64_t R, int C, jg_stream_t s);
 int jg_dwconv3x3_fwd(int dtype, const void* x, const float* w, const float* bias, void* pre, void* y, int B, int H, int W, int C, int gelu,

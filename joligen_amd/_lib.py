@@ -146,6 +146,7 @@ SIGNATURES = {
     "jg_layernorm_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p],
     "jg_layernorm_bwd_add": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_p],
     "jg_layernorm_fwd_add": [c_i32, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_f32, c_p],
+    "jg_layernorm_bwd_add2": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_i32, c_p],
     "jg_dwconv3x3_fwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dwconv3x3_bwd": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_dwconv3x3_bwd_ws": [c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],

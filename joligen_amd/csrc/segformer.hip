@@ -197,7 +197,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, const float* __restrict__ gamma,
                                                             const float* __restrict__ mr, const T* __restrict__ res, T* __restrict__ dx,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, long R, int C, int lpr) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, long R, int C, int lpr,
+                                                            const float* __restrict__ scale = nullptr, long rows_per_image = 1, T* __restrict__ dx2 = nullptr) {
+  // scale / dx2 (round 6, jg_layernorm_bwd_add2): dx2 = dx * scale[image] as a second output -- the gradient of the DropPath-scaled branch of
+  // the residual sum this LayerNorm read (jg_layernorm_fwd_add), which used to be a jg_scale launch over dx
   __shared__ float s_red[2][512];
   const int lane = threadIdx.x & 63;
   const int sub = lane % lpr, rsub = lane / lpr, rpw = 64 / lpr;
@@ -256,7 +259,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         unpack8<T>(vr[u], r8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = r8[j] + rstd[u] * (gy[j] - m1 - xh[j] * m2);
-        *reinterpret_cast<uint4*>(dx + row[u] * C + sub * 8) = pack8<T>(o8);
+        const uint4 packed = pack8<T>(o8);
+        *reinterpret_cast<uint4*>(dx + row[u] * C + sub * 8) = packed;
+        if (dx2) {          // from the ROUNDED dx, as the separate launch computed it
+          const float sc = scale ? scale[row[u] / rows_per_image] : 1.f;
+          unpack8<T>(packed, o8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o8[j] *= sc;
+          *reinterpret_cast<uint4*>(dx2 + row[u] * C + sub * 8) = pack8<T>(o8);
+        }
       }
     }
   }
@@ -1570,6 +1581,16 @@ extern "C" int jg_layernorm_bwd_add(int dtype, const void* x, const void* dy, co
   const long waves = (R + 64 / lpr - 1) / (64 / lpr);
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, dgamma ? jg_tune(JG_TUNE_LN_BWD_CAP) : 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
                                               (const T*)dy, gamma, mr, (const T*)res, (T*)dx, dgamma, dbeta, (long)R, C, lpr););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+extern "C" int jg_layernorm_bwd_add2(int dtype, const void* x, const void* dy, const float* gamma, const float* mr, const void* res, void* dx,
+                                     const float* scale, int64_t rows_per_image, void* dx2, float* dgamma, float* dbeta, int64_t R, int C, jg_stream_t s) {
+  if (!x || !dy || !gamma || !mr || !dx || !dx2 || R < 1 || C < 8 || C % 8 || C > 512 || (!dgamma != !dbeta) || rows_per_image < 1) return JG_ERR_BAD_ARG;
+  const int lpr = lanes_per_row(C);
+  const long waves = (R + 64 / lpr - 1) / (64 / lpr);
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(grid_for(waves, 4, dgamma ? jg_tune(JG_TUNE_LN_BWD_CAP) : 1024)), dim3(256), 0, (hipStream_t)s, (const T*)x,
+                                              (const T*)dy, gamma, mr, (const T*)res, (T*)dx, dgamma, dbeta, (long)R, C, lpr, scale, (long)rows_per_image, (T*)dx2););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -132,6 +132,12 @@ class _AddLayerNormIdFn(JGFunction):
                 raise RuntimeError("LayerNorm parameters have no arena-backed .grad")
             dtot = torch.empty_like(y)
             res = did.contiguous() if did is not None else None
+            if sc is not None and ctx.needs_input_grad[1]:          # the scaled branch gradient from the same pass
+                dbranch = torch.empty_like(y)
+                check(_lib.lib().jg_layernorm_bwd_add2(_dt(y), y.data_ptr(), dh.data_ptr(), weight.data_ptr(), mr.data_ptr(), _p(res), dtot.data_ptr(),
+                                                       sc.data_ptr(), R // B, dbranch.data_ptr(), _p(ctx.gw) if want_p else None,
+                                                       _p(ctx.gb) if want_p else None, R, C, _st()), "jg_layernorm_bwd_add2")
+                return (dtot if ctx.needs_input_grad[0] else None), dbranch, None, None, None, None
             check(_lib.lib().jg_layernorm_bwd_add(_dt(y), y.data_ptr(), dh.data_ptr(), weight.data_ptr(), mr.data_ptr(), _p(res), dtot.data_ptr(),
                                                   _p(ctx.gw) if want_p else None, _p(ctx.gb) if want_p else None, R, C, _st()), "jg_layernorm_bwd_add")
         dbranch = None
