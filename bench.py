@@ -460,7 +460,10 @@ def compact_leg(leg):
     """An extra leg (cut / cut_effnet / c4_512 / cm) as the few numbers a reader of the record needs; the full object is in the detail line."""
     if not isinstance(leg, dict):
         return leg
-    out = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "dtype", "step_driver", "graph_canary", "step_frac_of_mfma_peak", "error") if k in leg}
+    # ms_per_step_median next to the mean: the pool's boxes are shared (another tenant's job showed 183 GB of VRAM in use on an "idle" box and one
+    # cm leg in ~20 read 327 ms per step against 121): the median of the same K steps says whether a mean is a stall or the step
+    out = {k: leg[k] for k in ("value", "unit", "ms_per_step", "ms_per_step_median", "steps", "dtype", "step_driver", "graph_canary", "step_frac_of_mfma_peak", "error")
+           if k in leg}
     r = leg.get("roofline")
     if r:
         out["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us")}
