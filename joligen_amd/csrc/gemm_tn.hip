@@ -859,7 +859,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_tn_big_group_kernel(const WgGrou
 
 // the big tile pays where a 128 x 128 tiling would re-read: at least 256 output channels and 256 columns, and a long reduction
 static inline bool wg_big_ok(const WgP& p) {
-  return jg_tune(JG_TUNE_WGRAD_BIG) != 0 && p.Cout >= 256 && p.Ktot >= 256 && p.Mpix >= 8192;
+  // (its epilogue is the fp32-atomic accumulation only: the store modes of the batched attention products stay on the 128 x 128 tile)
+  return jg_tune(JG_TUNE_WGRAD_BIG) != 0 && p.out_mode == JG_OUT_ATOMIC_F32 && p.Cout >= 256 && p.Ktot >= 256 && p.Mpix >= 8192;
 }
 
 }  // namespace

@@ -2223,6 +2223,13 @@ def test_wgrad_big_tile(case, dtype):
         assert relerr(dw, ref_w) < TOL[dtype], (key, relerr(dw, ref_w))
         assert relerr(db, br.grad[:real]) < TOL[dtype], (key, relerr(db, br.grad[:real]))
     assert relerr(outs[(1, False)][0], outs[(0, False)][0]) < 1e-4 and relerr(outs[(1, True)][0], outs[(1, False)][0]) < 1e-4
+    # the STORE modes (batched attention products) never take the big tile -- its epilogue only accumulates: a store into a poisoned buffer
+    if k == 1 and real == Cout:
+        dws = torch.full((Cout, Cin), float("nan"), device=dev())
+        ops.wgrad_tn(gyd, xd, dws, B=B, H=H, W=W, Cin=Cin, Cout=Cout, R=1, S=1, pad=0, stride=1, Ho=Ho, Wo=Wo, lddy=Cout, ldx=Cin, lddw=Cin, splitk=1,
+                     out_mode=_lib.JG_OUT_STORE_F32)
+        torch.cuda.synchronize()
+        assert _lib.lib().jg_last_kernel().decode() != "wgrad_tn_big_kernel" and relerr(dws.cpu(), ref_w) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
