@@ -719,6 +719,14 @@ def main():
     if rank == 0 and world == 1 and args.model == "palette" and not args.no_cut_leg and not args.force_exchange:
         # the CUT half of BASELINE's metric ("DDPM UNet & CUT G+D step") and configs[3] / configs[4] on the same line, each in its own
         # process and never at the palette line's expense
+        # the palette numbers are taken: hand the parent's cached device memory back before the legs allocate theirs (the pool's boxes are shared --
+        # 183 GB of VRAM in use by another tenant on an "idle" box -- and a cm leg (batch 64) that has to evict its way to 100 GB read one step of
+        # 15 s among twenty of 121 ms: mean 872 ms, median 121 ms)
+        model = None
+        import gc
+
+        gc.collect()
+        torch.cuda.empty_cache()
         print("[bench] cut leg", file=sys.stderr, flush=True)
         cut = leg_subprocess("cut", args.no_cpu_baseline)
         for key in list(EXTRA_LEGS) + ["cut_effnet"]:
