@@ -963,17 +963,20 @@ def test_cut_step_through_torch_ops(dtype_name, driver, which):
         m1 = {f"{n}.{k}": v.detach().double().cpu() for n in m.model_names for k, v in m._net(n).arena.named_views(m._net(n).arena.m).items()}
         return losses, m1                          # Adam's first moment after one step = (1 - beta1) x the gradient of every parameter
 
-    # the boundary runs SegformerHead in its concatenating form (the commuted form of round 6 is built from ctypes-only nodes and moves the 16-bit
-    # rounding points): both sides of this comparison use that form, so that it stays a comparison of the same kernels on the same operands
+    # the boundary runs SegformerHead in its concatenating form and the 7x7 head on the 7x7 kernels (the commuted / row-packed forms of round 6 are
+    # built from ctypes-only nodes and move the 16-bit rounding points): both sides of this comparison use those forms, so that it stays a
+    # comparison of the same kernels on the same operands
     from joligen_amd.modules import segformer as _seg
 
     keep_commute, _seg.HEAD_COMMUTE = _seg.HEAD_COMMUTE, False
+    keep_head7, ops.HEAD7_PACKED = ops.HEAD7_PACKED, False          # (likewise the row-packed 7x7 head of the resnet generator: ctypes-only)
     try:
         la, ga = run(False)
         la2, ga2 = run(False)
         lo, go = run(True)
     finally:
         _seg.HEAD_COMMUTE = keep_commute
+        ops.HEAD7_PACKED = keep_head7
     keys = [k for k in ga if float(ga[k].norm()) > 0]
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-300))
     floor_l = max(abs(la2[k] - la[k]) / abs(la[k]) for k in la)
