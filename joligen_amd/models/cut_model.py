@@ -556,12 +556,15 @@ class CUTModel(BaseModel):
             self.real_A, self.real_B = st["real_A"], st["real_B"]
             gf, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(gf, capture_error_mode="thread_local"):
+                ops.zero_pool_reset(self.device, True)          # the zeroed reduction rows of this graph come out of a chunk it clears itself
                 self._forward_core()
                 self.compute_G_loss()
             st["outs"] = {k: getattr(self, k) for k in self._g_outputs()}
             with torch.cuda.graph(gb, pool=gf.pool(), capture_error_mode="thread_local"):
+                ops.zero_pool_reset(self.device, True)
                 with ops.deferred_wgrads(self._wgrad_stream()):     # the ~190 weight gradients of the generator leave as grouped launches on a forked stream
                     (self.loss_G_tot / its).backward(retain_graph=True)
+            ops.zero_pool_reset(self.device)
             st["fwd"], st["bwd"] = gf, gb
 
             def once():
@@ -586,6 +589,7 @@ class CUTModel(BaseModel):
             if not ok:
                 raise RuntimeError(f"replays of the generator graphs disagree after interleaved eager launches ({first.tolist()} vs {second.tolist()})")
         except Exception as e:
+            ops.zero_pool_reset(self.device)
             warnings.warn(f"jg_graph_G: the generator half stays eager ({e})")
             self.step_driver_note = (self.step_driver_note + "; " if self.step_driver_note else "") + f"generator graph dropped: {e}"
             self._gg_failed = True
@@ -684,7 +688,9 @@ class CUTModel(BaseModel):
         try:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):      # other threads (pinned staging, checkpoint writer) may allocate
+                ops.zero_pool_reset(self.device, True)
                 st["vals"], st["tot"] = self._d_half_body(st["real"], st["fakes"], its)
+            ops.zero_pool_reset(self.device)
             graph.replay()
             first = st["tot"].detach().clone()
             burst = torch.zeros(64, device=self.device)
@@ -707,6 +713,7 @@ class CUTModel(BaseModel):
                 raise RuntimeError(f"replays of an untouched graph disagree after interleaved eager launches ({float(first)} vs {float(second)}): "
                                    "export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first HIP call")
         except Exception as e:
+            ops.zero_pool_reset(self.device)
             warnings.warn(f"jg_graph_D: the discriminator half stays eager ({e})")
             self.step_driver_note = f"graph dropped: {e}"
             self._dg_failed = True

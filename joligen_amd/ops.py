@@ -650,6 +650,46 @@ def reflect_conv2d(x, meta: ConvMeta):
 # ======================================================================================
 # GroupNorm (+FiLM, +SiLU) / InstanceNorm1d
 # ======================================================================================
+# Zeroed fp32 scratch for the accumulating reductions of the norm nodes (round 6): jg_gn_stats / jg_gn_bwd_reduce clear their [B, C, 2] rows with a
+# hipMemsetAsync of their own -- one 5 us launch per norm and direction, 245 per step of the mobile ResNet generator.  The rows now come out of a
+# chunk that ONE torch.zeros clears (4 MB, ~60 norms); a chunk lives as long as any row handed out of it.
+ZERO_POOL = os.environ.get("JG_ZERO_POOL", "1") != "0"
+_ZERO_CHUNK = {}
+
+
+def zero_pool_reset(device=None, allocate=False):
+    """forget the current chunk(s); allocate: start a fresh one NOW on the current stream.  A hipGraph capture calls this as its first action
+    (allocate=True: the chunk's clear becomes a node of THAT graph and is replayed with it) and again after the capture (the eager code must
+    not take rows out of a captured chunk, whose clear it does not replay)."""
+    for k in [k for k in _ZERO_CHUNK if device is None or k[0] == device]:
+        del _ZERO_CHUNK[k]
+    if allocate and ZERO_POOL and device is not None:
+        _ZERO_CHUNK[(device, torch.cuda.current_stream(device).cuda_stream)] = [torch.zeros(1 << 20, device=device, dtype=torch.float32), 0,
+                                                                               torch.cuda.is_current_stream_capturing()]
+
+
+def zeros_f32(n, device):
+    """n zeroed fp32 values (a view of a pooled chunk; never written by anyone else).  Chunks are per STREAM: a row is used on the stream
+    that enqueued its chunk's clear (a forked branch of a capture gets a chunk of its own, cleared on that branch).  Inside a capture that did
+    not prepare a chunk (zero_pool_reset) every request is a torch.zeros of its own: a row is only ever cleared by a launch of the graph
+    that accumulates into it."""
+    n = (int(n) + 63) // 64 * 64
+    if not ZERO_POOL or n > (1 << 18) or device.type != "cuda":
+        return torch.zeros(n, device=device, dtype=torch.float32)
+    cap = torch.cuda.is_current_stream_capturing()
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    st = _ZERO_CHUNK.get(key)
+    if st is not None and st[2] != cap:
+        st = None
+    if st is None and cap and not any(v[2] for v in _ZERO_CHUNK.values()):
+        return torch.zeros(n, device=device, dtype=torch.float32)          # a capture that did not opt in
+    if st is None or st[1] + n > st[0].numel():
+        st = _ZERO_CHUNK[key] = [torch.zeros(1 << 20, device=device, dtype=torch.float32), 0, cap]
+    out = st[0][st[1]:st[1] + n]
+    st[1] += n
+    return out
+
+
 class _GroupNormFn(JGFunction):
     @staticmethod
     def forward(ctx, x, gamma, beta, film, G, act, eps, sums=None):
@@ -663,8 +703,8 @@ class _GroupNormFn(JGFunction):
         y = torch.empty_like(x)
         ldfilm = film.stride(0) if film is not None else 0
         if sums is None:            # (given: the producing convolution's epilogue has accumulated them, ops.conv2d_stats)
-            sums = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
-            check(L.jg_gn_stats(dt, x.data_ptr(), sums.data_ptr(), B, HW, C, st), "jg_gn_stats")
+            sums = zeros_f32(B * C * 2, dev)[:B * C * 2].view(B, C, 2)
+            check(L.jg_gn_stats_ld(dt, x.data_ptr(), C, sums.data_ptr(), C, B, HW, C, st), "jg_gn_stats_ld")
         check(L.jg_gn_coef(sums.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, ab.data_ptr(), mr.data_ptr(), B, HW, C,
                            G, eps, st), "jg_gn_coef")
         check(L.jg_gn_apply(dt, x.data_ptr(), ab.data_ptr(), y.data_ptr(), B, HW, C, act, st), "jg_gn_apply")
@@ -681,7 +721,7 @@ class _GroupNormFn(JGFunction):
         B, C = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C)
         dev, st, dt = x.device, _st(), _dt(x)
-        red = torch.empty((B, C, 2), device=dev, dtype=torch.float32)
+        red = zeros_f32(B * C * 2, dev)[:B * C * 2].view(B, C, 2)
         pqr = torch.empty((B, C, 3), device=dev, dtype=torch.float32)
         want_film = film is not None and ctx.needs_input_grad[3]
         dfilm = torch.empty((B, 2 * C), device=dev, dtype=torch.float32) if want_film else None
@@ -690,8 +730,8 @@ class _GroupNormFn(JGFunction):
         if (gamma is not None and ctx.needs_input_grad[1] and dgamma is None):
             raise RuntimeError("norm weight has no arena-backed .grad")
         ldfilm = film.stride(0) if film is not None else 0
-        check(L.jg_gn_bwd_reduce(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), red.data_ptr(), B, HW, C, ctx.act, st),
-              "jg_gn_bwd_reduce")
+        check(L.jg_gn_bwd_reduce_ld_acc(dt, x.data_ptr(), C, dy.data_ptr(), C, ab.data_ptr(), red.data_ptr(), B, HW, C, ctx.act, st),
+              "jg_gn_bwd_reduce_ld_acc")
         check(L.jg_gn_bwd_coef(red.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, mr.data_ptr(), pqr.data_ptr(),
                                _p(dgamma), _p(dbeta), _p(dfilm), 2 * C, B, HW, C, ctx.G, st), "jg_gn_bwd_coef")
         dx = None

@@ -2173,6 +2173,57 @@ def test_conv3x3_few_output_channels_halo_kernel(dtype):
     assert relerr(y, y2) < TOL[dtype]
 
 
+def test_zero_pool_rows_inside_a_captured_graph_with_a_forked_branch():
+    """round 6 (`ops.zeros_f32`): the zeroed reduction rows of the norm nodes come out of pooled chunks -- one clear per ~60 norms instead of one
+    memset per norm and direction.  Inside a hipGraph the chunk's clear has to be a node of THAT graph, on the stream that uses the rows: a
+    capture with a forked branch, enough norms on both branches to exhaust a chunk on each, replayed three times against the eager result
+    (a chunk shared between the branches made replays return NaN on the resnet CUT generator: the branch's rows were cleared by the other
+    stream)."""
+    import joligen_amd
+    from joligen_amd import ops
+
+    if not joligen_amd.HIP_GRAPHS_SAFE:
+        pytest.skip("hipGraph replays are not safe in this process (HIP initialised before DEBUG_CLR_GRAPH_PACKET_CAPTURE=0)")
+    d = dev()
+    xa = torch.randn(32, 32, 32, 256, device=d, dtype=torch.bfloat16, requires_grad=True)
+    xb = torch.randn(32, 32, 32, 256, device=d, dtype=torch.bfloat16, requires_grad=True)
+    ga, gb = torch.randn_like(xa), torch.randn_like(xb)
+    side = torch.cuda.Stream(device=d)
+
+    def chain(x, g):
+        y = x
+        for _ in range(70):                       # 70 forward + 70 backward rows of 16384 floats: more than one 2^20-float chunk each way
+            y = ops.group_norm(y, 256, None, None, None, 2, 1e-5)
+        y.backward(g)
+
+    def both():
+        main = torch.cuda.current_stream(d)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            chain(xb, gb)
+        chain(xa, ga)
+        main.wait_stream(side)
+
+    for _ in range(2):
+        xa.grad = xb.grad = None
+        both()
+    torch.cuda.synchronize()
+    ea, eb = xa.grad.clone(), xb.grad.clone()
+    graph = torch.cuda.CUDAGraph()
+    xa.grad = xb.grad = None
+    with torch.cuda.graph(graph):
+        ops.zero_pool_reset(d, True)
+        both()
+    ops.zero_pool_reset(d)
+    for _ in range(3):
+        xa.grad.zero_()
+        xb.grad.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(xa.grad).all() and torch.isfinite(xb.grad).all()
+        assert relerr(xa.grad, ea) < 2e-2 and relerr(xb.grad, eb) < 2e-2, (relerr(xa.grad, ea), relerr(xb.grad, eb))
+
+
 BIG_WGRAD_CASES = [
     # B, H, W, Cin, Cout, k, pad, stride, real_cout
     (2, 64, 64, 256, 256, 1, 0, 1, 256),       # the point-wise layers of the mobile ResNet blocks: ONE 256 x 256 tile, split over pixels
