@@ -43,8 +43,11 @@ __host__ __device__ inline Map make_map_red(int C, int mult) {
 }
 inline int red_mult(int B, int HW, int C) {
   const Map m = make_map(C);
+  // fewest workgroups a larger chunk must still leave (JG_GN_RED_MINBLK, A/B; see the statistics pass below: the closing global atomics of every
+  // workgroup weigh more than an underfilled grid on the CUT generators' maps)
+  static const int minblk = getenv("JG_GN_RED_MINBLK") ? atoi(getenv("JG_GN_RED_MINBLK")) : 2048;
   for (int mult = 64; mult > 16; mult >>= 1)
-    if ((long)B * ((HW + m.pl * mult - 1) / (m.pl * mult)) >= 2048) return mult;
+    if ((long)B * ((HW + m.pl * mult - 1) / (m.pl * mult)) >= minblk) return mult;
   return 16;
 }
 
@@ -72,9 +75,10 @@ __device__ __forceinline__ void ordered_octet_sum(float* s_acc, const float (&s1
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, long ldx, float* __restrict__ sums, long ldsums,
-                                                       int HW, int C, int det) {
+                                                       int HW, int C, int det, int chunk) {
   extern __shared__ float s_acc[];  // [C][2] (+ [256][16] in the deterministic form)
-  const Map mp = make_map(C);
+  Map mp = make_map(C);
+  mp.chunk = chunk;
   const int tid = threadIdx.x, b = blockIdx.y;
   for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.f;
   __syncthreads();
@@ -546,11 +550,22 @@ inline bool bad_shape(int B, int HW, int C) { return B < 1 || HW < 1 || C < 8 ||
 extern "C" int jg_gn_stats_ld(int dtype, const void* x, int64_t ldx, float* sums, int64_t ldsums, int B, int HW, int C,
                               jg_stream_t s) {
   if (!x || !sums || bad_shape(B, HW, C) || ldx < C || (ldx % 8) || ldsums < C) return JG_ERR_BAD_ARG;
-  const Map mp = make_map(C);
+  Map mp = make_map(C);
+  {      // pixels per thread of a statistics workgroup.  Round 6: 64 instead of 16 wherever that still leaves >= 256 workgroups -- every workgroup ends
+         // with 2 C global atomics, and on the CUT generators' maps (64 x 64 x 256 channels x 32 images) those, not the bytes, set the time:
+         // mobile_resnet_attn + [projected_d, basic] 370 -> 380 images/s, resnet + basic 476 -> 486 (8: 355, 32: 377, 128: 376, 256: 365); the
+         // UNet step does not change.  JG_GN_STATS_MULT overrides (A/B).
+    static const int forced = getenv("JG_GN_STATS_MULT") ? atoi(getenv("JG_GN_STATS_MULT")) : 0;
+    int mult = 16;
+    for (int m = 64; m > 16; m >>= 1)
+      if ((long)B * ((HW + mp.pl * m - 1) / (mp.pl * m)) >= 256) { mult = m; break; }
+    if (forced >= 4 && forced <= 256) mult = forced;
+    mp.chunk = mp.pl * mult;
+  }
   const int det = jg_tune(JG_TUNE_DETERMINISTIC) != 0;
   dim3 grid(det ? 1 : (HW + mp.chunk - 1) / mp.chunk, B);
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((gn_stats_kernel<T>), grid, dim3(256), (2 * C + (det ? 4096 : 0)) * sizeof(float), (hipStream_t)s,
-                                              (const T*)x, (long)ldx, sums, (long)ldsums, HW, C, det););
+                                              (const T*)x, (long)ldx, sums, (long)ldsums, HW, C, det, mp.chunk););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
