@@ -2224,6 +2224,24 @@ def test_zero_pool_rows_inside_a_captured_graph_with_a_forked_branch():
         assert relerr(xa.grad, ea) < 2e-2 and relerr(xb.grad, eb) < 2e-2, (relerr(xa.grad, ea), relerr(xb.grad, eb))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("P,C,ld", [(65536, 64, 64), (8192, 128, 128), (5000, 24, 32), (4096, 2048, 2048), (100, 64, 64), (9000, 12, 16)])
+def test_channel_sum(P, C, ld, dtype):
+    """jg_channel_sum (bias gradient of a transposed convolution): the 16-byte-load form of round 6 (C % 8 == 0, >= 4096 pixels) and the
+    element-wise form (small or ragged shapes) against an fp64 column sum; accumulates onto `out` with a scale."""
+    from joligen_amd import _lib
+    from joligen_amd.ops import _st
+
+    x = rnd((P, ld), dtype, 96)
+    out0 = torch.randn(C, generator=torch.Generator().manual_seed(7))
+    ref = out0.double() + 0.5 * x[:, :C].double().sum(0)
+    xd, out = x.to(dev()), out0.clone().to(dev())
+    code = _lib.JG_F16 if dtype == torch.float16 else _lib.JG_BF16
+    _lib.check(_lib.lib().jg_channel_sum(code, xd.data_ptr(), ld, out.data_ptr(), P, C, 0.5, _st()), "jg_channel_sum")
+    torch.cuda.synchronize()
+    assert relerr(out.double().cpu(), ref) < 1e-4, relerr(out.double().cpu(), ref)
+
+
 BIG_WGRAD_CASES = [
     # B, H, W, Cin, Cout, k, pad, stride, real_cout
     (2, 64, 64, 256, 256, 1, 0, 1, 256),       # the point-wise layers of the mobile ResNet blocks: ONE 256 x 256 tile, split over pixels
