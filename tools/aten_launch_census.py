@@ -12,8 +12,13 @@ from torch.profiler import ProfilerActivity, profile
 import bench
 
 which = sys.argv[1] if len(sys.argv) > 1 else "palette"
-if which == "cut":      # BASELINE configs[2] shape
+if which in ("cut", "mobile", "resnet"):      # BASELINE configs[2] shape; "mobile" / "resnet": the other selections
     args = argparse.Namespace(model="cut", efficient=1, size=256, batch=16, dtype="bf16", netG="segformer_attn_conv", netDs="projected_d,basic", force_exchange=False, proj="vitsmall")
+    if which == "mobile":
+        args.netG, args.proj = "mobile_resnet_attn", "efficientnet"
+    if which == "resnet":
+        args.netG, args.netDs, args.proj = "resnet", "basic", "efficientnet"
+    os.environ["JG_GRAPH_G"] = os.environ["JG_GRAPH_D"] = "0"      # eager: the profiler sees the ATen ops of the step
     import warnings
     warnings.simplefilter("ignore")
     model, opt = bench.build_model(args, 0, 0, 1)
