@@ -595,7 +595,7 @@ class _ReflectConv2dFn(JGFunction):
     the input gradient is the full convolution over the (H+2, W+2) padded domain folded back by the reflection's adjoint."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, meta):
+    def forward(ctx, x, weight, bias, meta, with_identity=False):
         _require_cuda(x)
         x = x.contiguous()
         B, H, W, Cin = x.shape
@@ -605,23 +605,32 @@ class _ReflectConv2dFn(JGFunction):
                 ldy=m.Cout, bias=m.bias_pad if m.bias_pad is not None else m.bias, pad_mode=1)
         ctx.save_for_backward(x)
         ctx.meta = m
+        ctx.with_identity = with_identity
+        if with_identity:          # (x, conv(x)): the gradient of the residual branch `x + f(x)` comes back through the first output
+            return x.view_as(x), y
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dy):
+    def backward(ctx, *grads):
         (x,) = ctx.saved_tensors
         m = ctx.meta
+        did, dy = grads if ctx.with_identity else (None, grads[0])
+        if dy is None:
+            return did, None, None, None, None
         dy = dy.contiguous()
         B, H, W, Cin = x.shape
         dx = None
         if ctx.needs_input_grad[0]:
             if REFLECT_DGRAD_HALO and m.Cout % 64 == 0 and Cin % 64 == 0:
                 # round 6: the interior of the padded-domain gradient IS the zero-padded input gradient on H x W (halo-resident kernel); the
-                # one-pixel ring of the reflection's adjoint is added by jg_reflect_dgrad_border (csrc/reflect_border.hip)
+                # one-pixel ring of the reflection's adjoint is added by jg_reflect_dgrad_border (csrc/reflect_border.hip).  The residual
+                # branch's gradient (with_identity) rides in as the residual addend of that convolution: no accumulation launch of autograd's
                 dx = torch.empty_like(x)
+                res = did.contiguous() if did is not None else None
+                did = None
                 conv_nt(dy, m.w16T, dx, B=B, H=H, W=W, Cin=m.Cout, Cout=Cin, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, ldx=m.Cout, ldw=9 * m.Cout,
-                        ldy=Cin)
+                        ldy=Cin, res=res, ldres=Cin)
                 ws = torch.empty(_lib.lib().jg_reflect_dgrad_border_ws_floats(B, H, W, Cin), device=x.device, dtype=torch.float32)
                 check(_lib.lib().jg_reflect_dgrad_border(_dt(dy), dy.data_ptr(), m.Cout, m.w16T.data_ptr(), dx.data_ptr(), Cin, ws.data_ptr(), B, H, W,
                                                          m.Cout, Cin, 1.0, _st()), "jg_reflect_dgrad_border")
@@ -637,7 +646,17 @@ class _ReflectConv2dFn(JGFunction):
             wgrad_tn(dy, x, wg, B=B, H=H, W=W, Cin=Cin, Cout=m.Cout, R=3, S=3, pad=1, stride=1, Ho=H, Wo=W, lddy=m.Cout, ldx=Cin,
                      lddw=9 * m.Cin_real, dbias=dbias, Cin_out=m.Cin_real, Cout_out=m.Cout_real,
                      splitk=_wgrad_splitk(((m.Cout + 127) // 128) * ((9 * Cin + 127) // 128), B * H * W), pad_mode=1)
-        return dx, None, None, None
+        if did is not None and dx is not None:          # (the fold path: no residual epilogue there)
+            dx = axpby(dx, 1.0, did.contiguous(), 1.0)
+        elif did is not None:
+            dx = did
+        return dx, None, None, None, None
+
+
+def reflect_conv2d_id(x, meta: ConvMeta):
+    """(x, conv(reflection_pad(x, 1))): use the first output as the identity of `x + f(x)` -- its gradient is added inside the input-gradient
+    convolution of this layer (round 6) instead of by autograd's accumulation kernel"""
+    return _ReflectConv2dFn.apply(x, meta.weight, meta.bias, meta, True)
 
 
 def reflect_conv2d(x, meta: ConvMeta):
