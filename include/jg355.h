@@ -179,6 +179,10 @@ int jg_conv2d_wgrad_tn_group(int dtype, const jg_wgrad_args* a, int n, jg_stream
 int jg_gn_stats(int dtype, const void* x, float* sums, int B, int HW, int C, jg_stream_t s);
 int jg_gn_coef(const float* sums, const float* gamma, const float* beta, const float* film, int64_t ldfilm,
                float* ab, float* mr, int B, int HW, int C, int G, float eps, jg_stream_t s);
+/* Round 6: jg_gn_apply_ld with a residual addend: y = act(a x + b) + add (add [B, HW, C], pixel stride ldadd) -- `x + self.conv_block(x)` of
+ * ResnetBlock / resnet_block_attn (resnet_generator.py:11-95, 350-385), whose branch ends in an InstanceNorm, in the norm's apply pass. */
+int jg_gn_apply_add(int dtype, const void* x, int64_t ldx, const float* ab, const void* add, int64_t ldadd, void* y, int64_t ldy, int B, int HW,
+                    int C, int act, jg_stream_t s);
 int jg_gn_apply(int dtype, const void* x, const float* ab, void* y, int B, int HW, int C, int act, jg_stream_t s);
 /* backward: red[B][C][2] = (sum du, sum du*x), du = dy * act'(a*x+b)      (zeroed inside)
  *   bwd_coef: pqr[B][C][3] so that dx = du*P + x*Q + R;  dgamma/dbeta += (atomic, may be NULL);

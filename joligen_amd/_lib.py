@@ -66,6 +66,7 @@ SIGNATURES = {
     "jg_gn_stats": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_p],
     "jg_gn_coef": [c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_f32, c_p],
     "jg_gn_apply": [c_i32, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_gn_apply_add": [c_i32, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_gn_bwd_reduce": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_p],
     "jg_subpixel_fold": [c_i32, c_p, c_p, c_i32, c_i32, c_p],
     "jg_transposed_fold": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],

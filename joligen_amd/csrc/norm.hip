@@ -179,7 +179,9 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const float* __restrict__ 
 
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ ab,
-                                                       T* __restrict__ y, long ldy, int HW, int C) {
+                                                       T* __restrict__ y, long ldy, int HW, int C, const T* __restrict__ add = nullptr, long ldadd = 0) {
+  // add (round 6, jg_gn_apply_add): y = act(a x + b) + add -- the residual sum `x + conv_block(x)` of a ResnetBlock, whose branch ends in an
+  // InstanceNorm (resnet_generator.py:11-95), formed in the norm's apply pass instead of by a sum kernel behind it
   const Map mp = make_map(C);
   const int tid = threadIdx.x, b = blockIdx.y;
   if (tid >= mp.active) return;
@@ -200,6 +202,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     for (int q = 0; q < 8; ++q) {
       const float u = a[q] * f[q] + bb[q];
       f[q] = act_f<ACT>(u);
+    }
+    if (add) {          // the ROUNDED norm output plus the addend, as the separate sum kernel computed it
+      float r8[8], g8[8];
+      unpack8<T>(pack8<T>(f), g8);
+      unpack8<T>(*reinterpret_cast<const uint4*>(add + (row0 + p) * ldadd + co * 8), r8);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = g8[q] + r8[q];
     }
     *reinterpret_cast<uint4*>(y + (row0 + p) * ldy + co * 8) = pack8<T>(f);
   };
@@ -611,6 +620,18 @@ extern "C" int jg_gn_apply_pool(int dtype, const void* x, int64_t ldx, const flo
   dim3 grid((HWo + mp.chunk - 1) / mp.chunk, B);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_apply_pool_kernel<T, ACT>), grid, dim3(256), 0, (hipStream_t)s,
                                                             (const T*)x, (long)ldx, ab, (T*)y, (long)ldy, HWo, W / 2, C, scale);););
+  JG_CHECK_LAUNCH();
+  return JG_OK;
+}
+
+extern "C" int jg_gn_apply_add(int dtype, const void* x, int64_t ldx, const float* ab, const void* add, int64_t ldadd, void* y, int64_t ldy, int B,
+                               int HW, int C, int act, jg_stream_t s) {
+  if (!x || !ab || !y || !add || bad_shape(B, HW, C) || ldx < C || ldy < C || ldadd < C || (ldx % 8) || (ldy % 8) || (ldadd % 8)) return JG_ERR_BAD_ARG;
+  const Map mp = make_map(C);
+  dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
+  hipStream_t st = (hipStream_t)s;
+  JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_apply_kernel<T, ACT>), grid, dim3(256), 0, st, (const T*)x,
+                                                            (long)ldx, ab, (T*)y, (long)ldy, HW, C, (const T*)add, (long)ldadd);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }

@@ -16,6 +16,8 @@ Built for G_padding_type = 'reflect', no spectral norm, no wavelet feature space
 """
 from __future__ import annotations
 
+import os
+
 import torch.nn as nn
 
 from .. import ops
@@ -25,11 +27,14 @@ from .layers import JGConv2d, JGConvTranspose2d
 from .resnet_generator import _AddFn
 
 
-def _in_act(x, norm, act, sums=None):
-    return ops.group_norm(x, x.shape[-1], None, None, None, act, norm.eps, sums=sums)
+NORM_ADD = os.environ.get("JG_NORM_ADD", "1") != "0"      # round 6: the residual sum of a block inside the apply pass of its last InstanceNorm
 
 
-def _conv_in_act(conv, x, norm, act):
+def _in_act(x, norm, act, sums=None, add=None):
+    return ops.group_norm(x, x.shape[-1], None, None, None, act, norm.eps, sums=sums, add=add)
+
+
+def _conv_in_act(conv, x, norm, act, add=None):
     """InstanceNorm2d(conv(x)) + act with the statistics taken in the convolution's epilogue where that form exists (ops.conv2d_stats)"""
     if isinstance(conv, SeparableConv2d):
         y, sums = conv(x, want_stats=True)
@@ -37,7 +42,7 @@ def _conv_in_act(conv, x, norm, act):
         y, sums = ops.conv2d_stats(x, conv.meta)
     else:
         y, sums = conv(x), None
-    return _in_act(y, norm, act, sums)
+    return _in_act(y, norm, act, sums, add)
 
 
 def _reflect_conv3(x, conv):
@@ -96,13 +101,14 @@ class resnet_block_attn(nn.Module):
         return conv(x) if self.mobile else _reflect_conv3(x, conv)
 
     def forward(self, x):
+        add = x if (NORM_ADD and not ops.TORCH_OPS_BOUNDARY) else None      # x + IN(conv2(.)) formed in that InstanceNorm's apply pass
         if self.mobile:             # the point-wise convolution's epilogue takes the statistics of the InstanceNorm behind it
             h = _conv_in_act(self.conv1, x, self.conv1_norm, JG_ACT_RELU)
-            h = _conv_in_act(self.conv2, h, self.conv2_norm, JG_ACT_NONE)
+            h = _conv_in_act(self.conv2, h, self.conv2_norm, JG_ACT_NONE, add)
         else:
             h = _in_act(self._conv(self.conv1, x), self.conv1_norm, JG_ACT_RELU)
-            h = _in_act(self._conv(self.conv2, h), self.conv2_norm, JG_ACT_NONE)
-        return _AddFn.apply(x, h)
+            h = _in_act(self._conv(self.conv2, h), self.conv2_norm, JG_ACT_NONE, add=add)
+        return h if add is not None else _AddFn.apply(x, h)
 
 
 class ResnetGenerator_attn(nn.Module):

@@ -71,6 +71,7 @@ def _run(seq, x, taps=None, feats=None, upto=None):
 
 
 RES_ID = os.environ.get("JG_RES_ID", "1") != "0"
+NORM_ADD = os.environ.get("JG_NORM_ADD", "1") != "0"
 
 
 class ResnetBlock(nn.Module):
@@ -88,13 +89,17 @@ class ResnetBlock(nn.Module):
                 c.bias = None
 
     def forward(self, x):
-        cb = self.conv_block
+        cb = list(self.conv_block)
         if RES_ID and FUSE_REFLECT and not ops.TORCH_OPS_BOUNDARY and ops.reflect_conv_ok(x, cb[1].meta):
             # round 6: the first convolution hands x back as the identity of the sum, so that the residual branch's gradient is added inside
             # its input-gradient launch (9 blocks x 2 backward passes of a 67 MB accumulation kernel per CUT step)
             xi, h = ops.reflect_conv2d_id(x, cb[1].meta)
-            return _AddFn.apply(xi, _run(list(cb)[2:], h))
-        return _AddFn.apply(x, _run(self.conv_block, x))     # out = x + conv_block(x)
+            h = _run(cb[2:-1], h)
+        else:
+            xi, h = x, _run(cb[:-1], x)
+        if NORM_ADD and not ops.TORCH_OPS_BOUNDARY:       # ... and the sum itself is formed in the apply pass of the block's last InstanceNorm
+            return ops.group_norm(h, h.shape[-1], None, None, None, JG_ACT_NONE, cb[-1].eps, add=xi)
+        return _AddFn.apply(xi, _run(cb[-1:], h))     # out = x + conv_block(x)
 
 
 class _AddFn(JGFunction):

@@ -711,7 +711,7 @@ def zeros_f32(n, device):
 
 class _GroupNormFn(JGFunction):
     @staticmethod
-    def forward(ctx, x, gamma, beta, film, G, act, eps, sums=None):
+    def forward(ctx, x, gamma, beta, film, G, act, eps, sums=None, add=None):
         _require_cuda(x)
         L = _lib.lib()
         B, C = x.shape[0], x.shape[-1]
@@ -726,7 +726,11 @@ class _GroupNormFn(JGFunction):
             check(L.jg_gn_stats_ld(dt, x.data_ptr(), C, sums.data_ptr(), C, B, HW, C, st), "jg_gn_stats_ld")
         check(L.jg_gn_coef(sums.data_ptr(), _p(gamma), _p(beta), _p(film), ldfilm, ab.data_ptr(), mr.data_ptr(), B, HW, C,
                            G, eps, st), "jg_gn_coef")
-        check(L.jg_gn_apply(dt, x.data_ptr(), ab.data_ptr(), y.data_ptr(), B, HW, C, act, st), "jg_gn_apply")
+        if add is not None:          # y = act(norm(x)) + add in the apply pass (round 6); d(add) = dy
+            add = add.contiguous()
+            check(L.jg_gn_apply_add(dt, x.data_ptr(), C, ab.data_ptr(), add.data_ptr(), C, y.data_ptr(), C, B, HW, C, act, st), "jg_gn_apply_add")
+        else:
+            check(L.jg_gn_apply(dt, x.data_ptr(), ab.data_ptr(), y.data_ptr(), B, HW, C, act, st), "jg_gn_apply")
         ctx.save_for_backward(x, ab, mr, gamma, beta, film)
         ctx.G, ctx.act = G, act
         return y
@@ -758,7 +762,7 @@ class _GroupNormFn(JGFunction):
             dx = torch.empty_like(x)
             check(L.jg_gn_bwd_apply(dt, x.data_ptr(), dy.data_ptr(), ab.data_ptr(), pqr.data_ptr(), dx.data_ptr(), B, HW,
                                     C, ctx.act, st), "jg_gn_bwd_apply")
-        return dx, None, None, dfilm, None, None, None, None
+        return dx, None, None, dfilm, None, None, None, None, (dy if ctx.needs_input_grad[8] else None)
 
 
 _GN_STATUS = {}
@@ -780,12 +784,13 @@ def check_gn_status():
             raise RuntimeError(f"jg_gn_bwd_fused: an inter-workgroup wait expired on cuda:{k} (results of that launch are invalid)")
 
 
-def group_norm(x, G, gamma=None, beta=None, film=None, act=JG_ACT_NONE, eps=1e-5, sums=None):
+def group_norm(x, G, gamma=None, beta=None, film=None, act=JG_ACT_NONE, eps=1e-5, sums=None, add=None):
     """act(GroupNorm_G(x) * gamma + beta [* (1 + scale) + shift]); statistics in fp32.  sums: the [B, C, 2] statistics of x where a
     convolution's epilogue has already taken them (conv2d_stats)."""
     if TORCH_OPS_BOUNDARY:
-        return torch.ops.jg355.group_norm_act(x, gamma, beta, film, G, act, eps)
-    return _GroupNormFn.apply(x, gamma, beta, film, G, act, eps, sums)
+        y = torch.ops.jg355.group_norm_act(x, gamma, beta, film, G, act, eps)
+        return y if add is None else y + add
+    return _GroupNormFn.apply(x, gamma, beta, film, G, act, eps, sums, add)
 
 
 # ======================================================================================

@@ -2242,6 +2242,28 @@ def test_channel_sum(P, C, ld, dtype):
     assert relerr(out.double().cpu(), ref) < 1e-4, relerr(out.double().cpu(), ref)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", [0, 2])
+def test_instance_norm_with_residual_addend(dtype, act):
+    """round 6 (`jg_gn_apply_add`, `ops.group_norm(..., add=)`): act(InstanceNorm(x)) + add in the norm's apply pass -- the residual sum of a
+    ResnetBlock -- output and both gradients against torch autograd."""
+    from joligen_amd import ops
+
+    B, C, H, W = 3, 64, 24, 20
+    x, add = rnd((B, C, H, W), dtype, 97), rnd((B, C, H, W), dtype, 98)
+    gy = rnd((B, C, H, W), dtype, 99)
+    xr, ar = x.float().requires_grad_(True), add.float().requires_grad_(True)
+    yr = F.instance_norm(xr, eps=1e-5)
+    yr = (torch.relu(yr) if act == 2 else yr) + ar
+    yr.backward(gy.float())
+    xd, ad = nhwc(x).to(dev()).requires_grad_(True), nhwc(add).to(dev()).requires_grad_(True)
+    y = ops.group_norm(xd, C, None, None, None, act, 1e-5, add=ad)
+    y.backward(nhwc(gy).to(dev()))
+    torch.cuda.synchronize()
+    assert relerr(nchw(y), yr.detach()) < TOL[dtype]
+    assert relerr(nchw(xd.grad), xr.grad) < 2 * TOL[dtype] and relerr(nchw(ad.grad), ar.grad) < TOL[dtype]
+
+
 BIG_WGRAD_CASES = [
     # B, H, W, Cin, Cout, k, pad, stride, real_cout
     (2, 64, 64, 256, 256, 1, 0, 1, 256),       # the point-wise layers of the mobile ResNet blocks: ONE 256 x 256 tile, split over pixels
