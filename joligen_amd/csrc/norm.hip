@@ -179,11 +179,14 @@ __global__ __launch_bounds__(256) void gn_coef_kernel(const float* __restrict__ 
 
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ ab,
-                                                       T* __restrict__ y, long ldy, int HW, int C, const T* __restrict__ add = nullptr, long ldadd = 0) {
+                                                       T* __restrict__ y, long ldy, int HW, int C, const T* __restrict__ add = nullptr, long ldadd = 0,
+                                                       int rev = 0) {
   // add (round 6, jg_gn_apply_add): y = act(a x + b) + add -- the residual sum `x + conv_block(x)` of a ResnetBlock, whose branch ends in an
   // InstanceNorm (resnet_generator.py:11-95), formed in the norm's apply pass instead of by a sum kernel behind it
   const Map mp = make_map(C);
-  const int tid = threadIdx.x, b = blockIdx.y;
+  // rev (JG_GN_REVERSE bit 2, A/B): from the END -- the producing convolution's last tiles may still be in the Infinity Cache, and the
+  // consumer behind (a convolution that starts at image 0) finds what this pass wrote last
+  const int tid = threadIdx.x, b = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
   if (tid >= mp.active) return;
   const int co = tid % mp.noct, pl = tid / mp.noct;
   float a[8], bb[8];
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
     a[q] = ab[((long)b * C + co * 8 + q) * 2];
     bb[q] = ab[((long)b * C + co * 8 + q) * 2 + 1];
   }
-  const int pbeg = blockIdx.x * mp.chunk;
+  const int pbeg = (rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * mp.chunk;
   const int pend = min(HW, pbeg + mp.chunk);
   const long row0 = (long)b * HW;
   auto one = [&](const uint4& v, int p) {
@@ -270,10 +273,12 @@ template <typename T, int ACT, bool UP = false>
 __global__ JG_GN_BWD_BOUNDS void gn_bwd_reduce_kernel(const T* __restrict__ x, long ldx, const T* __restrict__ dy,
                                                             long lddy, const float* __restrict__ ab,
                                                             float* __restrict__ red, int HW, int C, int mult, int W = 0,
-                                                            float dysc = 1.f, int det = 0) {
+                                                            float dysc = 1.f, int det = 0, int rev = 0) {
   extern __shared__ float s_acc[];  // [C][2] (+ [256][16] in the deterministic form, see gn_stats_kernel)
   const Map mp = make_map_red(C, mult);
-  const int tid = threadIdx.x, b = blockIdx.y;
+  // rev (JG_GN_REVERSE bit 1, A/B): walk from the END -- the tail of dy that the producing convolution wrote last may still sit in the
+  // 256 MB Infinity Cache; the apply pass behind then walks forward (bit 0 clear)
+  const int tid = threadIdx.x, b = rev ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
   for (int i = tid; i < 2 * C; i += 256) s_acc[i] = 0.f;
   __syncthreads();
   float s1[8], s2[8];
@@ -287,7 +292,7 @@ __global__ JG_GN_BWD_BOUNDS void gn_bwd_reduce_kernel(const T* __restrict__ x, l
       a[q] = ab[((long)b * C + co * 8 + q) * 2];
       bb[q] = ab[((long)b * C + co * 8 + q) * 2 + 1];
     }
-    const int pbeg = det ? 0 : blockIdx.x * mp.chunk;
+    const int pbeg = det ? 0 : (rev ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * mp.chunk;
     const int pend = det ? HW : min(HW, pbeg + mp.chunk);
     const long row0 = (long)b * HW;
     auto dy_row = [&](int p) -> long {
@@ -607,7 +612,8 @@ extern "C" int jg_gn_apply_ld(int dtype, const void* x, int64_t ldx, const float
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   hipStream_t st = (hipStream_t)s;
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_apply_kernel<T, ACT>), grid, dim3(256), 0, st, (const T*)x,
-                                                            (long)ldx, ab, (T*)y, (long)ldy, HW, C);););
+                                                            (long)ldx, ab, (T*)y, (long)ldy, HW, C, (const T*)nullptr, 0L,
+                                                            (jg_tune(JG_TUNE_GN_REVERSE) >> 2) & 1);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -652,7 +658,7 @@ static int gn_bwd_reduce_ld_impl(int dtype, const void* x, int64_t ldx, const vo
   dim3 grid(det ? 1 : (HW + mp.chunk - 1) / mp.chunk, B);
   const size_t shm = (2 * C + (det ? 4096 : 0)) * sizeof(float);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, ACT>), grid, dim3(256), shm, st, (const T*)x,
-                                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult, 0, 1.f, det);););
+                                                            (long)ldx, (const T*)dy, (long)lddy, ab, red, HW, C, mult, 0, 1.f, det, (jg_tune(JG_TUNE_GN_REVERSE) >> 1) & 1);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -679,7 +685,7 @@ static int gn_bwd_reduce_up_impl(int dtype, const void* x, int64_t ldx, const vo
   dim3 grid(det ? 1 : (HW + mp.chunk - 1) / mp.chunk, B);
   const size_t shm = (2 * C + (det ? 4096 : 0)) * sizeof(float);
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, ACT, true>), grid, dim3(256), shm, st, (const T*)x,
-                                                            (long)ldx, (const T*)dy_low, (long)lddy, ab, red, HW, C, mult, W, dy_scale, det);););
+                                                            (long)ldx, (const T*)dy_low, (long)lddy, ab, red, HW, C, mult, W, dy_scale, det, (jg_tune(JG_TUNE_GN_REVERSE) >> 1) & 1);););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -702,7 +708,7 @@ extern "C" int jg_gn_bwd_apply_up(int dtype, const void* x, int64_t ldx, const v
   if ((add1_low && (ldadd1 < C || ldadd1 % 8)) || (add2 && (ldadd2 < C || ldadd2 % 8))) return JG_ERR_BAD_ARG;
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  const int rev = jg_tune(JG_TUNE_GN_REVERSE);
+  const int rev = jg_tune(JG_TUNE_GN_REVERSE) & 1;
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, true>), grid, dim3(256), 0, (hipStream_t)s,
                                                             (const T*)x, (long)ldx, (const T*)dy_low, (long)lddy, ab, pqr, (T*)dx, (long)lddx,
                                                             (const T*)add1_low, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2, scale2,
@@ -726,7 +732,7 @@ extern "C" int jg_gn_bwd_apply_fc(int dtype, int up, const void* x, int64_t ldx,
   if ((add1 && (ldadd1 < C || ldadd1 % 8)) || (add2 && (ldadd2 < C || ldadd2 % 8))) return JG_ERR_BAD_ARG;
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
-  const int rev = jg_tune(JG_TUNE_GN_REVERSE);
+  const int rev = jg_tune(JG_TUNE_GN_REVERSE) & 1;
   GnFc fc{red, gamma, beta, film, mr, dgamma, dbeta, dfilm, (long)ldfilm, (long)lddfilm, G};
   if (up) {
     JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT, true, true>), grid, dim3(256), 0, (hipStream_t)s,
@@ -778,7 +784,7 @@ extern "C" int jg_gn_bwd_apply_ld(int dtype, const void* x, int64_t ldx, const v
   const Map mp = make_map(C);
   dim3 grid((HW + mp.chunk - 1) / mp.chunk, B);
   hipStream_t st = (hipStream_t)s;
-  const int rev = jg_tune(JG_TUNE_GN_REVERSE);
+  const int rev = jg_tune(JG_TUNE_GN_REVERSE) & 1;
   JG_DISPATCH_DTYPE(dtype, JG_DISPATCH_ACT(act, hipLaunchKernelGGL((gn_bwd_apply_kernel<T, ACT>), grid, dim3(256), 0, st, (const T*)x,
                                                             (long)ldx, (const T*)dy, (long)lddy, ab, pqr, (T*)dx, (long)lddx,
                                                             (const T*)add1, (long)ldadd1, scale1, (const T*)add2, (long)ldadd2,

@@ -1302,10 +1302,11 @@ __global__ __launch_bounds__(256) void attn_kv64_bwd_kernel(const T* __restrict_
   for (int it = 0; it < tiles_per_wave; ++it) {        // the same trip count for every wave: the barriers below are block-wide
     const int tile = (blockIdx.x * 4 + wave) * tiles_per_wave + it;
     const int q0 = tile * 64;
-    const bool live = tile < ntiles;
+    const bool live = tile < ntiles;      // wave-uniform: a wave without a tile only keeps the block's barriers company
     // ---- this tile's Q / dO rows (B operands), D and lse per query, transposed copies --------------------------------------------
     uint4 fq[4], fdo[4];
     float Dq[4], Lq[4];
+    if (live) {
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const int qi = q0 + qt * 16 + l15;
@@ -1353,7 +1354,9 @@ __global__ __launch_bounds__(256) void attn_kv64_bwd_kernel(const T* __restrict_
         *reinterpret_cast<uint2*>(sdS + qloc * KV64_LD + kt * 16 + kg * 4) = pack4<T>(dsv[0], dsv[1], dsv[2], dsv[3]);
       }
     }
+    }
     __syncthreads();
+    if (live) {
     // ---- second stage ----------------------------------------------------------------------------------------------------------------
     // dQ^T [c][q] = sum_k K^T[c][k] dS[q][k]
 #pragma unroll
@@ -1389,6 +1392,7 @@ __global__ __launch_bounds__(256) void attn_kv64_bwd_kernel(const T* __restrict_
           dVa[ct][kt] = Mfma<T>::run(da[qs], *reinterpret_cast<const uint4*>(sPt + (kt * 16 + l15) * KV64_LD + qs * 32 + kg * 8), dVa[ct][kt]);
         }
       }
+    }
     }
     __syncthreads();      // the next tile overwrites this wave's LDS tiles
   }
@@ -1470,6 +1474,7 @@ __global__ __launch_bounds__(256) void attn_kv64_fwd_kernel(const T* __restrict_
     const int q0 = tile * 64;
     const bool live = tile < ntiles;
     float linv[4];
+    if (live) {
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
       const int qi = q0 + qt * 16 + l15;
@@ -1504,7 +1509,9 @@ __global__ __launch_bounds__(256) void attn_kv64_fwd_kernel(const T* __restrict_
       linv[qt] = 1.0f / l;
       if (ok && lse && kg == 0) lse[((long)b * heads + h) * Tq + qi] = m + logf(l);
     }
+    }
     __syncthreads();
+    if (live) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       uint4 va[2];
@@ -1521,6 +1528,7 @@ __global__ __launch_bounds__(256) void attn_kv64_fwd_kernel(const T* __restrict_
           *reinterpret_cast<uint2*>(o + ((long)b * Tq + qi) * ldo + h * 32 + ct * 16 + kg * 4) =
               pack4<T>(acc[0] * linv[qt], acc[1] * linv[qt], acc[2] * linv[qt], acc[3] * linv[qt]);
       }
+    }
     }
     __syncthreads();
   }
@@ -1670,7 +1678,7 @@ extern "C" int jg_attn_smallkv_fwd(int dtype, const void* q, const void* k, cons
   if (Tkv <= 64) {
     const int ntiles = (Tq + 63) / 64;
     int tpw = 1;
-    while (tpw < 8 && (long)((ntiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) * heads * B >= 512) tpw *= 2;
+    while (tpw < 8 && 4 * tpw * 2 <= ntiles && (long)((ntiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) * heads * B >= 512) tpw *= 2;   // (never more tiles per block than exist: at T_q = 64, batch 64, 8 heads every wave ran 8 trips for ONE live tile)
     const dim3 gridm((ntiles + 4 * tpw - 1) / (4 * tpw), heads, B);
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_kv64_fwd_kernel<T>), gridm, dim3(256), 0, (hipStream_t)s, (const T*)q, (const T*)k,
                                                 (const T*)v, (T*)o, lse, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo, scale, tpw););
@@ -1698,7 +1706,7 @@ extern "C" int jg_attn_smallkv_bwd2(int dtype, const void* q, const void* k, con
     // matrix-core kernel: a wave per 64-query tile, 4 waves per block; tiles per wave chosen so that the grid still has >= 512 blocks
     const int ntiles = (Tq + 63) / 64;
     int tpw = 1;
-    while (tpw < 8 && (long)((ntiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) * heads * B >= 512) tpw *= 2;
+    while (tpw < 8 && 4 * tpw * 2 <= ntiles && (long)((ntiles + 4 * tpw * 2 - 1) / (4 * tpw * 2)) * heads * B >= 512) tpw *= 2;   // (never more tiles per block than exist: at T_q = 64, batch 64, 8 heads every wave ran 8 trips for ONE live tile)
     const dim3 gridm((ntiles + 4 * tpw - 1) / (4 * tpw), heads, B);
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((attn_kv64_bwd_kernel<T>), gridm, dim3(256), 0, st, (const T*)q, (const T*)k, (const T*)v,
                                                 (const T*)o, (const T*)dout, lse, (T*)dq, dkf, dvf, Tq, Tkv, heads, (long)ldq, (long)ldkv, (long)ldo,

@@ -49,6 +49,8 @@ class _ScaleGradFn(JGFunction):
 
 
 FORK_GAN_DEFAULT = True
+# round 6: the history-pool draws of the early-D drivers run on the discriminator stream (JG_POOL_SIDE=0: on the main stream, as in round 5)
+POOL_ON_SIDE = os.environ.get("JG_POOL_SIDE", "1") != "0"
 
 
 class CUTModel(BaseModel):
@@ -320,13 +322,19 @@ class CUTModel(BaseModel):
             counts.append(ids.shape[1])
         T, monce = o.alg_cut_nce_T, o.alg_cut_nce_loss == "monce"
         tot = [0.0, 0.0]
-        for Pl in sorted(set(counts)):
+
+        def one_set(Pl):
             ls = [i for i, c in enumerate(counts) if c == Pl]
             n = B * Pl
             q = torch.cat([rows[i][0] for i in ls], dim=0)                           # [layer][term][B * P_l] problems
             k = torch.cat([rows[i][1] for i in ls], dim=0)
             loss = ops.patch_nce_loss(q, k, 2 * len(ls) * B, T, P, monce).view(len(ls), 2, n)
-            m = loss.mean(dim=2).sum(dim=0) * o.alg_cut_lambda_NCE
+            return loss.mean(dim=2).sum(dim=0) * o.alg_cut_lambda_NCE
+
+        # (round 6, measured and removed: the smaller patch-count set on a forked third stream inside the graphs -- 20.0 -> 23.5 ms,
+        #  profiles/r06_fork_nce_sets_ab.txt; like the third fork of the key-side encoder pass, a second fork costs the graph more than it hides)
+        for Pl in sorted(set(counts)):
+            m = one_set(Pl)
             tot = [tot[0] + m[0], tot[1] + m[1]]
         L = len(self.nce_layers)
         self.loss_G_NCE, self.loss_G_NCE_Y = tot[0] / L, tot[1] / L
@@ -421,6 +429,13 @@ class CUTModel(BaseModel):
         image (a view of an earlier generator output, allocated on the main stream) and drops the last reference to it, so on the side
         stream the clone would only be queued when the caching allocator hands the block back to the main stream's pool (ADVICE r4:
         cross-stream use-after-free).  The drawn batches are then marked as in use by the side stream."""
+        if POOL_ON_SIDE:
+            # round 6: the draws themselves on the discriminator stream (~40 copy launches per step that graph B no longer queues behind):
+            # the pool marks every stored image it reads there (`reader_stream`), the fresh batch is marked here
+            self.fake_B.record_stream(side)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                return [self.fake_B_pool.query(self.fake_B, reader_stream=side).detach() for _ in self.discriminators_names]
         fakes = [self.fake_B_pool.query(self.fake_B).detach() for _ in self.discriminators_names]
         for f in fakes:
             f.record_stream(side)

@@ -16,9 +16,12 @@ class ImagePool:
             self.num_imgs = 0
             self.images = []
 
-    def query(self, images):
+    def query(self, images, reader_stream=None):
         """Each incoming image: stored and returned while the pool fills; afterwards with probability 1/2 swapped against a
-        random stored image (which is returned instead), else returned as is.  Draw order: uniform(0,1) then randint."""
+        random stored image (which is returned instead), else returned as is.  Draw order: uniform(0,1) then randint.
+        reader_stream: the (non-allocating) stream this call runs on when that is not the stream the stored images were allocated on
+        (cut_model's discriminator stream): a stored image is marked as read there before its last reference is dropped, so the caching
+        allocator does not hand its block out again while the copy is still queued."""
         if self.pool_size == 0:
             return images
         out = []
@@ -30,6 +33,8 @@ class ImagePool:
                 out.append(image)
             elif self.rng.uniform(0, 1) > 0.5:
                 idx = self.rng.randint(0, self.pool_size - 1)
+                if reader_stream is not None:
+                    self.images[idx].record_stream(reader_stream)
                 old = self.images[idx].clone()
                 self.images[idx] = image
                 out.append(old)
