@@ -9,7 +9,13 @@ from __future__ import annotations
 
 import torch.nn as nn
 
+import os
+
+import torch
+
 from .. import ops
+
+BATCH_REAL_FAKE = os.environ.get("JG_D_BATCH_REAL_FAKE", "1") != "0"
 
 
 class GANLoss(nn.Module):
@@ -46,6 +52,16 @@ class DiscriminatorGANLoss(nn.Module):
 
     def compute_loss_D(self, netD, real, fake, fake_2=None):
         self.real, self.fake = real, fake
+        if BATCH_REAL_FAKE and getattr(netD, "per_sample", False) and real.shape == fake.shape and real.dtype == fake.dtype:
+            # round 6: a discriminator that is a per-sample function with no state tied to the call (no BatchNorm statistics, no spectral-norm
+            # power iteration: the ViT projector with its MLP heads) sees real and fake as ONE batch -- half the launches of the
+            # discriminator half, GEMMs of twice the rows; the two losses are taken on the halves of the logits (loss.py:288-307 calls
+            # netD twice; same function, the weight gradients of the heads are summed inside one GEMM instead of over two)
+            n = real.shape[0]
+            pred = netD(torch.cat((self.real, self.fake.detach()), dim=0))
+            self.pred_real = pred[:n]
+            self.loss_D_real = self.criterionGAN(self.pred_real, True)
+            return (self.loss_D_real + self.criterionGAN(pred[n:], False)) * 0.5
         self.pred_real = netD(self.real)
         self.loss_D_real = self.criterionGAN(self.pred_real, True)
         pred_fake = netD(self.fake.detach())

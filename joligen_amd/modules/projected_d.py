@@ -772,6 +772,7 @@ class ProjectedDiscriminator(nn.Module):
                               "cannot be downloaded here.  A projected GAN on random features is not the reference's discriminator: pass "
                               "jg_projd_pretrained=<vit_small_patch16_224 state_dict .pth> or load a reference D checkpoint.", stacklevel=2)
             self.discriminator = MultiScaleDVit(self.freeze_feature_network.CHANNELS, self.freeze_feature_network.RESOLUTIONS)
+            self.per_sample = True          # LayerNorm backbone, Conv1d / MLP projector and heads: no batch statistics, no spectral norm (loss.py)
             return
         self.backbone = backbone
         self.freeze_feature_network = Proj(cout=cout, expand=expand, interp=size, backbone=backbone)
