@@ -939,6 +939,106 @@ __global__ void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx
   }
 }
 
+// ---- adjoint of resize_sum_kernel in separable form (round 6, jg_resize_sum_bwd) --------------------------------------------------------
+// The gather kernel above walks a (2r + 3)^2 window of dy per input pixel: at ratio 8 (the 8 x 8 map of the SegFormer head against 64 x 64)
+// 361 dependent trips on 65 K threads -- 112 us for 67 MB, and three such launches behind an activation-gradient pass read dy four times.
+// Here dx_s = R_y^T (R_x^T g), g = dy act'(y): pass X (one workgroup per output row: the row of g in LDS, written out once as the gradient
+// of the full-resolution term) reduces along x for ALL terms, pass Y reduces the fp32 intermediates along y.  Two launches, dy read once.
+struct ResizeBwdP {
+  void* dx[3];
+  int H[3], W[3];
+  long off[3];      // float offset of a term's intermediate [B, Ho, W_s, C] in the workspace
+  int n;
+};
+__device__ __forceinline__ void bil_window(int i, int in, int out, int& lo, int& hi) {      // output indices whose two taps may include input index i
+  const float r = (float)out / (float)in;
+  lo = max(0, (int)floorf(((float)i - 0.5f) * r - 0.5f) - 1);
+  hi = min(out - 1, (int)ceilf(((float)i + 1.5f) * r - 0.5f) + 1);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_sum_bwd_x_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ g, ResizeBwdP rp,
+                                                               float* __restrict__ ws, int C, int Ho, int Wo, int act) {
+  extern __shared__ uint4 s_row[];      // [Wo][C / 8] 16-byte chunks of g
+  const int c8n = C >> 3, tid = threadIdx.x;
+  const long row = blockIdx.x;          // b * Ho + oy
+  const int nrow = Wo * c8n;
+  for (int i = tid; i < nrow; i += 256) {
+    uint4 v = *reinterpret_cast<const uint4*>(dy + (row * Wo) * C + (long)i * 8);
+    if (act == JG_ACT_RELU) {
+      float f[8], d[8];
+      unpack8<T>(*reinterpret_cast<const uint4*>(y + (row * Wo) * C + (long)i * 8), f);
+      unpack8<T>(v, d);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) d[q] = f[q] > 0.f ? d[q] : 0.f;
+      v = pack8<T>(d);
+    }
+    if (g) *reinterpret_cast<uint4*>(g + (row * Wo) * C + (long)i * 8) = v;
+    s_row[i] = v;
+  }
+  __syncthreads();
+  for (int t = 0; t < rp.n; ++t) {
+    const int W = rp.W[t], items = W * c8n;
+    float* wt = ws + rp.off[t] + row * (long)W * C;
+    for (int it = tid; it < items; it += 256) {
+      const int ix = it / c8n, c8 = it - ix * c8n;
+      int lo, hi;
+      bil_window(ix, W, Wo, lo, hi);
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int ox = lo; ox <= hi; ++ox) {
+        int x0, x1;
+        float wx;
+        bil_coord<false>(ox, W, Wo, x0, x1, wx);
+        const float kx = (x0 == ix ? 1.f - wx : 0.f) + (x1 == ix ? wx : 0.f);
+        if (kx == 0.f) continue;
+        float f[8];
+        unpack8<T>(s_row[ox * c8n + c8], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += kx * f[j];
+      }
+      float4* o = reinterpret_cast<float4*>(wt + (long)ix * C + c8 * 8);
+      o[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      o[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_sum_bwd_y_kernel(const float* __restrict__ ws, ResizeBwdP rp, int B, int C, int Ho) {
+  const int c8n = C >> 3;
+  long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  int t = 0;
+  for (; t < rp.n; ++t) {
+    const long cnt = (long)B * rp.H[t] * rp.W[t] * c8n;
+    if (i < cnt) break;
+    i -= cnt;
+  }
+  if (t >= rp.n) return;
+  const int H = rp.H[t], W = rp.W[t];
+  const int c8 = i % c8n;
+  long p = i / c8n;
+  const int ix = p % W;
+  p /= W;
+  const int iy = p % H, b = p / H;
+  int lo, hi;
+  bil_window(iy, H, Ho, lo, hi);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  const float* wt = ws + rp.off[t] + ((long)b * Ho * W + ix) * C + c8 * 8;
+  for (int oy = lo; oy <= hi; ++oy) {
+    int y0, y1;
+    float wy;
+    bil_coord<false>(oy, H, Ho, y0, y1, wy);
+    const float ky = (y0 == iy ? 1.f - wy : 0.f) + (y1 == iy ? wy : 0.f);
+    if (ky == 0.f) continue;
+    const float4 a = *reinterpret_cast<const float4*>(wt + (long)oy * W * C), c = *reinterpret_cast<const float4*>(wt + (long)oy * W * C + 4);
+    acc[0] += ky * a.x; acc[1] += ky * a.y; acc[2] += ky * a.z; acc[3] += ky * a.w;
+    acc[4] += ky * c.x; acc[5] += ky * c.y; acc[6] += ky * c.z; acc[7] += ky * c.w;
+  }
+  *reinterpret_cast<uint4*>((T*)rp.dx[t] + (((long)b * H + iy) * W + ix) * C + c8 * 8) = pack8<T>(acc);
+}
+
 // ---- BatchNorm2d coefficients from the per-(image, channel) sums of jg_gn_stats -----------------------------------------------
 __global__ void bn_coef_kernel(const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
                                float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ ab, float* __restrict__ mr,
@@ -1783,6 +1883,42 @@ extern "C" int jg_resize_sum(int dtype, const void* x0, const void* x1, int H1, 
 }
 extern "C" int jg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, int C, int Ho, int Wo, int64_t lddy, jg_stream_t s) {
   return jg_bilinear2_bwd(dtype, dy, dx, B, H, W, C, Ho, Wo, lddy, 0, s);
+}
+// workspace of jg_resize_sum_bwd in floats: B * Ho * (W1 + W2 + W3) * C over the terms that are present
+extern "C" int64_t jg_resize_sum_bwd_ws_floats(int B, int Ho, int C, int W1, int W2, int W3) {
+  return (int64_t)B * Ho * C * ((W1 > 0 ? W1 : 0) + (W2 > 0 ? W2 : 0) + (W3 > 0 ? W3 : 0));
+}
+extern "C" int jg_resize_sum_bwd(int dtype, const void* y, const void* dy, void* g, void* dx1, int H1, int W1, void* dx2, int H2, int W2, void* dx3,
+                                 int H3, int W3, float* ws, int B, int Ho, int Wo, int C, int act, jg_stream_t s) {
+  if (!dy || B < 1 || Ho < 1 || Wo < 1 || C < 8 || C % 8 || (act != JG_ACT_NONE && act != JG_ACT_RELU) || (act == JG_ACT_RELU && !y)) return JG_ERR_BAD_ARG;
+  const size_t shm = (size_t)Wo * C * 2;
+  if (shm > 65536) return JG_ERR_UNSUPPORTED;        // the row of g in LDS: the caller keeps the gather kernels for wider rows
+  ResizeBwdP rp;
+  void* dxs[3] = {dx1, dx2, dx3};
+  const int Hs[3] = {H1, H2, H3}, Ws[3] = {W1, W2, W3};
+  rp.n = 0;
+  long off = 0, threads = 0;
+  for (int t = 0; t < 3; ++t) {
+    rp.dx[t] = nullptr; rp.H[t] = 1; rp.W[t] = 1; rp.off[t] = 0;
+  }
+  for (int t = 0; t < 3; ++t) {
+    if (!dxs[t]) continue;
+    if (Hs[t] < 1 || Ws[t] < 1 || Hs[t] > Ho || Ws[t] > Wo) return JG_ERR_BAD_ARG;
+    rp.dx[rp.n] = dxs[t]; rp.H[rp.n] = Hs[t]; rp.W[rp.n] = Ws[t]; rp.off[rp.n] = off;
+    off += (long)B * Ho * Ws[t] * C;
+    threads += (long)B * Hs[t] * Ws[t] * (C / 8);
+    ++rp.n;
+  }
+  if (rp.n && !ws) return JG_ERR_BAD_ARG;
+  if (!rp.n && !g) return JG_OK;
+  JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_sum_bwd_x_kernel<T>), dim3((unsigned)((long)B * Ho)), dim3(256), shm, (hipStream_t)s, (const T*)y,
+                                              (const T*)dy, (T*)g, rp, ws, C, Ho, Wo, act););
+  if (rp.n) {
+    JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_sum_bwd_y_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, ws, rp, B,
+                                                C, Ho););
+  }
+  JG_CHECK_LAUNCH();
+  return JG_OK;
 }
 extern "C" int jg_bn_coef(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* ab, float* mr,
                           int B, int HW, int C, float eps, float momentum, int training, jg_stream_t s) {

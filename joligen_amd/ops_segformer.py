@@ -17,6 +17,8 @@ from .ops import _DT, _dt, _p, _require_cuda, _st, copy_channels
 JG_ACT_NONE, JG_ACT_RELU = 0, 2
 # depth-wise 3x3 weight gradient: per-block partials through a workspace + one summing launch (1) or atomics from every block (0)
 DW_TWO_PHASE = os.environ.get("JG_DW_TWO_PHASE", "1") != "0"
+# round 6: backward of resize_sum through jg_resize_sum_bwd (separable adjoint, two launches); 0 = activation gradient + one gather launch per term
+RESIZE_BWD_SEPARABLE = os.environ.get("JG_RESIZE_BWD_SEPARABLE", "1") != "0"
 
 
 # ---- LayerNorm ---------------------------------------------------------------------------------------------------------------
@@ -598,6 +600,22 @@ class _ResizeSumFn(JGFunction):
         act, shapes = ctx.cfg
         dy = dy.contiguous()
         B, Ho, Wo, C = y.shape
+        if RESIZE_BWD_SEPARABLE and Wo * C * dy.element_size() <= 65536 and any(ctx.needs_input_grad[2:]):
+            # round 6 (jg_resize_sum_bwd): activation gradient + the bilinear adjoints of all terms in two launches, dy read once
+            want_g = ctx.needs_input_grad[1] and act != JG_ACT_NONE
+            g = torch.empty_like(y) if want_g else None
+            outs, a = [], []
+            for i in range(3):
+                dx = None
+                if i < len(shapes) and ctx.needs_input_grad[2 + i]:
+                    dx = torch.empty((B, shapes[i][1], shapes[i][2], C), device=dy.device, dtype=dy.dtype)
+                if i < len(shapes):
+                    outs.append(dx)
+                a += [_p(dx), shapes[i][1] if dx is not None else 1, shapes[i][2] if dx is not None else 1]
+            nws = int(_lib.lib().jg_resize_sum_bwd_ws_floats(B, Ho, C, *(a[3 * i + 2] if a[3 * i] else 0 for i in range(3))))
+            ws = torch.empty(max(nws, 1), device=dy.device, dtype=torch.float32)
+            check(_lib.lib().jg_resize_sum_bwd(_dt(y), y.data_ptr(), dy.data_ptr(), _p(g), *a, ws.data_ptr(), B, Ho, Wo, C, act, _st()), "jg_resize_sum_bwd")
+            return (None, (g if act != JG_ACT_NONE else dy) if ctx.needs_input_grad[1] else None) + tuple(outs)
         g = dy
         if act != JG_ACT_NONE:
             g = torch.empty_like(y)

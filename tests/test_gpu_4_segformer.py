@@ -203,11 +203,14 @@ def test_resize_concat(dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act", [0, 2])
-def test_resize_sum(dtype, act):
-    """round 6 (`jg_resize_sum`): act(x0 + sum_i F.interpolate(x_i)) and its adjoint against torch, 1 .. 3 resized terms, ragged sizes"""
+@pytest.mark.parametrize("separable", [True, False])
+def test_resize_sum(dtype, act, separable, monkeypatch):
+    """round 6 (`jg_resize_sum`): act(x0 + sum_i F.interpolate(x_i)) and its adjoint against torch, 1 .. 3 resized terms, ragged sizes;
+    the adjoint in its separable two-launch form (`jg_resize_sum_bwd`, default) and as activation gradient + one gather launch per term"""
     from joligen_amd import ops_segformer as S
+    monkeypatch.setattr(S, "RESIZE_BWD_SEPARABLE", separable)
     B, Ho, Wo, C = 2, 16, 24, 40
-    for sizes in ([(8, 12)], [(8, 12), (4, 6), (2, 3)], [(5, 7), (16, 24)]):
+    for sizes in ([(8, 12)], [(8, 12), (4, 6), (2, 3)], [(5, 7), (16, 24)], [(2, 3), (1, 1)]):
         x0 = rnd((B, C, Ho, Wo), dtype, 40)
         xs = [rnd((B, C, h, w), dtype, 41 + i) for i, (h, w) in enumerate(sizes)]
         gy = rnd((B, C, Ho, Wo), dtype, 50)
@@ -223,6 +226,31 @@ def test_resize_sum(dtype, act):
         assert relerr(y.permute(0, 3, 1, 2), yr) < TOL[dtype]
         for a, b in zip([d0] + ds, [r0] + rs):
             assert relerr(a.grad.permute(0, 3, 1, 2), b.grad) < TOL[dtype], (sizes, relerr(a.grad.permute(0, 3, 1, 2), b.grad))
+
+
+def test_resize_sum_backward_forms_agree_at_the_head_shape():
+    """the two adjoint forms of `resize_sum` on the SegformerHead shape of BASELINE configs[2] (64 x 64 x 256 against 32 / 16 / 8, ReLU): same
+    g = dy relu'(y), the term gradients agree to fp32 summation order before the 16-bit store; a term that wants no gradient is skipped"""
+    from joligen_amd import ops_segformer as S
+    B, Ho, C = 4, 64, 256
+    x0 = rnd((B, Ho, Ho, C), torch.bfloat16, 80).to(D0)
+    xs = [rnd((B, Ho >> (i + 1), Ho >> (i + 1), C), torch.bfloat16, 81 + i).to(D0) for i in range(3)]
+    gy = rnd((B, Ho, Ho, C), torch.bfloat16, 90).to(D0)
+    res = {}
+    for sep in (True, False):
+        S.RESIZE_BWD_SEPARABLE = sep
+        try:
+            d0 = x0.clone().requires_grad_(True)
+            ds = [x.clone().requires_grad_(i != 1) for i, x in enumerate(xs)]
+            S.resize_sum(d0, ds, 2).backward(gy)
+            torch.cuda.synchronize()
+        finally:
+            S.RESIZE_BWD_SEPARABLE = True
+        assert ds[1].grad is None
+        res[sep] = [d0.grad.float(), ds[0].grad.float(), ds[2].grad.float()]
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b in zip(res[True][1:], res[False][1:]):
+        assert relerr(a, b) < 2e-3, relerr(a, b)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
