@@ -507,16 +507,17 @@ int jg_bilinear_bwd(int dtype, const void* dy, void* dx, int B, int H, int W, in
 /* Round 6: y[B,Ho,Wo,C] = act(x0 + sum_i F.interpolate(x_i, (Ho, Wo), "bilinear", align_corners=False)) for up to three lower-resolution maps
  * x_i [B,H_i,W_i,C] (NULL = absent); act JG_ACT_NONE / JG_ACT_RELU.  SegformerHead.forward (mmseg decode head used by
  * models/modules/segformer/segformer_generator.py): `fusion_conv(cat([resize(conv_i(f_i))]))` evaluated as
- * relu(sum_i resize(W_i conv_i(f_i)) + b) -- the 1x1 fusion convolution and the bilinear resize commute. */
+ * relu(sum_i resize(W_i conv_i(f_i)) + b) -- the 1x1 fusion convolution and the bilinear resize commute.  chscale (NULL = none): fp32 [B, C]
+ * factors >= 0 applied behind the activation -- the head's nn.Dropout2d ((U >= p) / (1 - p) per image and channel) without a pass of its own. */
 int jg_resize_sum(int dtype, const void* x0, const void* x1, int H1, int W1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
-                  void* y, int B, int Ho, int Wo, int C, int act, jg_stream_t s);
+                  void* y, int B, int Ho, int Wo, int C, int act, const float* chscale, jg_stream_t s);
 /* Round 6: adjoint of jg_resize_sum in separable form: g = dy * act'(y) (written when `g` != NULL: the gradient of the full-resolution term),
  * dx_i = R_y^T (R_x^T g) for every lower-resolution term (NULL = not wanted); `ws`: jg_resize_sum_bwd_ws_floats(...) floats.  Two launches for the
  * activation-gradient pass + three gather launches of jg_bilinear_bwd (autograd of SegformerHead.forward's resize + sum);
- * JG_ERR_UNSUPPORTED when a row of g (Wo * C 16-bit values) exceeds 64 KB of LDS. */
+ * chscale as in jg_resize_sum (y is then the scaled output).  JG_ERR_UNSUPPORTED when a row of g (Wo * C 16-bit values) exceeds 64 KB of LDS. */
 int64_t jg_resize_sum_bwd_ws_floats(int B, int Ho, int C, int W1, int W2, int W3);
 int jg_resize_sum_bwd(int dtype, const void* y, const void* dy, void* g, void* dx1, int H1, int W1, void* dx2, int H2, int W2, void* dx3, int H3,
-                      int W3, float* ws, int B, int Ho, int Wo, int C, int act, jg_stream_t s);
+                      int W3, float* ws, int B, int Ho, int Wo, int C, int act, const float* chscale, jg_stream_t s);
 int jg_bn_coef(const float* sums, const float* gamma, const float* beta, float* running_mean, float* running_var, float* ab, float* mr, int B,
                int HW, int C, float eps, float momentum, int training, jg_stream_t s);
 int jg_bn_bwd_coef(const float* red, const float* gamma, const float* mr, float* pqr, float* dgamma, float* dbeta, int B, int HW, int C,

@@ -162,8 +162,8 @@ SIGNATURES = {
     "jg_bilinear_fwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_p],
     "jg_bilinear_bwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_p],
     "jg_resize_sum_bwd_ws_floats": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
-    "jg_resize_sum_bwd": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
-    "jg_resize_sum": [c_i32, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p],
+    "jg_resize_sum_bwd": [c_i32, c_p, c_p, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p],
+    "jg_resize_sum": [c_i32, c_p, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p],
     "jg_bilinear2_fwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_p],
     "jg_bilinear2_bwd": [c_i32, c_p, c_p, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i32, c_p],
     "jg_spectral_power_iter": [c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f32, c_p],

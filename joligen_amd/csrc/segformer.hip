@@ -859,7 +859,8 @@ struct ResizeSumP {
   int n;
 };
 template <typename T>
-__global__ void resize_sum_kernel(const T* __restrict__ x0, ResizeSumP rp, T* __restrict__ y, int B, int C, int Ho, int Wo, int act) {
+__global__ void resize_sum_kernel(const T* __restrict__ x0, ResizeSumP rp, T* __restrict__ y, int B, int C, int Ho, int Wo, int act,
+                                  const float* __restrict__ chs) {
   const int c8n = C >> 3;
   const long total = (long)B * Ho * Wo * c8n;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -892,6 +893,10 @@ __global__ void resize_sum_kernel(const T* __restrict__ x0, ResizeSumP rp, T* __
     if (act == JG_ACT_RELU) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) o8[j] = fmaxf(o8[j], 0.f);
+    }
+    if (chs) {      // nn.Dropout2d behind the head's ReLU as a per-(image, channel) factor >= 0 (round 6: no pass of its own)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] *= chs[(long)b * C + c8 * 8 + j];
     }
     *reinterpret_cast<uint4*>(y + i * 8) = pack8<T>(o8);
   }
@@ -957,19 +962,26 @@ __device__ __forceinline__ void bil_window(int i, int in, int out, int& lo, int&
 }
 template <typename T>
 __global__ __launch_bounds__(256) void resize_sum_bwd_x_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ g, ResizeBwdP rp,
-                                                               float* __restrict__ ws, int C, int Ho, int Wo, int act) {
+                                                               float* __restrict__ ws, int C, int Ho, int Wo, int act, const float* __restrict__ chs) {
   extern __shared__ uint4 s_row[];      // [Wo][C / 8] 16-byte chunks of g
   const int c8n = C >> 3, tid = threadIdx.x;
   const long row = blockIdx.x;          // b * Ho + oy
   const int nrow = Wo * c8n;
   for (int i = tid; i < nrow; i += 256) {
     uint4 v = *reinterpret_cast<const uint4*>(dy + (row * Wo) * C + (long)i * 8);
-    if (act == JG_ACT_RELU) {
+    if (act == JG_ACT_RELU || chs) {
       float f[8], d[8];
-      unpack8<T>(*reinterpret_cast<const uint4*>(y + (row * Wo) * C + (long)i * 8), f);
       unpack8<T>(v, d);
+      if (chs) {      // y = relu(.) * s with s >= 0: y > 0 exactly where the ReLU passed AND the channel was kept
+        const float* sc = chs + (row / Ho) * C + (i % c8n) * 8;
 #pragma unroll
-      for (int q = 0; q < 8; ++q) d[q] = f[q] > 0.f ? d[q] : 0.f;
+        for (int q = 0; q < 8; ++q) d[q] *= sc[q];
+      }
+      if (act == JG_ACT_RELU) {
+        unpack8<T>(*reinterpret_cast<const uint4*>(y + (row * Wo) * C + (long)i * 8), f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = f[q] > 0.f ? d[q] : 0.f;
+      }
       v = pack8<T>(d);
     }
     if (g) *reinterpret_cast<uint4*>(g + (row * Wo) * C + (long)i * 8) = v;
@@ -1861,7 +1873,7 @@ extern "C" int jg_bilinear2_bwd(int dtype, const void* dy, void* dx, int B, int 
   return JG_OK;
 }
 extern "C" int jg_resize_sum(int dtype, const void* x0, const void* x1, int H1, int W1, const void* x2, int H2, int W2, const void* x3, int H3, int W3,
-                             void* y, int B, int Ho, int Wo, int C, int act, jg_stream_t s) {
+                             void* y, int B, int Ho, int Wo, int C, int act, const float* chscale, jg_stream_t s) {
   if (!x0 || !y || B < 1 || Ho < 1 || Wo < 1 || C < 8 || C % 8 || (act != JG_ACT_NONE && act != JG_ACT_RELU)) return JG_ERR_BAD_ARG;
   ResizeSumP rp;
   const void* xs[3] = {x1, x2, x3};
@@ -1877,7 +1889,7 @@ extern "C" int jg_resize_sum(int dtype, const void* x0, const void* x1, int H1, 
     ++rp.n;
   }
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_sum_kernel<T>), dim3(grid_for((long)B * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)s, (const T*)x0, rp,
-                                              (T*)y, B, C, Ho, Wo, act););
+                                              (T*)y, B, C, Ho, Wo, act, chscale););
   JG_CHECK_LAUNCH();
   return JG_OK;
 }
@@ -1889,7 +1901,7 @@ extern "C" int64_t jg_resize_sum_bwd_ws_floats(int B, int Ho, int C, int W1, int
   return (int64_t)B * Ho * C * ((W1 > 0 ? W1 : 0) + (W2 > 0 ? W2 : 0) + (W3 > 0 ? W3 : 0));
 }
 extern "C" int jg_resize_sum_bwd(int dtype, const void* y, const void* dy, void* g, void* dx1, int H1, int W1, void* dx2, int H2, int W2, void* dx3,
-                                 int H3, int W3, float* ws, int B, int Ho, int Wo, int C, int act, jg_stream_t s) {
+                                 int H3, int W3, float* ws, int B, int Ho, int Wo, int C, int act, const float* chscale, jg_stream_t s) {
   if (!dy || B < 1 || Ho < 1 || Wo < 1 || C < 8 || C % 8 || (act != JG_ACT_NONE && act != JG_ACT_RELU) || (act == JG_ACT_RELU && !y)) return JG_ERR_BAD_ARG;
   const size_t shm = (size_t)Wo * C * 2;
   if (shm > 65536) return JG_ERR_UNSUPPORTED;        // the row of g in LDS: the caller keeps the gather kernels for wider rows
@@ -1912,7 +1924,7 @@ extern "C" int jg_resize_sum_bwd(int dtype, const void* y, const void* dy, void*
   if (rp.n && !ws) return JG_ERR_BAD_ARG;
   if (!rp.n && !g) return JG_OK;
   JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_sum_bwd_x_kernel<T>), dim3((unsigned)((long)B * Ho)), dim3(256), shm, (hipStream_t)s, (const T*)y,
-                                              (const T*)dy, (T*)g, rp, ws, C, Ho, Wo, act););
+                                              (const T*)dy, (T*)g, rp, ws, C, Ho, Wo, act, chscale););
   if (rp.n) {
     JG_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((resize_sum_bwd_y_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)s, ws, rp, B,
                                                 C, Ho););

@@ -272,6 +272,7 @@ class MixVisionTransformer(nn.Module):
 
 
 HEAD_COMMUTE = os.environ.get("JG_HEAD_COMMUTE", "1") != "0"     # SegformerHead: fusion convolution before the resize (below)
+HEAD_DROPOUT_FUSED = os.environ.get("JG_HEAD_DROPOUT_FUSED", "1") != "0"      # round 6: the head's Dropout2d inside jg_resize_sum / jg_resize_sum_bwd
 
 
 class SegformerHead(nn.Module):
@@ -302,6 +303,10 @@ class SegformerHead(nn.Module):
             # results are resized and summed in one pass -- no 4 C-channel concatenation (268 MB per direction at batch 32), a quarter of the
             # GEMM work.  Same function; the 16-bit rounding points move from the resized maps to the convolved ones.
             ts = [S.sliced_in_conv(o, fm, i * C, with_bias=(i == 0)) for i, o in enumerate(outs)]
+            if self.dropout is not None and self.training and HEAD_DROPOUT_FUSED:
+                # nn.Dropout2d as the channel factor of the same pass (and of its adjoint): no scale pass over the 64 x 64 x C map per direction
+                u = self._rand[0]((ts[0].shape[0], ts[0].shape[-1]), ts[0].device)
+                return self.conv_seg(S.resize_sum(ts[0], ts[1:], JG_ACT_RELU, (u >= self.dropout_ratio).float() / (1.0 - self.dropout_ratio)))
             h = S.resize_sum(ts[0], ts[1:], JG_ACT_RELU)
         else:
             h = ops.activation(self.fusion_conv.conv(S.resize_concat(outs, Ho, Wo)), JG_ACT_RELU)

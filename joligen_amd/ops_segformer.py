@@ -574,10 +574,11 @@ def sliced_in_conv(x, meta, col0, with_bias=False):
 
 
 class _ResizeSumFn(JGFunction):
-    """act(x0 + sum_i bilinear(x_i -> size of x0)) (jg_resize_sum); backward: act' once, then the bilinear adjoint per resized term."""
+    """act(x0 + sum_i bilinear(x_i -> size of x0)) [* chscale[b, c]] (jg_resize_sum); backward: jg_resize_sum_bwd (separable adjoint of all
+    terms, two launches) or act' once + the gather adjoint per resized term."""
 
     @staticmethod
-    def forward(ctx, act, x0, *xs):
+    def forward(ctx, act, chscale, x0, *xs):
         _require_cuda(x0, *xs)
         x0 = x0.contiguous()
         xs = [x.contiguous() for x in xs]
@@ -588,34 +589,41 @@ class _ResizeSumFn(JGFunction):
         a = []
         for i in range(3):
             a += [xs[i].data_ptr(), xs[i].shape[1], xs[i].shape[2]] if i < len(xs) else [None, 1, 1]
-        check(_lib.lib().jg_resize_sum(_dt(x0), x0.data_ptr(), *a, y.data_ptr(), B, Ho, Wo, C, act, _st()), "jg_resize_sum")
-        ctx.save_for_backward(y)
+        if chscale is not None:
+            chscale = chscale.contiguous().float()
+            assert tuple(chscale.shape) == (B, C), tuple(chscale.shape)
+        check(_lib.lib().jg_resize_sum(_dt(x0), x0.data_ptr(), *a, y.data_ptr(), B, Ho, Wo, C, act, _p(chscale), _st()), "jg_resize_sum")
+        ctx.save_for_backward(y, chscale)
         ctx.cfg = (act, [tuple(x.shape) for x in xs])
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
-        (y,) = ctx.saved_tensors
+        y, chscale = ctx.saved_tensors
         act, shapes = ctx.cfg
         dy = dy.contiguous()
         B, Ho, Wo, C = y.shape
-        if RESIZE_BWD_SEPARABLE and Wo * C * dy.element_size() <= 65536 and any(ctx.needs_input_grad[2:]):
+        need0, needs = ctx.needs_input_grad[2], ctx.needs_input_grad[3:]
+        if (RESIZE_BWD_SEPARABLE and Wo * C * dy.element_size() <= 65536 and any(needs)) or chscale is not None:
             # round 6 (jg_resize_sum_bwd): activation gradient + the bilinear adjoints of all terms in two launches, dy read once
-            want_g = ctx.needs_input_grad[1] and act != JG_ACT_NONE
-            g = torch.empty_like(y) if want_g else None
+            if Wo * C * dy.element_size() > 65536:
+                raise NotImplementedError("resize_sum with a channel scale: rows of more than 64 KB")
+            plain = act == JG_ACT_NONE and chscale is None       # g is dy itself
+            g = torch.empty_like(y) if (need0 and not plain) else None
             outs, a = [], []
             for i in range(3):
                 dx = None
-                if i < len(shapes) and ctx.needs_input_grad[2 + i]:
+                if i < len(shapes) and needs[i]:
                     dx = torch.empty((B, shapes[i][1], shapes[i][2], C), device=dy.device, dtype=dy.dtype)
                 if i < len(shapes):
                     outs.append(dx)
                 a += [_p(dx), shapes[i][1] if dx is not None else 1, shapes[i][2] if dx is not None else 1]
             nws = int(_lib.lib().jg_resize_sum_bwd_ws_floats(B, Ho, C, *(a[3 * i + 2] if a[3 * i] else 0 for i in range(3))))
             ws = torch.empty(max(nws, 1), device=dy.device, dtype=torch.float32)
-            check(_lib.lib().jg_resize_sum_bwd(_dt(y), y.data_ptr(), dy.data_ptr(), _p(g), *a, ws.data_ptr(), B, Ho, Wo, C, act, _st()), "jg_resize_sum_bwd")
-            return (None, (g if act != JG_ACT_NONE else dy) if ctx.needs_input_grad[1] else None) + tuple(outs)
+            check(_lib.lib().jg_resize_sum_bwd(_dt(y), y.data_ptr(), dy.data_ptr(), _p(g), *a, ws.data_ptr(), B, Ho, Wo, C, act, _p(chscale), _st()),
+                  "jg_resize_sum_bwd")
+            return (None, None, (dy if plain else g) if need0 else None) + tuple(outs)
         g = dy
         if act != JG_ACT_NONE:
             g = torch.empty_like(y)
@@ -623,15 +631,16 @@ class _ResizeSumFn(JGFunction):
         outs = []
         for i, (_, H, W, _c) in enumerate(shapes):
             dx = None
-            if ctx.needs_input_grad[2 + i]:
+            if needs[i]:
                 dx = torch.empty((B, H, W, C), device=dy.device, dtype=dy.dtype)
                 check(_lib.lib().jg_bilinear_bwd(_dt(g), g.data_ptr(), dx.data_ptr(), B, H, W, C, Ho, Wo, C, _st()), "jg_bilinear_bwd")
             outs.append(dx)
-        return (None, g if ctx.needs_input_grad[1] else None) + tuple(outs)
+        return (None, None, g if need0 else None) + tuple(outs)
 
 
-def resize_sum(x0, xs, act=JG_ACT_NONE):
-    return _ResizeSumFn.apply(act, x0, *xs)
+def resize_sum(x0, xs, act=JG_ACT_NONE, chscale=None):
+    """chscale: optional fp32 [B, C] factors >= 0 applied behind the activation (Dropout2d of the SegFormer head)."""
+    return _ResizeSumFn.apply(act, chscale, x0, *xs)
 
 
 def sliced_linear(x, meta, row0, n):

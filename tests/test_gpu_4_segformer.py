@@ -228,6 +228,30 @@ def test_resize_sum(dtype, act, separable, monkeypatch):
             assert relerr(a.grad.permute(0, 3, 1, 2), b.grad) < TOL[dtype], (sizes, relerr(a.grad.permute(0, 3, 1, 2), b.grad))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_resize_sum_with_channel_dropout(dtype):
+    """`resize_sum(..., chscale)`: relu(x0 + sum_i resize(x_i)) * s[b, c] with s = Dropout2d's (U >= p) / (1 - p) (zeros included) and its adjoint
+    against torch"""
+    from joligen_amd import ops_segformer as S
+    B, Ho, Wo, C = 3, 16, 24, 40
+    x0 = rnd((B, C, Ho, Wo), dtype, 40)
+    xs = [rnd((B, C, h, w), dtype, 41 + i) for i, (h, w) in enumerate([(8, 12), (4, 6)])]
+    gy = rnd((B, C, Ho, Wo), dtype, 50)
+    sc = (torch.rand(B, C, generator=torch.Generator().manual_seed(3)) >= 0.3).float() / 0.7
+    assert float(sc.min()) == 0.0
+    r0, rs = x0.float().requires_grad_(True), [x.float().requires_grad_(True) for x in xs]
+    yr = torch.relu(r0 + sum(F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False) for x in rs)) * sc[:, :, None, None]
+    yr.backward(gy.float())
+    d0 = x0.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True)
+    ds = [x.permute(0, 2, 3, 1).contiguous().to(D0).requires_grad_(True) for x in xs]
+    y = S.resize_sum(d0, ds, 2, sc.to(D0))
+    y.backward(gy.permute(0, 2, 3, 1).contiguous().to(D0))
+    torch.cuda.synchronize()
+    assert relerr(y.permute(0, 3, 1, 2), yr) < TOL[dtype]
+    for a, b in zip([d0] + ds, [r0] + rs):
+        assert relerr(a.grad.permute(0, 3, 1, 2), b.grad) < TOL[dtype], relerr(a.grad.permute(0, 3, 1, 2), b.grad)
+
+
 def test_resize_sum_backward_forms_agree_at_the_head_shape():
     """the two adjoint forms of `resize_sum` on the SegformerHead shape of BASELINE configs[2] (64 x 64 x 256 against 32 / 16 / 8, ReLU): same
     g = dy relu'(y), the term gradients agree to fp32 summation order before the 16-bit store; a term that wants no gradient is skipped"""
