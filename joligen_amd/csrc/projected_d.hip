@@ -204,7 +204,12 @@ __global__ __launch_bounds__(256) void sn_dot_group_kernel(const SnDesc* __restr
   float acc = 0.f;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) acc += a[i] * d.W[i];
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(dots + blockIdx.y, acc);
+  // ONE atomic per block (round 6): the L sums share a cache line, and with one atomic per wave of 256 blocks the 14 layers queued 14 K
+  // read-modify-writes on it -- 189 us per launch for 80 MB of reads (profiles/r06_cut_mobile_kernel_stats.md)
+  __shared__ float s_w[4];
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dots + blockIdx.y, (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]));
 }
 __global__ __launch_bounds__(256) void sn_fix_group_kernel(const SnDesc* __restrict__ tab, const float* __restrict__ fbuf, const float* __restrict__ dbuf,
                                                            const float* __restrict__ dots, unsigned long long mask) {
@@ -301,7 +306,7 @@ extern "C" int jg_spectral_group_wgrad_fix(const void* table, int L, const float
   if (!table || !fbuf || !dbuf || !dots || L < 1 || L > 64 || max_n < 1) return JG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)s;
   const SnDesc* tab = (const SnDesc*)table;
-  hipLaunchKernelGGL(sn_dot_group_kernel, dim3(grid1(max_n, 256), L), dim3(256), 0, st, tab, dbuf, dots, (unsigned long long)mask);
+  hipLaunchKernelGGL(sn_dot_group_kernel, dim3(grid1(max_n, 64), L), dim3(256), 0, st, tab, dbuf, dots, (unsigned long long)mask);
   hipLaunchKernelGGL(sn_fix_group_kernel, dim3(grid1(max_n, 512), L), dim3(256), 0, st, tab, fbuf, dbuf, (const float*)dots, (unsigned long long)mask);
   JG_CHECK_LAUNCH();
   return JG_OK;
