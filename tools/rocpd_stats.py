@@ -40,6 +40,14 @@ def main():
             for name, k, t, avg in db.execute("select name, count(*), sum(duration), avg(duration) from kernels" + cond + " group by name order by sum(duration) desc limit 40").fetchall():
                 print(f"| `{short(name)}` | {k / steps:.1f} | {t / 1e6 / steps:.3f} | {avg / 1e3:.1f} |")
         return
+    if "--by-grid" in sys.argv:         # one row per (kernel, launch geometry): under-filled grids and long launches of small problems stand out
+        print("| kernel | queue | workgroups | threads | LDS KB | VGPRs | calls/step | avg us | ms/step |")
+        print("|---|---|---|---|---|---|---|---|---|")
+        q = ("select name, queue_id, (grid_x / workgroup_x) * (grid_y / workgroup_y) * (grid_z / workgroup_z), workgroup_x * workgroup_y * workgroup_z, lds_size, "
+             "vgpr_count + accum_vgpr_count, count(*), avg(duration), sum(duration) from kernels" + where + " group by 1, 2, 3, 4, 5, 6 order by sum(duration) desc limit 120")
+        for name, qu, wgs, th, lds, vg, k, avg, tot in db.execute(q).fetchall():
+            print(f"| `{short(name)}` | {qu} | {wgs} | {th} | {lds / 1024:.0f} | {vg} | {k / steps:.2f} | {avg / 1e3:.1f} | {tot / 1e6 / steps:.3f} |")
+        return
     rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels" + where +
                       " group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows)
