@@ -232,8 +232,16 @@ __global__ __launch_bounds__(256) void conv_nt_glds_kernel(ConvP p) {
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   const int tilesN = (p.N + BN - 1) / BN;
-  const int n0 = (blockIdx.x % tilesN) * BN;
-  const int m0 = (blockIdx.x / tilesN) * BM;
+  // XCD-aware tile order (round 6; conv_halo.hip has had it since round 2): workgroup b runs on XCD b % 8, so with the plain order the tilesN
+  // column tiles of one row block -- which read the SAME rows of x -- sat in different L2s and x crossed HBM tilesN times (PMC: 1.49 x the
+  // algorithmic bytes on the 128 x 128 tile).  Each XCD now owns a contiguous run of tile ids: neighbours in n (and, for R > 1, in m) share an L2.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r8 = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  }
+  const int n0 = (bid % tilesN) * BN;
+  const int m0 = (bid / tilesN) * BM;
 
   const int z = blockIdx.z;
   const int zb = z / p.nh, zh = z % p.nh;

@@ -455,10 +455,23 @@ __device__ __forceinline__ void wgrad_tn_tr_body(const WgP& p, const int bx, con
   }
 }
 
+// XCD-aware (tile, K-slice) order (round 6): workgroup b runs on XCD b % 8, and with the plain order the tiles of ONE K-slice -- which read the same
+// pixel rows of dy and x -- sat in eight different L2s (a 512 x 1024 weight on the 256 x 256 tile: dy crossed HBM four times, x twice; PMC 232 MB
+// read per launch for 100 MB of operands).  Each XCD now owns a contiguous run of the slice-major ids: all tiles of a slice share an L2.
+__device__ __forceinline__ void wgrad_xcd_order(int& bx, int& bz) {
+  const int tiles = gridDim.x, nwg = tiles * gridDim.z, lin = blockIdx.x + blockIdx.z * tiles;
+  const int q = nwg >> 3, r8 = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+  const int id = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  bx = id % tiles;
+  bz = id / tiles;
+}
+
 template <typename T, int WAVES_M, bool DEEP = false>
 __global__ __launch_bounds__(256, 2) void wgrad_tn_tr_kernel(WgP p) {
   __shared__ uint4 sm[2][2 * TR_TILE];
-  wgrad_tn_tr_body<T, WAVES_M, DEEP>(p, blockIdx.x, blockIdx.z, sm);
+  int bx, bz;
+  wgrad_xcd_order(bx, bz);
+  wgrad_tn_tr_body<T, WAVES_M, DEEP>(p, bx, bz, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -816,8 +829,10 @@ __device__ __forceinline__ void wgrad_tn_dma_body(const WgP& p, const int bx, co
 template <typename T, bool DMA = true, int ABL = 0>
 __global__ __launch_bounds__(512, 1) void wgrad_tn_big_kernel(WgP p) {
   __shared__ uint4 sm[2][2 * BIG_TILE];
-  if constexpr (DMA) wgrad_tn_dma_body<T, ABL == 4, ABL == 4 ? 0 : ABL>(p, blockIdx.x, blockIdx.z, sm);      // ABL 4: the SPREAD form (A/B)
-  else wgrad_tn_big_body<T>(p, blockIdx.x, blockIdx.z, sm);
+  int bx, bz;
+  wgrad_xcd_order(bx, bz);
+  if constexpr (DMA) wgrad_tn_dma_body<T, ABL == 4, ABL == 4 ? 0 : ABL>(p, bx, bz, sm);      // ABL 4: the SPREAD form (A/B)
+  else wgrad_tn_big_body<T>(p, bx, bz, sm);
 }
 
 // GROUPED launch (round 5): up to GROUP_MAX independent small weight-gradient problems in ONE grid.  The SegFormer generator's backward issues
