@@ -232,6 +232,29 @@ def test_image_pool_replays_reference_draws():
         assert torch.equal(a, b.cpu())
 
 
+def test_image_pool_queried_on_another_stream():
+    """round 6 (`JG_POOL_SIDE`): the early-D drivers query the history pool on the discriminator stream (`reader_stream`): same draws, same
+    images as on the allocating stream, also when the stored images' blocks are freed and reused right behind the query"""
+    from joligen_amd.util.image_pool import ImagePool
+    ref_rng, my_rng = random.Random(7), random.Random(7)
+    ref_pool, my_pool = O.OracleImagePool(3, ref_rng), ImagePool(3, my_rng)
+    side = torch.cuda.Stream(device=D0)
+    main = torch.cuda.current_stream(torch.device(D0))
+    for it in range(40):
+        x = torch.full((2, 64, 64, 8), float(it)) + torch.arange(2).view(2, 1, 1, 1) * 0.5
+        a = ref_pool.query(x)
+        xd = x.to(D0)
+        xd.record_stream(side)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            b = my_pool.query(xd, reader_stream=side)
+        del xd
+        junk = torch.full((2, 64, 64, 8), -1.0, device=D0)      # the allocator may hand out a just-freed block here: it must not be one still being read
+        side.synchronize()
+        assert torch.equal(a, b.cpu()), it
+        del junk
+
+
 def build_cut_model(g, dtype, **extra):
     from joligen_amd.models import create_model
     from joligen_amd.options import opt_from_json

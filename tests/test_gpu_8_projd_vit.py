@@ -260,6 +260,45 @@ def test_projected_discriminator_vit_first_step_vs_oracle(golden_dir, fixture):
     assert errs[len(errs) // 2][0] < max(6e-3, 2.0 * y["grad_median"]), (errs[len(errs) // 2], y)
 
 
+@pytest.mark.parametrize("fixture", FIXTURES)
+def test_projected_discriminator_vit_real_and_fake_as_one_batch(golden_dir, fixture, monkeypatch):
+    """round 6 (`JG_D_BATCH_REAL_FAKE`): `DiscriminatorGANLoss.compute_loss_D` sends real and fake through the ViT projector as ONE batch (the
+    network is per-sample: `per_sample`) -- loss and the gradients of the 24 head tensors against the CPU oracle of the reference's two calls
+    (loss.py:288-307), and against the two-call form on the same kernels"""
+    from joligen_amd import ops
+    from joligen_amd.modules import loss as LM
+
+    dtype = torch.float16
+    g = load(golden_dir, fixture)
+    g = dict(g, real=g["real"].half().float(), fake=g["fake"].half().float())
+    P0 = {k: (v.half().float() if torch.is_floating_point(v) else v) for k, v in projd_state(g).items()}
+    net = _build(g, dtype, P0)
+    assert net.per_sample
+    r = projd_run_oracle({k: v.clone() for k, v in P0.items()}, g)
+    real, fake = ops.to_nhwc(g["real"].to(D0), dtype, 8), ops.to_nhwc(g["fake"].to(D0), dtype, 8)
+    calc = LM.DiscriminatorGANLoss(net, torch.device(D0), train_gan_mode="projected")
+    res = {}
+    for batched in (True, False):
+        monkeypatch.setattr(LM, "BATCH_REAL_FAKE", batched)
+        calls = []
+        h = net.register_forward_pre_hook(lambda m, a: calls.append(a[0].shape[0]))
+        net.arena.g.zero_()
+        loss_D = calc.compute_loss_D(net, real, fake)
+        h.remove()
+        assert calls == ([2 * real.shape[0]] if batched else [real.shape[0]] * 2), calls
+        loss_D.backward()
+        torch.cuda.synchronize()
+        res[batched] = (float(loss_D), {k: p.grad.detach().float().clone() for k, p in net.named_parameters() if k in r["grads"]})
+        assert tuple(calc.pred_real.shape) == (real.shape[0], 400)
+    assert abs(res[True][0] - float(r["loss_D"])) < 6e-3 * abs(float(r["loss_D"]))
+    assert abs(res[True][0] - res[False][0]) < 2e-3 * abs(res[False][0])
+    y = _yard(fixture, dtype)
+    errs = sorted(((relerr(v, r["grads"][k]), k) for k, v in res[True][1].items()), reverse=True)
+    assert len(errs) == 24 and errs[0][0] < max(2e-2, 2.0 * y["grad_worst"]), (errs[:6], y)
+    both = max(relerr(res[True][1][k], res[False][1][k]) for k in res[True][1])
+    assert both < max(1e-2, y["grad_worst"]), both
+
+
 def test_vit_pretrained_backbone_loads_timm_keys(tmp_path):
     """`jg_projd_pretrained`: a timm-keyed `vit_small_patch16_224` state_dict (here: the torch mirror's, random) loads strictly, and a
     reference-layout discriminator checkpoint round-trips through state_dict() / load_state_dict()"""
