@@ -1296,7 +1296,7 @@ def test_fused_unet_node_is_a_torch_op(golden_dir, efficient, monkeypatch):
     emb0 = torch.randn(c["B"], unet.cond_embed_dim, generator=g).to(d)
     R = ops.to_nhwc(torch.randn(c["B"], 3, c["S"], c["S"], generator=g).to(d), dtype, 8)
     res = {}
-    for as_op in (False, True, False):
+    for as_op in (False, True, False, False, False):       # the floor below is the largest of three repeats (a single repeat is a noisy yardstick)
         monkeypatch.setattr(unet_exec, "FUSED_TORCH_OPS", as_op)
         net.arena.g.zero_()
         x = x0.clone().requires_grad_(True)
@@ -1308,7 +1308,7 @@ def test_fused_unet_node_is_a_torch_op(golden_dir, efficient, monkeypatch):
         res.setdefault(as_op, []).append((y.detach().float(), x.grad.float(), emb.grad.clone(), net.arena.g.clone()))
     assert not unet_exec._TAPES, "the backward consumed its tape"
     for i, name in enumerate(("y", "dx", "demb", "gradient arena")):
-        floor = relerr(res[False][1][i], res[False][0][i])
+        floor = max(relerr(r[i], res[False][0][i]) for r in res[False][1:])
         e = relerr(res[True][0][i], res[False][0][i])
         assert e <= 3 * floor + 1e-6, (name, e, floor)
     assert float(res[True][0][3].norm()) > 0
